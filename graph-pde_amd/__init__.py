@@ -1,0 +1,12 @@
+"""graph-pde_amd: the MI355X-native edge-conditioned graph convolution (NNConv) of
+neuraloperator/graph-pde — hand-written HIP for gfx950 behind the reference's module surface.
+
+    from graph_pde_amd import NNConv_old, NNConv          # drop-in modules (nn_conv.py)
+    from graph_pde_amd import ops                          # CSR / packing / raw forward
+
+(The directory is named `graph-pde_amd`; `graph_pde_amd.py` at the repo root makes it importable.)
+"""
+from . import _lib, ops, synth          # noqa: F401
+from .nn_conv import ECConv, NNConv, NNConv_old   # noqa: F401
+
+__all__ = ["NNConv_old", "NNConv", "ECConv", "ops", "synth"]

@@ -1,0 +1,85 @@
+"""ctypes binding of libgpde.so (the C ABI declared in include/gpde.h).
+
+The library is loaded lazily and never stored on a module/`nn.Module` instance, so models stay
+picklable (`torch.save(model)`, /root/reference/graph-neural-operator/UAI1_full_resolution.py:317).
+There is NO fallback: if the shared object is missing or a symbol is absent this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libgpde.so")
+
+GPDE_OK = 0
+GPDE_AGGR_ADD, GPDE_AGGR_MEAN = 0, 1
+GPDE_WIDTH = 64
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+
+# name -> (restype, argtypes); mirrors include/gpde.h one to one (tests check the two agree)
+SIGNATURES = {
+    "gpde_version": (ctypes.c_int, []),
+    "gpde_last_error": (ctypes.c_char_p, []),
+    "gpde_csr_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64]),
+    "gpde_csr_from_coo": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                         ctypes.c_void_p]),
+    "gpde_mlp_pack_bytes": (ctypes.c_size_t, [ctypes.c_int, c_i32p]),
+    "gpde_mlp_pack": (ctypes.c_int, [ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p),
+                                     ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p,
+                                     ctypes.c_size_t, ctypes.c_void_p]),
+    "gpde_nnconv_fwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64,
+                                                          ctypes.c_int, c_i32p]),
+    "gpde_nnconv_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_size_t, ctypes.c_void_p]),
+    "gpde_nnconv_fwd_plan": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, c_i32p,
+                                            ctypes.c_size_t, c_i32p, c_i64p, c_i32p, c_i32p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+n_native_calls = 0          # incremented by every gpde_nnconv_fwd call (tests assert it moves)
+
+
+class GpdeError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load libgpde.so (once). Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise GpdeError(
+                        f"{LIB_PATH} not found - build it with `python graph-pde_amd/build.py` "
+                        "(or __graft_entry__.build()); the NNConv hot path has no non-HIP fallback")
+                l = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(l, name)          # AttributeError if a declared symbol is missing
+                    fn.restype, fn.argtypes = res, args
+                _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != GPDE_OK:
+        msg = lib().gpde_last_error().decode("utf-8", "replace")
+        if rc == -2:
+            raise NotImplementedError(f"{what}: {msg}")
+        raise GpdeError(f"{what} failed (code {rc}): {msg}")
+
+
+def dims_array(dims):
+    return (ctypes.c_int32 * len(dims))(*[int(d) for d in dims])

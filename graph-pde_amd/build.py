@@ -1,0 +1,68 @@
+"""Build libgpde.so (hand-written HIP for gfx950 + the C ABI of include/gpde.h) in-tree.
+
+    python graph-pde_amd/build.py            # incremental: recompiles sources newer than the .so
+    python graph-pde_amd/build.py --force
+
+hipcc cross-compiles for gfx950 without a GPU.  The .so is git-ignored but travels to the GPU
+box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INCLUDE = os.path.join(REPO, "include")
+LIB = os.path.join(PKG, "libgpde.so")
+OBJDIR = os.path.join(PKG, "build")
+
+SOURCES = ["gpde_api.hip", "gpde_csr.hip", "gpde_pack.hip", "gpde_fused.hip", "gpde_gemm3.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
+         "-Wall", "-Wno-unused-function"]
+
+
+def _deps():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(INCLUDE, "gpde.h"))
+    return hdrs
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, force, extra):
+    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+    path = os.path.join(CSRC, src)
+    if force or _stale(obj, [path] + _deps()):
+        cmd = [HIPCC] + FLAGS + list(extra) + ["-c", path, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, extra_flags=()) -> str:
+    os.makedirs(OBJDIR, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force, extra_flags), SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

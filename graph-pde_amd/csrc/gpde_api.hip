@@ -1,0 +1,217 @@
+// C-ABI entry points of libgpde.so: launch planning and orchestration of the NNConv forward.
+// Boundary replaced: nn_conv.NNConv_old.forward -> propagate -> message -> aggregate -> update
+// (/root/reference/graph-neural-operator/nn_conv.py:267-282) — see include/gpde.h.
+#include "gpde_common.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void gpde_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int gpde_version(void) { return GPDE_VERSION; }
+extern "C" const char* gpde_last_error(void) { return g_err; }
+
+namespace {
+
+constexpr size_t kAlign = 256;
+size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+
+int num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+        else
+            cus = 256;   // MI355X
+    }
+    return cus;
+}
+
+struct Plan {
+    GpdePackLayout L;
+    int64_t nodes_per_chunk;
+    int n_chunks;
+    int n_groups;        // fused-kernel edge groups (workgroups per hidden slice)
+    size_t off_part, off_z, off_ha, off_hb;
+    size_t h_floats;     // mode 2: floats per ping-pong activation buffer
+};
+
+int pick_splits(int64_t nn) {
+    const int64_t tiles = (nn + 63) / 64;
+    int s = 1;
+    while (s < 64 && tiles * s < 512) s *= 2;
+    return s;
+}
+
+int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws_bytes, bool sizing,
+              Plan* P, size_t* needed) {
+    int rc = gpde_pack_layout(n_layers, dims, &P->L);
+    if (rc != GPDE_OK) return rc;
+    const GpdePackLayout& L = P->L;
+    const size_t zrow = (size_t)GP_W * L.K2P * sizeof(float);
+    const size_t prow = (size_t)64 * GP_W * sizeof(float);   // worst case: 64 splits
+    size_t fixed = 0;
+    P->h_floats = 0;
+    if (L.mode == 2) {
+        int kmax = 0;
+        for (int l = 1; l <= n_layers - 1; ++l) kmax = kmax > L.frontKP[l] ? kmax : L.frontKP[l];
+        P->h_floats = (size_t)(E > 0 ? E : 1) * kmax;
+        fixed = 2 * align_up(P->h_floats * sizeof(float));
+    }
+    int64_t npc;
+    if (sizing) {
+        // recommended: all nodes if Z fits 4 GiB, else 4 GiB worth of nodes (at least one tile)
+        int64_t cap = (int64_t)(((size_t)4 << 30) / zrow);
+        if (cap < 64) cap = 64;
+        npc = N < cap ? N : cap;
+        if (npc < 1) npc = 1;
+    } else {
+        if (ws_bytes < fixed + 2 * kAlign) {
+            gpde_set_error("gpde_nnconv_fwd: workspace %zu bytes cannot hold the %zu-byte hidden "
+                           "activation buffers", ws_bytes, fixed);
+            return GPDE_EWORKSPACE;
+        }
+        npc = (int64_t)((ws_bytes - fixed - 2 * kAlign) / (zrow + prow));
+        if (npc > N) npc = N;
+        const int64_t min_nodes = N < 64 ? N : 64;
+        if (npc < min_nodes || (N > 0 && npc < 1)) {
+            gpde_set_error("gpde_nnconv_fwd: workspace %zu bytes holds %lld destination nodes, need >= %lld "
+                           "(%zu bytes per node)", ws_bytes, (long long)npc, (long long)min_nodes, zrow + prow);
+            return GPDE_EWORKSPACE;
+        }
+        if (npc > 64) npc = npc / 64 * 64;
+    }
+    if (npc < 1) npc = 1;
+    P->nodes_per_chunk = npc;
+    P->n_chunks = (int)((N + npc - 1) / npc);
+    if (P->n_chunks < 1) P->n_chunks = 1;
+    size_t off = 0;
+    P->off_part = off; off += align_up((size_t)npc * prow);
+    P->off_z = off;    off += align_up((size_t)npc * zrow);
+    P->off_ha = off;   off += (L.mode == 2) ? align_up(P->h_floats * sizeof(float)) : 0;
+    P->off_hb = off;   off += (L.mode == 2) ? align_up(P->h_floats * sizeof(float)) : 0;
+    if (needed) *needed = off;
+    // fused-kernel grid: ~one workgroup per CU, never more edge groups than 4-wave tile sets
+    const int ns = L.K2P / GP_TN;
+    int groups = num_cus() / ns;
+    if (groups < 1) groups = 1;
+    const int64_t tiles_chunk = ((E + GP_TE - 1) / GP_TE + P->n_chunks - 1) / P->n_chunks;
+    const int64_t gcap = (tiles_chunk + GP_WAVES - 1) / GP_WAVES;
+    if (groups > gcap) groups = (int)(gcap < 1 ? 1 : gcap);
+    P->n_groups = groups;
+    return GPDE_OK;
+}
+
+}  // namespace
+
+extern "C" size_t gpde_nnconv_fwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers,
+                                                  const int32_t* dims) {
+    Plan P;
+    size_t need = 0;
+    if (!dims || n_nodes < 0 || n_edges < 0) return 0;
+    if (make_plan(n_nodes, n_edges, n_layers, dims, 0, true, &P, &need) != GPDE_OK) return 0;
+    return need + 2 * kAlign;
+}
+
+extern "C" int gpde_nnconv_fwd_plan(int64_t n_nodes, int64_t n_edges, int n_layers,
+                                    const int32_t* dims, size_t ws_bytes, int32_t* n_chunks,
+                                    int64_t* nodes_per_chunk, int32_t* fused_workgroups,
+                                    int32_t* mode) {
+    Plan P;
+    if (!dims) { gpde_set_error("gpde_nnconv_fwd_plan: dims is null"); return GPDE_EINVAL; }
+    int rc = make_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P, nullptr);
+    if (rc != GPDE_OK) return rc;
+    if (n_chunks) *n_chunks = P.n_chunks;
+    if (nodes_per_chunk) *nodes_per_chunk = P.nodes_per_chunk;
+    if (fused_workgroups) *fused_workgroups = P.n_groups * (P.L.K2P / GP_TN);
+    if (mode) *mode = P.L.mode;
+    return GPDE_OK;
+}
+
+extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edge_attr,
+                               int64_t n_edges, const int32_t* rowptr, const int32_t* src,
+                               const int32_t* dst, const int32_t* perm, int n_layers,
+                               const int32_t* dims, const void* packed, const float* root,
+                               const float* bias, int aggr, float* out, void* ws, size_t ws_bytes,
+                               void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_nodes < 0 || n_edges < 0 || !dims || !packed || !rowptr || (n_nodes > 0 && (!x || !out)) ||
+        (n_edges > 0 && (!edge_attr || !src || !dst || !perm))) {
+        gpde_set_error("gpde_nnconv_fwd: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) {
+        gpde_set_error("gpde_nnconv_fwd: aggr %d not implemented (add=0, mean=1)", aggr);
+        return GPDE_EUNSUPPORTED;
+    }
+    if (n_nodes == 0) return GPDE_OK;
+    if (!ws) { gpde_set_error("gpde_nnconv_fwd: workspace is null"); return GPDE_EWORKSPACE; }
+    Plan P;
+    int rc = make_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P, nullptr);
+    if (rc != GPDE_OK) return rc;
+    const GpdePackLayout& L = P.L;
+    const float* pk = (const float*)packed;
+    char* w = (char*)ws;
+    w = (char*)(((uintptr_t)w + kAlign - 1) / kAlign * kAlign);
+    float* part = (float*)(w + P.off_part);
+    float* zbuf = (float*)(w + P.off_z);
+    float* ha = (float*)(w + P.off_ha);
+    float* hb = (float*)(w + P.off_hb);
+
+    const float* hfinal = nullptr;
+    if (L.mode == 2 && n_edges > 0) {
+        // front layers over all edges (CSR order), ping-pong between ha / hb
+        const float* in = edge_attr;
+        int ldx = L.k0, kin = L.k0;
+        const int32_t* gather = perm;
+        float* bufs[2] = {ha, hb};
+        for (int l = 0; l < n_layers - 1; ++l) {
+            GpdeDenseArgs d;
+            d.X = in; d.ldx = ldx; d.kin = kin; d.gather = gather; d.row0 = 0;
+            d.W = pk + L.off_front_w[l]; d.ldw = L.frontKP[l];
+            d.b = pk + L.off_front_b[l];
+            d.Y = bufs[l & 1]; d.KoutP = L.frontKP[l + 1];
+            d.rows = (int)n_edges; d.relu = 1;
+            rc = gpde_launch_dense(d, stream);
+            if (rc != GPDE_OK) return rc;
+            in = d.Y; ldx = kin = d.KoutP; gather = nullptr;
+        }
+        hfinal = in;
+    }
+
+    for (int64_t nc0 = 0; nc0 < n_nodes; nc0 += P.nodes_per_chunk) {
+        const int64_t nc1 = (nc0 + P.nodes_per_chunk < n_nodes) ? nc0 + P.nodes_per_chunk : n_nodes;
+        const int nn = (int)(nc1 - nc0);
+        const int splits = pick_splits(nn);
+        if (n_edges > 0) {
+            GpdeFusedArgs f;
+            f.x = x; f.attr = edge_attr; f.rowptr = rowptr; f.src = src; f.dst = dst; f.perm = perm;
+            f.w1 = pk + L.off_w1; f.w2t = pk + L.off_w2t; f.b2 = pk + L.off_b2;
+            f.hbuf = hfinal; f.zbuf = zbuf;
+            f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
+            f.nc0 = (int)nc0; f.nc1 = (int)nc1; f.e_chunk0 = 0; f.n_groups = P.n_groups;
+            rc = gpde_launch_fused(L.mode, f, stream);
+            if (rc != GPDE_OK) return rc;
+            GpdeGemm3Args g;
+            g.zbuf = zbuf; g.w3q = pk + L.off_w3q; g.part = part; g.nn = nn; g.K2P = L.K2P;
+            g.splits = splits;
+            rc = gpde_launch_gemm3(g, stream);
+            if (rc != GPDE_OK) return rc;
+        }
+        GpdeEpilogueArgs e;
+        e.part = part; e.x = x; e.rowptr = rowptr; e.src = src;
+        e.b3 = pk + L.off_b3; e.root = root; e.bias = bias; e.out = out;
+        e.nc0 = (int)nc0; e.nn = nn; e.splits = splits; e.aggr = aggr;
+        rc = gpde_launch_epilogue(e, stream);
+        if (rc != GPDE_OK) return rc;
+    }
+    return GPDE_OK;
+}

@@ -1,0 +1,119 @@
+// Shared declarations for libgpde.so (gfx950 only; no CUDA path, no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "gpde.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- tile constants of the fused kernel ---------------------------------------
+constexpr int GP_W = GPDE_WIDTH;   // node feature width (in = out = 64)
+constexpr int GP_TE = 32;          // edges per wave tile (one MFMA row block)
+constexpr int GP_TN = 128;         // hidden columns per workgroup slice (4 MFMA col blocks)
+constexpr int GP_BK = 32;          // k1 chunk streamed through LDS per step
+constexpr int GP_WAVES = 4;        // waves per workgroup, one per SIMD
+constexpr int GP_BS_STRIDE = 36;   // LDS row stride (floats) of a [128][32] W2 tile: 144 B rows
+                                   // -> conflict-free ds_read_b128 across a 16-lane group
+
+static inline int gp_round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- packed MLP layout (all offsets in floats from the start of `packed`) --------------------
+//  mode 0: n_layers == 2            H = relu(L1(attr))                      (K2 = k1)
+//  mode 1: n_layers == 3            H = relu(L2(relu(L1(attr))))            (K1 = k1, K2 = k2)
+//  mode 2: n_layers >= 4 or k0 > 7  front layers run as plain dense layers, H read from memory
+struct GpdePackLayout {
+    int mode;
+    int n_layers;
+    int k0;          // edge-attribute width
+    int k1, K1P;     // first hidden width and its padding to GP_BK      (mode 1)
+    int k2, K2P;     // last hidden width (input of the last Linear) and its padding to GP_TN
+    size_t off_w1;   // [rows][2][4]  rows = K1P (mode 1) or K2P (mode 0): W1 with b1 folded in
+    size_t off_w2t;  // [K2P/128][K1P/32][128][32]  W2 in LDS-tile order        (mode 1)
+    size_t off_b2;   // [K2P]                                                     (mode 1)
+    size_t off_w3q;  // [64 c][K2P/4][64 o][4]  last Linear, re-associated order
+    size_t off_b3;   // [64 c][64 o]            last Linear bias as a 64x64 matrix (zeros if none)
+    size_t off_front;// mode 2: per front layer l: W [KP(l+1)][KP(l)] zero padded, then b [KP(l+1)]
+    int frontKP[GPDE_MAX_LAYERS + 1];
+    size_t off_front_w[GPDE_MAX_LAYERS];
+    size_t off_front_b[GPDE_MAX_LAYERS];
+    size_t total_floats;
+    int has_b3;
+};
+
+int gpde_pack_layout(int n_layers, const int32_t* dims, GpdePackLayout* L);
+
+void gpde_set_error(const char* fmt, ...);
+
+#define GP_HIP_CHECK(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            gpde_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                           __FILE__, __LINE__);                                         \
+            return GPDE_EHIP;                                                           \
+        }                                                                               \
+    } while (0)
+
+#define GP_LAUNCH_CHECK(name)                                                           \
+    do {                                                                                \
+        hipError_t _e = hipGetLastError();                                              \
+        if (_e != hipSuccess) {                                                         \
+            gpde_set_error("launch of %s failed: %s", name, hipGetErrorString(_e));     \
+            return GPDE_EHIP;                                                           \
+        }                                                                               \
+    } while (0)
+
+// ---- kernel launchers (one translation unit each) ---------------------------------------------
+struct GpdeFusedArgs {
+    const float* x;        // [N][64]
+    const float* attr;     // [E][k0], original edge order
+    const int32_t* rowptr; // [N+1]
+    const int32_t* src;    // [E] CSR order
+    const int32_t* dst;    // [E] CSR order
+    const int32_t* perm;   // [E] CSR slot -> original edge id
+    const float* w1;       // packed, see GpdePackLayout
+    const float* w2t;
+    const float* b2;
+    const float* hbuf;     // mode 2: [edges of chunk][K2P] in CSR order, relu already applied
+    float* zbuf;           // [nc1-nc0][64][K2P]
+    int k0, K1P, K2P;
+    int nc0, nc1;          // destination-node chunk
+    int e_chunk0;          // rowptr[nc0] (mode 2: first row of hbuf)
+    int n_groups;          // edge groups (workgroups per slice)
+};
+int gpde_launch_fused(int mode, const GpdeFusedArgs& a, hipStream_t stream);
+
+struct GpdeGemm3Args {
+    const float* zbuf;     // [nn][64*K2P]
+    const float* w3q;      // [64*K2P/4][64][4]
+    float* part;           // [splits][nn][64]
+    int nn, K2P, splits;
+};
+int gpde_launch_gemm3(const GpdeGemm3Args& a, hipStream_t stream);
+
+struct GpdeEpilogueArgs {
+    const float* part;     // [splits][nn][64]
+    const float* x;        // [N][64]
+    const int32_t* rowptr;
+    const int32_t* src;
+    const float* b3;       // [64][64] or nullptr
+    const float* root;     // [64][64] or nullptr
+    const float* bias;     // [64] or nullptr
+    float* out;            // [N][64]
+    int nc0, nn, splits, aggr;
+};
+int gpde_launch_epilogue(const GpdeEpilogueArgs& a, hipStream_t stream);
+
+// generic dense layer  Y[rows][KoutP] = relu(X[row_or_perm][0:kin] . W^T + b)   (mode 2 front)
+struct GpdeDenseArgs {
+    const float* X; int ldx; int kin;   // X row stride (floats) and valid input width
+    const int32_t* gather;              // optional row gather (perm), nullptr = identity
+    int row0;                           // first row (CSR slot) handled; output row 0 = row0
+    const float* W; int ldw;            // [KoutP][ldw] zero padded, ldw multiple of 32
+    const float* b;                     // [KoutP]
+    float* Y; int KoutP;                // [rows][KoutP]
+    int rows; int relu;
+};
+int gpde_launch_dense(const GpdeDenseArgs& a, hipStream_t stream);

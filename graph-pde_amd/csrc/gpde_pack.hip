@@ -1,0 +1,164 @@
+// Kernel-MLP weight repacking into MFMA-tile order (layout only, no arithmetic).
+// Source layout: torch `nn.Linear` weight[out][in], bias[out], as held by DenseNet
+// (/root/reference/graph-neural-operator/utilities.py:201-227).
+#include "gpde_common.h"
+#include <string.h>
+
+int gpde_pack_layout(int n_layers, const int32_t* dims, GpdePackLayout* L) {
+    memset(L, 0, sizeof(*L));
+    if (n_layers < 2 || n_layers > GPDE_MAX_LAYERS) {
+        gpde_set_error("kernel MLP must have 2..%d Linear layers, got %d", GPDE_MAX_LAYERS, n_layers);
+        return GPDE_EUNSUPPORTED;
+    }
+    for (int l = 0; l <= n_layers; ++l)
+        if (dims[l] < 1) { gpde_set_error("dims[%d] = %d", l, dims[l]); return GPDE_EINVAL; }
+    if (dims[n_layers] != GP_W * GP_W) {
+        gpde_set_error("last layer must emit %d = width^2 values (width %d), got %d", GP_W * GP_W,
+                       GP_W, dims[n_layers]);
+        return GPDE_EUNSUPPORTED;
+    }
+    L->n_layers = n_layers;
+    L->k0 = dims[0];
+    const bool attr_fits = dims[0] + 1 <= 8;      // attributes + bias slot fit one K=8 MFMA group
+    if (n_layers == 2 && attr_fits) L->mode = 0;
+    else if (n_layers == 3 && attr_fits) L->mode = 1;
+    else L->mode = 2;
+    L->k2 = dims[n_layers - 1];
+    L->K2P = gp_round_up(L->k2, GP_TN);
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += (n + 3) / 4 * 4; return o; };
+    if (L->mode == 0) {
+        L->off_w1 = take((size_t)L->K2P * 8);
+    } else if (L->mode == 1) {
+        L->k1 = dims[1];
+        L->K1P = gp_round_up(L->k1, GP_BK);
+        L->off_w1 = take((size_t)L->K1P * 8);
+        L->off_w2t = take((size_t)L->K2P * L->K1P);
+        L->off_b2 = take((size_t)L->K2P);
+    } else {
+        // front layers 0 .. n_layers-2 as dense layers; widths padded to 128 (inputs of layer 0: 32)
+        L->frontKP[0] = gp_round_up(dims[0], 32);
+        for (int l = 1; l <= n_layers - 1; ++l) L->frontKP[l] = gp_round_up(dims[l], GP_TN);
+        for (int l = 0; l < n_layers - 1; ++l) {
+            L->off_front_w[l] = take((size_t)L->frontKP[l + 1] * L->frontKP[l]);
+            L->off_front_b[l] = take((size_t)L->frontKP[l + 1]);
+        }
+    }
+    L->off_w3q = take((size_t)GP_W * L->K2P * GP_W);
+    L->off_b3 = take((size_t)GP_W * GP_W);
+    L->total_floats = off;
+    return GPDE_OK;
+}
+
+namespace {
+
+// W1 with the bias folded in as input slot k0:  out[row][h][s] = W1b[row][2s+h]
+__global__ void pack_w1_kernel(const float* __restrict__ W, const float* __restrict__ b, int k_out,
+                               int k0, int rowsP, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rowsP * 8) return;
+    const int row = i >> 3, hh = (i >> 2) & 1, s = i & 3;
+    const int d = 2 * s + hh;
+    float v = 0.f;
+    if (row < k_out) {
+        if (d < k0) v = W[(size_t)row * k0 + d];
+        else if (d == k0 && b) v = b[row];
+    }
+    out[i] = v;
+}
+
+// W2 [k2][k1] -> tiles [K2P/128][K1P/32][128][32], zero padded
+__global__ void pack_w2_kernel(const float* __restrict__ W, int k2, int k1, int K2P, int K1P,
+                               float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)K2P * K1P) return;
+    const int k = i & 31;
+    const int n = (i >> 5) & 127;
+    const size_t tile = i >> 12;
+    const int NKC = K1P / 32;
+    const int kc = tile % NKC, slice = tile / NKC;
+    const int ng = slice * 128 + n, kg = kc * 32 + k;
+    out[i] = (ng < k2 && kg < k1) ? W[(size_t)ng * k1 + kg] : 0.f;
+}
+
+__global__ void pack_pad_vec_kernel(const float* __restrict__ v, int n, int nP, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nP) out[i] = (v && i < n) ? v[i] : 0.f;
+}
+
+// W [kout][kin] -> [KoutP][KinP] zero padded
+__global__ void pack_pad_mat_kernel(const float* __restrict__ W, int kout, int kin, int KoutP,
+                                    int KinP, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)KoutP * KinP) return;
+    const int c = i % KinP;
+    const int r = i / KinP;
+    out[i] = (r < kout && c < kin) ? W[(size_t)r * kin + c] : 0.f;
+}
+
+// W3 [4096][k2] -> w3q[c][k/4][o][k%4]  (= W3[c*64+o][k]), zero padded in k
+__global__ void pack_w3_kernel(const float* __restrict__ W3, int k2, int K2P, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)GP_W * K2P * GP_W) return;
+    const int k4 = i & 3;
+    const int o = (i >> 2) & 63;
+    const size_t rest = i >> 8;              // c * (K2P/4) + kq
+    const int kq = rest % (K2P / 4);
+    const int c = rest / (K2P / 4);
+    const int k = kq * 4 + k4;
+    out[i] = (k < k2) ? W3[((size_t)c * GP_W + o) * k2 + k] : 0.f;
+}
+
+}  // namespace
+
+extern "C" size_t gpde_mlp_pack_bytes(int n_layers, const int32_t* dims) {
+    GpdePackLayout L;
+    if (!dims || gpde_pack_layout(n_layers, dims, &L) != GPDE_OK) return 0;
+    return L.total_floats * sizeof(float);
+}
+
+extern "C" int gpde_mlp_pack(int n_layers, const int32_t* dims, const float* const* W,
+                             const float* const* b, void* packed, size_t packed_bytes,
+                             void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!dims || !W || !b || !packed) { gpde_set_error("gpde_mlp_pack: null argument"); return GPDE_EINVAL; }
+    GpdePackLayout L;
+    int rc = gpde_pack_layout(n_layers, dims, &L);
+    if (rc != GPDE_OK) return rc;
+    if (packed_bytes < L.total_floats * sizeof(float)) {
+        gpde_set_error("gpde_mlp_pack: packed buffer %zu < %zu bytes", packed_bytes,
+                       L.total_floats * sizeof(float));
+        return GPDE_EWORKSPACE;
+    }
+    for (int l = 0; l < n_layers; ++l)
+        if (!W[l]) { gpde_set_error("gpde_mlp_pack: W[%d] is null", l); return GPDE_EINVAL; }
+    float* P = (float*)packed;
+    const int T = 256;
+    auto blocks = [&](size_t n) { return (unsigned)((n + T - 1) / T); };
+    if (L.mode == 0) {
+        hipLaunchKernelGGL(pack_w1_kernel, dim3(blocks((size_t)L.K2P * 8)), dim3(T), 0, stream, W[0],
+                           b[0], dims[1], L.k0, L.K2P, P + L.off_w1);
+    } else if (L.mode == 1) {
+        hipLaunchKernelGGL(pack_w1_kernel, dim3(blocks((size_t)L.K1P * 8)), dim3(T), 0, stream, W[0],
+                           b[0], dims[1], L.k0, L.K1P, P + L.off_w1);
+        hipLaunchKernelGGL(pack_w2_kernel, dim3(blocks((size_t)L.K2P * L.K1P)), dim3(T), 0, stream,
+                           W[1], dims[2], dims[1], L.K2P, L.K1P, P + L.off_w2t);
+        hipLaunchKernelGGL(pack_pad_vec_kernel, dim3(blocks(L.K2P)), dim3(T), 0, stream, b[1],
+                           dims[2], L.K2P, P + L.off_b2);
+    } else {
+        for (int l = 0; l < n_layers - 1; ++l) {
+            hipLaunchKernelGGL(pack_pad_mat_kernel,
+                               dim3(blocks((size_t)L.frontKP[l + 1] * L.frontKP[l])), dim3(T), 0,
+                               stream, W[l], dims[l + 1], dims[l], L.frontKP[l + 1], L.frontKP[l],
+                               P + L.off_front_w[l]);
+            hipLaunchKernelGGL(pack_pad_vec_kernel, dim3(blocks(L.frontKP[l + 1])), dim3(T), 0,
+                               stream, b[l], dims[l + 1], L.frontKP[l + 1], P + L.off_front_b[l]);
+        }
+    }
+    hipLaunchKernelGGL(pack_w3_kernel, dim3(blocks((size_t)GP_W * L.K2P * GP_W)), dim3(T), 0, stream,
+                       W[n_layers - 1], L.k2, L.K2P, P + L.off_w3q);
+    hipLaunchKernelGGL(pack_pad_vec_kernel, dim3(blocks(GP_W * GP_W)), dim3(T), 0, stream,
+                       b[n_layers - 1], GP_W * GP_W, GP_W * GP_W, P + L.off_b3);
+    GP_LAUNCH_CHECK("gpde_mlp_pack kernels");
+    return GPDE_OK;
+}

@@ -1,0 +1,246 @@
+"""Host side of the NNConv hot path: CSR / packed-weight caches and the forward call.
+
+PyTorch is used for device memory, the caching allocator and the current HIP stream only; all
+arithmetic happens in libgpde.so (hand-written HIP, include/gpde.h).  Everything here refuses to
+run on CPU tensors: there is no non-HIP path.
+"""
+from __future__ import annotations
+
+import ctypes
+import weakref
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+WIDTH = _lib.GPDE_WIDTH
+
+
+# ----------------------------------------------------------------------------------------------
+# destination-sorted CSR, cached per edge_index tensor
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class Csr:
+    n_nodes: int
+    n_edges: int
+    rowptr: torch.Tensor   # int32 [N+1]
+    src: torch.Tensor      # int32 [E]  source node of each CSR slot
+    dst: torch.Tensor      # int32 [E]  target node of each CSR slot (sorted ascending)
+    perm: torch.Tensor     # int32 [E]  CSR slot -> original edge id (stable within a target)
+
+
+def _stream_ptr(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_cuda(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: the NNConv hot path runs only on an MI355X through libgpde.so "
+            "(no CPU / composite fallback exists by design)")
+
+
+def build_csr(edge_index: torch.Tensor, n_nodes: int) -> Csr:
+    """gpde_csr_from_coo on the current stream. `edge_index` int64 [2,E], any strides."""
+    _require_cuda(edge_index, "edge_index")
+    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
+        raise ValueError(f"edge_index must be int64 [2,E], got {edge_index.dtype} {tuple(edge_index.shape)}")
+    lib = _lib.lib()
+    dev = edge_index.device
+    e = int(edge_index.size(1))
+    rowptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+    src = torch.empty(e, dtype=torch.int32, device=dev)
+    dst = torch.empty(e, dtype=torch.int32, device=dev)
+    perm = torch.empty(e, dtype=torch.int32, device=dev)
+    n_bad = torch.empty(1, dtype=torch.int32, device=dev)
+    ws_bytes = int(lib.gpde_csr_workspace_bytes(e, n_nodes))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gpde_csr_from_coo(edge_index.data_ptr(), edge_index.stride(0), edge_index.stride(1),
+                                   e, n_nodes, rowptr.data_ptr(), src.data_ptr(), dst.data_ptr(),
+                                   perm.data_ptr(), n_bad.data_ptr(), ws.data_ptr(), ws_bytes,
+                                   _stream_ptr(dev))
+    _lib.check(rc, "gpde_csr_from_coo")
+    bad = int(n_bad.item())          # one sync per *new* graph (the result is cached)
+    if bad:
+        raise IndexError(f"edge_index has {bad} edges with an endpoint outside [0, {n_nodes})")
+    return Csr(n_nodes, e, rowptr, src, dst, perm)
+
+
+_csr_cache: "dict[tuple, tuple]" = {}      # key -> (storage kept alive, nbytes, Csr); LRU order
+_CSR_CACHE_MAX_ENTRIES = 64
+_CSR_CACHE_MAX_BYTES = 8 << 30
+
+
+def csr_for(edge_index: torch.Tensor, n_nodes: int) -> Csr:
+    """Cached CSR: the reference calls the same conv `depth` times with the same edge_index
+    (UAI1_full_resolution.py:29-30), and MGKN re-slices the same tensors every V-cycle
+    (MGKN_general_darcy2d.py:79-89).  Key = storage pointer, offset, shape, strides, in-place
+    version counter, node count.  The entry keeps the index storage alive so that its address
+    cannot be recycled for a different graph while cached; the cache is a byte-bounded LRU."""
+    storage = edge_index.untyped_storage()
+    key = (str(edge_index.device), storage.data_ptr(), edge_index.storage_offset(),
+           tuple(edge_index.shape), tuple(edge_index.stride()), edge_index._version, n_nodes)
+    hit = _csr_cache.pop(key, None)
+    if hit is not None:
+        _csr_cache[key] = hit            # move to the MRU end
+        return hit[2]
+    csr = build_csr(edge_index, n_nodes)
+    _csr_cache[key] = (storage, storage.nbytes(), csr)
+    while len(_csr_cache) > _CSR_CACHE_MAX_ENTRIES or \
+            (len(_csr_cache) > 1 and sum(v[1] for v in _csr_cache.values()) > _CSR_CACHE_MAX_BYTES):
+        _csr_cache.pop(next(iter(_csr_cache)))
+    return csr
+
+
+def clear_caches():
+    _csr_cache.clear()
+    _pack_cache.clear()
+
+
+# ----------------------------------------------------------------------------------------------
+# kernel MLP: parameter extraction and MFMA-order packing, cached per parameter version
+# ----------------------------------------------------------------------------------------------
+def mlp_linears(mlp: torch.nn.Module) -> List[torch.nn.Linear]:
+    """The Linear layers of a DenseNet-style kernel MLP (Linear, ReLU, ..., Linear):
+    /root/reference/graph-neural-operator/utilities.py:201-227.  Anything else is rejected loudly."""
+    if hasattr(mlp, "layers") and isinstance(mlp.layers, torch.nn.ModuleList):
+        layers = list(mlp.layers)
+    elif isinstance(mlp, torch.nn.Sequential):
+        layers = list(mlp)
+    elif isinstance(mlp, torch.nn.Linear):
+        layers = [mlp]
+    else:
+        raise NotImplementedError(
+            f"kernel network of type {type(mlp).__name__} is not a Linear/ReLU chain; the fused "
+            "MI355X operator implements the DenseNet kernels used by the reference scripts")
+    lin: List[torch.nn.Linear] = []
+    expect_linear = True
+    for l in layers:
+        if isinstance(l, torch.nn.Linear):
+            if not expect_linear:
+                raise NotImplementedError("two Linear layers without ReLU between them")
+            lin.append(l)
+            expect_linear = False
+        elif isinstance(l, torch.nn.ReLU):
+            if expect_linear:
+                raise NotImplementedError("ReLU without a preceding Linear layer")
+            expect_linear = True
+        else:
+            raise NotImplementedError(f"kernel network layer {type(l).__name__} is not supported "
+                                      "(Linear/ReLU chains only)")
+    if expect_linear or len(lin) < 2:
+        raise NotImplementedError("kernel network must be Linear,(ReLU,Linear)+ ending in Linear")
+    return lin
+
+
+@dataclass
+class PackedMlp:
+    dims: Tuple[int, ...]
+    packed: torch.Tensor            # float32 flat buffer in libgpde layout
+    dims_c: object                  # ctypes int32 array (kept alive)
+
+
+_pack_cache: "dict[tuple, tuple]" = {}       # key -> (weakrefs of the parameters, PackedMlp)
+
+
+def pack_mlp(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]) -> PackedMlp:
+    lib = _lib.lib()
+    n = len(weights)
+    for w in weights:
+        _require_cuda(w, "kernel-network weight")
+        if w.dtype != torch.float32:
+            raise NotImplementedError(f"kernel-network weights must be float32, got {w.dtype}")
+    dims = tuple([int(weights[0].size(1))] + [int(w.size(0)) for w in weights])
+    key = tuple((w.data_ptr(), w._version) for w in weights) + \
+        tuple((0, 0) if b is None else (b.data_ptr(), b._version) for b in biases) + (dims,)
+    hit = _pack_cache.get(key)
+    if hit is not None:
+        refs, pm = hit
+        # same parameter objects still alive => the addresses were not recycled
+        if all(r() is t for r, t in zip(refs, list(weights) + [b for b in biases if b is not None])):
+            return pm
+    dims_c = _lib.dims_array(dims)
+    nbytes = int(lib.gpde_mlp_pack_bytes(n, dims_c))
+    if nbytes == 0:
+        _lib.check(-2, "gpde_mlp_pack_bytes")      # message was set by the failed layout query
+    dev = weights[0].device
+    packed = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    ws = [w.detach().contiguous() for w in weights]
+    bs = [None if b is None else b.detach().contiguous() for b in biases]
+    wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+    bp = (ctypes.c_void_p * n)(*[None if b is None else b.data_ptr() for b in bs])
+    with torch.cuda.device(dev):
+        rc = lib.gpde_mlp_pack(n, dims_c, wp, bp, packed.data_ptr(), nbytes, _stream_ptr(dev))
+    _lib.check(rc, "gpde_mlp_pack")
+    pm = PackedMlp(dims, packed, dims_c)
+    if len(_pack_cache) >= 256:
+        _pack_cache.pop(next(iter(_pack_cache)))
+    refs = [weakref.ref(t) for t in list(weights) + [b for b in biases if b is not None]]
+    _pack_cache[key] = (refs, pm)
+    return pm
+
+
+# ----------------------------------------------------------------------------------------------
+# forward
+# ----------------------------------------------------------------------------------------------
+_AGGR = {"add": _lib.GPDE_AGGR_ADD, "mean": _lib.GPDE_AGGR_MEAN}
+
+
+def workspace_bytes(n_nodes: int, n_edges: int, pm: PackedMlp) -> int:
+    return int(_lib.lib().gpde_nnconv_fwd_workspace_bytes(n_nodes, n_edges, len(pm.dims) - 1, pm.dims_c))
+
+
+def nnconv_forward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor, pm: PackedMlp,
+                       root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,
+                       out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None
+                       ) -> torch.Tensor:
+    """One gpde_nnconv_fwd call on the current stream. x [N,64] f32, edge_attr [E,k0] f32."""
+    lib = _lib.lib()
+    _require_cuda(x, "x")
+    _require_cuda(edge_attr, "edge_attr")
+    if aggr not in _AGGR:
+        raise NotImplementedError(
+            f"aggr={aggr!r}: the fused MI355X operator implements 'add' and 'mean' (every reference "
+            "script uses 'mean'); 'max' cannot use the re-associated contraction")
+    if x.dtype != torch.float32 or edge_attr.dtype != torch.float32:
+        raise NotImplementedError(f"float32 only (got x {x.dtype}, edge_attr {edge_attr.dtype})")
+    if x.dim() != 2 or x.size(1) != WIDTH:
+        raise NotImplementedError(f"node features must be [N,{WIDTH}] (in_channels = out_channels = "
+                                  f"{WIDTH}), got {tuple(x.shape)}")
+    n, e = csr.n_nodes, csr.n_edges
+    if x.size(0) != n:
+        raise ValueError(f"x has {x.size(0)} rows, CSR was built for {n} nodes")
+    if edge_attr.dim() != 2 or edge_attr.size(0) != e or edge_attr.size(1) != pm.dims[0]:
+        raise ValueError(f"edge_attr must be [{e},{pm.dims[0]}], got {tuple(edge_attr.shape)}")
+    x = x.contiguous()
+    edge_attr = edge_attr.contiguous()
+    root_c = None if root is None else root.detach().contiguous()
+    bias_c = None if bias is None else bias.detach().contiguous()
+    if out is None:
+        out = torch.empty(n, WIDTH, dtype=torch.float32, device=x.device)
+    if ws is None:
+        ws = torch.empty(max(workspace_bytes(n, e, pm), 1), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.gpde_nnconv_fwd(x.data_ptr(), n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(),
+                                 csr.src.data_ptr(), csr.dst.data_ptr(), csr.perm.data_ptr(),
+                                 len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(),
+                                 None if root_c is None else root_c.data_ptr(),
+                                 None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
+                                 out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
+    _lib.check(rc, "gpde_nnconv_fwd")
+    _lib.n_native_calls += 1
+    return out
+
+
+def launch_plan(n_nodes: int, n_edges: int, pm: PackedMlp, ws_bytes: int):
+    lib = _lib.lib()
+    nch, npc, wgs, mode = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+    rc = lib.gpde_nnconv_fwd_plan(n_nodes, n_edges, len(pm.dims) - 1, pm.dims_c, ws_bytes,
+                                  ctypes.byref(nch), ctypes.byref(npc), ctypes.byref(wgs),
+                                  ctypes.byref(mode))
+    _lib.check(rc, "gpde_nnconv_fwd_plan")
+    return {"n_chunks": nch.value, "nodes_per_chunk": npc.value, "fused_workgroups": wgs.value,
+            "mode": mode.value}

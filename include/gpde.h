@@ -1,0 +1,117 @@
+/*
+ * gpde.h — C ABI of libgpde.so: the MI355X (gfx950) edge-conditioned graph convolution
+ * (NNConv) hot path of neuraloperator/graph-pde.
+ *
+ * The reference has no FFI: the path sits behind a Python `torch.nn.Module`
+ * (`nn_conv.NNConv_old`, /root/reference/graph-neural-operator/nn_conv.py:197-286, and
+ * `torch_geometric.nn.NNConv`) whose `forward(x, edge_index, edge_attr)` dispatches stock
+ * PyTorch / torch_scatter kernels.  These entry points are what a binding for that path binds
+ * (INTEGRATION.md shows the ctypes stub); each one names the reference code it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless marked "host"; buffers are row-major, contiguous,
+ *    float32 / int32 / int64 exactly as named; `edge_index` alone carries explicit strides;
+ *  - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream),
+ *    re-entrant, never synchronise, never allocate: the caller supplies the workspace
+ *    (query with the *_workspace_bytes functions);
+ *  - return value: GPDE_OK or a negative GPDE_E* code; gpde_last_error() (thread-local) gives
+ *    the message.  Nothing throws across the ABI.
+ */
+#ifndef GPDE_H
+#define GPDE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPDE_VERSION 100 /* 0.1.0 */
+
+enum {
+    GPDE_OK = 0,
+    GPDE_EINVAL = -1,       /* bad argument (null pointer, negative size, ...) */
+    GPDE_EUNSUPPORTED = -2, /* shape outside what the kernels implement */
+    GPDE_EWORKSPACE = -3,   /* workspace too small */
+    GPDE_EHIP = -4          /* a HIP runtime call / kernel launch failed */
+};
+
+enum { GPDE_AGGR_ADD = 0, GPDE_AGGR_MEAN = 1 };
+
+#define GPDE_MAX_LAYERS 8
+#define GPDE_WIDTH 64 /* node-feature width (in_channels == out_channels) the kernels are built for */
+
+int gpde_version(void);
+const char* gpde_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Destination-sorted CSR of a COO edge list.
+ * Replaces what `MessagePassing.propagate` does implicitly on every call: the gather by
+ * `edge_index[0]` and the scatter by `edge_index[1]` (call site nn_conv.py:271; PyG semantics in
+ * SURVEY.md Appendix B).  The sort is STABLE: within one destination the edges keep their input
+ * order, so the per-destination summation order is fixed run to run.
+ *
+ *   edge_index : int64, element (r, e) at edge_index[r*stride_row + e*stride_col]
+ *                (row 0 = source j, row 1 = target i; may be a strided view)
+ *   rowptr[N+1]: in-edges of node i are CSR slots rowptr[i] .. rowptr[i+1]-1
+ *   src[E], dst[E] : source / target node of each CSR slot;  perm[E] : its original edge id
+ *   n_bad      : int32 device word, receives the number of edges with an endpoint outside [0,N)
+ *                (those edges are dropped from the CSR; the reference would raise IndexError)
+ */
+size_t gpde_csr_workspace_bytes(int64_t n_edges, int64_t n_nodes);
+int gpde_csr_from_coo(const int64_t* edge_index, int64_t stride_row, int64_t stride_col,
+                      int64_t n_edges, int64_t n_nodes, int32_t* rowptr, int32_t* src,
+                      int32_t* dst, int32_t* perm, int32_t* n_bad, void* ws, size_t ws_bytes,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Kernel-MLP weights, repacked once per parameter update into MFMA-tile order.
+ * Replaces nothing arithmetic: it is the layout step for `DenseNet`'s `nn.Linear` weights
+ * (/root/reference/graph-neural-operator/utilities.py:201-227; torch layout weight[out][in]).
+ *
+ *   n_layers      : number of Linear layers (>= 2); ReLU between them, none after the last
+ *   dims[n_layers+1] (host): k0, k1, ..., 4096 (= GPDE_WIDTH^2)
+ *   W[l], b[l] (host arrays of device pointers): weight [dims[l+1]][dims[l]], bias [dims[l+1]]
+ *                (b[l] may be NULL = no bias)
+ *   packed        : device buffer of gpde_mlp_pack_bytes() bytes
+ */
+size_t gpde_mlp_pack_bytes(int n_layers, const int32_t* dims);
+int gpde_mlp_pack(int n_layers, const int32_t* dims, const float* const* W,
+                  const float* const* b, void* packed, size_t packed_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused NNConv forward:  out[i] = aggr_{e: j->i} ( x[j] . reshape(mlp(edge_attr[e]), [64,64]) )
+ *                                 + x[i] . root + bias
+ * Replaces NNConv_old.forward / message / update (nn_conv.py:267-282), DenseNet.forward
+ * (utilities.py:223-227) and PyG's gather + scatter-add/mean in one pass
+ * that never materialises the [E,4096] per-edge weight tensor.
+ *
+ *   x [N][64], edge_attr [E][k0] in ORIGINAL edge order (gathered through perm),
+ *   rowptr/src/dst/perm from gpde_csr_from_coo, packed from gpde_mlp_pack (same n_layers/dims),
+ *   root [64][64] or NULL, bias [64] or NULL, aggr = GPDE_AGGR_ADD | GPDE_AGGR_MEAN
+ *   (mean = sum / max(in_degree,1): zero in-degree rows receive only root/bias terms),
+ *   out [N][64] (fully overwritten).
+ *   ws: gpde_nnconv_fwd_workspace_bytes() is the recommended size; any size that holds one
+ *   64-node tile works (more workspace = more destination nodes per launch), else GPDE_EWORKSPACE.
+ */
+size_t gpde_nnconv_fwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers,
+                                       const int32_t* dims);
+int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
+                    const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                    const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
+                    const float* root, const float* bias, int aggr, float* out, void* ws,
+                    size_t ws_bytes, void* stream);
+
+/* Launch plan gpde_nnconv_fwd will follow for these sizes and this workspace (host-side query, no
+ * device work): number of destination-node chunks, nodes per chunk, workgroups of the fused
+ * kernel per chunk, and which fused variant runs (0: one hidden layer, 1: two hidden layers with
+ * the first generated on the fly, 2: hidden activations precomputed by dense front layers). */
+int gpde_nnconv_fwd_plan(int64_t n_nodes, int64_t n_edges, int n_layers, const int32_t* dims,
+                         size_t ws_bytes, int32_t* n_chunks, int64_t* nodes_per_chunk,
+                         int32_t* fused_workgroups, int32_t* mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPDE_H */

@@ -1,0 +1,147 @@
+"""CPU oracle for the edge-conditioned graph convolution (NNConv) forward.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product path (`graph-pde_amd/`) may import this
+module; only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` do,
+and there only as the checker / the timed CPU baseline.
+
+This is a plain-PyTorch *restatement* (not a copy) of the reference operator's arithmetic, in
+the reference's own op order, so its fp32 round-off behaviour is that of the reference CPU path:
+
+* kernel MLP  `DenseNet.forward`          -> /root/reference/graph-neural-operator/utilities.py:223-227
+  (a chain of `torch.nn.Linear` (weight `[out,in]`) with ReLU between, no final non-linearity,
+  built at utilities.py:201-221)
+* `NNConv_old.forward`                    -> /root/reference/graph-neural-operator/nn_conv.py:267-271
+  (1-D `x` / `edge_attr` are promoted to 2-D, then `propagate(edge_index, x=x, pseudo=edge_attr)`)
+* `NNConv_old.message`                    -> nn_conv.py:273-275
+  (`weight = nn(pseudo).view(-1, in, out)`; `m = matmul(x_j.unsqueeze(1), weight).squeeze(1)`)
+* `NNConv_old.update`                     -> nn_conv.py:277-282  (`+ mm(x, root)`, `+ bias`)
+* `MessagePassing.propagate` is third-party (torch_geometric, unpinned, NOT vendored in the
+  reference and not installable here).  Its published semantics for flow='source_to_target'
+  (SURVEY.md Appendix B): `x_j = x.index_select(0, edge_index[0])`, aggregation over
+  `edge_index[1]` with `dim_size = N`; 'add' = index_add, 'mean' = sum / clamp(count, min=1)
+  (zero in-degree -> 0), 'max' = segment max with empty -> 0.
+
+Parity pinning: the reference ships no tests / golden vectors for this path.
+This oracle is pinned against the reference's *own* `nn_conv.NNConv_old` + `utilities.DenseNet`
+classes executed in the build container under import stubs (see `tests/golden/make_golden.py`,
+which commits the resulting vectors under `tests/golden/`); the only restated third-party piece
+is `propagate`, per the semantics quoted above.
+
+The `[E, in*out]` per-edge weight tensor is 16 KiB/edge at width 64, so edges are processed in
+chunks; the chunking does not change any per-element arithmetic except the order of the
+destination scatter-add, which is kept in ascending edge order exactly like a sequential
+`index_add_` on CPU.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+
+def densenet_forward(edge_attr: torch.Tensor, weights: Sequence[torch.Tensor],
+                     biases: Sequence[Optional[torch.Tensor]]) -> torch.Tensor:
+    """Linear -> ReLU -> ... -> Linear  (utilities.py:223-227; no out_nonlinearity, no BatchNorm:
+    neither is ever enabled by the reference scripts)."""
+    h = edge_attr
+    n = len(weights)
+    for l in range(n):
+        h = torch.nn.functional.linear(h, weights[l], biases[l])
+        if l != n - 1:
+            h = torch.relu(h)
+    return h
+
+
+def nnconv_forward(x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor,
+                   weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
+                   root: Optional[torch.Tensor], bias: Optional[torch.Tensor],
+                   aggr: str = "mean", in_channels: Optional[int] = None,
+                   out_channels: Optional[int] = None, dtype: torch.dtype = torch.float32,
+                   chunk_edges: int = 65536) -> torch.Tensor:
+    """Reference-order forward of NNConv_old / torch_geometric.nn.NNConv on CPU.
+
+    x [N,in] (or [N]), edge_index [2,E] int64 (row 0 = source j, row 1 = target i),
+    edge_attr [E,k0] (or [E]); returns [N,out] in `dtype` (float32 = the reference's arithmetic,
+    float64 = adjudicator).
+    """
+    x = x.detach().to("cpu", dtype)
+    edge_attr = edge_attr.detach().to("cpu", dtype)
+    edge_index = edge_index.detach().to("cpu", torch.int64)
+    weights = [w.detach().to("cpu", dtype) for w in weights]
+    biases = [None if b is None else b.detach().to("cpu", dtype) for b in biases]
+    root = None if root is None else root.detach().to("cpu", dtype)
+    bias = None if bias is None else bias.detach().to("cpu", dtype)
+
+    # nn_conv.py:269-270
+    if x.dim() == 1:
+        x = x.unsqueeze(-1)
+    if edge_attr.dim() == 1:
+        edge_attr = edge_attr.unsqueeze(-1)
+    n_nodes = x.size(0)
+    cin = x.size(1) if in_channels is None else in_channels
+    cout = (weights[-1].size(0) // cin) if out_channels is None else out_channels
+    n_edges = edge_index.size(1)
+    src, dst = edge_index[0], edge_index[1]
+
+    if aggr in ("add", "mean"):
+        out = torch.zeros(n_nodes, cout, dtype=dtype)
+    elif aggr == "max":
+        out = torch.full((n_nodes, cout), float("-inf"), dtype=dtype)
+    else:
+        raise ValueError(f"unknown aggr {aggr!r}")
+
+    for e0 in range(0, n_edges, chunk_edges):
+        e1 = min(e0 + chunk_edges, n_edges)
+        x_j = x.index_select(0, src[e0:e1])                              # propagate: gather
+        w = densenet_forward(edge_attr[e0:e1], weights, biases)          # nn_conv.py:274
+        w = w.view(-1, cin, cout)
+        m = torch.matmul(x_j.unsqueeze(1), w).squeeze(1)                 # nn_conv.py:275
+        if aggr == "max":
+            out = out.scatter_reduce(0, dst[e0:e1].unsqueeze(1).expand_as(m), m, reduce="amax",
+                                     include_self=True)
+        else:
+            out.index_add_(0, dst[e0:e1], m)                             # scatter add
+    count = torch.bincount(dst, minlength=n_nodes)
+    if aggr == "mean":
+        out = out / count.clamp(min=1).to(dtype).unsqueeze(1)
+    elif aggr == "max":
+        out = torch.where(count.unsqueeze(1) > 0, out, torch.zeros_like(out))
+    # nn_conv.py:277-282
+    if root is not None:
+        out = out + torch.mm(x, root)
+    if bias is not None:
+        out = out + bias
+    return out
+
+
+def rel_l2(y: torch.Tensor, y_ref: torch.Tensor) -> float:
+    """Relative L2 over the whole output, the `LpLoss.rel` formula for one sample
+    (/root/reference/graph-neural-operator/utilities.py:184-196)."""
+    y = y.detach().to("cpu", torch.float64).reshape(-1)
+    y_ref = y_ref.detach().to("cpu", torch.float64).reshape(-1)
+    denom = torch.linalg.vector_norm(y_ref)
+    if denom == 0:
+        return float(torch.linalg.vector_norm(y - y_ref))
+    return float(torch.linalg.vector_norm(y - y_ref) / denom)
+
+
+def mlp_params(mlp: torch.nn.Module):
+    """Pull (weights, biases) of the Linear layers out of a DenseNet-like module, checking that
+    the module really is Linear/ReLU alternation (what the oracle restates)."""
+    ws: List[torch.Tensor] = []
+    bs: List[Optional[torch.Tensor]] = []
+    layers = list(mlp.layers) if hasattr(mlp, "layers") else list(mlp)
+    expect_linear = True
+    for l in layers:
+        if isinstance(l, torch.nn.Linear):
+            assert expect_linear, "two Linear layers without a non-linearity"
+            ws.append(l.weight)
+            bs.append(l.bias)
+            expect_linear = False
+        elif isinstance(l, torch.nn.ReLU):
+            assert not expect_linear
+            expect_linear = True
+        else:
+            raise TypeError(f"oracle restates Linear/ReLU chains only, got {type(l).__name__}")
+    assert not expect_linear, "DenseNet ends with a Linear layer in every reference script"
+    return ws, bs

@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own classes.
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_golden.py
+
+What is executed is the reference's code, imported from where it lies:
+  * `NNConv_old` (forward / message / update)  /root/reference/graph-neural-operator/nn_conv.py:197-286
+  * `DenseNet`                                 /root/reference/graph-neural-operator/utilities.py:201-227
+  * the trained weights of /root/reference/graph-neural-operator/model/grain_new_r64_s64testm100
+    (legacy `torch.save(model)` pickle; only its `conv1` tensors are exported, as data).
+`torch_geometric` and `h5py` are not installable here, so the imports are satisfied by stubs
+defined below.  The only *behaviour* the stubs supply is `MessagePassing.propagate`, restated from
+PyG ~1.3: gather `x_j = x[edge_index[0]]`, call the subclass `message`,
+scatter over `edge_index[1]` with dim_size=N ('add' | 'mean' = sum/clamp(count,1) | 'max' with
+empty -> 0), call `update`.  Every vector therefore carries the reference's own per-edge
+arithmetic; the scatter is plain `index_add_` in ascending edge order.
+
+Each case is written as tests/golden/<name>.npz with the inputs, the parameters, and the
+reference outputs in float32 (`out_f32`, the reference's arithmetic) and float64 (`out_f64`, the
+same module after `.double()`, the adjudicator).
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/graph-neural-operator"
+
+
+# ----------------------------------------------------------------------------- import stubs
+def _install_stubs():
+    tg = types.ModuleType("torch_geometric")
+    tg_nn = types.ModuleType("torch_geometric.nn")
+    tg_conv = types.ModuleType("torch_geometric.nn.conv")
+    tg_inits = types.ModuleType("torch_geometric.nn.inits")
+    tg_data = types.ModuleType("torch_geometric.data")
+
+    class MessagePassing(torch.nn.Module):
+        def __init__(self, aggr="add", flow="source_to_target"):
+            super().__init__()
+            assert flow == "source_to_target"
+            self.aggr = aggr
+
+        def propagate(self, edge_index, size=None, **kwargs):
+            x, pseudo = kwargs["x"], kwargs["pseudo"]
+            n = x.size(0)
+            x_j = x.index_select(0, edge_index[0])
+            msg = self.message(x_j, pseudo)
+            idx = edge_index[1]
+            if self.aggr in ("add", "mean"):
+                out = torch.zeros(n, msg.size(1), dtype=msg.dtype)
+                out.index_add_(0, idx, msg)
+                if self.aggr == "mean":
+                    cnt = torch.bincount(idx, minlength=n).clamp(min=1).to(msg.dtype)
+                    out = out / cnt.unsqueeze(1)
+            elif self.aggr == "max":
+                out = torch.full((n, msg.size(1)), -1e9, dtype=msg.dtype)
+                out = out.scatter_reduce(0, idx.unsqueeze(1).expand_as(msg), msg, "amax")
+                out[out == -1e9] = 0
+            else:
+                raise ValueError(self.aggr)
+            return self.update(out, x)
+
+    def reset(nn):
+        def _reset(item):
+            if hasattr(item, "reset_parameters"):
+                item.reset_parameters()
+        if nn is not None:
+            if hasattr(nn, "children") and len(list(nn.children())) > 0:
+                for item in nn.children():
+                    reset(item) if len(list(item.children())) > 0 else _reset(item)
+            else:
+                _reset(nn)
+
+    def uniform(size, tensor):
+        if tensor is not None:
+            bound = 1.0 / np.sqrt(size)
+            tensor.data.uniform_(-bound, bound)
+
+    class Data:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    tg_conv.MessagePassing = MessagePassing
+    tg_inits.reset, tg_inits.uniform = reset, uniform
+    tg_data.Data = Data
+    tg.nn, tg.data = tg_nn, tg_data
+    tg_nn.conv, tg_nn.inits = tg_conv, tg_inits
+    for name, mod in [("torch_geometric", tg), ("torch_geometric.nn", tg_nn),
+                      ("torch_geometric.nn.conv", tg_conv), ("torch_geometric.nn.inits", tg_inits),
+                      ("torch_geometric.data", tg_data), ("h5py", types.ModuleType("h5py"))]:
+        sys.modules[name] = mod
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _checkpoint_conv(ref_nn_conv, ref_util):
+    """conv1 of the shipped trained model (k0=6, DenseNet[6,64,128,4096], aggr='mean')."""
+    main = sys.modules["__main__"]
+
+    class KernelNN(torch.nn.Module):        # placeholder for the pickled `__main__.KernelNN`
+        pass
+    main.KernelNN = KernelNN
+    model = torch.load(os.path.join(REF, "model", "grain_new_r64_s64testm100"),
+                       weights_only=False, map_location="cpu")
+    sd = {k: v for k, v in model.state_dict().items() if k.startswith("conv1.")}
+    conv = ref_nn_conv.NNConv_old(64, 64, ref_util.DenseNet([6, 64, 128, 4096], torch.nn.ReLU),
+                                  aggr="mean")
+    conv.load_state_dict({k[len("conv1."):]: v for k, v in sd.items()})
+    return conv
+
+
+def _run(conv, x, ei, ea):
+    with torch.no_grad():
+        y32 = conv(x, ei, ea)
+        conv64 = conv.double()
+        y64 = conv64(x.double(), ei, ea.double())
+        conv.float()
+    return y32, y64
+
+
+def _save(name, conv, x, ei, ea, y32, y64):
+    layers = [l for l in conv.nn.layers if isinstance(l, torch.nn.Linear)]
+    d = {
+        "x": x.numpy(), "edge_index": ei.numpy(), "edge_attr": ea.numpy(),
+        "aggr": np.array(conv.aggr), "n_layers": np.array(len(layers)),
+        "out_f32": y32.numpy(), "out_f64": y64.numpy(),
+    }
+    for i, l in enumerate(layers):
+        d[f"W{i}"] = l.weight.detach().float().numpy()
+        d[f"b{i}"] = l.bias.detach().float().numpy()
+    if conv.root is not None:
+        d["root"] = conv.root.detach().float().numpy()
+    if conv.bias is not None:
+        d["bias"] = conv.bias.detach().float().numpy()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}: N={x.shape[0]} E={ei.shape[1]} k0={ea.shape[1]} layers={len(layers)} "
+          f"|y|={float(y32.norm()):.4f} rel(f32,f64)="
+          f"{float((y32.double() - y64).norm() / y64.norm()):.2e} -> {os.path.getsize(path)} B")
+
+
+def main():
+    _install_stubs()
+    ref_util = _load("utilities", os.path.join(REF, "utilities.py"))
+    ref_nn_conv = _load("nn_conv", os.path.join(REF, "nn_conv.py"))
+    sys.path.insert(0, os.path.join(REPO, "graph-pde_amd"))
+    import synth
+
+    # 1. trained checkpoint weights on the Darcy s=16, r=0.15 lattice (BASELINE config 1 graph)
+    torch.manual_seed(0)
+    conv = _checkpoint_conv(ref_nn_conv, ref_util)
+    ei, ea, n = synth.darcy_graph(16, 0.15)
+    x = torch.randn(n, 64)
+    _save("ckpt_g16", conv, x, ei, ea, *_run(conv, x, ei, ea))
+
+    # 2. ragged graph: isolated nodes, duplicate edges, self-loops, unsorted edges;
+    #    aggr='add', no root weight; 3-layer MLP with non-multiple-of-16 widths
+    torch.manual_seed(1)
+    conv = ref_nn_conv.NNConv_old(64, 64, ref_util.DenseNet([6, 20, 24, 4096], torch.nn.ReLU),
+                                  aggr="add", root_weight=False, bias=True)
+    n, e = 97, 700
+    g = torch.Generator().manual_seed(11)
+    src = torch.randint(0, n, (e,), generator=g)
+    dst = torch.randint(0, n - 9, (e,), generator=g)        # nodes n-9.. have zero in-degree
+    dst[dst == 5] = 6                                       # node 5 isolated too
+    src[:8], dst[:8] = 3, 7                                 # 8 duplicate edges 3 -> 7
+    src[8:16] = dst[8:16]                                   # self-loops
+    ei = torch.stack([src, dst])
+    ea = torch.randn(e, 6, generator=g)
+    x = torch.randn(n, 64, generator=g)
+    _save("ragged_add", conv, x, ei, ea, *_run(conv, x, ei, ea))
+
+    # 3. 2-layer MLP (MGKN inter-level shape), root_weight=False, bias=False, aggr='mean',
+    #    bipartite-like "down" graph given on a shared index space
+    torch.manual_seed(2)
+    conv = ref_nn_conv.NNConv_old(64, 64, ref_util.DenseNet([6, 24, 4096], torch.nn.ReLU),
+                                  aggr="mean", root_weight=False, bias=False)
+    n, e = 160, 1500
+    g = torch.Generator().manual_seed(12)
+    ei = torch.stack([torch.randint(0, 120, (e,), generator=g),
+                      torch.randint(120, 160, (e,), generator=g)])
+    ea = torch.rand(e, 6, generator=g)
+    x = torch.randn(n, 64, generator=g)
+    _save("mlp2_mean_noroot", conv, x, ei, ea, *_run(conv, x, ei, ea))
+
+    # 4. Burgers shape: k0 = 4, periodic 1-D interactive-neighbour graph (level with 512 nodes)
+    torch.manual_seed(3)
+    conv = ref_nn_conv.NNConv_old(64, 64, ref_util.DenseNet([4, 32, 32, 4096], torch.nn.ReLU),
+                                  aggr="mean")
+    graphs = synth.burgers_multipole_graphs(512)
+    ei, ea, n = graphs[1]
+    x = torch.randn(n, 64)
+    _save("burgers_k4", conv, x, ei, ea, *_run(conv, x, ei, ea))
+
+    # 5. 5-layer MLP (UAI8_kernel.py:21 shape, narrow) on the s=16 lattice, 1-D x promoted
+    torch.manual_seed(4)
+    conv = ref_nn_conv.NNConv_old(64, 64,
+                                  ref_util.DenseNet([6, 8, 16, 24, 24, 4096], torch.nn.ReLU),
+                                  aggr="mean")
+    ei, ea, n = synth.darcy_graph(16, 0.15, seed=3)
+    x = torch.randn(n, 64)
+    _save("mlp5_g16", conv, x, ei, ea, *_run(conv, x, ei, ea))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,96 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/gpde.h
+declares, and its host-side queries / argument validation behave."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import graph_pde_amd as gp
+from graph_pde_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(REPO, "include", "gpde.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpde_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    declared = _declared_functions()
+    assert declared, "no functions parsed from include/gpde.h"
+    assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_library_exports_every_declared_symbol():
+    l = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared_functions():
+        assert hasattr(l, name), f"libgpde.so does not export {name}"
+
+
+def test_version_and_pack_queries():
+    l = _lib.lib()
+    assert l.gpde_version() == 100
+    d = _lib.dims_array([6, 1024, 1024, 4096])
+    nbytes = l.gpde_mlp_pack_bytes(3, d)
+    # W1|b1 [1024][8] + W2 tiles 1024*1024 + b2 1024 + W3 64*1024*64 + B3 4096 floats
+    assert nbytes == 4 * (1024 * 8 + 1024 * 1024 + 1024 + 64 * 1024 * 64 + 4096)
+    # widths that are not tile multiples are padded (1000 -> K1P 1024 / K2P 1024, 500 -> 512)
+    d = _lib.dims_array([6, 500, 1000, 4096])
+    assert l.gpde_mlp_pack_bytes(3, d) == 4 * (512 * 8 + 1024 * 512 + 1024 + 64 * 1024 * 64 + 4096)
+    # last layer must emit width^2 values
+    d = _lib.dims_array([6, 32, 100])
+    assert l.gpde_mlp_pack_bytes(2, d) == 0
+    assert b"width" in l.gpde_last_error()
+
+
+def test_plan_modes_and_chunking():
+    l = _lib.lib()
+    i32, i64 = ctypes.c_int32, ctypes.c_int64
+    nch, npc, wgs, mode = i32(), i64(), i32(), i32()
+    d = _lib.dims_array([6, 1024, 1024, 4096])
+    n, e = 58081, 95539625
+    ws = l.gpde_nnconv_fwd_workspace_bytes(n, e, 3, d)
+    assert ws > 0
+    rc = l.gpde_nnconv_fwd_plan(n, e, 3, d, ws, ctypes.byref(nch), ctypes.byref(npc),
+                                ctypes.byref(wgs), ctypes.byref(mode))
+    assert rc == 0 and mode.value == 1
+    assert nch.value * npc.value >= n and nch.value >= 1
+    assert wgs.value % 8 == 0                      # 8 hidden slices of 128 columns
+    # a 1 GiB workspace still works, with more chunks
+    nch2 = i32()
+    rc = l.gpde_nnconv_fwd_plan(n, e, 3, d, 1 << 30, ctypes.byref(nch2), ctypes.byref(npc),
+                                ctypes.byref(wgs), ctypes.byref(mode))
+    assert rc == 0 and nch2.value > nch.value
+    # too small a workspace is an error, not a crash
+    rc = l.gpde_nnconv_fwd_plan(n, e, 3, d, 1 << 20, ctypes.byref(nch2), ctypes.byref(npc),
+                                ctypes.byref(wgs), ctypes.byref(mode))
+    assert rc == -3 and b"workspace" in l.gpde_last_error()
+    for dims, want in (([6, 64, 4096], 0), ([4, 16, 16, 4096], 1), ([6, 8, 16, 24, 24, 4096], 2),
+                       ([9, 16, 4096], 2)):
+        dd = _lib.dims_array(dims)
+        rc = l.gpde_nnconv_fwd_plan(100, 1000, len(dims) - 1, dd, 1 << 30, ctypes.byref(nch),
+                                    ctypes.byref(npc), ctypes.byref(wgs), ctypes.byref(mode))
+        assert rc == 0 and mode.value == want, (dims, mode.value)
+
+
+def test_argument_validation_without_gpu():
+    l = _lib.lib()
+    d = _lib.dims_array([6, 16, 4096])
+    # null pointers / bad aggr are rejected before any device work
+    rc = l.gpde_nnconv_fwd(None, 4, None, 0, None, None, None, None, 2, d, None, None, None, 1,
+                           None, None, 0, None)
+    assert rc == -1
+    rc = l.gpde_csr_from_coo(None, 0, 0, -1, 4, None, None, None, None, None, None, 0, None)
+    assert rc == -1
+    rc = l.gpde_mlp_pack(2, d, None, None, None, 0, None)
+    assert rc == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgpde.so")
+    with pytest.raises(_lib.GpdeError):
+        _lib.lib()

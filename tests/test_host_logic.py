@@ -1,0 +1,90 @@
+"""Host-side mirror of the reference module surface (no GPU)."""
+import io
+import pickle
+
+import pytest
+import torch
+
+import graph_pde_amd as gp
+from graph_pde_amd import ops
+
+
+class DenseNet(torch.nn.Module):
+    """Shape of the reference kernel network (utilities.py:201-227): ModuleList `layers`."""
+    def __init__(self, layers, nonlinearity):
+        super().__init__()
+        self.n_layers = len(layers) - 1
+        self.layers = torch.nn.ModuleList()
+        for j in range(self.n_layers):
+            self.layers.append(torch.nn.Linear(layers[j], layers[j + 1]))
+            if j != self.n_layers - 1:
+                self.layers.append(nonlinearity())
+
+    def forward(self, x):
+        for l in self.layers:
+            x = l(x)
+        return x
+
+
+def test_module_surface_matches_reference():
+    conv = gp.NNConv_old(64, 64, DenseNet([6, 32, 48, 4096], torch.nn.ReLU), aggr="mean")
+    assert (conv.in_channels, conv.out_channels, conv.aggr) == (64, 64, "mean")
+    assert tuple(conv.root.shape) == (64, 64) and tuple(conv.bias.shape) == (64,)
+    assert repr(conv) == "NNConv_old(64, 64)"
+    sd = conv.state_dict()
+    # names the reference checkpoints use
+    for k in ("root", "bias", "nn.layers.0.weight", "nn.layers.2.bias", "nn.layers.4.weight"):
+        assert k in sd
+    bound = 1.0 / 8.0
+    assert float(conv.root.abs().max()) <= bound and float(conv.bias.abs().max()) <= bound
+    c2 = gp.NNConv(64, 64, DenseNet([6, 16, 4096], torch.nn.ReLU), aggr="mean", root_weight=False,
+                   bias=False)
+    assert c2.root is None and c2.bias is None and repr(c2) == "NNConv(64, 64)"
+    assert "root" not in c2.state_dict()
+
+
+def test_module_pickles_like_torch_save_model():
+    conv = gp.NNConv_old(64, 64, DenseNet([6, 8, 4096], torch.nn.ReLU), aggr="mean")
+    buf = io.BytesIO()
+    torch.save(conv, buf)
+    buf.seek(0)
+    c2 = torch.load(buf, weights_only=False)
+    assert torch.equal(c2.root, conv.root) and repr(c2) == repr(conv)
+    pickle.dumps(conv)
+
+
+def test_cpu_tensors_are_refused_not_silently_computed():
+    conv = gp.NNConv_old(64, 64, DenseNet([6, 8, 4096], torch.nn.ReLU), aggr="mean")
+    x = torch.randn(5, 64)
+    ei = torch.tensor([[0, 1, 2], [1, 2, 3]])
+    ea = torch.randn(3, 6)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        conv(x, ei, ea)
+
+
+def test_unsupported_configurations_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        ops.mlp_linears(torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(),
+                                            torch.nn.Linear(8, 4096)))
+    with pytest.raises(NotImplementedError):
+        ops.mlp_linears(torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Linear(8, 4096)))
+    lin = ops.mlp_linears(DenseNet([6, 8, 16, 4096], torch.nn.ReLU))
+    assert [tuple(l.weight.shape) for l in lin] == [(8, 6), (16, 8), (4096, 16)]
+    lin = ops.mlp_linears(torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.ReLU(),
+                                              torch.nn.Linear(8, 4096)))
+    assert len(lin) == 2
+
+
+def test_synthetic_graphs_have_reference_shape():
+    from graph_pde_amd import synth
+    ei, ea, n = synth.darcy_graph(16, 0.15)
+    assert n == 256 and ei.shape == (2, 4692) and ea.shape == (4692, 6)
+    assert bool((ei[0, 1:] >= ei[0, :-1]).all())                              # sorted by source
+    assert int((ei[0] == ei[1]).sum()) == n                                   # self-loops included
+    # symmetric (exact integer arithmetic)
+    fw = set(map(tuple, ei.t().tolist()))
+    assert all((j, i) in fw for (i, j) in list(fw)[:500])
+    assert synth.lattice_radius_graph(61, 0.10).shape[1] == 386221
+    g = synth.burgers_multipole_graphs(8192)
+    assert [x[0].shape[1] for x in g][:4] == [16384, 24570, 12282, 6138]
+    assert sum(x[0].shape[1] for x in g) == 65462

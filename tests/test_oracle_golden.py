@@ -1,0 +1,45 @@
+"""The CPU oracle against the committed reference vectors (CPU tier).
+
+The vectors were produced by the reference's own NNConv_old + DenseNet classes
+(tests/golden/make_golden.py); the oracle must reproduce them — that is what pins it."""
+import torch
+
+from oracle.nnconv_oracle import nnconv_forward, rel_l2
+
+
+def test_oracle_fp32_matches_reference(golden):
+    g = golden
+    y = nnconv_forward(g["x"], g["edge_index"], g["edge_attr"], g["weights"], g["biases"],
+                       g["root"], g["bias"], aggr=g["aggr"], dtype=torch.float32)
+    # same op order as the reference; only the destination scatter is chunked
+    assert rel_l2(y, g["out_f32"]) <= 2e-7, rel_l2(y, g["out_f32"])
+
+
+def test_oracle_fp64_matches_reference(golden):
+    g = golden
+    y = nnconv_forward(g["x"], g["edge_index"], g["edge_attr"], g["weights"], g["biases"],
+                       g["root"], g["bias"], aggr=g["aggr"], dtype=torch.float64)
+    assert rel_l2(y, g["out_f64"]) <= 1e-13, rel_l2(y, g["out_f64"])
+
+
+def test_oracle_chunking_is_immaterial(golden):
+    g = golden
+    a = nnconv_forward(g["x"], g["edge_index"], g["edge_attr"], g["weights"], g["biases"],
+                       g["root"], g["bias"], aggr=g["aggr"], dtype=torch.float64, chunk_edges=97)
+    assert rel_l2(a, g["out_f64"]) <= 1e-13
+
+
+def test_oracle_1d_inputs_and_isolated_nodes():
+    # nn_conv.py:269-270: 1-D x / edge_attr are promoted; zero in-degree rows get root/bias only
+    torch.manual_seed(0)
+    n, e = 9, 20
+    ei = torch.stack([torch.randint(0, n, (e,)), torch.randint(0, 5, (e,))])
+    x = torch.randn(n)
+    ea = torch.randn(e)
+    ws = [torch.randn(4, 1), torch.randn(1, 4)]
+    bs = [torch.randn(4), torch.randn(1)]
+    root, bias = torch.randn(1, 1), torch.randn(1)
+    y = nnconv_forward(x, ei, ea, ws, bs, root, bias, aggr="mean", in_channels=1, out_channels=1)
+    assert y.shape == (n, 1)
+    iso = torch.arange(5, n)
+    assert torch.allclose(y[iso, 0], x[iso] * root[0, 0] + bias[0])
