@@ -4,6 +4,7 @@
 #include "gpde_common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -18,6 +19,26 @@ extern "C" int gpde_version(void) { return GPDE_VERSION; }
 extern "C" const char* gpde_last_error(void) { return g_err; }
 
 namespace {
+
+// ---- optional HIP-event timing of the kernels of gpde_nnconv_fwd (bench.py roofline leg) -------
+struct EvPair { hipEvent_t a, b; int kind; };   // kind 0 = fused kernel, 1 = gemm3 + epilogue
+thread_local bool g_prof_on = false;
+thread_local std::vector<EvPair> g_prof;
+
+struct ProfScope {
+    bool on; EvPair p; hipStream_t s;
+    ProfScope(int kind, hipStream_t stream) : on(g_prof_on), s(stream) {
+        if (!on) return;
+        p.kind = kind;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(p.a, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(p.b, s);
+        g_prof.push_back(p);
+    }
+};
 
 constexpr size_t kAlign = 256;
 size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
@@ -198,8 +219,12 @@ extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edg
             f.hbuf = hfinal; f.zbuf = zbuf;
             f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
             f.nc0 = (int)nc0; f.nc1 = (int)nc1; f.e_chunk0 = 0; f.n_groups = P.n_groups;
-            rc = gpde_launch_fused(L.mode, f, stream);
+            {
+                ProfScope ps(0, stream);
+                rc = gpde_launch_fused(L.mode, f, stream);
+            }
             if (rc != GPDE_OK) return rc;
+            ProfScope ps1(1, stream);
             GpdeGemm3Args g;
             g.zbuf = zbuf; g.w3q = pk + L.off_w3q; g.part = part; g.nn = nn; g.K2P = L.K2P;
             g.splits = splits;
@@ -210,8 +235,35 @@ extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edg
         e.part = part; e.x = x; e.rowptr = rowptr; e.src = src;
         e.b3 = pk + L.off_b3; e.root = root; e.bias = bias; e.out = out;
         e.nc0 = (int)nc0; e.nn = nn; e.splits = splits; e.aggr = aggr;
+        ProfScope ps2(1, stream);
         rc = gpde_launch_epilogue(e, stream);
         if (rc != GPDE_OK) return rc;
     }
+    return GPDE_OK;
+}
+
+extern "C" int gpde_profile_begin(void) {
+    for (auto& p : g_prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    g_prof.clear();
+    g_prof_on = true;
+    return GPDE_OK;
+}
+
+extern "C" int gpde_profile_end(double* fused_ms, int32_t* fused_launches, double* other_ms) {
+    g_prof_on = false;
+    double f = 0.0, o = 0.0;
+    int nf = 0;
+    for (auto& p : g_prof) {
+        float ms = 0.f;
+        GP_HIP_CHECK(hipEventSynchronize(p.b));
+        GP_HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+        if (p.kind == 0) { f += ms; ++nf; } else { o += ms; }
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    g_prof.clear();
+    if (fused_ms) *fused_ms = f;
+    if (fused_launches) *fused_launches = nf;
+    if (other_ms) *other_ms = o;
     return GPDE_OK;
 }

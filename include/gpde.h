@@ -111,6 +111,14 @@ int gpde_nnconv_fwd_plan(int64_t n_nodes, int64_t n_edges, int n_layers, const i
                          size_t ws_bytes, int32_t* n_chunks, int64_t* nodes_per_chunk,
                          int32_t* fused_workgroups, int32_t* mode);
 
+/* HIP-event timing of the kernels launched by gpde_nnconv_fwd on the calling thread (used by
+ * bench.py for the roofline figure; events are recorded on the same stream as the kernels).
+ * gpde_profile_begin() arms it; gpde_profile_end() disarms it, SYNCHRONISES on the recorded
+ * events and returns the summed duration (ms) and launch count of the fused edge kernel and the
+ * summed duration of the node-side kernels (gemm3 + epilogue).  Not for production calls. */
+int gpde_profile_begin(void);
+int gpde_profile_end(double* fused_ms, int32_t* fused_launches, double* other_ms);
+
 #ifdef __cplusplus
 }
 #endif
