@@ -1,0 +1,84 @@
+"""Multi-GPU layer of the hot path: independent PDE samples shard across the
+ranks of one node, weights are replicated, the forward needs NO collective; training adds ONE
+flat gradient all-reduce per step (<= 5.3 M fp32 = 21 MB for the 1024^2 kernel MLP -> a single
+bucket; over xGMI a ring all-reduce of 21 MB is ~0.24 ms against >= 1 s of compute per sample, so
+there is nothing to overlap).  One process per GPU; backend 'nccl' is RCCL on ROCm, 'gloo' on CPU
+(tests).  The reference has no distributed code at all.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; returns
+    (rank, world, local_rank).  No-op for a single process."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int) -> range:
+    """Contiguous, balanced shard of `n_items` independent units (samples / sub-graphs):
+    sizes differ by at most one, every item belongs to exactly one rank."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return range(lo, lo + base + (1 if rank < rem else 0))
+
+
+def shard(items: Sequence, rank: int, world: int) -> List:
+    return [items[i] for i in shard_range(len(items), rank, world)]
+
+
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], world: int | None = None,
+                        group=None, average: bool = True) -> int:
+    """Sum (or average) `p.grad` of every parameter across ranks with ONE flat all-reduce.
+    Parameters without a gradient contribute zeros so all ranks agree on the layout.  Returns the
+    number of elements reduced."""
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return 0
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return sum(p.numel() for p in params)
+    dev, dt = params[0].device, params[0].dtype
+    flat = torch.zeros(sum(p.numel() for p in params), device=dev, dtype=dt)
+    off = 0
+    for p in params:
+        if p.grad is not None:
+            flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        off += p.numel()
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= world
+    off = 0
+    for p in params:
+        g = flat[off:off + p.numel()].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += p.numel()
+    return flat.numel()
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Replicate rank `src`'s weights (start of a data-parallel run)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src, group=group)
