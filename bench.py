@@ -76,8 +76,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="g241", choices=sorted(CONFIGS))
     ap.add_argument("--kernel-width", type=int, default=1024)
-    ap.add_argument("--cpu-rows", type=int, default=192, help="destination rows of the CPU sample")
+    ap.add_argument("--cpu-rows", type=int, default=512, help="destination rows of the CPU sample")
+    ap.add_argument("--cpu-threads", type=int, default=64, help="threads of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default=None, choices=["f32", "f16split"],
+                    help="arithmetic of the hidden layer (default: graph_pde_amd.ops.DEFAULT_PRECISION)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,8 +129,11 @@ def main():
     out = torch.empty(n, 64, dtype=torch.float32, device=dev)
     plan = ops.launch_plan(n, e, pm, ws.numel())
 
+    precision = args.precision or ops.DEFAULT_PRECISION
+
     def step():
-        ops.nnconv_forward_raw(x, csr, ea, pm, conv.root, conv.bias, "mean", out=out, ws=ws)
+        ops.nnconv_forward_raw(x, csr, ea, pm, conv.root, conv.bias, "mean", out=out, ws=ws,
+                               precision=precision)
 
     def barrier():
         torch.cuda.synchronize()
@@ -199,7 +205,9 @@ def main():
     rel = None
     if not args.no_cpu_baseline and world == 1:
         from oracle.nnconv_oracle import nnconv_forward, rel_l2
-        ncores = os.cpu_count() or 1
+        # plain PyTorch CPU GEMMs stop scaling (and then regress) far below the 256 hardware
+        # threads of the GPU box; `cores` reports the threads actually used
+        ncores = min(os.cpu_count() or 1, args.cpu_threads)
         torch.set_num_threads(ncores)
         rows = torch.linspace(0, n - 1, min(args.cpu_rows, n)).round().long().unique()
         rowptr = csr.rowptr.cpu().long()
@@ -212,10 +220,10 @@ def main():
         bs_c = [l.bias.detach().cpu() for l in lin]
         root_c, bias_c = conv.root.detach().cpu(), conv.bias.detach().cpu()
         run = lambda: nnconv_forward(x_c, ei_s, ea_s, ws_c, bs_c, root_c, bias_c, aggr="mean",
-                                     dtype=torch.float32, chunk_edges=16384)
+                                     dtype=torch.float32, chunk_edges=65536)
         # warm-up on a slice, then one timed pass over the whole sample
-        nnconv_forward(x_c, ei_s[:, :16384], ea_s[:16384], ws_c, bs_c, root_c, bias_c, aggr="mean",
-                       chunk_edges=16384)
+        nnconv_forward(x_c, ei_s[:, :65536], ea_s[:65536], ws_c, bs_c, root_c, bias_c, aggr="mean",
+                       chunk_edges=65536)
         tc = time.perf_counter()
         y_cpu = run()
         tcpu = time.perf_counter() - tc

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_PKG, "libgpde.so")
 
 GPDE_OK = 0
 GPDE_AGGR_ADD, GPDE_AGGR_MEAN = 0, 1
+GPDE_FWD_DEFAULT, GPDE_FWD_F16SPLIT = 0, 1
 GPDE_WIDTH = 64
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
@@ -40,8 +41,8 @@ SIGNATURES = {
                                        ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-                                       ctypes.c_size_t, ctypes.c_void_p]),
+                                       ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "gpde_nnconv_fwd_plan": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, c_i32p,
                                             ctypes.c_size_t, c_i32p, c_i64p, c_i32p, c_i32p]),
     "gpde_profile_begin": (ctypes.c_int, []),

@@ -161,8 +161,8 @@ extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edg
                                int64_t n_edges, const int32_t* rowptr, const int32_t* src,
                                const int32_t* dst, const int32_t* perm, int n_layers,
                                const int32_t* dims, const void* packed, const float* root,
-                               const float* bias, int aggr, float* out, void* ws, size_t ws_bytes,
-                               void* stream_) {
+                               const float* bias, int aggr, uint32_t flags, float* out, void* ws,
+                               size_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_nodes < 0 || n_edges < 0 || !dims || !packed || !rowptr || (n_nodes > 0 && (!x || !out)) ||
         (n_edges > 0 && (!edge_attr || !src || !dst || !perm))) {
@@ -216,12 +216,13 @@ extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edg
             GpdeFusedArgs f;
             f.x = x; f.attr = edge_attr; f.rowptr = rowptr; f.src = src; f.dst = dst; f.perm = perm;
             f.w1 = pk + L.off_w1; f.w2t = pk + L.off_w2t; f.b2 = pk + L.off_b2;
+            f.w2h = pk + L.off_w2h; f.ucol = pk + L.off_ucol;
             f.hbuf = hfinal; f.zbuf = zbuf;
             f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
             f.nc0 = (int)nc0; f.nc1 = (int)nc1; f.e_chunk0 = 0; f.n_groups = P.n_groups;
             {
                 ProfScope ps(0, stream);
-                rc = gpde_launch_fused(L.mode, f, stream);
+                rc = gpde_launch_fused(L.mode, (flags & GPDE_FWD_F16SPLIT) != 0, f, stream);
             }
             if (rc != GPDE_OK) return rc;
             ProfScope ps1(1, stream);

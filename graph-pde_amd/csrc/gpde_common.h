@@ -29,9 +29,13 @@ struct GpdePackLayout {
     int k0;          // edge-attribute width
     int k1, K1P;     // first hidden width and its padding to GP_BK      (mode 1)
     int k2, K2P;     // last hidden width (input of the last Linear) and its padding to GP_TN
-    size_t off_w1;   // [rows][2][4]  rows = K1P (mode 1) or K2P (mode 0): W1 with b1 folded in
+    size_t off_w1;   // [rows][2][4]  rows = K1P (mode 1) or K2P (mode 0): W1 with b1 folded in;
+                     // mode 1 appends one row: max_k |W1b[k][d]| per input slot d (same [2][4] order)
     size_t off_w2t;  // [K2P/128][K1P/32][128][32]  W2 in LDS-tile order        (mode 1)
     size_t off_b2;   // [K2P]                                                     (mode 1)
+    size_t off_w2h;  // f16-split W2 tiles [K2P/128][K1P/32][128][2 parts][32] halves, rows scaled
+                     // by 2^t_n (mode 1); same byte size as off_w2t
+    size_t off_ucol; // [K2P] 2^-t_n per hidden column                            (mode 1)
     size_t off_w3q;  // [64 c][K2P/4][64 o][4]  last Linear, re-associated order
     size_t off_b3;   // [64 c][64 o]            last Linear bias as a 64x64 matrix (zeros if none)
     size_t off_front;// mode 2: per front layer l: W [KP(l+1)][KP(l)] zero padded, then b [KP(l+1)]
@@ -76,6 +80,8 @@ struct GpdeFusedArgs {
     const float* w1;       // packed, see GpdePackLayout
     const float* w2t;
     const float* b2;
+    const void* w2h;       // f16-split W2 tiles (mode 1, GPDE_FWD_F16SPLIT)
+    const float* ucol;     // [K2P] 2^-t_n
     const float* hbuf;     // mode 2: [edges of chunk][K2P] in CSR order, relu already applied
     float* zbuf;           // [nc1-nc0][64][K2P]
     int k0, K1P, K2P;
@@ -83,7 +89,7 @@ struct GpdeFusedArgs {
     int e_chunk0;          // rowptr[nc0] (mode 2: first row of hbuf)
     int n_groups;          // edge groups (workgroups per slice)
 };
-int gpde_launch_fused(int mode, const GpdeFusedArgs& a, hipStream_t stream);
+int gpde_launch_fused(int mode, bool f16split, const GpdeFusedArgs& a, hipStream_t stream);
 
 struct GpdeGemm3Args {
     const float* zbuf;     // [nn][64*K2P]

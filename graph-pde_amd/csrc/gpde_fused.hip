@@ -34,6 +34,38 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// relu without the canonicalising v_max the compiler puts in front of fmaxf on MFMA results
+__device__ __forceinline__ float relu1(float v) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// two-term f16 split of 16 non-negative, pre-scaled H1 values (registers r = 0..15 of the H1
+// MFMA result) into the two K=16 A operands of v_mfma_f32_32x32x16_f16: operand m, element j
+// = register 8m + j.  hi = rtz16(y) (packed convert), lo = rn16(y - hi):  y = hi + lo + O(2^-21 y).
+__device__ __forceinline__ void split_f16(const f32x16& v, h8 (&hi)[2], h8 (&lo)[2]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+            const float y0 = v[8 * m + 2 * jp], y1 = v[8 * m + 2 * jp + 1];
+            const auto p = __builtin_amdgcn_cvt_pkrtz(y0, y1);
+            const _Float16 p0 = (_Float16)p[0], p1 = (_Float16)p[1];
+            hi[m][2 * jp] = p0;
+            hi[m][2 * jp + 1] = p1;
+            lo[m][2 * jp] = (_Float16)(y0 - (float)p0);
+            lo[m][2 * jp + 1] = (_Float16)(y1 - (float)p1);
+        }
+}
+
 // first node n in [lo, hi] with rowptr[n] >= target
 __device__ __forceinline__ int lower_bound_node(const int32_t* __restrict__ rowptr, int lo, int hi,
                                                 long target) {
@@ -47,12 +79,13 @@ __device__ __forceinline__ int lower_bound_node(const int32_t* __restrict__ rowp
 constexpr int BS_TILE = GP_TN * GP_BS_STRIDE;        // floats per LDS W2 buffer
 constexpr int XS_WAVE = GP_TE * GP_W;                // floats per wave x-stage
 
-template <int MODE>
+template <int MODE, bool F16S>
 __global__ __launch_bounds__(256, 1) void gpde_fused_kernel(GpdeFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bs = smem;                                 // [2][128][36]      (mode 1)
     float* Xs_all = smem + 2 * BS_TILE;               // [4][32][64]
     int* red = (int*)(Xs_all + GP_WAVES * XS_WAVE);   // [4]
+    float* Es_all = (float*)(red + 4);                // [4][32] per-edge 2^-s_e (f16 split)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -60,6 +93,7 @@ __global__ __launch_bounds__(256, 1) void gpde_fused_kernel(GpdeFusedArgs a) {
     const int l31 = lane & 31;
     const int h = lane >> 5;
     float* Xs = Xs_all + wave * XS_WAVE;
+    float* Es = Es_all + wave * GP_TE;
 
     const int ns = a.K2P / GP_TN;
     const int slice = blockIdx.x % ns;
@@ -85,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void gpde_fused_kernel(GpdeFusedArgs a) {
     }
 
     // ---- W2 tile staging (mode 1) ---------------------------------------------------------------
-    const float* w2s = a.w2t + (size_t)slice * NKC * (GP_TN * GP_BK);
+    const float* w2s = (F16S ? (const float*)a.w2h : a.w2t) + (size_t)slice * NKC * (GP_TN * GP_BK);
     f32x4 stage[4];
     auto load_stage = [&](int kc) {
         const f32x4* p = (const f32x4*)(w2s + (size_t)kc * (GP_TN * GP_BK));
@@ -103,11 +137,16 @@ __global__ __launch_bounds__(256, 1) void gpde_fused_kernel(GpdeFusedArgs a) {
     auto load_w1 = [&](int kc) {
         return *(const f32x4*)&a.w1[((size_t)(kc * GP_BK + l31) * 2 + h) * 4];
     };
-    float b2v[4];
-    f32x4 w1f0 = {0.f, 0.f, 0.f, 0.f}, w1f1 = {0.f, 0.f, 0.f, 0.f};
+    float b2v[4], ucv[4];
+    f32x4 w1f0 = {0.f, 0.f, 0.f, 0.f}, w1f1 = {0.f, 0.f, 0.f, 0.f}, wmx = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 1) {
         w1f0 = load_w1(0);
         w1f1 = load_w1(NKC > 1 ? 1 : 0);
+        if (F16S) {
+            wmx = *(const f32x4*)&a.w1[((size_t)a.K1P * 2 + h) * 4];     // appended max-|W1b| row
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) ucv[nb] = a.ucol[slice * GP_TN + nb * 32 + l31];
+        }
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) b2v[nb] = a.b2[slice * GP_TN + nb * 32 + l31];
         if (maxtiles > 0) {
@@ -177,10 +216,27 @@ __global__ __launch_bounds__(256, 1) void gpde_fused_kernel(GpdeFusedArgs a) {
         // ---- H2 pre-activation tile [32 edges x 128 cols] in acc1 ---------------------------------
         f32x16 acc1[4];
         if (MODE == 1) {
+            if (F16S) {
+                // Per-edge power-of-two scale for the f16 split: max_k H1[e][k] <= B_e =
+                // sum_d max_k|W1b[k][d]| * |attr_e[d]|; 2^s_e puts B_e into [2^13, 2^14), well inside
+                // the f16 range, and is applied to the attributes (exact), so H1 comes out of the
+                // MFMA pre-scaled.  2^-s_e goes to LDS for the un-scaling after the K loop.
+                float part = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) part = fmaf(wmx[s], fabsf(attrv[s]), part);
+                const float bnd = part + __shfl_xor(part, 32);
+                const int eb = (__float_as_int(bnd) >> 23) & 0xff;
+                const bool okb = (eb >= 20) && (eb <= 230);
+                const float sc = okb ? __int_as_float((267 - eb) << 23) : 1.f;      // 2^(13 - E(B))
+                const float isc = okb ? __int_as_float((eb - 13) << 23) : 1.f;      // 2^(E(B) - 13)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) attrv[s] *= sc;
+                if (h == 0) Es[l31] = isc;
+            }
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc1[nb][r] = b2v[nb];
+                for (int r = 0; r < 16; ++r) acc1[nb][r] = F16S ? 0.f : b2v[nb];
 
             auto h1gen = [&](const f32x4& w1f) {
                 f32x16 d;
@@ -192,7 +248,9 @@ __global__ __launch_bounds__(256, 1) void gpde_fused_kernel(GpdeFusedArgs a) {
             };
             f32x16 a_cur = h1gen(w1f0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a_cur[r] = fmaxf(a_cur[r], 0.f);
+            for (int r = 0; r < 16; ++r) a_cur[r] = relu1(a_cur[r]);
+            h8 ahi[2], alo[2];
+            if (F16S) split_f16(a_cur, ahi, alo);
             f32x4 w1f_nxt = w1f1;                               // (W1|b1) rows of chunk 1
 
             for (int kc = 0; kc < NKC; ++kc, ++g) {
@@ -205,25 +263,58 @@ __global__ __launch_bounds__(256, 1) void gpde_fused_kernel(GpdeFusedArgs a) {
                 load_stage(kn);
                 w1f_nxt = load_w1(kn2);
                 __builtin_amdgcn_sched_barrier(0);
-                const f32x16 a_nxt = h1gen(w1f_use);            // wasted only on the tile's last chunk
-                const float* bt = Bs + buf * BS_TILE + l31 * GP_BS_STRIDE + h * 4;
+                f32x16 a_nxt = h1gen(w1f_use);                  // wasted only on the tile's last chunk
+                if (F16S) {
+                    // W2 tile rows: [hi: 4 x 8 halves | lo: 4 x 8 halves], 144-byte row stride
+                    const char* bt = (const char*)(Bs + buf * BS_TILE) + l31 * (GP_BS_STRIDE * 4) + h * 16;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 bf[4];
+                    for (int m = 0; m < 2; ++m) {
+                        h8 bhi[4], blo[4];
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
-                        bf[nb] = *(const f32x4*)&bt[nb * 32 * GP_BS_STRIDE + q * 8];
+                        for (int nb = 0; nb < 4; ++nb) {
+                            bhi[nb] = *(const h8*)(bt + nb * 32 * (GP_BS_STRIDE * 4) + m * 32);
+                            blo[nb] = *(const h8*)(bt + nb * 32 * (GP_BS_STRIDE * 4) + m * 32 + 64);
+                        }
 #pragma unroll
-                    for (int t4 = 0; t4 < 4; ++t4)
+                        for (int nb = 0; nb < 4; ++nb) acc1[nb] = mfma16(ahi[m], bhi[nb], acc1[nb]);
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) acc1[nb] = mfma16(ahi[m], blo[nb], acc1[nb]);
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) acc1[nb] = mfma16(alo[m], bhi[nb], acc1[nb]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a_nxt[r] = relu1(a_nxt[r]);
+                    split_f16(a_nxt, ahi, alo);
+                } else {
+                    const float* bt = Bs + buf * BS_TILE + l31 * GP_BS_STRIDE + h * 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 bf[4];
 #pragma unroll
                         for (int nb = 0; nb < 4; ++nb)
-                            acc1[nb] = mfma32(a_cur[q * 4 + t4], bf[nb][t4], acc1[nb]);
-                }
+                            bf[nb] = *(const f32x4*)&bt[nb * 32 * GP_BS_STRIDE + q * 8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a_cur[r] = fmaxf(a_nxt[r], 0.f);
+                        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+                            for (int nb = 0; nb < 4; ++nb)
+                                acc1[nb] = mfma32(a_cur[q * 4 + t4], bf[nb][t4], acc1[nb]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a_cur[r] = relu1(a_nxt[r]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 write_stage(buf ^ 1);
                 __syncthreads();
+            }
+            if (F16S) {
+                // undo the row (edge) and column scales, add the bias
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ie = Es[(r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+                        acc1[nb][r] = fmaf(acc1[nb][r], ie * ucv[nb], b2v[nb]);
+                }
             }
         } else if (MODE == 0) {
             // single hidden layer: H = relu((W1|b1) . attr); operands swapped so that D is [edge][col]
@@ -256,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void gpde_fused_kernel(GpdeFusedArgs a) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[nb][r] = fmaxf(acc1[nb][r], 0.f);
+            for (int r = 0; r < 16; ++r) acc1[nb][r] = relu1(acc1[nb][r]);
 
         // ---- GEMM2 with destination segments -------------------------------------------------------
         int e_seg = e0;
@@ -290,24 +381,25 @@ __global__ __launch_bounds__(256, 1) void gpde_fused_kernel(GpdeFusedArgs a) {
 
 }  // namespace
 
-int gpde_launch_fused(int mode, const GpdeFusedArgs& a, hipStream_t stream) {
+int gpde_launch_fused(int mode, bool f16split, const GpdeFusedArgs& a, hipStream_t stream) {
     const int ns = a.K2P / GP_TN;
     const dim3 grid(a.n_groups * ns), block(256);
-    const size_t lds = (size_t)(2 * BS_TILE + GP_WAVES * XS_WAVE) * sizeof(float) + 64;
+    const size_t lds = (size_t)(2 * BS_TILE + GP_WAVES * XS_WAVE + GP_WAVES * GP_TE) * sizeof(float) + 64;
     static bool attr_set = false;
     if (!attr_set) {
-        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_kernel<0>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_kernel<1>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_kernel<2>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const void* fns[4] = {(const void*)gpde_fused_kernel<0, false>, (const void*)gpde_fused_kernel<1, false>,
+                              (const void*)gpde_fused_kernel<1, true>, (const void*)gpde_fused_kernel<2, false>};
+        for (const void* f : fns)
+            GP_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     switch (mode) {
-        case 0: hipLaunchKernelGGL(gpde_fused_kernel<0>, grid, block, lds, stream, a); break;
-        case 1: hipLaunchKernelGGL(gpde_fused_kernel<1>, grid, block, lds, stream, a); break;
-        case 2: hipLaunchKernelGGL(gpde_fused_kernel<2>, grid, block, lds, stream, a); break;
+        case 0: hipLaunchKernelGGL((gpde_fused_kernel<0, false>), grid, block, lds, stream, a); break;
+        case 1:
+            if (f16split) hipLaunchKernelGGL((gpde_fused_kernel<1, true>), grid, block, lds, stream, a);
+            else hipLaunchKernelGGL((gpde_fused_kernel<1, false>), grid, block, lds, stream, a);
+            break;
+        case 2: hipLaunchKernelGGL((gpde_fused_kernel<2, false>), grid, block, lds, stream, a); break;
         default: gpde_set_error("bad fused mode %d", mode); return GPDE_EINVAL;
     }
     GP_LAUNCH_CHECK("gpde_fused_kernel");

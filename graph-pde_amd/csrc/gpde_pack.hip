@@ -32,9 +32,11 @@ int gpde_pack_layout(int n_layers, const int32_t* dims, GpdePackLayout* L) {
     } else if (L->mode == 1) {
         L->k1 = dims[1];
         L->K1P = gp_round_up(L->k1, GP_BK);
-        L->off_w1 = take((size_t)L->K1P * 8);
+        L->off_w1 = take((size_t)(L->K1P + 1) * 8);
         L->off_w2t = take((size_t)L->K2P * L->K1P);
         L->off_b2 = take((size_t)L->K2P);
+        L->off_w2h = take((size_t)L->K2P * L->K1P);
+        L->off_ucol = take((size_t)L->K2P);
     } else {
         // front layers 0 .. n_layers-2 as dense layers; widths padded to 128 (inputs of layer 0: 32)
         L->frontKP[0] = gp_round_up(dims[0], 32);
@@ -79,6 +81,56 @@ __global__ void pack_w2_kernel(const float* __restrict__ W, int k2, int k1, int 
     const int kc = tile % NKC, slice = tile / NKC;
     const int ng = slice * 128 + n, kg = kc * 32 + k;
     out[i] = (ng < k2 && kg < k1) ? W[(size_t)ng * k1 + kg] : 0.f;
+}
+
+// per-input-slot max_k |W1b[k][d]| appended to the packed W1 as row `rows` ([h][s] order): the
+// fused kernel bounds max_k |H1[e][k]| <= sum_d wmax[d] |attr_e[d]| with it (f16-split scaling)
+__global__ void pack_w1max_kernel(const float* __restrict__ w1p, int rows, float* __restrict__ out) {
+    const int d8 = threadIdx.x;          // 8 threads: position in the [h][s] row
+    if (d8 >= 8) return;
+    float m = 0.f;
+    for (int r = 0; r < rows; ++r) m = fmaxf(m, fabsf(w1p[(size_t)r * 8 + d8]));
+    out[d8] = m;
+}
+
+// W2 [k2][k1] -> f16 two-term split tiles. Row n is scaled by 2^t_n so that its largest
+// magnitude lies in [2^13, 2^14); hi = rn16(w), lo = rn16(w - hi).  Within a 32-wide k chunk the
+// halves are stored in MFMA operand order: position p = (m*2+h)*8 + j  <->
+// k = 16m + 8(j>>2) + 4h + (j&3)   (matches the D-layout of the on-the-fly H1).
+__global__ void pack_w2_f16split_kernel(const float* __restrict__ W, int k2, int k1, int K2P,
+                                        int K1P, _Float16* __restrict__ out,
+                                        float* __restrict__ ucol) {
+    __shared__ float red[256];
+    const int ng = blockIdx.x;           // hidden row (output unit of layer 2)
+    float m = 0.f;
+    if (ng < k2)
+        for (int k = threadIdx.x; k < k1; k += blockDim.x) m = fmaxf(m, fabsf(W[(size_t)ng * k1 + k]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    m = red[0];
+    int tn = 0;
+    const int eb = (__float_as_int(m) >> 23) & 0xff;
+    if (eb >= 20 && eb <= 230) tn = 13 - (eb - 127);
+    const float scale = __int_as_float((tn + 127) << 23);
+    if (threadIdx.x == 0) ucol[ng] = __int_as_float((127 - tn) << 23);
+    const int NKC = K1P / 32;
+    const int slice = ng / 128, nl = ng % 128;
+    for (int k = threadIdx.x; k < K1P; k += blockDim.x) {
+        const float w = (ng < k2 && k < k1) ? W[(size_t)ng * k1 + k] * scale : 0.f;
+        const _Float16 hi = (_Float16)w;
+        const _Float16 lo = (_Float16)(w - (float)hi);
+        const int kc = k >> 5, kk = k & 31;
+        const int mm = kk >> 4, k16 = kk & 15;
+        const int jh = k16 >> 3, hh = (k16 >> 2) & 1, jl = k16 & 3;
+        const int pos = (mm * 2 + hh) * 8 + jh * 4 + jl;
+        _Float16* row = out + ((size_t)(slice * NKC + kc) * 128 + nl) * 64;
+        row[pos] = hi;
+        row[32 + pos] = lo;
+    }
 }
 
 __global__ void pack_pad_vec_kernel(const float* __restrict__ v, int n, int nP, float* __restrict__ out) {
@@ -145,6 +197,10 @@ extern "C" int gpde_mlp_pack(int n_layers, const int32_t* dims, const float* con
                            W[1], dims[2], dims[1], L.K2P, L.K1P, P + L.off_w2t);
         hipLaunchKernelGGL(pack_pad_vec_kernel, dim3(blocks(L.K2P)), dim3(T), 0, stream, b[1],
                            dims[2], L.K2P, P + L.off_b2);
+        hipLaunchKernelGGL(pack_w1max_kernel, dim3(1), dim3(64), 0, stream, P + L.off_w1, L.K1P,
+                           P + L.off_w1 + (size_t)L.K1P * 8);
+        hipLaunchKernelGGL(pack_w2_f16split_kernel, dim3(L.K2P), dim3(256), 0, stream, W[1], dims[2],
+                           dims[1], L.K2P, L.K1P, (_Float16*)(P + L.off_w2h), P + L.off_ucol);
     } else {
         for (int l = 0; l < n_layers - 1; ++l) {
             hipLaunchKernelGGL(pack_pad_mat_kernel,

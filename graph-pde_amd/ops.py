@@ -7,6 +7,7 @@ run on CPU tensors: there is no non-HIP path.
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -187,6 +188,10 @@ def pack_mlp(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Te
 # forward
 # ----------------------------------------------------------------------------------------------
 _AGGR = {"add": _lib.GPDE_AGGR_ADD, "mean": _lib.GPDE_AGGR_MEAN}
+# arithmetic of the hidden k1 x k2 layer: "f32" = fp32 MFMA (exact fmaf chains); "f16split" = f16
+# MFMA on two-term split operands with fp32 accumulation (include/gpde.h GPDE_FWD_F16SPLIT)
+_PRECISION = {"f32": _lib.GPDE_FWD_DEFAULT, "f16split": _lib.GPDE_FWD_F16SPLIT}
+DEFAULT_PRECISION = os.environ.get("GPDE_PRECISION", "f32")
 
 
 def workspace_bytes(n_nodes: int, n_edges: int, pm: PackedMlp) -> int:
@@ -195,8 +200,8 @@ def workspace_bytes(n_nodes: int, n_edges: int, pm: PackedMlp) -> int:
 
 def nnconv_forward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor, pm: PackedMlp,
                        root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,
-                       out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None
-                       ) -> torch.Tensor:
+                       out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
+                       precision: Optional[str] = None) -> torch.Tensor:
     """One gpde_nnconv_fwd call on the current stream. x [N,64] f32, edge_attr [E,k0] f32."""
     lib = _lib.lib()
     _require_cuda(x, "x")
@@ -205,6 +210,9 @@ def nnconv_forward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor, pm: P
         raise NotImplementedError(
             f"aggr={aggr!r}: the fused MI355X operator implements 'add' and 'mean' (every reference "
             "script uses 'mean'); 'max' cannot use the re-associated contraction")
+    precision = DEFAULT_PRECISION if precision is None else precision
+    if precision not in _PRECISION:
+        raise ValueError(f"precision must be one of {sorted(_PRECISION)}, got {precision!r}")
     if x.dtype != torch.float32 or edge_attr.dtype != torch.float32:
         raise NotImplementedError(f"float32 only (got x {x.dtype}, edge_attr {edge_attr.dtype})")
     if x.dim() != 2 or x.size(1) != WIDTH:
@@ -229,7 +237,7 @@ def nnconv_forward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor, pm: P
                                  len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(),
                                  None if root_c is None else root_c.data_ptr(),
                                  None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
-                                 out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
+                                 _PRECISION[precision], out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
     _lib.check(rc, "gpde_nnconv_fwd")
     _lib.n_native_calls += 1
     return out

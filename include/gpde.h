@@ -39,6 +39,14 @@ enum {
 
 enum { GPDE_AGGR_ADD = 0, GPDE_AGGR_MEAN = 1 };
 
+/* gpde_nnconv_fwd flags */
+enum {
+    GPDE_FWD_DEFAULT = 0,  /* every contraction on v_mfma_f32_32x32x2_f32: exact fp32 (fmaf chains) */
+    GPDE_FWD_F16SPLIT = 1  /* hidden k1 x k2 layer on f16 MFMA with two-term operand splitting
+                              (x = hi + lo, 3 MFMAs, fp32 accumulate; per-product error < 2^-21,
+                              DESIGN.md §3b); ignored for kernels without a hidden GEMM */
+};
+
 #define GPDE_MAX_LAYERS 8
 #define GPDE_WIDTH 64 /* node-feature width (in_channels == out_channels) the kernels are built for */
 
@@ -100,8 +108,8 @@ size_t gpde_nnconv_fwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_l
 int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
                     const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                     const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
-                    const float* root, const float* bias, int aggr, float* out, void* ws,
-                    size_t ws_bytes, void* stream);
+                    const float* root, const float* bias, int aggr, uint32_t flags, float* out,
+                    void* ws, size_t ws_bytes, void* stream);
 
 /* Launch plan gpde_nnconv_fwd will follow for these sizes and this workspace (host-side query, no
  * device work): number of destination-node chunks, nodes per chunk, workgroups of the fused

@@ -35,11 +35,11 @@ def test_version_and_pack_queries():
     assert l.gpde_version() == 100
     d = _lib.dims_array([6, 1024, 1024, 4096])
     nbytes = l.gpde_mlp_pack_bytes(3, d)
-    # W1|b1 [1024][8] + W2 tiles 1024*1024 + b2 1024 + W3 64*1024*64 + B3 4096 floats
-    assert nbytes == 4 * (1024 * 8 + 1024 * 1024 + 1024 + 64 * 1024 * 64 + 4096)
+    # W1|b1 [1024+1][8] + W2 tiles (fp32 and f16-split) 2*1024*1024 + b2, ucol 2*1024 + W3 + B3
+    assert nbytes == 4 * (1025 * 8 + 2 * (1024 * 1024 + 1024) + 64 * 1024 * 64 + 4096)
     # widths that are not tile multiples are padded (1000 -> K1P 1024 / K2P 1024, 500 -> 512)
     d = _lib.dims_array([6, 500, 1000, 4096])
-    assert l.gpde_mlp_pack_bytes(3, d) == 4 * (512 * 8 + 1024 * 512 + 1024 + 64 * 1024 * 64 + 4096)
+    assert l.gpde_mlp_pack_bytes(3, d) == 4 * (513 * 8 + 2 * (1024 * 512 + 1024) + 64 * 1024 * 64 + 4096)
     # last layer must emit width^2 values
     d = _lib.dims_array([6, 32, 100])
     assert l.gpde_mlp_pack_bytes(2, d) == 0
@@ -81,7 +81,7 @@ def test_argument_validation_without_gpu():
     d = _lib.dims_array([6, 16, 4096])
     # null pointers / bad aggr are rejected before any device work
     rc = l.gpde_nnconv_fwd(None, 4, None, 0, None, None, None, None, 2, d, None, None, None, 1,
-                           None, None, 0, None)
+                           0, None, None, 0, None)
     assert rc == -1
     rc = l.gpde_csr_from_coo(None, 0, 0, -1, 4, None, None, None, None, None, None, 0, None)
     assert rc == -1

@@ -18,7 +18,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def run_native(x, ei, ea, weights, biases, root, bias, aggr, ws_bytes=None):
+def run_native(x, ei, ea, weights, biases, root, bias, aggr, ws_bytes=None, precision=None):
     d = dev()
     calls = _lib.n_native_calls
     csr = ops.build_csr(ei.to(d), x.shape[0])
@@ -27,7 +27,7 @@ def run_native(x, ei, ea, weights, biases, root, bias, aggr, ws_bytes=None):
     if ws_bytes is not None:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=d)
     y = ops.nnconv_forward_raw(x.to(d), csr, ea.to(d), pm, None if root is None else root.to(d),
-                               None if bias is None else bias.to(d), aggr, ws=ws)
+                               None if bias is None else bias.to(d), aggr, ws=ws, precision=precision)
     torch.cuda.synchronize()
     assert _lib.n_native_calls == calls + 1          # the HIP entry point really ran
     return y.cpu()
@@ -165,3 +165,38 @@ def test_module_forward_drop_in():
     with pytest.raises(NotImplementedError):
         gp.NNConv_old(64, 64, DenseNet([6, 8, 4096], torch.nn.ReLU), aggr="max").to(d)(
             g["x"].to(d), g["edge_index"].to(d), g["edge_attr"].to(d))
+
+
+@pytest.mark.parametrize("name", ["ckpt_g16", "burgers_k4"])
+def test_f16split_hidden_layer_golden(name):
+    """GPDE_FWD_F16SPLIT (hidden layer on f16 MFMA with two-term split operands, fp32 accumulate)
+    against the reference vectors: same 1e-5 bar, and within a small factor of the fp32-MFMA path."""
+    from tests.conftest import load_golden
+    g = load_golden(name)
+    args = (g["x"], g["edge_index"], g["edge_attr"], g["weights"], g["biases"], g["root"], g["bias"], g["aggr"])
+    y16 = run_native(*args, precision="f16split")
+    y32 = run_native(*args, precision="f32")
+    e16, e32 = rel_l2(y16, g["out_f64"]), rel_l2(y32, g["out_f64"])
+    assert e16 <= TOL and e16 <= 4 * e32 + 2e-7, (name, e16, e32)
+
+
+def test_f16split_wide_dynamic_range():
+    """Attributes and weights spanning many binades (per-edge and per-row power-of-two scaling)."""
+    torch.manual_seed(11)
+    n, e = 400, 8000
+    ei = torch.stack([torch.randint(0, n, (e,)), torch.randint(0, n, (e,))])
+    ea = torch.randn(e, 6) * torch.logspace(-3, 3, e).unsqueeze(1)       # edges from 1e-3 to 1e3
+    x = torch.randn(n, 64)
+    mlp = torch.nn.Sequential(torch.nn.Linear(6, 128), torch.nn.ReLU(), torch.nn.Linear(128, 256),
+                              torch.nn.ReLU(), torch.nn.Linear(256, 4096))
+    with torch.no_grad():
+        mlp[2].weight.mul_(torch.logspace(-4, 4, 256).unsqueeze(1))      # rows from 1e-4 to 1e4
+        mlp[2].weight[:, ::7] *= 1e-3                                    # small entries inside rows
+    ws_ = [l.weight.detach() for l in mlp if isinstance(l, torch.nn.Linear)]
+    bs_ = [l.bias.detach() for l in mlp if isinstance(l, torch.nn.Linear)]
+    y64 = nnconv_forward(x, ei, ea, ws_, bs_, None, None, aggr="mean", dtype=torch.float64)
+    y16 = run_native(x, ei, ea, ws_, bs_, None, None, "mean", precision="f16split")
+    y32 = run_native(x, ei, ea, ws_, bs_, None, None, "mean", precision="f32")
+    e16, e32 = rel_l2(y16, y64), rel_l2(y32, y64)
+    assert torch.isfinite(y16).all()
+    assert e16 <= TOL and e16 <= 4 * e32 + 2e-7, (e16, e32)
