@@ -42,6 +42,7 @@ if REPO not in sys.path:
 CONFIGS = {
     # name: (s, r)   BASELINE.json configs[1] is g241; g61/g16 are quick-look sizes
     "g241": (241, 0.10),
+    "g121": (121, 0.10),
     "g61": (61, 0.10),
     "g16": (16, 0.15),
 }

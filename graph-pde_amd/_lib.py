@@ -11,7 +11,7 @@ import os
 import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libgpde.so")
+LIB_PATH = os.environ.get("GPDE_LIB", os.path.join(_PKG, "libgpde.so"))   # GPDE_LIB: experiments
 
 GPDE_OK = 0
 GPDE_AGGR_ADD, GPDE_AGGR_MEAN = 0, 1

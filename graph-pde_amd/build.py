@@ -17,10 +17,12 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(REPO, "include")
-LIB = os.path.join(PKG, "libgpde.so")
-OBJDIR = os.path.join(PKG, "build")
+_SUFFIX = os.environ.get("GPDE_BUILD_SUFFIX", "")          # ablation builds: libgpde<suffix>.so
+LIB = os.path.join(PKG, f"libgpde{_SUFFIX}.so")
+OBJDIR = os.path.join(PKG, "build" + _SUFFIX)
 
-SOURCES = ["gpde_api.hip", "gpde_csr.hip", "gpde_pack.hip", "gpde_fused.hip", "gpde_gemm3.hip"]
+SOURCES = ["gpde_api.hip", "gpde_csr.hip", "gpde_pack.hip", "gpde_fused.hip", "gpde_fused_f16.hip",
+           "gpde_gemm3.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
          "-Wall", "-Wno-unused-function"]
@@ -65,4 +67,5 @@ def build(force: bool = False, extra_flags=()) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    extra = [a for a in sys.argv[1:] if a.startswith("-D")]
+    print(build(force="--force" in sys.argv, extra_flags=extra))

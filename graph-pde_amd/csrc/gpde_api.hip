@@ -222,7 +222,9 @@ extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edg
             f.nc0 = (int)nc0; f.nc1 = (int)nc1; f.e_chunk0 = 0; f.n_groups = P.n_groups;
             {
                 ProfScope ps(0, stream);
-                rc = gpde_launch_fused(L.mode, (flags & GPDE_FWD_F16SPLIT) != 0, f, stream);
+                const bool f16s = (flags & GPDE_FWD_F16SPLIT) != 0 && L.mode == 1;
+                if (f16s && gpde_fused_f16_supported(f)) rc = gpde_launch_fused_f16(f, stream);
+                else rc = gpde_launch_fused(L.mode, f16s, f, stream);
             }
             if (rc != GPDE_OK) return rc;
             ProfScope ps1(1, stream);

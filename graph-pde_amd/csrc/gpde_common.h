@@ -90,6 +90,9 @@ struct GpdeFusedArgs {
     int n_groups;          // edge groups (workgroups per slice)
 };
 int gpde_launch_fused(int mode, bool f16split, const GpdeFusedArgs& a, hipStream_t stream);
+// f16-split + LDS-DMA variant (gpde_fused_f16.hip); supported for 3 <= K1P/32 and K1P <= ~1000
+bool gpde_fused_f16_supported(const GpdeFusedArgs& a);
+int gpde_launch_fused_f16(const GpdeFusedArgs& a, hipStream_t stream);
 
 struct GpdeGemm3Args {
     const float* zbuf;     // [nn][64*K2P]

@@ -138,10 +138,11 @@ __global__ __launch_bounds__(256, 1) void gpde_fused_kernel(GpdeFusedArgs a) {
         return *(const f32x4*)&a.w1[((size_t)(kc * GP_BK + l31) * 2 + h) * 4];
     };
     float b2v[4], ucv[4];
-    f32x4 w1f0 = {0.f, 0.f, 0.f, 0.f}, w1f1 = {0.f, 0.f, 0.f, 0.f}, wmx = {0.f, 0.f, 0.f, 0.f};
+    f32x4 w1f0 = {0.f, 0.f, 0.f, 0.f}, w1f1 = w1f0, w1f2 = w1f0, wmx = w1f0;
     if (MODE == 1) {
         w1f0 = load_w1(0);
-        w1f1 = load_w1(NKC > 1 ? 1 : 0);
+        w1f1 = load_w1(1 % NKC);
+        w1f2 = load_w1(2 % NKC);
         if (F16S) {
             wmx = *(const f32x4*)&a.w1[((size_t)a.K1P * 2 + h) * 4];     // appended max-|W1b| row
 #pragma unroll
@@ -246,11 +247,94 @@ __global__ __launch_bounds__(256, 1) void gpde_fused_kernel(GpdeFusedArgs a) {
                 for (int s = 0; s < 4; ++s) d = mfma32(w1f[s], attrv[s], d);
                 return d;
             };
+            if constexpr (F16S) {
+                // ---- f16-split hidden GEMM, software-pipelined two chunks deep ----------------------
+                // iteration kc: (a) 4 fp32 MFMAs produce the raw H1 of chunk kc+2, (b) VALU turns
+                // the raw H1 of chunk kc+1 (made in the previous iteration) into f16 hi/lo operands,
+                // (c) 24 f16 MFMAs consume chunk kc's operands.  (a)-(c) are independent, so the
+                // conversion hides under the MFMAs; sched_barrier(0) fences keep that interleave.
+                h8 ahi[2], alo[2], ahi_n[2], alo_n[2];
+                f32x16 a_raw;
+                {
+                    f32x16 a0 = h1gen(w1f0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a0[r] = relu1(a0[r]);
+                    split_f16(a0, ahi, alo);
+                    a_raw = h1gen(w1f1);
+                }
+                f32x4 w1f_nxt = w1f2;                               // (W1|b1) rows of chunk 2
+                auto conv_piece = [&](int p_) {                     // one register pair of a_raw
+                    const int m = p_ >> 2, jp = p_ & 3;
+                    const float y0 = relu1(a_raw[8 * m + 2 * jp]), y1 = relu1(a_raw[8 * m + 2 * jp + 1]);
+                    const auto pk = __builtin_amdgcn_cvt_pkrtz(y0, y1);
+                    const _Float16 p0 = (_Float16)pk[0], p1 = (_Float16)pk[1];
+                    ahi_n[m][2 * jp] = p0;
+                    ahi_n[m][2 * jp + 1] = p1;
+                    alo_n[m][2 * jp] = (_Float16)(y0 - (float)p0);
+                    alo_n[m][2 * jp + 1] = (_Float16)(y1 - (float)p1);
+                };
+                for (int kc = 0; kc < NKC; ++kc, ++g) {
+                    const int buf = g & 1;
+                    [[maybe_unused]] const int kn = (kc + 1 < NKC) ? kc + 1 : 0;   // next chunk
+                    int kn3 = kc + 3;
+                    while (kn3 >= NKC) kn3 -= NKC;
+                    const f32x4 w1f_use = w1f_nxt;
+                    // W2 tile rows: [hi: 4 x 8 halves | lo: 4 x 8 halves], 144-byte row stride
+                    const char* bt = (const char*)(Bs + buf * BS_TILE) + l31 * (GP_BS_STRIDE * 4);
+                    const int sw = (l31 >> 1) & 7;            // unit swizzle of the packed image
+                    const int u0 = ((0 + h) ^ sw) << 4, u1 = ((2 + h) ^ sw) << 4;
+                    h8 bhi[2][4], blo[2][4];
+#ifndef GPDE_ABL_NOSTAGE
+                    load_stage(kn);
+#endif
+                    w1f_nxt = load_w1(kn3);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) {
+                        bhi[0][nb] = *(const h8*)(bt + nb * 32 * (GP_BS_STRIDE * 4) + u0);
+                        blo[0][nb] = *(const h8*)(bt + nb * 32 * (GP_BS_STRIDE * 4) + (u0 ^ 64));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x16 a_raw_n = h1gen(w1f_use);                  // raw H1 of chunk kc+2
+                    conv_piece(0);
+                    conv_piece(1);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) {
+                        bhi[1][nb] = *(const h8*)(bt + nb * 32 * (GP_BS_STRIDE * 4) + u1);
+                        blo[1][nb] = *(const h8*)(bt + nb * 32 * (GP_BS_STRIDE * 4) + (u1 ^ 64));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) acc1[nb] = mfma16(ahi[m], bhi[m][nb], acc1[nb]);
+                        conv_piece(2 + 3 * m);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) acc1[nb] = mfma16(ahi[m], blo[m][nb], acc1[nb]);
+                        conv_piece(3 + 3 * m);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) acc1[nb] = mfma16(alo[m], bhi[m][nb], acc1[nb]);
+                        conv_piece(4 + 3 * m);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        ahi[m] = ahi_n[m];
+                        alo[m] = alo_n[m];
+                    }
+                    a_raw = a_raw_n;
+#ifndef GPDE_ABL_NOSTAGE
+                    write_stage(buf ^ 1);
+#endif
+#ifndef GPDE_ABL_NOBARRIER
+                    __syncthreads();
+#endif
+                }
+            } else {
             f32x16 a_cur = h1gen(w1f0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) a_cur[r] = relu1(a_cur[r]);
-            h8 ahi[2], alo[2];
-            if (F16S) split_f16(a_cur, ahi, alo);
             f32x4 w1f_nxt = w1f1;                               // (W1|b1) rows of chunk 1
 
             for (int kc = 0; kc < NKC; ++kc, ++g) {
@@ -260,51 +344,35 @@ __global__ __launch_bounds__(256, 1) void gpde_fused_kernel(GpdeFusedArgs a) {
                 const f32x4 w1f_use = w1f_nxt;
                 // issue next chunk's W2 tile loads and the W1 rows of the chunk after it right
                 // behind the barrier; they are consumed a full chunk of MFMAs later
+#ifndef GPDE_ABL_NOSTAGE
                 load_stage(kn);
+#endif
                 w1f_nxt = load_w1(kn2);
                 __builtin_amdgcn_sched_barrier(0);
-                f32x16 a_nxt = h1gen(w1f_use);                  // wasted only on the tile's last chunk
-                if (F16S) {
-                    // W2 tile rows: [hi: 4 x 8 halves | lo: 4 x 8 halves], 144-byte row stride
-                    const char* bt = (const char*)(Bs + buf * BS_TILE) + l31 * (GP_BS_STRIDE * 4) + h * 16;
+                const f32x16 a_nxt = h1gen(w1f_use);            // wasted only on the tile's last chunk
+                const float* bt = Bs + buf * BS_TILE + l31 * GP_BS_STRIDE + h * 4;
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        h8 bhi[4], blo[4];
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 bf[4];
 #pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) {
-                            bhi[nb] = *(const h8*)(bt + nb * 32 * (GP_BS_STRIDE * 4) + m * 32);
-                            blo[nb] = *(const h8*)(bt + nb * 32 * (GP_BS_STRIDE * 4) + m * 32 + 64);
-                        }
+                    for (int nb = 0; nb < 4; ++nb)
+                        bf[nb] = *(const f32x4*)&bt[nb * 32 * GP_BS_STRIDE + q * 8];
 #pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) acc1[nb] = mfma16(ahi[m], bhi[nb], acc1[nb]);
-#pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) acc1[nb] = mfma16(ahi[m], blo[nb], acc1[nb]);
-#pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) acc1[nb] = mfma16(alo[m], bhi[nb], acc1[nb]);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) a_nxt[r] = relu1(a_nxt[r]);
-                    split_f16(a_nxt, ahi, alo);
-                } else {
-                    const float* bt = Bs + buf * BS_TILE + l31 * GP_BS_STRIDE + h * 4;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f32x4 bf[4];
+                    for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
                         for (int nb = 0; nb < 4; ++nb)
-                            bf[nb] = *(const f32x4*)&bt[nb * 32 * GP_BS_STRIDE + q * 8];
-#pragma unroll
-                        for (int t4 = 0; t4 < 4; ++t4)
-#pragma unroll
-                            for (int nb = 0; nb < 4; ++nb)
-                                acc1[nb] = mfma32(a_cur[q * 4 + t4], bf[nb][t4], acc1[nb]);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) a_cur[r] = relu1(a_nxt[r]);
+                            acc1[nb] = mfma32(a_cur[q * 4 + t4], bf[nb][t4], acc1[nb]);
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a_cur[r] = relu1(a_nxt[r]);
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef GPDE_ABL_NOSTAGE
                 write_stage(buf ^ 1);
+#endif
+#ifndef GPDE_ABL_NOBARRIER
                 __syncthreads();
+#endif
+            }
             }
             if (F16S) {
                 // undo the row (edge) and column scales, add the bias
@@ -351,6 +419,11 @@ __global__ __launch_bounds__(256, 1) void gpde_fused_kernel(GpdeFusedArgs a) {
 
         // ---- GEMM2 with destination segments -------------------------------------------------------
         int e_seg = e0;
+#ifdef GPDE_ABL_NOGEMM2
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) asm volatile("" ::"v"(acc1[nb]));
+        e_seg = e_end;
+#endif
         while (e_seg < e_end) {
             const int node = a.dst[e_seg];
             const int seg_end = min(a.rowptr[node + 1], e_end);

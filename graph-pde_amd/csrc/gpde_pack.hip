@@ -96,7 +96,8 @@ __global__ void pack_w1max_kernel(const float* __restrict__ w1p, int rows, float
 // W2 [k2][k1] -> f16 two-term split tiles. Row n is scaled by 2^t_n so that its largest
 // magnitude lies in [2^13, 2^14); hi = rn16(w), lo = rn16(w - hi).  Within a 32-wide k chunk the
 // halves are stored in MFMA operand order: position p = (m*2+h)*8 + j  <->
-// k = 16m + 8(j>>2) + 4h + (j&3)   (matches the D-layout of the on-the-fly H1).
+// k = 16m + 8(j>>2) + 4h + (j&3)   (matches the D-layout of the on-the-fly H1);
+// rows are 128 B = 8 units of 16 B: units 0-3 = hi (m,h), 4-7 = lo (m,h), XOR-swizzled (below).
 __global__ void pack_w2_f16split_kernel(const float* __restrict__ W, int k2, int k1, int K2P,
                                         int K1P, _Float16* __restrict__ out,
                                         float* __restrict__ ucol) {
@@ -126,10 +127,14 @@ __global__ void pack_w2_f16split_kernel(const float* __restrict__ W, int k2, int
         const int kc = k >> 5, kk = k & 31;
         const int mm = kk >> 4, k16 = kk & 15;
         const int jh = k16 >> 3, hh = (k16 >> 2) & 1, jl = k16 & 3;
-        const int pos = (mm * 2 + hh) * 8 + jh * 4 + jl;
+        // 16-byte unit q = (part*4 + m*2 + h) is stored at unit q ^ ((n>>1)&7): a linear (DMA) copy
+        // of the tile into LDS is then conflict-free for ds_read_b128 without row padding
+        const int sw = (nl >> 1) & 7;
+        const int uh = (mm * 2 + hh) ^ sw, ul = (4 + mm * 2 + hh) ^ sw;
+        const int j = jh * 4 + jl;
         _Float16* row = out + ((size_t)(slice * NKC + kc) * 128 + nl) * 64;
-        row[pos] = hi;
-        row[32 + pos] = lo;
+        row[uh * 8 + j] = hi;
+        row[ul * 8 + j] = lo;
     }
 }
 
