@@ -13,7 +13,11 @@ the barrier only), each rank runs its own independent sample: weak scaling, no d
 collective.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      dominant kernel = gpde_fused_kernel (edge MLP + outer-product aggregation).
+  precision     "f16split" (default): the k1 x k2 hidden layer runs on f16 MFMA with two-term
+                operand splitting and fp32 accumulation (error class of fp32, DESIGN.md §3b);
+                "f32": every contraction on fp32 MFMA (exact fmaf chains).  `alt_precision`
+                carries the other mode's throughput and the distance between the two outputs.
+  roofline      dominant kernel = gpde_fused_*kernel (edge MLP + outer-product aggregation).
                 bound 'mfma' (fp32 MFMA, 157.3 TFLOP/s): the path is compute-bound.
                 achieved = ALGORITHMIC FLOPs of the reference formulation (10,506,304 FLOP/edge at
                 1024^2) x edges per launch / average launch duration (HIP events recorded inside
@@ -47,6 +51,7 @@ CONFIGS = {
     "g16": (16, 0.15),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md
+PEAK_F16_MFMA_TFLOPS = 2500.0      # dense, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
@@ -62,12 +67,16 @@ def algorithmic_flops_per_edge(dims, w=64):
     return f + 2 * w * w + w
 
 
-def executed_flops_per_edge(dims, w=64):
-    """FLOPs the fused kernel issues per edge for a 3-Linear MLP: H1 generation
-    (K padded to 8, repeated per 128-column slice), the k1 x k2 layer, the 64 x k2 outer product."""
+def executed_flops_per_edge(dims, w=64, precision="f32"):
+    """MFMA FLOPs the fused kernel issues per edge for a 3-Linear MLP, as
+    (fp32-MFMA FLOPs, f16-MFMA FLOPs): H1 generation (K padded to 8, repeated per 128-column
+    slice) and the 64 x k2 outer product are always fp32 MFMA; the k1 x k2 layer is fp32 MFMA
+    ("f32") or 3 f16 MFMAs per product ("f16split")."""
     k1p = (dims[1] + 31) // 32 * 32
     k2p = (dims[2] + 127) // 128 * 128
-    return 2 * 8 * k1p * (k2p // 128) + 2 * k1p * k2p + 2 * w * k2p
+    side = 2 * 8 * k1p * (k2p // 128) + 2 * w * k2p
+    hidden = 2 * k1p * k2p
+    return (side + hidden, 0) if precision == "f32" else (side, 3 * hidden)
 
 
 def main():
@@ -169,12 +178,14 @@ def main():
     value = world * e / (elapsed / args.steps) / 1e6                  # M-edges/s, whole job
 
     # ---- roofline of the dominant kernel (rank 0's launches) --------------------------------------
-    f_alg, f_exe = algorithmic_flops_per_edge(dims), executed_flops_per_edge(dims)
+    f_alg = algorithmic_flops_per_edge(dims)
+    f_exe32, f_exe16 = executed_flops_per_edge(dims, precision=precision)
     n_launch = max(int(launches.value), 1)
     avg_launch_ms = fused_ms.value / n_launch
     edges_per_launch = e * args.steps / n_launch
     achieved_tf = f_alg * edges_per_launch / (avg_launch_ms * 1e-3) / 1e12
-    executed_tf = f_exe * edges_per_launch / (avg_launch_ms * 1e-3) / 1e12
+    executed_tf = f_exe32 * edges_per_launch / (avg_launch_ms * 1e-3) / 1e12
+    executed_tf16 = f_exe16 * edges_per_launch / (avg_launch_ms * 1e-3) / 1e12
     bytes_per_edge = (40.0 * e + 512.0 * n + 4.0 * sum(p.numel() for p in conv.parameters())) / e
     edges_per_s_rank = e / (elapsed / args.steps)
     traffic = None
@@ -183,23 +194,43 @@ def main():
         try:
             tj = json.load(open(tpath))
             if tj.get("config") == args.config and tj.get("kernel_width") == kw:
-                traffic = tj.get("fused_hbm_bytes_per_launch")
+                traffic = tj.get("fused_hbm_bytes_per_launch", {}).get(precision)
         except Exception:
             traffic = None
     roofline = {
-        "kernel": "gpde_fused_kernel<1>", "bound": "mfma",
+        "kernel": "gpde_fused_f16_kernel" if precision == "f16split" else "gpde_fused_kernel<1>",
+        "bound": "mfma",
         "achieved": round(achieved_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved_tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
         "avg_launch_ms": round(avg_launch_ms, 3), "launches_per_step": n_launch // args.steps,
-        "algorithmic_flop_per_edge": f_alg, "executed_flop_per_edge": f_exe,
-        "executed_tflops": round(executed_tf, 2),
-        "frac_executed": round(executed_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+        "algorithmic_flop_per_edge": f_alg,
+        "executed_f32_mfma_flop_per_edge": f_exe32, "executed_f16_mfma_flop_per_edge": f_exe16,
+        "executed_f32_mfma_tflops": round(executed_tf, 2),
+        "executed_f16_mfma_tflops": round(executed_tf16, 2),
+        # share of the matrix pipe's time the executed MFMAs need at peak rate
+        "frac_executed": round(executed_tf / PEAK_FP32_MFMA_TFLOPS + executed_tf16 / PEAK_F16_MFMA_TFLOPS, 4),
         "fused_share_of_step": round(fused_ms.value / (1e3 * elapsed), 4),
         "node_kernels_ms_per_step": round(other_ms.value / args.steps, 3),
         "hbm_algorithmic_bytes_per_edge": round(bytes_per_edge, 2),
         "hbm_achieved_GBs": round(edges_per_s_rank * bytes_per_edge / 1e9, 2),
         "hbm_frac": round(edges_per_s_rank * bytes_per_edge / 1e9 / PEAK_HBM_GBS, 6),
     }
+
+    # ---- the other arithmetic on the same inputs, one step, for reference ---------------------------
+    alt = None
+    if world == 1:
+        other = "f32" if precision == "f16split" else "f16split"
+        out_main = out.clone()
+        ops.nnconv_forward_raw(x, csr, ea, pm, conv.root, conv.bias, "mean", out=out, ws=ws, precision=other)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        ops.nnconv_forward_raw(x, csr, ea, pm, conv.root, conv.bias, "mean", out=out, ws=ws, precision=other)
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - ta
+        d = (out.double() - out_main.double()).norm() / out.double().norm()
+        alt = {"precision": other, "value": round(e / tb / 1e6, 3), "unit": "M-edges/s",
+               "rel_l2_between_precisions": float(d)}
+        out.copy_(out_main)
 
     # ---- CPU baseline + parity on a bounded sample --------------------------------------------------
     cpu = None
@@ -240,13 +271,16 @@ def main():
         "metric": "M-edges/s through fused NNConv fwd (width=64)",
         "value": round(value, 3), "unit": "M-edges/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if precision == "f32" else "f32 (hidden GEMM: 2-term f16-split MFMA, f32 accumulate)",
+        "precision": precision, "data": "synthetic",
         "config": {"workload": f"GKN Darcy-2D {s}x{s} lattice radius graph r={r} "
                                f"(N={n}, E={e} per sample), NNConv_old fwd width=64, kernel MLP "
                                f"[6,{kw},{kw},4096], aggr=mean, root+bias; one sample per GPU",
                    "graph": args.config, "edges_per_sample": e, "nodes_per_sample": n,
                    "plan": plan},
         "rel_l2_sample": rel,
+        "alt_precision": alt,
         "roofline": roofline,
         "cpu_baseline": cpu,
     }

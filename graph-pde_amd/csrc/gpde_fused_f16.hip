@@ -138,7 +138,10 @@ __global__ __launch_bounds__(256, 1) void gpde_fused_f16_kernel(GpdeFusedArgs a)
         for (int i = 0; i < GP_TE / 4; ++i)
             dma16(a.x + (size_t)sidx[i] * GP_W + (lane & 15) * 4, Xs + i * 4 * GP_W);
     };
-    const int K1 = (NKC >= 10) ? 8 : NKC - 2;     // iteration of stage B (1 <= K1 <= NKC-2)
+#ifndef GPDE_K1
+#define GPDE_K1 8
+#endif
+    const int K1 = (NKC >= GPDE_K1 + 2) ? GPDE_K1 : NKC - 2;     // iteration of stage B (1 <= K1 <= NKC-2)
 
     // ---- kernel prologue: fill the ring three chunks deep, fetch tile 0's attributes ---------------
     issue_w2(0, 0);
