@@ -43,7 +43,7 @@ struct ProfScope {
 constexpr size_t kAlign = 256;
 size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
-int num_cus() {
+int num_cus_impl() {
     static int cus = 0;
     if (cus == 0) {
         int dev = 0, v = 0;
@@ -122,7 +122,7 @@ int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws
     if (needed) *needed = off;
     // fused-kernel grid: ~one workgroup per CU, never more edge groups than 4-wave tile sets
     const int ns = L.K2P / GP_TN;
-    int groups = num_cus() / ns;
+    int groups = num_cus_impl() / ns;
     if (groups < 1) groups = 1;
     const int64_t tiles_chunk = ((E + GP_TE - 1) / GP_TE + P->n_chunks - 1) / P->n_chunks;
     const int64_t gcap = (tiles_chunk + GP_WAVES - 1) / GP_WAVES;
@@ -132,6 +132,8 @@ int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws
 }
 
 }  // namespace
+
+int gpde_num_cus() { return num_cus_impl(); }
 
 extern "C" size_t gpde_nnconv_fwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers,
                                                   const int32_t* dims) {

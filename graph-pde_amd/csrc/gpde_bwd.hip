@@ -1,0 +1,472 @@
+// Native backward of the fused NNConv.
+//
+// Replaces what autograd does in the reference on `loss.backward()`
+// (/root/reference/graph-neural-operator/UAI1_full_resolution.py:266) through
+// NNConv_old.update / message (nn_conv.py:273-282), the scatter-mean and gather of PyG's propagate
+// and the Linear/ReLU chain of DenseNet (utilities.py:223-227) — without ever forming the
+// [E,4096] per-edge weight tensor or its gradient.
+//
+// With  H_e = last hidden activation, Z_i = sum_{e->i} x_j (x) H_e, S_i = sum_{e->i} x_j,
+//       T_i = Z_i : W3 + S_i . B3,  out_i = T_i / deg_i + x_i . root + bias            (forward)
+// and g = dL/dout, gT_i = g_i / deg_i ('mean') or g_i ('add'):
+//   dbias = sum_i g_i              droot = X^T g                  dx_i += g_i . root^T
+//   dW3[c*64+o][k] = sum_i gT_i[o] Z_i[c][k]                      db3[c*64+o] = sum_i S_i[c] gT_i[o]
+//   dZ_i[c][k] = sum_o W3[c*64+o][k] gT_i[o]                      dS_i[c] = sum_o b3[c*64+o] gT_i[o]
+//   per edge e: j -> i:   dH_e = x_j . dZ_i ,   dx_j += dZ_i . H_e + dS_i
+//   then the plain MLP backward over edges: dU_l = dH_l * (H_l > 0), dW_l = dU_l^T H_{l-1},
+//   db_l = colsum dU_l, dH_{l-1} = dU_l W_l.
+//
+// Edges are processed in node-aligned chunks (host partition from rowptr_host) so that the hidden
+// activations of a chunk ([edges][k], recomputed, never saved by the forward) fit the workspace;
+// all contractions run on fp32 MFMA: gpde_gemm (dense layers, weight gradients), the mode-2 fused
+// kernel of gpde_fused.hip (Z of the chunk from the recomputed H) and gpde_edge_bwd_kernel below.
+// Weight-gradient reductions use ordered split partials (deterministic); dx_j uses fp32 atomics
+// (as the reference's scatter backward does on a GPU).
+#include "gpde_common.h"
+#include <vector>
+
+namespace {
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ---- small layout kernels ------------------------------------------------------------------------
+__global__ void k_pad_mat(const float* __restrict__ W, int rows, int cols, int ld, int rowsP, int colsP,
+                          float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rowsP * colsP) return;
+    const int c = i % colsP, r = i / colsP;
+    out[i] = (r < rows && c < cols) ? W[(size_t)r * ld + c] : 0.f;
+}
+__global__ void k_unpad_mat(const float* __restrict__ P, int rows, int cols, int ldp, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * cols) return;
+    const int c = i % cols, r = i / cols;
+    out[i] = P[(size_t)r * ldp + c];
+}
+__global__ void k_gather_attr(const float* __restrict__ attr, const int32_t* __restrict__ perm, int e0,
+                              int rows, int k0, int KP0, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * KP0) return;
+    const int d = i % KP0, r = i / KP0;
+    out[i] = (d < k0) ? attr[(size_t)perm[e0 + r] * k0 + d] : 0.f;
+}
+// gT_i = g_i / max(deg,1) ('mean') or g_i ('add'); rows with no in-edge get 0 (they have no Z)
+__global__ void k_scale_g(const float* __restrict__ g, const int32_t* __restrict__ rowptr, int aggr,
+                          int n0, int nn, float* __restrict__ gT) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= nn) return;
+    const int deg = rowptr[n0 + i + 1] - rowptr[n0 + i];
+    float v = g[(size_t)(n0 + i) * GP_W + lane];
+    if (deg == 0) v = 0.f;
+    else if (aggr == GPDE_AGGR_MEAN) v = v / (float)deg;
+    gT[(size_t)i * GP_W + lane] = v;
+}
+__global__ void k_nbr_sum(const float* __restrict__ x, const int32_t* __restrict__ rowptr,
+                          const int32_t* __restrict__ src, int n0, int nn, float* __restrict__ S) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= nn) return;
+    float s = 0.f;
+    for (int e = rowptr[n0 + i]; e < rowptr[n0 + i + 1]; ++e) s += x[(size_t)src[e] * GP_W + lane];
+    S[(size_t)i * GP_W + lane] = s;
+}
+// partial column sums: P[split][col] = sum over the split's rows of M[row][col]
+__global__ void k_colsum(const float* __restrict__ M, int rows, int cols, int ld, int splits,
+                         float* __restrict__ P) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane, split = blockIdx.y;
+    const int rps = (rows + splits - 1) / splits;
+    const int r_lo = split * rps, r_hi = min(rows, r_lo + rps);
+    float s = 0.f;
+    if (col < cols)
+        for (int r = r_lo + rg; r < r_hi; r += 4) s += M[(size_t)r * ld + col];
+    red[rg][lane] = s;
+    __syncthreads();
+    if (rg == 0 && col < cols) P[(size_t)split * cols + col] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+// ---- per-edge backward through the aggregation -----------------------------------------------------
+//   dU[e][n]  = (sum_c x_j[c] dZ_i[c][n]) * (H[e][n] > 0)
+//   dx[j][c] += sum_n dZ_i[c][n] H[e][n] + dS_i[c]                       (fp32 atomics)
+// One wave per tile of 32 CSR slots; destination segments inside a tile are handled by masking,
+// exactly like the forward aggregation.  dZ: [nodes of chunk][64][K2P].
+constexpr int EB_XS = 65, EB_HS = 129;
+struct EdgeBwdArgs {
+    const float* x; const int32_t* rowptr; const int32_t* src; const int32_t* dst;
+    const float* dZ; const float* dS; const float* H; float* dU; float* dx;
+    int e0, e1, n0, K2P;
+};
+__global__ __launch_bounds__(256) void gpde_edge_bwd_kernel(EdgeBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* Xs = smem + wave * (32 * EB_XS + 32 * EB_HS);
+    float* Hs = Xs + 32 * EB_XS;
+    const int t0 = a.e0 + (blockIdx.x * 4 + wave) * 32;
+    if (t0 >= a.e1) return;
+    const int t1 = min(t0 + 32, a.e1);
+
+    // x_j rows of the tile -> LDS (zero rows past the end)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int er = (lane >> 4) + 4 * i, e = t0 + er;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (e < t1) v = *(const f32x4*)&a.x[(size_t)a.src[e] * GP_W + (lane & 15) * 4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Xs[er * EB_XS + (lane & 15) * 4 + q] = v[q];
+    }
+    f32x16 dxa[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dxa[cb][r] = 0.f;
+
+    for (int nc = 0; nc < a.K2P; nc += 128) {
+        // H tile [32][128] -> LDS
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int f = i * 64 + lane, er = f >> 5, q4 = f & 31, e = t0 + er;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < t1) v = *(const f32x4*)&a.H[(size_t)(e - a.e0) * a.K2P + nc + q4 * 4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Hs[er * EB_HS + q4 * 4 + q] = v[q];
+        }
+        f32x16 dh[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dh[nb][r] = 0.f;
+
+        int e_seg = t0;
+        while (e_seg < t1) {
+            const int node = a.dst[e_seg];
+            const int seg_end = min(a.rowptr[node + 1], t1);
+            const float* dZi = a.dZ + (size_t)(node - a.n0) * GP_W * a.K2P + nc;
+            const bool mine = (t0 + l31 >= e_seg) && (t0 + l31 < seg_end);     // lane's edge in segment
+            // dH[e][n] += sum_c x[e][c] dZ_i[c][n]      (A = x from LDS, B = dZ_i from L2)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float av = mine ? Xs[l31 * EB_XS + c] : 0.f;
+                    const float* zp = dZi + (size_t)c * a.K2P + l31;
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) dh[nb] = mfma32(av, zp[nb * 32], dh[nb]);
+                }
+            // dXg^T[c][e] += sum_n dZ_i[c][n] H[e][n]   (A = dZ_i rows c, B = H^T from LDS)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float bv = mine ? Hs[l31 * EB_HS + n] : 0.f;
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+                        dxa[cb] = mfma32(dZi[(size_t)(cb * 32 + l31) * a.K2P + n], bv, dxa[cb]);
+                }
+            e_seg = seg_end;
+        }
+        // dU = dH * (H > 0)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int er = (r & 3) + 8 * (r >> 2) + 4 * h, e = t0 + er;
+                if (e < t1) {
+                    const float v = (Hs[er * EB_HS + nb * 32 + l31] > 0.f) ? dh[nb][r] : 0.f;
+                    a.dU[(size_t)(e - a.e0) * a.K2P + nc + nb * 32 + l31] = v;
+                }
+            }
+    }
+    // dx_j += dXg + dS_i
+    const int e = t0 + l31;
+    if (e < t1) {
+        const int j = a.src[e], node = a.dst[e];
+        const float* ds = a.dS + (size_t)(node - a.n0) * GP_W;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                atomicAdd(&a.dx[(size_t)j * GP_W + c], dxa[cb][r] + ds[c]);
+            }
+    }
+}
+
+size_t al(size_t v) { return (v + 255) / 256 * 256; }
+unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+struct BwdPlan {
+    int n_layers, nh;                 // nh = hidden layers = n_layers - 1
+    int KP[GPDE_MAX_LAYERS + 1];      // padded widths: KP[0] = pad32(k0), KP[l] = pad128(k_l), l < n_layers
+    int K2P;
+    int64_t Ec, Nc;                   // edges / nodes per chunk
+    size_t off_wp[GPDE_MAX_LAYERS], off_bp[GPDE_MAX_LAYERS], off_dwp[GPDE_MAX_LAYERS], off_dbp[GPDE_MAX_LAYERS];
+    size_t off_w3p, off_dw3p, off_b3, off_db3, off_part, part_floats;
+    size_t off_H[GPDE_MAX_LAYERS + 1], off_dU[2], off_Z, off_dZ, off_gT, off_S, off_dS;
+    size_t total;
+};
+
+int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws_bytes, bool sizing,
+                  BwdPlan* P) {
+    if (n_layers < 2 || n_layers > GPDE_MAX_LAYERS) { gpde_set_error("kernel MLP must have 2..%d Linear layers", GPDE_MAX_LAYERS); return GPDE_EUNSUPPORTED; }
+    if (dims[n_layers] != GP_W * GP_W) { gpde_set_error("last layer must emit %d values", GP_W * GP_W); return GPDE_EUNSUPPORTED; }
+    P->n_layers = n_layers; P->nh = n_layers - 1;
+    P->KP[0] = gp_round_up(dims[0], 32);
+    int kmax = 0;
+    size_t hsum = P->KP[0];
+    for (int l = 1; l < n_layers; ++l) { P->KP[l] = gp_round_up(dims[l], 128); kmax = kmax > P->KP[l] ? kmax : P->KP[l]; hsum += P->KP[l]; }
+    P->K2P = P->KP[n_layers - 1];
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off += al(floats * 4); return o; };
+    size_t wmax = 0;
+    for (int l = 1; l < n_layers; ++l) {
+        const size_t w = (size_t)P->KP[l] * P->KP[l - 1];
+        P->off_wp[l] = take(w); P->off_bp[l] = take(P->KP[l]);
+        P->off_dwp[l] = take(w); P->off_dbp[l] = take(P->KP[l]);
+        wmax = wmax > w ? wmax : w;
+    }
+    const size_t w3 = (size_t)GP_W * GP_W * P->K2P;
+    P->off_w3p = take(w3); P->off_dw3p = take(w3);
+    P->off_b3 = take(GP_W * GP_W); P->off_db3 = take(GP_W * GP_W);
+    const int max_splits = 16;
+    P->part_floats = (size_t)max_splits * (wmax > 4096 ? wmax : 4096);
+    P->off_part = take(P->part_floats);
+    const size_t fixed = off;
+    // per-chunk buffers: per edge (hsum + 2*kmax) floats, per node (2*64*K2P + 3*64) floats
+    const size_t per_edge = (hsum + 2 * (size_t)kmax) * 4, per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4;
+    int64_t Ec, Nc;
+    if (sizing) {
+        Ec = (int64_t)(((size_t)6 << 30) / per_edge); Nc = (int64_t)(((size_t)4 << 30) / per_node);
+    } else {
+        if (ws_bytes < fixed + (1 << 20)) { gpde_set_error("gpde_nnconv_bwd: workspace %zu bytes too small (%zu fixed)", ws_bytes, fixed); return GPDE_EWORKSPACE; }
+        const size_t avail = ws_bytes - fixed - 64 * 256;
+        Ec = (int64_t)(avail * 6 / 10 / per_edge); Nc = (int64_t)(avail * 4 / 10 / per_node);
+    }
+    if (Ec > E) Ec = E;
+    if (Nc > N) Nc = N;
+    if (Ec < 1) Ec = 1;
+    if (Nc < 1) Nc = 1;
+    P->Ec = Ec; P->Nc = Nc;
+    P->off_H[0] = take((size_t)Ec * P->KP[0]);
+    for (int l = 1; l < n_layers; ++l) P->off_H[l] = take((size_t)Ec * P->KP[l]);
+    P->off_dU[0] = take((size_t)Ec * kmax); P->off_dU[1] = take((size_t)Ec * kmax);
+    P->off_Z = take((size_t)Nc * GP_W * P->K2P); P->off_dZ = take((size_t)Nc * GP_W * P->K2P);
+    P->off_gT = take((size_t)Nc * GP_W); P->off_S = take((size_t)Nc * GP_W); P->off_dS = take((size_t)Nc * GP_W);
+    P->total = off + 256;
+    if (!sizing && P->total > ws_bytes) { gpde_set_error("gpde_nnconv_bwd: internal plan %zu > workspace %zu", P->total, ws_bytes); return GPDE_EWORKSPACE; }
+    return GPDE_OK;
+}
+
+GpdeGemmArgs gemm0() {
+    GpdeGemmArgs g{};
+    g.a_kcontig = 1; g.b_kcontig = 1; g.batches = 1; g.splits = 1;
+    return g;
+}
+
+// C (+)= A^T . B over `rows` rows, split-K with ordered partial reduction
+int gemm_tn_acc(const float* A, int lda, int M, const float* B, int ldb, int Ncols, int rows, float* C,
+                int ldc_dense, float* part, size_t part_floats, int accumulate, hipStream_t st) {
+    const int tiles = ((M + 127) / 128) * ((Ncols + 127) / 128);
+    int splits = 1;
+    while (splits < 16 && tiles * splits < 512 && rows / (splits * 2) >= 256) splits *= 2;
+    const size_t cn = (size_t)M * Ncols;
+    if ((size_t)splits * cn > part_floats) splits = (int)(part_floats / cn) ? (int)(part_floats / cn) : 1;
+    GpdeGemmArgs g = gemm0();
+    g.A = A; g.lda = lda; g.a_kcontig = 0; g.B = B; g.ldb = ldb; g.b_kcontig = 0;
+    g.M = M; g.N = Ncols; g.K = rows; g.ldc = Ncols;
+    (void)ldc_dense;
+    g.C = part; g.splits = splits; g.strideSplit = cn;
+    int rc = gpde_launch_gemm(g, st);
+    if (rc != GPDE_OK) return rc;
+    return gpde_launch_reduce_splits(part, cn, splits, cn, C, accumulate, st);
+}
+
+}  // namespace
+
+extern "C" size_t gpde_nnconv_bwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers,
+                                                  const int32_t* dims) {
+    BwdPlan P;
+    if (!dims || n_nodes < 0 || n_edges < 0) return 0;
+    if (make_bwd_plan(n_nodes, n_edges, n_layers, dims, 0, true, &P) != GPDE_OK) return 0;
+    return P.total;
+}
+
+extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
+                               const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                               const int32_t* perm, const int32_t* rowptr_host, int n_layers,
+                               const int32_t* dims, const float* const* W, const float* const* b,
+                               const float* root, int aggr, const float* grad_out, float* grad_x,
+                               float* const* grad_W, float* const* grad_b, float* grad_root,
+                               float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    if (n_nodes < 0 || n_edges < 0 || !dims || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws ||
+        (n_nodes > 0 && !x) || (n_edges > 0 && (!edge_attr || !src || !dst || !perm))) {
+        gpde_set_error("gpde_nnconv_bwd: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
+    BwdPlan P;
+    int rc = make_bwd_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P);
+    if (rc != GPDE_OK) return rc;
+    const int n = n_layers, K2P = P.K2P;
+    const int N = (int)n_nodes;
+    char* w = (char*)(((uintptr_t)ws + 255) / 256 * 256);
+    auto F = [&](size_t off) { return (float*)(w + off); };
+    const int T = 256;
+
+    // ---- padded weights, zeroed gradient accumulators --------------------------------------------------
+    for (int l = 1; l < n; ++l) {
+        const size_t wn = (size_t)P.KP[l] * P.KP[l - 1];
+        hipLaunchKernelGGL(k_pad_mat, dim3(nblk(wn)), dim3(T), 0, st, W[l - 1], dims[l], dims[l - 1], dims[l - 1],
+                           P.KP[l], P.KP[l - 1], F(P.off_wp[l]));
+        if (b[l - 1]) hipLaunchKernelGGL(k_pad_mat, dim3(nblk(P.KP[l])), dim3(T), 0, st, b[l - 1], 1, dims[l], dims[l], 1, P.KP[l], F(P.off_bp[l]));
+        else GP_HIP_CHECK(hipMemsetAsync(F(P.off_bp[l]), 0, (size_t)P.KP[l] * 4, st));
+        GP_HIP_CHECK(hipMemsetAsync(F(P.off_dwp[l]), 0, wn * 4, st));
+        GP_HIP_CHECK(hipMemsetAsync(F(P.off_dbp[l]), 0, (size_t)P.KP[l] * 4, st));
+    }
+    const size_t w3n = (size_t)GP_W * GP_W * K2P;
+    hipLaunchKernelGGL(k_pad_mat, dim3(nblk(w3n)), dim3(T), 0, st, W[n - 1], GP_W * GP_W, dims[n - 1], dims[n - 1],
+                       GP_W * GP_W, K2P, F(P.off_w3p));
+    if (b[n - 1]) GP_HIP_CHECK(hipMemcpyAsync(F(P.off_b3), b[n - 1], GP_W * GP_W * 4, hipMemcpyDeviceToDevice, st));
+    else GP_HIP_CHECK(hipMemsetAsync(F(P.off_b3), 0, GP_W * GP_W * 4, st));
+    GP_HIP_CHECK(hipMemsetAsync(F(P.off_dw3p), 0, w3n * 4, st));
+    GP_HIP_CHECK(hipMemsetAsync(F(P.off_db3), 0, GP_W * GP_W * 4, st));
+    if (grad_x) GP_HIP_CHECK(hipMemsetAsync(grad_x, 0, (size_t)N * GP_W * 4, st));
+    float* dx = grad_x;
+
+    // ---- node-aligned chunks ----------------------------------------------------------------------------------
+    int na = 0;
+    while (na < N && n_edges > 0) {
+        // largest nb with (nb - na) <= Nc and edges <= Ec (at least one node)
+        int lo = na + 1, hi = (int)((int64_t)na + P.Nc < N ? na + P.Nc : N);
+        const int64_t ebase = rowptr_host[na];
+        if (rowptr_host[lo] - ebase > P.Ec) {
+            gpde_set_error("gpde_nnconv_bwd: node %d has in-degree %d > %lld edges per chunk; give more workspace",
+                           na, (int)(rowptr_host[lo] - ebase), (long long)P.Ec);
+            return GPDE_EWORKSPACE;
+        }
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (rowptr_host[mid] - ebase <= P.Ec) lo = mid; else hi = mid - 1;
+        }
+        const int nb = lo, nn = nb - na;
+        const int e0 = (int)ebase, e1 = rowptr_host[nb], rows = e1 - e0;
+        float* gT = F(P.off_gT); float* S = F(P.off_S); float* dS = F(P.off_dS);
+        float* Z = F(P.off_Z); float* dZ = F(P.off_dZ);
+        hipLaunchKernelGGL(k_scale_g, dim3((nn + 3) / 4), dim3(T), 0, st, grad_out, rowptr, aggr, na, nn, gT);
+        if (rows > 0) {
+            // forward recompute of the hidden chain for the chunk's edges
+            hipLaunchKernelGGL(k_gather_attr, dim3(nblk((size_t)rows * P.KP[0])), dim3(T), 0, st, edge_attr, perm, e0,
+                               rows, dims[0], P.KP[0], F(P.off_H[0]));
+            for (int l = 1; l < n; ++l) {
+                GpdeGemmArgs g = gemm0();
+                g.A = F(P.off_H[l - 1]); g.lda = P.KP[l - 1]; g.B = F(P.off_wp[l]); g.ldb = P.KP[l - 1];
+                g.C = F(P.off_H[l]); g.ldc = P.KP[l]; g.M = rows; g.N = P.KP[l]; g.K = P.KP[l - 1];
+                g.bias = F(P.off_bp[l]); g.relu = 1;
+                if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
+            }
+            const float* Hlast = F(P.off_H[n - 1]);
+            // Z of the chunk's nodes from the recomputed activations (mode-2 fused kernel)
+            GP_HIP_CHECK(hipMemsetAsync(Z, 0, (size_t)nn * GP_W * K2P * 4, st));
+            {
+                GpdeFusedArgs f{};
+                f.x = x; f.attr = edge_attr; f.rowptr = rowptr; f.src = src; f.dst = dst; f.perm = perm;
+                f.hbuf = Hlast; f.zbuf = Z; f.k0 = dims[0]; f.K1P = 32; f.K2P = K2P;
+                f.nc0 = na; f.nc1 = nb; f.e_chunk0 = e0;
+                const int ns = K2P / GP_TN;
+                int groups = gpde_num_cus() * 2 / ns; if (groups < 1) groups = 1;
+                const int gcap = (rows / GP_TE + GP_WAVES) / GP_WAVES; if (groups > gcap) groups = gcap;
+                f.n_groups = groups;
+                if ((rc = gpde_launch_fused(2, false, f, st)) != GPDE_OK) return rc;
+            }
+            hipLaunchKernelGGL(k_nbr_sum, dim3((nn + 3) / 4), dim3(T), 0, st, x, rowptr, src, na, nn, S);
+            // db3[c][o] += S^T gT ;  dW3[c][o][k] += gT^T Z[:, c, :]
+            if ((rc = gemm_tn_acc(S, GP_W, GP_W, gT, GP_W, GP_W, nn, F(P.off_db3), GP_W, F(P.off_part), P.part_floats, 1, st)) != GPDE_OK) return rc;
+            {
+                GpdeGemmArgs g = gemm0();
+                g.A = gT; g.lda = GP_W; g.a_kcontig = 0; g.B = Z; g.ldb = GP_W * K2P; g.b_kcontig = 0;
+                g.C = F(P.off_dw3p); g.ldc = K2P; g.M = GP_W; g.N = K2P; g.K = nn; g.accumulate = 1;
+                g.batches = GP_W; g.strideA = 0; g.strideB = K2P; g.strideC = (size_t)GP_W * K2P;
+                if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
+            }
+            // dZ[i][c][k] = sum_o gT[i][o] W3[c*64+o][k] ;  dS[i][c] = sum_o gT[i][o] b3[c*64+o]
+            {
+                GpdeGemmArgs g = gemm0();
+                g.A = gT; g.lda = GP_W; g.B = F(P.off_w3p); g.ldb = K2P; g.b_kcontig = 0;
+                g.C = dZ; g.ldc = GP_W * K2P; g.M = nn; g.N = K2P; g.K = GP_W;
+                g.batches = GP_W; g.strideA = 0; g.strideB = (size_t)GP_W * K2P; g.strideC = K2P;
+                if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
+                GpdeGemmArgs s2 = gemm0();
+                s2.A = gT; s2.lda = GP_W; s2.B = F(P.off_b3); s2.ldb = GP_W; s2.C = dS; s2.ldc = GP_W;
+                s2.M = nn; s2.N = GP_W; s2.K = GP_W;
+                if ((rc = gpde_launch_gemm(s2, st)) != GPDE_OK) return rc;
+            }
+            // per-edge backward through the aggregation -> dU_{n-1}, dx_j
+            float* dUc = F(P.off_dU[0]); float* dUo = F(P.off_dU[1]);
+            {
+                EdgeBwdArgs ea{x, rowptr, src, dst, dZ, dS, Hlast, dUc, dx, e0, e1, na, K2P};
+                const size_t lds = (size_t)4 * (32 * EB_XS + 32 * EB_HS) * 4;
+                static bool set = false;
+                if (!set) { GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_edge_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+                if (dx) hipLaunchKernelGGL(gpde_edge_bwd_kernel, dim3((rows + 127) / 128), dim3(T), lds, st, ea);
+                else { gpde_set_error("gpde_nnconv_bwd: grad_x must be provided"); return GPDE_EINVAL; }
+            }
+            // MLP backward over the chunk's edges
+            for (int l = n - 1; l >= 1; --l) {
+                const int Kl = P.KP[l], Kin = P.KP[l - 1];
+                if ((rc = gemm_tn_acc(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, F(P.off_dwp[l]), Kin,
+                                      F(P.off_part), P.part_floats, 1, st)) != GPDE_OK) return rc;
+                {
+                    int splits = 1; while (splits < 64 && (Kl / 64) * splits < 512 && rows / (splits * 2) >= 64) splits *= 2;
+                    if ((size_t)splits * Kl > P.part_floats) splits = 1;
+                    hipLaunchKernelGGL(k_colsum, dim3((Kl + 63) / 64, splits), dim3(T), 0, st, dUc, rows, Kl, Kl, splits, F(P.off_part));
+                    if ((rc = gpde_launch_reduce_splits(F(P.off_part), Kl, splits, Kl, F(P.off_dbp[l]), 1, st)) != GPDE_OK) return rc;
+                }
+                if (l > 1) {
+                    GpdeGemmArgs g = gemm0();
+                    g.A = dUc; g.lda = Kl; g.B = F(P.off_wp[l]); g.ldb = Kin; g.b_kcontig = 0;
+                    g.C = dUo; g.ldc = Kin; g.M = rows; g.N = Kin; g.K = Kl;
+                    g.mask = F(P.off_H[l - 1]); g.ldmask = Kin;
+                    if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
+                    float* t = dUc; dUc = dUo; dUo = t;
+                }
+            }
+        }
+        na = nb;
+    }
+    GP_LAUNCH_CHECK("gpde_nnconv_bwd kernels");
+
+    // ---- node-side terms of update(): dx += g root^T, droot = X^T g, dbias = colsum g ----------------------
+    if (root && dx) {
+        GpdeGemmArgs g = gemm0();
+        g.A = grad_out; g.lda = GP_W; g.B = root; g.ldb = GP_W; g.C = dx; g.ldc = GP_W;
+        g.M = N; g.N = GP_W; g.K = GP_W; g.accumulate = 1;
+        if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
+    }
+    if (grad_root)
+        if ((rc = gemm_tn_acc(x, GP_W, GP_W, grad_out, GP_W, GP_W, N, grad_root, GP_W, F(P.off_part), P.part_floats, 0, st)) != GPDE_OK) return rc;
+    if (grad_bias) {
+        int splits = 1; while (splits < 64 && N / (splits * 2) >= 64) splits *= 2;
+        hipLaunchKernelGGL(k_colsum, dim3(1, splits), dim3(T), 0, st, grad_out, N, GP_W, GP_W, splits, F(P.off_part));
+        if ((rc = gpde_launch_reduce_splits(F(P.off_part), GP_W, splits, GP_W, grad_bias, 0, st)) != GPDE_OK) return rc;
+    }
+    // ---- un-pad the weight gradients into torch layout -------------------------------------------------------
+    for (int l = 1; l < n; ++l) {
+        if (grad_W && grad_W[l - 1])
+            hipLaunchKernelGGL(k_unpad_mat, dim3(nblk((size_t)dims[l] * dims[l - 1])), dim3(T), 0, st, F(P.off_dwp[l]),
+                               dims[l], dims[l - 1], P.KP[l - 1], grad_W[l - 1]);
+        if (grad_b && grad_b[l - 1])
+            GP_HIP_CHECK(hipMemcpyAsync(grad_b[l - 1], F(P.off_dbp[l]), (size_t)dims[l] * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if (grad_W && grad_W[n - 1])
+        hipLaunchKernelGGL(k_unpad_mat, dim3(nblk((size_t)GP_W * GP_W * dims[n - 1])), dim3(T), 0, st, F(P.off_dw3p),
+                           GP_W * GP_W, dims[n - 1], K2P, grad_W[n - 1]);
+    if (grad_b && grad_b[n - 1])
+        GP_HIP_CHECK(hipMemcpyAsync(grad_b[n - 1], F(P.off_db3), GP_W * GP_W * 4, hipMemcpyDeviceToDevice, st));
+    GP_LAUNCH_CHECK("gpde_nnconv_bwd epilogue kernels");
+    return GPDE_OK;
+}

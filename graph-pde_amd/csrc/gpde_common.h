@@ -126,3 +126,22 @@ struct GpdeDenseArgs {
     int rows; int relu;
 };
 int gpde_launch_dense(const GpdeDenseArgs& a, hipStream_t stream);
+
+// general fp32 MFMA GEMM (gpde_gemm.hip): C = op(A).op(B) with optional bias / relu / relu-mask,
+// batching (grid.z) and split-K partial outputs
+struct GpdeGemmArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int a_kcontig, b_kcontig;       // 1: operand stored [row][k] ; 0: stored [k][row]
+    const float* bias;              // [N] or nullptr
+    int relu;
+    const float* mask; int ldmask;  // C = (mask > 0) ? C : 0
+    int accumulate;                 // C += result (after bias/relu/mask)
+    int batches; size_t strideA, strideB, strideC;
+    int splits; size_t strideSplit; // split-K: partial s written at C + s*strideSplit
+};
+int gpde_launch_gemm(const GpdeGemmArgs& g, hipStream_t stream);
+int gpde_launch_reduce_splits(const float* P, size_t n, int splits, size_t stride, float* C,
+                              int accumulate, hipStream_t stream);
+int gpde_num_cus();

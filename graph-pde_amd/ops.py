@@ -30,6 +30,15 @@ class Csr:
     src: torch.Tensor      # int32 [E]  source node of each CSR slot
     dst: torch.Tensor      # int32 [E]  target node of each CSR slot (sorted ascending)
     perm: torch.Tensor     # int32 [E]  CSR slot -> original edge id (stable within a target)
+    _rowptr_host: Optional[torch.Tensor] = None
+
+    @property
+    def rowptr_host(self) -> torch.Tensor:
+        """Host copy of rowptr (int32, pinned lifetime = the CSR): the backward plans its edge
+        chunks on the host.  One device->host copy per graph."""
+        if self._rowptr_host is None:
+            self._rowptr_host = self.rowptr.cpu().contiguous()
+        return self._rowptr_host
 
 
 def _stream_ptr(device) -> int:
@@ -252,3 +261,55 @@ def launch_plan(n_nodes: int, n_edges: int, pm: PackedMlp, ws_bytes: int):
     _lib.check(rc, "gpde_nnconv_fwd_plan")
     return {"n_chunks": nch.value, "nodes_per_chunk": npc.value, "fused_workgroups": wgs.value,
             "mode": mode.value}
+
+
+# ----------------------------------------------------------------------------------------------
+# backward
+# ----------------------------------------------------------------------------------------------
+def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
+                        weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
+                        root: Optional[torch.Tensor], aggr: str, grad_out: torch.Tensor,
+                        need_root: bool = True, need_bias: bool = True,
+                        ws: Optional[torch.Tensor] = None):
+    """One gpde_nnconv_bwd call on the current stream.
+    Returns (grad_x, [grad_W_l], [grad_b_l or None], grad_root or None, grad_bias or None)."""
+    lib = _lib.lib()
+    for t, nm in ((x, "x"), (edge_attr, "edge_attr"), (grad_out, "grad_out")):
+        _require_cuda(t, nm)
+    if aggr not in _AGGR:
+        raise NotImplementedError(f"aggr={aggr!r}")
+    n, e, dev = csr.n_nodes, csr.n_edges, x.device
+    nl = len(weights)
+    dims = [int(weights[0].size(1))] + [int(w.size(0)) for w in weights]
+    dims_c = _lib.dims_array(dims)
+    x = x.detach().contiguous()
+    edge_attr = edge_attr.detach().contiguous()
+    grad_out = grad_out.detach().contiguous().float()
+    ws_ = [w.detach().contiguous() for w in weights]
+    bs_ = [None if b is None else b.detach().contiguous() for b in biases]
+    root_c = None if root is None else root.detach().contiguous()
+    gx = torch.empty(n, WIDTH, dtype=torch.float32, device=dev)
+    gW = [torch.empty_like(w) for w in ws_]
+    gb = [None if b is None else torch.empty_like(b) for b in bs_]
+    groot = torch.empty(WIDTH, WIDTH, dtype=torch.float32, device=dev) if (need_root and root is not None) else None
+    gbias = torch.empty(WIDTH, dtype=torch.float32, device=dev) if need_bias else None
+    P = ctypes.c_void_p
+    arr = lambda ts: (P * nl)(*[None if t is None else t.data_ptr() for t in ts])
+    if ws is None:
+        nbytes = int(lib.gpde_nnconv_bwd_workspace_bytes(n, e, nl, dims_c))
+        if nbytes == 0:
+            _lib.check(-2, "gpde_nnconv_bwd_workspace_bytes")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    rph = csr.rowptr_host
+    with torch.cuda.device(dev):
+        rc = lib.gpde_nnconv_bwd(x.data_ptr(), n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(),
+                                 csr.src.data_ptr(), csr.dst.data_ptr(), csr.perm.data_ptr(),
+                                 rph.data_ptr(), nl, dims_c, arr(ws_), arr(bs_),
+                                 None if root_c is None else root_c.data_ptr(), _AGGR[aggr],
+                                 grad_out.data_ptr(), gx.data_ptr(), arr(gW), arr(gb),
+                                 None if groot is None else groot.data_ptr(),
+                                 None if gbias is None else gbias.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "gpde_nnconv_bwd")
+    _lib.n_native_calls += 1
+    return gx, gW, gb, groot, gbias

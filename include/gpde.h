@@ -119,6 +119,26 @@ int gpde_nnconv_fwd_plan(int64_t n_nodes, int64_t n_edges, int n_layers, const i
                          size_t ws_bytes, int32_t* n_chunks, int64_t* nodes_per_chunk,
                          int32_t* fused_workgroups, int32_t* mode);
 
+/* ---------------------------------------------------------------------------------------------
+ * Backward of the fused NNConv (what autograd computes through nn_conv.py:267-282,
+ * utilities.py:223-227 and PyG's gather/scatter on `loss.backward()`,
+ * UAI1_full_resolution.py:266).  Given grad_out = dL/d(out) [N][64] it writes (overwrites)
+ *   grad_x [N][64], grad_W[l] [dims[l+1]][dims[l]], grad_b[l] [dims[l+1]] (torch layouts; entries
+ *   or whole arrays may be NULL to skip), grad_root [64][64], grad_bias [64] (NULL to skip).
+ * W, b, grad_W, grad_b are HOST arrays of device pointers; rowptr_host is a HOST copy of rowptr
+ * (the edge chunks are planned on the host).  Hidden activations are recomputed per node-aligned
+ * chunk of edges; nothing from the forward needs to be saved.  Edge-attribute gradients are not
+ * produced (the reference never asks for them).  fp32 MFMA throughout. */
+size_t gpde_nnconv_bwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers,
+                                       const int32_t* dims);
+int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
+                    const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                    const int32_t* perm, const int32_t* rowptr_host, int n_layers,
+                    const int32_t* dims, const float* const* W, const float* const* b,
+                    const float* root, int aggr, const float* grad_out, float* grad_x,
+                    float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias,
+                    void* ws, size_t ws_bytes, void* stream);
+
 /* HIP-event timing of the kernels launched by gpde_nnconv_fwd on the calling thread (used by
  * bench.py for the roofline figure; events are recorded on the same stream as the kernels).
  * gpde_profile_begin() arms it; gpde_profile_end() disarms it, SYNCHRONISES on the recorded

@@ -200,3 +200,115 @@ def test_f16split_wide_dynamic_range():
     e16, e32 = rel_l2(y16, y64), rel_l2(y32, y64)
     assert torch.isfinite(y16).all()
     assert e16 <= TOL and e16 <= 4 * e32 + 2e-7, (e16, e32)
+
+
+def _oracle_grads(x, ei, ea, ws_, bs_, root, bias, aggr, gout):
+    """float64 autograd through the CPU oracle = the reference's backward."""
+    xs = x.double().requires_grad_(True)
+    Ws = [w.double().requires_grad_(True) for w in ws_]
+    Bs = [b.double().requires_grad_(True) for b in bs_]
+    r = None if root is None else root.double().requires_grad_(True)
+    bb = None if bias is None else bias.double().requires_grad_(True)
+    src, dst = ei[0], ei[1]
+    h = ea.double()
+    for l in range(len(Ws)):
+        h = torch.nn.functional.linear(h, Ws[l], Bs[l])
+        if l != len(Ws) - 1:
+            h = torch.relu(h)
+    m = torch.matmul(xs[src].unsqueeze(1), h.view(-1, 64, 64)).squeeze(1)
+    out = torch.zeros(x.shape[0], 64, dtype=torch.float64).index_add(0, dst, m)
+    if aggr == "mean":
+        out = out / torch.bincount(dst, minlength=x.shape[0]).clamp(min=1).double().unsqueeze(1)
+    if r is not None:
+        out = out + xs @ r
+    if bb is not None:
+        out = out + bb
+    (out * gout.double()).sum().backward()
+    return xs.grad, [w.grad for w in Ws], [b.grad for b in Bs], None if r is None else r.grad, None if bb is None else bb.grad
+
+
+@pytest.mark.parametrize("dims,aggr,use_root,use_bias", [
+    ([6, 40, 72, 4096], "mean", True, True),            # 3 Linear layers, non-tile widths
+    ([6, 48, 4096], "mean", False, False),              # 2 Linear layers (MGKN inter-level)
+    ([4, 24, 40, 56, 4096], "add", True, True),         # 4 Linear layers, Burgers attributes
+])
+def test_backward_against_reference_autograd(dims, aggr, use_root, use_bias):
+    """gpde_nnconv_bwd vs float64 autograd through the oracle (the reference's loss.backward())."""
+    d = dev()
+    torch.manual_seed(100 + sum(dims))
+    n, e = 300, 6000
+    ei = torch.stack([torch.randint(0, n, (e,)), torch.randint(0, n - 15, (e,))])
+    ei[1, :500] = 11                                       # one node spanning many tiles
+    ea, x = torch.randn(e, dims[0]), torch.randn(n, 64)
+    mlp = torch.nn.Sequential(*sum([[torch.nn.Linear(dims[i], dims[i + 1]), torch.nn.ReLU()]
+                                    for i in range(len(dims) - 1)], [])[:-1])
+    ws_ = [l.weight.detach() for l in mlp if isinstance(l, torch.nn.Linear)]
+    bs_ = [l.bias.detach() for l in mlp if isinstance(l, torch.nn.Linear)]
+    root = torch.empty(64, 64).uniform_(-0.125, 0.125) if use_root else None
+    bias = torch.empty(64).uniform_(-0.125, 0.125) if use_bias else None
+    gout = torch.randn(n, 64)
+    rx, rW, rb, rroot, rbias = _oracle_grads(x, ei, ea, ws_, bs_, root, bias, aggr, gout)
+    csr = ops.build_csr(ei.to(d), n)
+    gx, gW, gb, groot, gbias = ops.nnconv_backward_raw(
+        x.to(d), csr, ea.to(d), [w.to(d) for w in ws_], [b.to(d) for b in bs_],
+        None if root is None else root.to(d), aggr, gout.to(d), need_root=use_root, need_bias=use_bias)
+    torch.cuda.synchronize()
+    tol = 2e-5
+    assert rel_l2(gx.cpu(), rx) <= tol, ("dx", rel_l2(gx.cpu(), rx))
+    for l in range(len(ws_)):
+        assert rel_l2(gW[l].cpu(), rW[l]) <= tol, (f"dW{l}", rel_l2(gW[l].cpu(), rW[l]))
+        assert rel_l2(gb[l].cpu(), rb[l]) <= tol, (f"db{l}", rel_l2(gb[l].cpu(), rb[l]))
+    if use_root:
+        assert rel_l2(groot.cpu(), rroot) <= tol
+    if use_bias:
+        assert rel_l2(gbias.cpu(), rbias) <= tol
+
+
+def test_module_training_step_matches_reference():
+    """loss.backward() + Adam step through the drop-in module (what the GKN scripts do,
+    UAI1_full_resolution.py:258-273) vs the same step on the float64 oracle."""
+    from tests.test_host_logic import DenseNet
+    d = dev()
+    torch.manual_seed(7)
+    ei, ea, n = synth.darcy_graph(12, 0.2)
+    x0 = torch.randn(n, 64)
+    conv = gp.NNConv_old(64, 64, DenseNet([6, 32, 64, 4096], torch.nn.ReLU), aggr="mean")
+    lin = ops.mlp_linears(conv.nn)
+    ws_ = [l.weight.detach().clone() for l in lin]
+    bs_ = [l.bias.detach().clone() for l in lin]
+    root, bias = conv.root.detach().clone(), conv.bias.detach().clone()
+    y = torch.randn(n, 64)
+    conv = conv.to(d)
+    xg = x0.to(d).requires_grad_(True)
+    out = conv(xg, ei.to(d), ea.to(d))
+    out2 = conv(torch.relu(out), ei.to(d), ea.to(d))       # depth 2 with shared weights (UAI1:29-30)
+    loss = ((out2 - y.to(d)) ** 2).mean()
+    loss.backward()
+    # reference: same graph in float64 autograd
+    xs = x0.double().requires_grad_(True)
+    Ws = [w.double().requires_grad_(True) for w in ws_]
+    Bs = [b.double().requires_grad_(True) for b in bs_]
+    r, bb = root.double().requires_grad_(True), bias.double().requires_grad_(True)
+
+    def ref_conv(xin):
+        h = ea.double()
+        for l in range(3):
+            h = torch.nn.functional.linear(h, Ws[l], Bs[l])
+            if l != 2:
+                h = torch.relu(h)
+        m = torch.matmul(xin[ei[0]].unsqueeze(1), h.view(-1, 64, 64)).squeeze(1)
+        o = torch.zeros(n, 64, dtype=torch.float64).index_add(0, ei[1], m)
+        o = o / torch.bincount(ei[1], minlength=n).clamp(min=1).double().unsqueeze(1)
+        return o + xin @ r + bb
+    lref = ((ref_conv(torch.relu(ref_conv(xs))) - y.double()) ** 2).mean()
+    lref.backward()
+    assert abs(float(loss) - float(lref)) <= 1e-5 * abs(float(lref))
+    assert rel_l2(xg.grad.cpu(), xs.grad) <= 2e-5
+    assert rel_l2(conv.root.grad.cpu(), r.grad) <= 2e-5 and rel_l2(conv.bias.grad.cpu(), bb.grad) <= 2e-5
+    for l, k in enumerate((0, 2, 4)):
+        assert rel_l2(conv.nn.layers[k].weight.grad.cpu(), Ws[l].grad) <= 2e-5, l
+        assert rel_l2(conv.nn.layers[k].bias.grad.cpu(), Bs[l].grad) <= 2e-5, l
+    opt = torch.optim.Adam(conv.parameters(), lr=1e-3, weight_decay=5e-4)
+    opt.step()                                              # parameters updated in place -> repack
+    with torch.no_grad():
+        conv(x0.to(d), ei.to(d), ea.to(d))
