@@ -1,0 +1,140 @@
+"""Model-level GPU tests: the reference's model classes (restated from the scripts, which cannot be
+imported on the GPU box) running on the drop-in operator through the import shims."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIMS = os.path.join(REPO, "graph-pde_amd", "shims")
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def shims():
+    sys.path.insert(0, SHIMS)
+    import nn_conv                                   # noqa: F401  (the shim module)
+    from torch_geometric.data import Data, DataLoader
+    from torch_geometric.nn import NNConv
+    yield {"nn_conv": nn_conv, "Data": Data, "DataLoader": DataLoader, "NNConv": NNConv}
+    sys.path.remove(SHIMS)
+
+
+class DenseNet(torch.nn.Module):                     # utilities.py:201-227
+    def __init__(self, layers, nonlinearity):
+        super().__init__()
+        self.layers = torch.nn.ModuleList()
+        for j in range(len(layers) - 1):
+            self.layers.append(torch.nn.Linear(layers[j], layers[j + 1]))
+            if j != len(layers) - 2:
+                self.layers.append(nonlinearity())
+
+    def forward(self, x):
+        for l in self.layers:
+            x = l(x)
+        return x
+
+
+def make_kernelnn(nn_conv, width, ker_width, depth, ker_in, in_width):
+    class KernelNN(torch.nn.Module):                 # UAI1_full_resolution.py:14-33
+        def __init__(self):
+            super().__init__()
+            self.depth = depth
+            self.fc1 = torch.nn.Linear(in_width, width)
+            kernel = DenseNet([ker_in, ker_width, ker_width, width ** 2], torch.nn.ReLU)
+            self.conv1 = nn_conv.NNConv_old(width, width, kernel, aggr="mean")
+            self.fc2 = torch.nn.Linear(width, 1)
+
+        def forward(self, data):
+            x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
+            x = self.fc1(x)
+            for k in range(self.depth):
+                x = F.relu(self.conv1(x, edge_index, edge_attr))
+            return self.fc2(x)
+    return KernelNN()
+
+
+def test_kernelnn_training_loop_through_shims(shims):
+    """GKN training as UAI1_full_resolution.py:242-273 does it: PyG DataLoader batches (batch_size 2
+    -> edge_index offset by the collation rule), model(batch), L1-norm loss, backward, Adam."""
+    from graph_pde_amd import synth, _lib
+    d = torch.device("cuda:0")
+    torch.manual_seed(0)
+    Data, DataLoader = shims["Data"], shims["DataLoader"]
+    data = []
+    for j in range(4):
+        ei, ea, n = synth.darcy_graph(12, 0.2, seed=j)
+        a = synth.darcy_coefficient(12, j)
+        xin = torch.cat([synth.lattice_positions(12).float(), a.view(-1, 1), torch.randn(n, 3)], dim=1)
+        data.append(Data(x=xin, y=torch.sin(3 * a), edge_index=ei, edge_attr=ea))
+    loader = DataLoader(data, batch_size=2, shuffle=False)
+    model = make_kernelnn(shims["nn_conv"], 64, 64, 3, 6, 6).to(d)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3, weight_decay=5e-4)
+    calls = _lib.n_native_calls
+    losses = []
+    for ep in range(6):
+        tot = 0.0
+        for batch in loader:
+            batch = batch.to(d)
+            opt.zero_grad()
+            out = model(batch)
+            loss = torch.norm(out.view(-1) - batch.y.view(-1), 1)
+            loss.backward()
+            opt.step()
+            tot += loss.item()
+        losses.append(tot)
+    assert _lib.n_native_calls > calls
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    assert losses[-1] < 0.9 * losses[0], losses
+    # whole-model pickle round trip (UAI1:317) and evaluation of an un-batched sample (UAI1:328-331)
+    import io
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)
+    with torch.no_grad():
+        a_, b_ = model(data[0].to(d)), m2(data[0].to(d))
+    assert torch.equal(a_, b_)
+
+
+def test_mgkn_vcycle_slice_pattern(shims):
+    """The MGKN-general forward pattern (MGKN_general_darcy2d.py:76-90): strided edge_index views,
+    index shifting, in-place slice assignment around the operator, residual + ReLU, autograd."""
+    from graph_pde_amd import synth
+    d = torch.device("cuda:0")
+    torch.manual_seed(1)
+    NNConv = shims["NNConv"]
+    m = [300, 120, 40]
+    g = synth.sampled_multilevel_graphs(61, m, [0.12, 0.2, 0.4], [0.15, 0.3])
+    offs = [0, 300, 420, 460]
+    ei_mid = torch.cat([g["inner"][l][0] + offs[l] for l in range(3)], dim=1).to(d)
+    ea_mid = torch.cat([g["inner"][l][1] for l in range(3)], dim=0).to(d)
+    rng_mid = [0]
+    for l in range(3):
+        rng_mid.append(rng_mid[-1] + g["inner"][l][0].shape[1])
+    ei_down = torch.cat([torch.stack([g["down"][l][0][0] + offs[l], g["down"][l][0][1] + offs[l + 1]])
+                         for l in range(2)], dim=1).to(d)
+    ea_down = torch.cat([g["down"][l][1] for l in range(2)], dim=0).to(d)
+    rng_down = [0, g["down"][0][0].shape[1], g["down"][0][0].shape[1] + g["down"][1][0].shape[1]]
+    convs_mid = torch.nn.ModuleList([NNConv(64, 64, DenseNet([6, 64 >> l if l else 64, 64, 4096], torch.nn.ReLU),
+                                            aggr="mean", root_weight=True, bias=False) for l in range(3)]).to(d)
+    convs_down = torch.nn.ModuleList([NNConv(64, 64, DenseNet([6, 32, 4096], torch.nn.ReLU), aggr="mean",
+                                             root_weight=False, bias=False) for l in range(2)]).to(d)
+    fc = torch.nn.Linear(6, 64).to(d)
+    x = fc(torch.randn(460, 6, device=d))
+    for l in range(2):                                   # downward
+        x = x + convs_down[l](x, ei_down[:, rng_down[l]:rng_down[l + 1]], ea_down[rng_down[l]:rng_down[l + 1]])
+        x = F.relu(x)
+    for l in reversed(range(3)):                         # inner, in place on the level's node range
+        a, b = offs[l], offs[l + 1]
+        x = x.clone()
+        x[a:b] = convs_mid[l](x[a:b].clone(), ei_mid[:, rng_mid[l]:rng_mid[l + 1]] - a,
+                              ea_mid[rng_mid[l]:rng_mid[l + 1]])
+    loss = x[:300].pow(2).mean()
+    loss.backward()
+    params = list(convs_mid.parameters()) + list(convs_down.parameters()) + list(fc.parameters())
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+    assert float(fc.weight.grad.abs().sum()) > 0

@@ -312,3 +312,70 @@ def test_module_training_step_matches_reference():
     opt.step()                                              # parameters updated in place -> repack
     with torch.no_grad():
         conv(x0.to(d), ei.to(d), ea.to(d))
+
+
+def _dense(dims):
+    from tests.test_host_logic import DenseNet
+    return DenseNet(dims, torch.nn.ReLU)
+
+
+def _check_module(conv, x, ei, ea, tol=TOL):
+    d = dev()
+    lin = ops.mlp_linears(conv.nn)
+    ws_ = [l.weight.detach().cpu() for l in lin]
+    bs_ = [l.bias.detach().cpu() for l in lin]
+    root = None if conv.root is None else conv.root.detach().cpu()
+    bias = None if conv.bias is None else conv.bias.detach().cpu()
+    conv = conv.to(d)
+    with torch.no_grad():
+        y = conv(x.to(d), ei.to(d), ea.to(d)).cpu()
+    y64 = nnconv_forward(x, ei, ea, ws_, bs_, root, bias, aggr=conv.aggr, dtype=torch.float64,
+                         chunk_edges=8192)
+    err = rel_l2(y, y64)
+    assert err <= tol, err
+    return err
+
+
+def test_mgkn_orthogonal_burgers_shapes():
+    """BASELINE config 3: MGKN-orthogonal Burgers, s = 8192: one NNConv per multipole level with
+    kernel DenseNet([4, kl, kl, 4096]), kl = max(1024 // 2^l, 16), aggr='mean', root + bias
+    (MGKN_orthogonal_burgers1d.py:33-37, 74-82) on the restated multi_pole_grid1d graphs."""
+    torch.manual_seed(21)
+    graphs = synth.burgers_multipole_graphs(8192)
+    assert len(graphs) == 13
+    for l in (0, 1, 2, 5, 9, 12):
+        ei, ea, n = graphs[l]
+        kl = max(1024 // (2 ** l), 16)
+        conv = gp.NNConv(64, 64, _dense([4, kl, kl, 4096]), aggr="mean")
+        _check_module(conv, torch.randn(n, 64), ei, ea)
+
+
+def test_mgkn_general_darcy_shapes():
+    """BASELINE config 4 graph family: multi-level sampled radius graphs (m = [2400,1600,400,100,25],
+    radii of neurips1_MGKN.py:112-114) with the MKGN kernels: inner K_ll = DenseNet([6,kl,kl,4096])
+    (root, no bias), inter-level K_{l,l+1} / K_{l+1,l} = DenseNet([6,kl,4096]) (no root, no bias),
+    kl = 256 // 2^l (MGKN_general_darcy2d.py:41-61), inter graphs on the shared node index space."""
+    torch.manual_seed(22)
+    m = [2400, 1600, 400, 100, 25]
+    g = synth.sampled_multilevel_graphs(141, m, [0.5 / 8 * 1.41, 0.5 / 8, 0.5 / 4, 0.5 / 2, 0.5],
+                                        [0.5 / 8 * 1.1, 0.5 / 8 * 1.41, 0.5 / 4 * 1.41, 0.5 / 2 * 1.41])
+    offs = [0]
+    for ml in m:
+        offs.append(offs[-1] + ml)
+    ntot = offs[-1]
+    xall = torch.randn(ntot, 64)
+    for l in (0, 2, 4):
+        ei, ea, n, _ = g["inner"][l]
+        kl = 256 // (2 ** l)
+        conv = gp.NNConv(64, 64, _dense([6, kl, kl, 4096]), aggr="mean", root_weight=True, bias=False)
+        _check_module(conv, xall[offs[l]:offs[l + 1]].clone(), ei, ea)
+    for l in (0, 3):
+        kl = 256 // (2 ** l)
+        ei, ea, _, _ = g["down"][l]
+        ei = torch.stack([ei[0] + offs[l], ei[1] + offs[l + 1]])
+        conv = gp.NNConv(64, 64, _dense([6, kl, 4096]), aggr="mean", root_weight=False, bias=False)
+        _check_module(conv, xall, ei, ea)
+        ei, ea, _, _ = g["up"][l]
+        ei = torch.stack([ei[0] + offs[l + 1], ei[1] + offs[l]])
+        conv = gp.NNConv(64, 64, _dense([6, kl, 4096]), aggr="mean", root_weight=False, bias=False)
+        _check_module(conv, xall, ei, ea)
