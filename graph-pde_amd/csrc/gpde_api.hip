@@ -219,13 +219,15 @@ extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edg
             f.x = x; f.attr = edge_attr; f.rowptr = rowptr; f.src = src; f.dst = dst; f.perm = perm;
             f.w1 = pk + L.off_w1; f.w2t = pk + L.off_w2t; f.b2 = pk + L.off_b2;
             f.w2h = pk + L.off_w2h; f.ucol = pk + L.off_ucol;
+            f.w1h = pk + L.off_w1h; f.fcol = pk + L.off_fcol;
             f.hbuf = hfinal; f.zbuf = zbuf;
             f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
             f.nc0 = (int)nc0; f.nc1 = (int)nc1; f.e_chunk0 = 0; f.n_groups = P.n_groups;
             {
                 ProfScope ps(0, stream);
                 const bool f16s = (flags & GPDE_FWD_F16SPLIT) != 0 && L.mode == 1;
-                if (f16s && gpde_fused_f16_supported(f)) rc = gpde_launch_fused_f16(f, stream);
+                if (f16s && !(flags & GPDE_FWD_F16SPLIT_4WAVE) && gpde_fused_f16v3_supported(f)) rc = gpde_launch_fused_f16v3(f, stream);
+                else if (f16s && gpde_fused_f16_supported(f)) rc = gpde_launch_fused_f16(f, stream);
                 else rc = gpde_launch_fused(L.mode, f16s, f, stream);
             }
             if (rc != GPDE_OK) return rc;

@@ -36,6 +36,8 @@ struct GpdePackLayout {
     size_t off_w2h;  // f16-split W2 tiles [K2P/128][K1P/32][128][2 parts][32] halves, rows scaled
                      // by 2^t_n (mode 1); same byte size as off_w2t
     size_t off_ucol; // [K2P] 2^-t_n per hidden column                            (mode 1)
+    size_t off_w1h;  // [K1P][hi 8 halves | lo 8 halves]: (W1|b1) columns scaled by 2^u_d, f16 split (mode 1)
+    size_t off_fcol; // [8] 2^-u_d per input slot (0 for an all-zero column)      (mode 1)
     size_t off_w3q;  // [64 c][K2P/4][64 o][4]  last Linear, re-associated order
     size_t off_b3;   // [64 c][64 o]            last Linear bias as a 64x64 matrix (zeros if none)
     size_t off_front;// mode 2: per front layer l: W [KP(l+1)][KP(l)] zero padded, then b [KP(l+1)]
@@ -82,6 +84,8 @@ struct GpdeFusedArgs {
     const float* b2;
     const void* w2h;       // f16-split W2 tiles (mode 1, GPDE_FWD_F16SPLIT)
     const float* ucol;     // [K2P] 2^-t_n
+    const void* w1h;       // f16-split (W1|b1) image, column-scaled
+    const float* fcol;     // [8] per-input-slot 2^-u_d
     const float* hbuf;     // mode 2: [edges of chunk][K2P] in CSR order, relu already applied
     float* zbuf;           // [nc1-nc0][64][K2P]
     int k0, K1P, K2P;
@@ -93,6 +97,9 @@ int gpde_launch_fused(int mode, bool f16split, const GpdeFusedArgs& a, hipStream
 // f16-split + LDS-DMA variant (gpde_fused_f16.hip); supported for 3 <= K1P/32 and K1P <= ~1000
 bool gpde_fused_f16_supported(const GpdeFusedArgs& a);
 int gpde_launch_fused_f16(const GpdeFusedArgs& a, hipStream_t stream);
+// 8-wave (two per SIMD) variant with f16 H1 generation (gpde_fused_f16v3.hip)
+bool gpde_fused_f16v3_supported(const GpdeFusedArgs& a);
+int gpde_launch_fused_f16v3(const GpdeFusedArgs& a, hipStream_t stream);
 
 struct GpdeGemm3Args {
     const float* zbuf;     // [nn][64*K2P]

@@ -41,12 +41,9 @@ __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-// relu without the canonicalising v_max the compiler puts in front of fmaxf on MFMA results
-__device__ __forceinline__ float relu1(float v) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
-    return r;
-}
+// NOT inline asm: hipcc does not pad the MFMA-result -> reader hazard for an asm statement that
+// reads a VGPR an MFMA has just written (seen as ~1e-5 errors when the accumulators live in VGPRs)
+__device__ __forceinline__ float relu1(float v) { return fmaxf(v, 0.f); }
 
 // two-term f16 split of 16 non-negative, pre-scaled H1 values (registers r = 0..15 of the H1
 // MFMA result) into the two K=16 A operands of v_mfma_f32_32x32x16_f16: operand m, element j

@@ -30,11 +30,9 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ float relu1(float v) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
-    return r;
-}
+// NOT inline asm: hipcc does not pad the MFMA-result -> reader hazard for an asm statement that
+// reads a VGPR an MFMA has just written (seen as ~1e-5 errors when the accumulators live in VGPRs)
+__device__ __forceinline__ float relu1(float v) { return fmaxf(v, 0.f); }
 // 16-byte-per-lane DMA: LDS destination = wave-uniform base + lane*16, global source per lane
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

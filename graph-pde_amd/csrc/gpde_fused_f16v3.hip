@@ -1,0 +1,381 @@
+// Fused edge kernel, f16-split, TWO WAVES PER SIMD (v3): 8 waves per workgroup, wave tile =
+// 32 edges x 64 hidden columns, H1 generated on f16 MFMA as well.
+//
+// Same contract and math as gpde_fused_f16_kernel (gpde_fused_f16.hip; replaces DenseNet.forward
+// hidden part, /root/reference/graph-neural-operator/utilities.py:223-227, NNConv_old.message,
+// nn_conv.py:273-275, and PyG's gather/scatter).  Why a second variant: a wave alone on its SIMD
+// hides only ~4 non-MFMA instructions per 32-cycle MFMA (scripts/ubench/mfma_valu_overlap.hip), so
+// in the 4-wave kernel MFMA time and issue time ADD (47 % matrix-pipe occupancy).  Halving the
+// wave tile to 64 columns brings the accumulators (32 + 64 registers) under the 256-register
+// budget of two waves per SIMD; the partner wave's MFMAs then run under this wave's VALU / LDS /
+// DMA issue.  The two waves of a pair (same 32 edges, column halves 0/1) both need H1, so its
+// generation must be cheap: (W1|b1) . attr is done as 2 f16 MFMAs (K = 16 holds [hi|hi] x [hi;lo]
+// and [lo|lo] x [hi;0]) instead of 4 fp32 ones, with per-input-slot column scales 2^u_d folded
+// into the attributes (pack_w1_f16split_kernel).
+#include "gpde_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// NOT inline asm: hipcc does not pad the MFMA-result -> reader hazard for an asm statement that
+// reads a VGPR an MFMA has just written (seen as ~1e-5 errors when the accumulators live in VGPRs)
+__device__ __forceinline__ float relu1(float v) { return fmaxf(v, 0.f); }
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int lower_bound_node(const int32_t* __restrict__ rowptr, int lo, int hi,
+                                                long target) {
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if ((long)rowptr[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+constexpr int RING = 4;                    // W2 chunk images in LDS; DMA runs 3 chunks ahead
+constexpr int TILE_B = GP_TN * 128;        // 16 KiB per W2 chunk image
+constexpr int XS_TILE = GP_TE * GP_W;      // floats per edge-tile x stage (shared by a wave pair)
+constexpr int NW = 8;                      // waves per workgroup
+constexpr int NET = 4;                     // edge tiles per workgroup
+
+__global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                               // [4][16 KiB]
+    char* w1s = smem + RING * TILE_B;                                // [K1P][hi 16 B | lo 16 B]
+    float* Xs_all = (float*)(w1s + (size_t)a.K1P * 32);              // [4 edge tiles][32][64]
+    int* red = (int*)(Xs_all + NET * XS_TILE);                       // [4]
+    float* Es_all = (float*)(red + 4);                               // [8][32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int et = wave >> 1, ch = wave & 1;                         // edge tile, column half
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+    float* Es = Es_all + wave * GP_TE;
+    float* Xs = Xs_all + et * XS_TILE;
+
+    const int ns = a.K2P / GP_TN;
+    const int slice = blockIdx.x % ns;
+    const int group = blockIdx.x / ns;
+    const int NKC = a.K1P / GP_BK;
+
+    for (int i = tid; i < a.K1P * 2; i += 512) ((f32x4*)w1s)[i] = ((const f32x4*)a.w1h)[i];
+
+    // ---- node-aligned edge range of this wave PAIR -------------------------------------------------
+    const int e_lo = a.rowptr[a.nc0], e_hi = a.rowptr[a.nc1];
+    const long tot = (long)e_hi - e_lo;
+    const int nranges = a.n_groups * NET;
+    const int wg = group * NET + et;
+    const int na = lower_bound_node(a.rowptr, a.nc0, a.nc1, e_lo + tot * wg / nranges);
+    const int nb_ = (wg == nranges - 1) ? a.nc1
+                                        : lower_bound_node(a.rowptr, a.nc0, a.nc1,
+                                                           e_lo + tot * (wg + 1) / nranges);
+    const int ea = a.rowptr[na], eb = a.rowptr[nb_];
+    const int ntiles = (eb - ea + GP_TE - 1) / GP_TE;
+    if (lane == 0 && ch == 0) red[et] = ntiles;
+    __syncthreads();
+    const int maxtiles = max(max(red[0], red[1]), max(red[2], red[3]));
+    if (maxtiles == 0) return;
+
+    // ---- W2 chunk DMA: 2 x 1 KiB per wave per chunk ---------------------------------------------------
+    const char* w2g = (const char*)a.w2h + (size_t)slice * NKC * TILE_B + wave * 1024 + lane * 16;
+    auto issue_w2 = [&](int chunk, int slot) {
+        const char* g = w2g + (size_t)chunk * TILE_B;
+        char* l = ring + slot * TILE_B + wave * 1024;
+        dma16(g, l);
+        dma16(g + 8192, l + 8192);
+    };
+
+    float b2v[2], ucv[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        b2v[nb] = a.b2[slice * GP_TN + ch * 64 + nb * 32 + l31];
+        ucv[nb] = a.ucol[slice * GP_TN + ch * 64 + nb * 32 + l31];
+    }
+    // per-input-slot constants: bound weights max_k|W1b[k][d]| and column un-scales 2^-u_d
+    float wmx8[8], fcol8[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        wmx8[d] = a.w1[(size_t)a.K1P * 8 + (d & 1) * 4 + (d >> 1)];
+        fcol8[d] = a.fcol[d];
+    }
+    const int sw = (l31 >> 1) & 7;
+    const int rowb = (ch * 64 + l31) * 128;                       // byte offset of this lane's W2 row
+    const int boff0 = rowb + (((0 + h) ^ sw) << 4);
+    const int boff1 = rowb + (((2 + h) ^ sw) << 4);
+
+    // ---- per-tile side loads (unconditional, clamped: exact VMEM op counts) ----------------------------
+    // stage A (iteration 0):  edge id of the NEXT tile (1 load) + source nodes of THIS tile's rows
+    //                         this wave stages (4 loads)
+    // stage B (iteration K1): attributes of the NEXT tile (8 loads) + this tile's x_j rows, the
+    //                         wave's half (4 DMA)
+    const int e_clamp = max(e_hi - 1, 0);
+    int perm_n = 0, sidx[4];
+    float attr_n[8];
+    auto load_perm = [&](int e0n) { perm_n = a.perm[min(e0n + l31, e_clamp)]; };
+    auto load_sidx = [&](int e0c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sidx[i] = a.src[min(e0c + (lane >> 4) + 4 * (ch * 4 + i), e_clamp)];
+    };
+    auto load_attr = [&]() {
+        const float* ap = a.attr + (size_t)perm_n * a.k0;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) attr_n[d] = ap[min(d, a.k0 - 1)];
+    };
+    auto issue_x = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            dma16(a.x + (size_t)sidx[i] * GP_W + (lane & 15) * 4, Xs + (ch * 4 + i) * 4 * GP_W);
+    };
+    const int K1 = (NKC >= 10) ? 8 : NKC - 2;
+
+    issue_w2(0, 0);
+    issue_w2(1 % NKC, 1);
+    issue_w2(2 % NKC, 2);
+    load_perm(ea);
+    load_attr();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 Z[2][2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Z[cb][nb][r] = 0.f;
+    int cur = -1;
+
+    auto flush = [&](int node) {
+        float* zrow = a.zbuf + ((size_t)(node - a.nc0) * GP_W) * a.K2P + slice * GP_TN + ch * 64 + l31;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    zrow[(size_t)c * a.K2P + nb * 32] = Z[cb][nb][r];
+                    Z[cb][nb][r] = 0.f;
+                }
+    };
+
+    auto conv_to = [&](const f32x16& v, int p_, h8 (&hi)[2], h8 (&lo)[2]) {
+        const int m = p_ >> 2, jp = p_ & 3;
+        const float y0 = relu1(v[8 * m + 2 * jp]), y1 = relu1(v[8 * m + 2 * jp + 1]);
+        const auto pk = __builtin_amdgcn_cvt_pkrtz(y0, y1);
+        const _Float16 p0 = (_Float16)pk[0], p1 = (_Float16)pk[1];
+        hi[m][2 * jp] = p0;
+        hi[m][2 * jp + 1] = p1;
+        lo[m][2 * jp] = (_Float16)(y0 - (float)p0);
+        lo[m][2 * jp + 1] = (_Float16)(y1 - (float)p1);
+    };
+
+    int g = 0;
+    for (int t = 0; t < maxtiles; ++t) {
+        const int e0 = ea + t * GP_TE;
+        const int e_end = min(e0 + GP_TE, eb);
+
+        // ---- attributes of this lane's edge: validity, bias slot, per-edge scale, f16 split --------
+        h8 B1, B2;          // H1 MFMA operands: B1 = h ? attr_lo : attr_hi ; B2 = h ? 0 : attr_hi
+        [[maybe_unused]] float dbg_attr[8];
+        {
+            const bool valid = (e0 + l31) < eb;
+            float bnd = 0.f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                float v = (valid && d < a.k0) ? attr_n[d] : 0.f;
+                if (valid && d == a.k0) v = 1.f;
+                attr_n[d] = v;
+                bnd = fmaf(wmx8[d], fabsf(v), bnd);
+            }
+            const int ebits = (__float_as_int(bnd) >> 23) & 0xff;
+            const bool okb = (ebits >= 20) && (ebits <= 230);
+            const float sc = okb ? __int_as_float((267 - ebits) << 23) : 1.f;     // 2^(13 - E(B))
+            const float isc = okb ? __int_as_float((ebits - 13) << 23) : 1.f;
+            if (h == 0) Es[l31] = isc;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                dbg_attr[d] = attr_n[d] * sc;
+                const float s = attr_n[d] * fcol8[d] * sc;
+                const _Float16 hi = (_Float16)s;
+                const _Float16 lo = (_Float16)(s - (float)hi);
+                B1[d] = h ? lo : hi;
+                B2[d] = h ? (_Float16)0.f : hi;
+            }
+        }
+        auto h1gen = [&](int chunk) {
+#ifdef GPDE_V3_H1F32   // debugging aid: H1 on fp32 MFMA straight from the fp32 packed W1
+            {
+                const f32x4 w1f = *(const f32x4*)&a.w1[((size_t)(chunk * GP_BK + l31) * 2 + h) * 4];
+                f32x16 dd;
+                for (int r = 0; r < 16; ++r) dd[r] = 0.f;
+                for (int s_ = 0; s_ < 4; ++s_) dd = mfma32(w1f[s_], dbg_attr[2 * s_ + h], dd);
+                return dd;
+            }
+#endif
+            const char* wp = w1s + (size_t)(chunk * GP_BK + l31) * 32;
+            const h8 A1 = *(const h8*)wp, A2 = *(const h8*)(wp + 16);
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+            d = mfma16(A1, B1, d);
+            d = mfma16(A2, B2, d);
+            return d;
+        };
+
+        f32x16 acc1[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[nb][r] = 0.f;
+
+        h8 ahi[2], alo[2];
+        {
+            const f32x16 a0 = h1gen(0);
+#pragma unroll
+            for (int p_ = 0; p_ < 8; ++p_) conv_to(a0, p_, ahi, alo);
+        }
+        const int e0n = e0 + GP_TE;
+        // destination of the tile's first / last edge (scalar loads issued now, used after the K
+        // loop): a tile inside one destination node needs no further index loads
+        const int n_first = a.dst[min(e0, e_clamp)];
+        const int n_last = a.dst[min(max(e_end - 1, e0), e_clamp)];
+
+        for (int kc = 0; kc < NKC; ++kc, ++g) {
+            const char* rb = ring + (g % RING) * TILE_B;
+            int c1 = kc + 1, c3 = kc + 3;
+            if (c1 >= NKC) c1 -= NKC;
+            while (c3 >= NKC) c3 -= NKC;
+#ifndef GPDE_ABL_NOSTAGE
+            issue_w2(c3, (g + 3) % RING);
+#endif
+            if (kc == 0) {
+                load_perm(e0n);
+                load_sidx(e0);
+            } else if (kc == K1) {
+                load_attr();
+                issue_x();
+            }
+            // raw H1 of the NEXT chunk first (2 MFMAs): it is converted behind this chunk's MFMAs,
+            // in place, as soon as the operand registers of each k-half are free.  The partner wave
+            // on this SIMD runs its MFMAs under this wave's conversion VALU and vice versa.
+            f32x16 d = h1gen(c1);
+            h8 bhi[2], blo[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int bo = m ? boff1 : boff0;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    bhi[nb] = *(const h8*)(rb + nb * 4096 + bo);
+                    blo[nb] = *(const h8*)(rb + nb * 4096 + (bo ^ 64));
+                }
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc1[nb] = mfma16(ahi[m], bhi[nb], acc1[nb]);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc1[nb] = mfma16(ahi[m], blo[nb], acc1[nb]);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc1[nb] = mfma16(alo[m], bhi[nb], acc1[nb]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+#ifndef GPDE_ABL_NOCONV
+                for (int p_ = 0; p_ < 4; ++p_) conv_to(d, 4 * m + p_, ahi, alo);
+#else
+                asm volatile("" ::"v"(d));
+#endif
+                asm volatile("" ::"v"(ahi[m]), "v"(alo[m]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // counted wait: this iteration issued 2 W2 DMA (+ 5 index loads at kc == 0, + 8 attribute
+            // loads and 4 x DMA at kc == K1); everything older is retired (chunk g+2: one iteration
+            // early on purpose — letting the DMA run two iterations deep measured 8 % slower)
+#ifndef GPDE_ABL_NOSTAGE
+            if (kc == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else if (kc == K1) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#endif
+#ifndef GPDE_ABL_NOBARRIER
+            __builtin_amdgcn_s_barrier();
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- undo the row (edge) and column scales, bias, ReLU ---------------------------------------
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ie = Es[(r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                acc1[nb][r] = relu1(fmaf(acc1[nb][r], ie * ucv[nb], b2v[nb]));
+        }
+
+        // ---- GEMM2 with destination segments (fp32 MFMA) ----------------------------------------------
+        int e_seg = e0;
+#ifdef GPDE_ABL_NOGEMM2
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) asm volatile("" ::"v"(acc1[nb]));
+        e_seg = e_end;
+#endif
+        int node = n_first;
+        while (e_seg < e_end) {
+            const int seg_end = (node == n_last) ? e_end : min(a.rowptr[node + 1], e_end);
+            if (node != cur) {
+                if (cur >= 0) flush(cur);
+                cur = node;
+            }
+            const int lo = e_seg - e0 - 4 * h, hi = seg_end - e0 - 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int er = (r & 3) + 8 * (r >> 2);
+                const bool m = (er >= lo) && (er < hi);
+                const float* xp = Xs + (er + 4 * h) * GP_W + l31;
+                float av0 = xp[0], av1 = xp[32];
+                av0 = m ? av0 : 0.f;
+                av1 = m ? av1 : 0.f;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    Z[0][nb] = mfma32(av0, acc1[nb][r], Z[0][nb]);
+                    Z[1][nb] = mfma32(av1, acc1[nb][r], Z[1][nb]);
+                }
+            }
+            e_seg = seg_end;
+            if (e_seg < e_end) node = a.dst[e_seg];
+        }
+    }
+    if (cur >= 0) flush(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace
+
+static size_t v3_lds_bytes(int K1P) {
+    return (size_t)RING * TILE_B + (size_t)K1P * 32 + (size_t)NET * XS_TILE * 4 + 16 + NW * GP_TE * 4 + 64;
+}
+
+bool gpde_fused_f16v3_supported(const GpdeFusedArgs& a) {
+    return a.K1P / GP_BK >= 3 && a.k0 + 1 <= 8 && v3_lds_bytes(a.K1P) <= 80 * 1024 * 2;
+}
+
+int gpde_launch_fused_f16v3(const GpdeFusedArgs& a, hipStream_t stream) {
+    const int ns = a.K2P / GP_TN;
+    const dim3 grid(a.n_groups * ns), block(512);
+    const size_t lds = v3_lds_bytes(a.K1P);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v3_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(gpde_fused_f16v3_kernel, grid, block, lds, stream, a);
+    GP_LAUNCH_CHECK("gpde_fused_f16v3_kernel");
+    return GPDE_OK;
+}

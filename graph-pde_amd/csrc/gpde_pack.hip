@@ -37,6 +37,8 @@ int gpde_pack_layout(int n_layers, const int32_t* dims, GpdePackLayout* L) {
         L->off_b2 = take((size_t)L->K2P);
         L->off_w2h = take((size_t)L->K2P * L->K1P);
         L->off_ucol = take((size_t)L->K2P);
+        L->off_w1h = take((size_t)L->K1P * 8);
+        L->off_fcol = take(8);
     } else {
         // front layers 0 .. n_layers-2 as dense layers; widths padded to 128 (inputs of layer 0: 32)
         L->frontKP[0] = gp_round_up(dims[0], 32);
@@ -91,6 +93,32 @@ __global__ void pack_w1max_kernel(const float* __restrict__ w1p, int rows, float
     float m = 0.f;
     for (int r = 0; r < rows; ++r) m = fmaxf(m, fabsf(w1p[(size_t)r * 8 + d8]));
     out[d8] = m;
+}
+
+// (W1|b1) -> f16 two-term split image for the f16 H1 generation: column d (input slot) is scaled
+// by 2^u_d so that its largest magnitude lies in [2^6, 2^7); fcol[d] = 2^-u_d (0 if the column is
+// all zero) is applied to the attributes in the kernel.  w1p/wmax are the fp32 packed W1 ([h][s]
+// order: slot d = 2s+h at position h*4+s) and its appended max row.
+__global__ void pack_w1_f16split_kernel(const float* __restrict__ w1p, int rows, _Float16* __restrict__ out,
+                                        float* __restrict__ fcol) {
+    __shared__ float sc[8];
+    if (threadIdx.x < 8) {
+        const int d = threadIdx.x;
+        const float m = w1p[(size_t)rows * 8 + (d & 1) * 4 + (d >> 1)];
+        const int eb = (__float_as_int(m) >> 23) & 0xff;
+        const bool ok = (m > 0.f) && eb >= 20 && eb <= 230;
+        const int u = ok ? 6 - (eb - 127) : 0;
+        sc[d] = ok ? __int_as_float((u + 127) << 23) : 0.f;
+        if (blockIdx.x == 0) fcol[d] = ok ? __int_as_float((127 - u) << 23) : 0.f;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 8) return;
+    const int row = i >> 3, d = i & 7;
+    const float w = w1p[(size_t)row * 8 + (d & 1) * 4 + (d >> 1)] * sc[d];
+    const _Float16 hi = (_Float16)w;
+    out[(size_t)row * 16 + d] = hi;
+    out[(size_t)row * 16 + 8 + d] = (_Float16)(w - (float)hi);
 }
 
 // W2 [k2][k1] -> f16 two-term split tiles. Row n is scaled by 2^t_n so that its largest
@@ -204,6 +232,8 @@ extern "C" int gpde_mlp_pack(int n_layers, const int32_t* dims, const float* con
                            dims[2], L.K2P, P + L.off_b2);
         hipLaunchKernelGGL(pack_w1max_kernel, dim3(1), dim3(64), 0, stream, P + L.off_w1, L.K1P,
                            P + L.off_w1 + (size_t)L.K1P * 8);
+        hipLaunchKernelGGL(pack_w1_f16split_kernel, dim3((L.K1P * 8 + 255) / 256), dim3(256), 0, stream,
+                           P + L.off_w1, L.K1P, (_Float16*)(P + L.off_w1h), P + L.off_fcol);
         hipLaunchKernelGGL(pack_w2_f16split_kernel, dim3(L.K2P), dim3(256), 0, stream, W[1], dims[2],
                            dims[1], L.K2P, L.K1P, (_Float16*)(P + L.off_w2h), P + L.off_ucol);
     } else {

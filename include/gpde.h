@@ -42,9 +42,10 @@ enum { GPDE_AGGR_ADD = 0, GPDE_AGGR_MEAN = 1 };
 /* gpde_nnconv_fwd flags */
 enum {
     GPDE_FWD_DEFAULT = 0,  /* every contraction on v_mfma_f32_32x32x2_f32: exact fp32 (fmaf chains) */
-    GPDE_FWD_F16SPLIT = 1  /* hidden k1 x k2 layer on f16 MFMA with two-term operand splitting
+    GPDE_FWD_F16SPLIT = 1, /* hidden k1 x k2 layer on f16 MFMA with two-term operand splitting
                               (x = hi + lo, 3 MFMAs, fp32 accumulate; per-product error < 2^-21,
                               DESIGN.md §3b); ignored for kernels without a hidden GEMM */
+    GPDE_FWD_F16SPLIT_4WAVE = 2 /* with F16SPLIT: use the one-wave-per-SIMD kernel (A/B, debugging) */
 };
 
 #define GPDE_MAX_LAYERS 8
