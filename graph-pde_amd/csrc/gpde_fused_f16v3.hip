@@ -17,6 +17,7 @@
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -40,7 +41,7 @@ __device__ __forceinline__ int lower_bound_node(const int32_t* __restrict__ rowp
     return lo;
 }
 
-constexpr int RING = 4;                    // W2 chunk images in LDS; DMA runs 3 chunks ahead
+constexpr int RING = 4;                    // W2 chunk images in LDS: two pairs of chunks
 constexpr int TILE_B = GP_TN * 128;        // 16 KiB per W2 chunk image
 constexpr int XS_TILE = GP_TE * GP_W;      // floats per edge-tile x stage (shared by a wave pair)
 constexpr int NW = 8;                      // waves per workgroup
@@ -136,11 +137,11 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
         for (int i = 0; i < 4; ++i)
             dma16(a.x + (size_t)sidx[i] * GP_W + (lane & 15) * 4, Xs + (ch * 4 + i) * 4 * GP_W);
     };
-    const int K1 = (NKC >= 10) ? 8 : NKC - 2;
+    const int NP = NKC / 2;                         // chunk pairs per tile (NKC is even)
+    const int KP1 = NP >= 3 ? 1 : NP - 1;           // pair that issues stage B
 
     issue_w2(0, 0);
-    issue_w2(1 % NKC, 1);
-    issue_w2(2 % NKC, 2);
+    issue_w2(1, 1);
     load_perm(ea);
     load_attr();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -169,15 +170,21 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                 }
     };
 
+    // two-term split of a pair of non-negative values: hi = rtz16(y) (packed convert),
+    // lo = rn16(y - hi) as ONE v_fma_mix per value (f32 y, f16 hi operand, f16 result): 5 VALU per
+    // pair instead of 10.  The asm reads only VALU results (y from v_max), never an MFMA register.
     auto conv_to = [&](const f32x16& v, int p_, h8 (&hi)[2], h8 (&lo)[2]) {
         const int m = p_ >> 2, jp = p_ & 3;
         const float y0 = relu1(v[8 * m + 2 * jp]), y1 = relu1(v[8 * m + 2 * jp + 1]);
-        const auto pk = __builtin_amdgcn_cvt_pkrtz(y0, y1);
-        const _Float16 p0 = (_Float16)pk[0], p1 = (_Float16)pk[1];
-        hi[m][2 * jp] = p0;
-        hi[m][2 * jp + 1] = p1;
-        lo[m][2 * jp] = (_Float16)(y0 - (float)p0);
-        lo[m][2 * jp + 1] = (_Float16)(y1 - (float)p1);
+        const unsigned ph = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(y0, y1));
+        unsigned pl;
+        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(pl) : "v"(y0), "v"(ph));
+        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(pl) : "v"(y1), "v"(ph));
+        u4 hv = __builtin_bit_cast(u4, hi[m]), lv = __builtin_bit_cast(u4, lo[m]);
+        hv[jp] = ph;
+        lv[jp] = pl;
+        hi[m] = __builtin_bit_cast(h8, hv);
+        lo[m] = __builtin_bit_cast(h8, lv);
     };
 
     int g = 0;
@@ -251,62 +258,78 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
         const int n_first = a.dst[min(e0, e_clamp)];
         const int n_last = a.dst[min(max(e_end - 1, e0), e_clamp)];
 
-        for (int kc = 0; kc < NKC; ++kc, ++g) {
-            const char* rb = ring + (g % RING) * TILE_B;
-            int c1 = kc + 1, c3 = kc + 3;
-            if (c1 >= NKC) c1 -= NKC;
-            while (c3 >= NKC) c3 -= NKC;
+        // K loop in PAIRS of chunks: one s_barrier per two chunks (the barrier is the most expensive
+        // thing in the loop, scripts/ubench/kloop_model_v3.hip).  Pair G lives in ring slots
+        // {2(G&1), 2(G&1)+1}; the next pair's 4 DMA are issued at the top of the iteration into the
+        // other two slots (free since the previous barrier) and retired before the closing barrier.
+        for (int kp = 0; kp < NP; ++kp, ++g) {
+            const int sb = (g & 1) * 2;
+            int cA = 2 * kp + 2, cB = 2 * kp + 3;
+            if (cA >= NKC) cA -= NKC;
+            if (cB >= NKC) cB -= NKC;
 #ifndef GPDE_ABL_NOSTAGE
-            issue_w2(c3, (g + 3) % RING);
+            issue_w2(cA, sb ^ 2);
+            issue_w2(cB, (sb ^ 2) + 1);
 #endif
-            if (kc == 0) {
+            if (kp == 0) {
                 load_perm(e0n);
                 load_sidx(e0);
-            } else if (kc == K1) {
+            }
+            if (kp == KP1) {
                 load_attr();
                 issue_x();
             }
-            // raw H1 of the NEXT chunk first (2 MFMAs): it is converted behind this chunk's MFMAs,
-            // in place, as soon as the operand registers of each k-half are free.  The partner wave
-            // on this SIMD runs its MFMAs under this wave's conversion VALU and vice versa.
-            f32x16 d = h1gen(c1);
-            h8 bhi[2], blo[2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int bo = m ? boff1 : boff0;
+            for (int cc = 0; cc < 2; ++cc) {
+                const char* rb = ring + (sb + cc) * TILE_B;
+                int c1 = 2 * kp + cc + 1;
+                if (c1 >= NKC) c1 -= NKC;
+                // raw H1 of the NEXT chunk first (2 MFMAs): converted behind this chunk's MFMAs, in
+                // place, as soon as the operand registers of each k-half are free.  The partner wave
+                // on this SIMD runs its MFMAs under this wave's conversion VALU and vice versa.
+                f32x16 d = h1gen(c1);
+                h8 bhi[2], blo[2];
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    bhi[nb] = *(const h8*)(rb + nb * 4096 + bo);
-                    blo[nb] = *(const h8*)(rb + nb * 4096 + (bo ^ 64));
-                }
+                for (int m = 0; m < 2; ++m) {
+                    const int bo = m ? boff1 : boff0;
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) acc1[nb] = mfma16(ahi[m], bhi[nb], acc1[nb]);
+                    for (int nb = 0; nb < 2; ++nb) {
+                        bhi[nb] = *(const h8*)(rb + nb * 4096 + bo);
+                        blo[nb] = *(const h8*)(rb + nb * 4096 + (bo ^ 64));
+                    }
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) acc1[nb] = mfma16(ahi[m], blo[nb], acc1[nb]);
+                    for (int nb = 0; nb < 2; ++nb) acc1[nb] = mfma16(ahi[m], bhi[nb], acc1[nb]);
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) acc1[nb] = mfma16(alo[m], bhi[nb], acc1[nb]);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int nb = 0; nb < 2; ++nb) acc1[nb] = mfma16(ahi[m], blo[nb], acc1[nb]);
 #pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) acc1[nb] = mfma16(alo[m], bhi[nb], acc1[nb]);
+                    __builtin_amdgcn_sched_barrier(0);
 #ifndef GPDE_ABL_NOCONV
-                for (int p_ = 0; p_ < 4; ++p_) conv_to(d, 4 * m + p_, ahi, alo);
+#pragma unroll
+                    for (int p_ = 0; p_ < 4; ++p_) conv_to(d, 4 * m + p_, ahi, alo);
 #else
-                asm volatile("" ::"v"(d));
+                    asm volatile("" ::"v"(d));
 #endif
-                asm volatile("" ::"v"(ahi[m]), "v"(alo[m]));
-                __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("" ::"v"(ahi[m]), "v"(alo[m]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            // counted wait: this iteration issued 2 W2 DMA (+ 5 index loads at kc == 0, + 8 attribute
-            // loads and 4 x DMA at kc == K1); everything older is retired (chunk g+2: one iteration
-            // early on purpose — letting the DMA run two iterations deep measured 8 % slower)
+            // counted wait: everything up to and including this iteration's 4 W2 DMA is retired; only
+            // the side loads issued after them (5 at kp == 0, 12 at kp == KP1) may stay in flight
 #ifndef GPDE_ABL_NOSTAGE
-            if (kc == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else if (kc == K1) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (kp == 0 && KP1 == 0) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+            else if (kp == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if (kp == KP1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 #ifndef GPDE_ABL_NOBARRIER
             __builtin_amdgcn_s_barrier();
 #endif
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (NP < 3) {      // the x_j rows were issued in the last pair: land them before the aggregation
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
 
         // ---- undo the row (edge) and column scales, bias, ReLU ---------------------------------------
@@ -362,7 +385,7 @@ static size_t v3_lds_bytes(int K1P) {
 }
 
 bool gpde_fused_f16v3_supported(const GpdeFusedArgs& a) {
-    return a.K1P / GP_BK >= 3 && a.k0 + 1 <= 8 && v3_lds_bytes(a.K1P) <= 80 * 1024 * 2;
+    return a.K1P / GP_BK >= 2 && (a.K1P / GP_BK) % 2 == 0 && a.k0 + 1 <= 8 && v3_lds_bytes(a.K1P) <= 80 * 1024 * 2;
 }
 
 int gpde_launch_fused_f16v3(const GpdeFusedArgs& a, hipStream_t stream) {
