@@ -74,9 +74,14 @@ def executed_flops_per_edge(dims, w=64, precision="f32"):
     ("f32") or 3 f16 MFMAs per product ("f16split")."""
     k1p = (dims[1] + 31) // 32 * 32
     k2p = (dims[2] + 127) // 128 * 128
-    side = 2 * 8 * k1p * (k2p // 128) + 2 * w * k2p
+    agg = 2 * w * k2p
     hidden = 2 * k1p * k2p
-    return (side + hidden, 0) if precision == "f32" else (side, 3 * hidden)
+    if precision == "f32":
+        return (2 * 8 * k1p * (k2p // 128) + agg + hidden, 0)
+    if precision == "f16split4w":            # 4-wave kernel: H1 on fp32 MFMA per 128-column slice
+        return (2 * 8 * k1p * (k2p // 128) + agg, 3 * hidden)
+    # default 8-wave kernel: H1 as 2 f16 MFMAs (K = 16) per 32-row chunk and 64-column wave tile
+    return (agg, 3 * hidden + 2 * 2 * 16 * k1p * (k2p // 64))
 
 
 def main():
@@ -198,7 +203,8 @@ def main():
         except Exception:
             traffic = None
     roofline = {
-        "kernel": "gpde_fused_f16_kernel" if precision == "f16split" else "gpde_fused_kernel<1>",
+        "kernel": {"f16split": "gpde_fused_f16v3_kernel", "f16split4w": "gpde_fused_f16_kernel"}.get(
+            precision, "gpde_fused_kernel<1>"),
         "bound": "mfma",
         "achieved": round(achieved_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved_tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
