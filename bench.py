@@ -108,7 +108,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torchrun (RANK set) the process group is always created, also for one rank, so the
+    # N = 1 launch exercises the same RCCL init / barrier / all-reduce path as N = 2, 4, 8
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -152,7 +155,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -169,14 +172,13 @@ def main():
     import ctypes
     fused_ms, launches, other_ms = ctypes.c_double(), ctypes.c_int32(), ctypes.c_double()
     lib.gpde_profile_end(ctypes.byref(fused_ms), ctypes.byref(launches), ctypes.byref(other_ms))
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     ms_per_step = 1e3 * elapsed / args.steps
@@ -291,7 +293,7 @@ def main():
         "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
