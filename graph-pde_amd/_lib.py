@@ -56,6 +56,11 @@ SIGNATURES = {
                                        ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_size_t, ctypes.c_void_p]),
+    "gpde_radius_graph_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                               ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    "gpde_radius_graph_fill": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                              ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_int64, ctypes.c_void_p]),
     "gpde_profile_begin": (ctypes.c_int, []),
     "gpde_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), c_i32p,
                                         ctypes.POINTER(ctypes.c_double)]),

@@ -314,3 +314,31 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
     _lib.check(rc, "gpde_nnconv_bwd")
     _lib.n_native_calls += 1
     return gx, gW, gb, groot, gbias
+
+
+# ----------------------------------------------------------------------------------------------
+# radius graph
+# ----------------------------------------------------------------------------------------------
+def radius_graph(pos: torch.Tensor, r: float) -> torch.Tensor:
+    """edge_index int64 [2,E] of the radius graph of `pos` [n,dim] (dim 1..3), in the reference's
+    order (sorted by source, then target; self-loops included) — the GPU replacement of
+    `ball_connectivity` (utilities.py:250-255).  One sync (the edge count) per graph."""
+    lib = _lib.lib()
+    _require_cuda(pos, "pos")
+    if pos.dim() == 1:
+        pos = pos.unsqueeze(1)
+    pos = pos.detach().to(torch.float64).contiguous()
+    n, dim = int(pos.size(0)), int(pos.size(1))
+    dev = pos.device
+    deg = torch.empty(n, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gpde_radius_graph_count(pos.data_ptr(), n, dim, float(r), deg.data_ptr(),
+                                               _stream_ptr(dev)), "gpde_radius_graph_count")
+    offs = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(deg, 0, out=offs[1:])
+    e = int(offs[-1].item())
+    ei = torch.empty(2, e, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gpde_radius_graph_fill(pos.data_ptr(), n, dim, float(r), offs.data_ptr(),
+                                              ei.data_ptr(), e, _stream_ptr(dev)), "gpde_radius_graph_fill")
+    return ei

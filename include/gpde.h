@@ -140,6 +140,18 @@ int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int
                     float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias,
                     void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Radius graph on the GPU.  Replaces SquareMeshGenerator / RandomMeshGenerator.ball_connectivity
+ * (utilities.py:250-255, 362-368: dense float64 pairwise_distances + np.where).  pos [n][dim]
+ * float64 (dim 1..3).  Pass 1 writes the out-degree of every source; the caller forms the
+ * exclusive prefix sum `offsets` [n+1] (int64) and allocates edge_index int64 [2][E], E =
+ * offsets[n]; pass 2 fills it: edge (j -> i) iff |pos_j - pos_i|^2 <= r^2 (float64, exact sum of
+ * squares), self-loops included, sorted by source then target — the reference's order. */
+int gpde_radius_graph_count(const double* pos, int64_t n, int dim, double r, int32_t* deg,
+                            void* stream);
+int gpde_radius_graph_fill(const double* pos, int64_t n, int dim, double r, const int64_t* offsets,
+                           int64_t* edge_index, int64_t n_edges, void* stream);
+
 /* HIP-event timing of the kernels launched by gpde_nnconv_fwd on the calling thread (used by
  * bench.py for the roofline figure; events are recorded on the same stream as the kernels).
  * gpde_profile_begin() arms it; gpde_profile_end() disarms it, SYNCHRONISES on the recorded

@@ -379,3 +379,24 @@ def test_mgkn_general_darcy_shapes():
         ei = torch.stack([ei[0] + offs[l + 1], ei[1] + offs[l]])
         conv = gp.NNConv(64, 64, _dense([6, kl, 4096]), aggr="mean", root_weight=False, bias=False)
         _check_module(conv, xall, ei, ea)
+
+
+def test_native_radius_graph_matches_reference_construction():
+    """gpde_radius_graph_* vs the reference construction (dense pairwise distances + np.where,
+    utilities.py:250-255) on random points (no ties at the radius) and vs the exact lattice."""
+    import numpy as np
+    from sklearn.metrics import pairwise_distances
+    d = dev()
+    rng = np.random.default_rng(5)
+    for n, dim, r in ((700, 2, 0.11), (300, 1, 0.03), (400, 3, 0.25)):
+        pos = rng.random((n, dim))
+        pwd = pairwise_distances(pos)
+        ref = np.vstack(np.where(pwd <= r))                              # the reference's lines
+        ei = ops.radius_graph(torch.from_numpy(pos).to(d), r).cpu().numpy()
+        assert ei.shape == ref.shape and (ei == ref).all(), (n, dim, ei.shape, ref.shape)
+    # exact-arithmetic lattice (synth) == native builder with a radius safely between lattice shells
+    s = 31
+    ei_lat = synth.lattice_radius_graph(s, 0.10)
+    pos = synth.lattice_positions(s)
+    ei = ops.radius_graph(pos.to(d), 0.10 + 1e-9).cpu()
+    assert torch.equal(ei, ei_lat)
