@@ -226,7 +226,8 @@ extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edg
             {
                 ProfScope ps(0, stream);
                 const bool f16s = (flags & GPDE_FWD_F16SPLIT) != 0 && L.mode == 1;
-                if (f16s && !(flags & GPDE_FWD_F16SPLIT_4WAVE) && gpde_fused_f16v3_supported(f)) rc = gpde_launch_fused_f16v3(f, stream);
+                if (f16s && (flags & GPDE_FWD_F16SPLIT_2WG) && gpde_fused_f16v4_supported(f)) rc = gpde_launch_fused_f16v4(f, stream);
+                else if (f16s && !(flags & GPDE_FWD_F16SPLIT_4WAVE) && gpde_fused_f16v3_supported(f)) rc = gpde_launch_fused_f16v3(f, stream);
                 else if (f16s && gpde_fused_f16_supported(f)) rc = gpde_launch_fused_f16(f, stream);
                 else rc = gpde_launch_fused(L.mode, f16s, f, stream);
             }

@@ -100,6 +100,9 @@ int gpde_launch_fused_f16(const GpdeFusedArgs& a, hipStream_t stream);
 // 8-wave (two per SIMD) variant with f16 H1 generation (gpde_fused_f16v3.hip)
 bool gpde_fused_f16v3_supported(const GpdeFusedArgs& a);
 int gpde_launch_fused_f16v3(const GpdeFusedArgs& a, hipStream_t stream);
+// two independent 4-wave workgroups per CU, 64-column slices (gpde_fused_f16v4.hip)
+bool gpde_fused_f16v4_supported(const GpdeFusedArgs& a);
+int gpde_launch_fused_f16v4(const GpdeFusedArgs& a, hipStream_t stream);
 
 struct GpdeGemm3Args {
     const float* zbuf;     // [nn][64*K2P]

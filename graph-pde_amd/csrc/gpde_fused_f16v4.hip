@@ -1,17 +1,14 @@
-// Fused edge kernel, f16-split, TWO WAVES PER SIMD (v3): 8 waves per workgroup, wave tile =
-// 32 edges x 64 hidden columns, H1 generated on f16 MFMA as well.
+// Fused edge kernel, f16-split, v4: TWO INDEPENDENT 4-wave workgroups per CU (64-column slices).
 //
-// Same contract and math as gpde_fused_f16_kernel (gpde_fused_f16.hip; replaces DenseNet.forward
-// hidden part, /root/reference/graph-neural-operator/utilities.py:223-227, NNConv_old.message,
-// nn_conv.py:273-275, and PyG's gather/scatter).  Why a second variant: a wave alone on its SIMD
-// hides only ~4 non-MFMA instructions per 32-cycle MFMA (scripts/ubench/mfma_valu_overlap.hip), so
-// in the 4-wave kernel MFMA time and issue time ADD (47 % matrix-pipe occupancy).  Halving the
-// wave tile to 64 columns brings the accumulators (32 + 64 registers) under the 256-register
-// budget of two waves per SIMD; the partner wave's MFMAs then run under this wave's VALU / LDS /
-// DMA issue.  The two waves of a pair (same 32 edges, column halves 0/1) both need H1, so its
-// generation must be cheap: (W1|b1) . attr is done as 2 f16 MFMAs (K = 16 holds [hi|hi] x [hi;lo]
-// and [lo|lo] x [hi;0]) instead of 4 fp32 ones, with per-input-slot column scales 2^u_d folded
-// into the attributes (pack_w1_f16split_kernel).
+// Same contract, math and arithmetic as gpde_fused_f16v3_kernel (gpde_fused_f16v3.hip; replaces
+// DenseNet.forward hidden part, /root/reference/graph-neural-operator/utilities.py:223-227,
+// NNConv_old.message, nn_conv.py:273-275, and PyG's gather/scatter).  v3 puts two waves on every
+// SIMD but couples all 8 through one s_barrier, and the barrier turned out to be the most expensive
+// item of the K loop (scripts/ubench/kloop_model_v3.hip).  Here the two waves of a SIMD belong to
+// DIFFERENT workgroups: each workgroup is 4 waves (one per SIMD), wave tile 32 edges x 64 columns,
+// slice width 64, with its own LDS ring (W2 half-tile 8 KiB + the next chunk's (W1|b1) rows 1 KiB
+// per slot) and its own barrier, so a workgroup parked at its barrier leaves the matrix pipe to
+// the other one.  70 KiB of LDS per workgroup -> two fit a CU.
 #include "gpde_common.h"
 
 namespace {
@@ -27,9 +24,7 @@ __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
 }
 // NOT inline asm: hipcc does not pad the MFMA-result -> reader hazard for an asm statement that
 // reads a VGPR an MFMA has just written (seen as ~1e-5 errors when the accumulators live in VGPRs)
-// Integer max on the bit pattern: negative floats are negative ints -> 0, everything else passes
-// (fmaxf costs two VALU: LLVM canonicalises an MFMA result before v_max_f32).
-__device__ __forceinline__ float relu1(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+__device__ __forceinline__ float relu1(float v) { return fmaxf(v, 0.f); }
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -44,37 +39,34 @@ __device__ __forceinline__ int lower_bound_node(const int32_t* __restrict__ rowp
 }
 
 constexpr int RING = 4;                    // W2 chunk images in LDS: two pairs of chunks
-#ifdef GPDE_V3_TIMING
-__device__ unsigned long long gpde_v3_tm[4];
-#endif
-constexpr int TILE_B = GP_TN * 128;        // 16 KiB per W2 chunk image
-constexpr int XS_TILE = GP_TE * GP_W;      // floats per edge-tile x stage (shared by a wave pair)
-constexpr int NW = 8;                      // waves per workgroup
-constexpr int NET = 4;                     // edge tiles per workgroup
+constexpr int SLW = 64;                    // hidden columns per workgroup slice
+constexpr int W2_B = SLW * 128;            // 8 KiB: W2 rows of the slice for one chunk
+constexpr int TILE_B = W2_B + 1024;        // + the NEXT chunk's (W1|b1) rows [32][hi 16 B | lo 16 B]
+constexpr int XS_TILE = GP_TE * GP_W;      // floats per wave x stage
+constexpr int NW = 4;                      // waves per workgroup = edge tiles per workgroup
+constexpr int NET = 4;
 
-__global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs a) {
+__global__ __launch_bounds__(256, 2) void gpde_fused_f16v4_kernel(GpdeFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ring = smem;                                               // [4][16 KiB]
-    char* w1s = smem + RING * TILE_B;                                // [K1P][hi 16 B | lo 16 B]
-    float* Xs_all = (float*)(w1s + (size_t)a.K1P * 32);              // [4 edge tiles][32][64]
+    char* ring = smem;                                               // [4][9 KiB]
+    float* Xs_all = (float*)(smem + RING * TILE_B);                  // [4 waves][32][64]
     int* red = (int*)(Xs_all + NET * XS_TILE);                       // [4]
-    float* Es_all = (float*)(red + 4);                               // [8][32]
+    float* Es_all = (float*)(red + 4);                               // [4][32]
+    const char* w1c0 = (const char*)(Es_all + NW * GP_TE);           // (W1|b1) rows of chunk 0, resident
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int et = wave >> 1, ch = wave & 1;                         // edge tile, column half
+    const int et = wave;                                             // one edge tile per wave
     const int l31 = lane & 31;
     const int h = lane >> 5;
     float* Es = Es_all + wave * GP_TE;
     float* Xs = Xs_all + et * XS_TILE;
 
-    const int ns = a.K2P / GP_TN;
-    const int slice = blockIdx.x % ns;
+    const int ns = a.K2P / SLW;
+    const int slice = blockIdx.x % ns;                               // 64-column slice
     const int group = blockIdx.x / ns;
     const int NKC = a.K1P / GP_BK;
-
-    for (int i = tid; i < a.K1P * 2; i += 512) ((f32x4*)w1s)[i] = ((const f32x4*)a.w1h)[i];
 
     // ---- node-aligned edge range of this wave PAIR -------------------------------------------------
     const int e_lo = a.rowptr[a.nc0], e_hi = a.rowptr[a.nc1];
@@ -87,25 +79,32 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                                                            e_lo + tot * (wg + 1) / nranges);
     const int ea = a.rowptr[na], eb = a.rowptr[nb_];
     const int ntiles = (eb - ea + GP_TE - 1) / GP_TE;
-    if (lane == 0 && ch == 0) red[et] = ntiles;
+    if (lane == 0) red[et] = ntiles;
     __syncthreads();
     const int maxtiles = max(max(red[0], red[1]), max(red[2], red[3]));
     if (maxtiles == 0) return;
 
-    // ---- W2 chunk DMA: 2 x 1 KiB per wave per chunk ---------------------------------------------------
-    const char* w2g = (const char*)a.w2h + (size_t)slice * NKC * TILE_B + wave * 1024 + lane * 16;
+    // ---- chunk DMA into a ring slot: this slice's 64 W2 rows of `chunk` (8 x 1 KiB pieces, two per
+    //      wave) and the (W1|b1) rows of chunk+1 (one 1 KiB piece, issued by wave chunk&3) --------------
+    const char* w2g = (const char*)a.w2h + (size_t)(slice >> 1) * NKC * (GP_TN * 128) + (slice & 1) * W2_B +
+                      wave * 1024 + lane * 16;
+    const char* w1g = (const char*)a.w1h + lane * 16;
     auto issue_w2 = [&](int chunk, int slot) {
-        const char* g = w2g + (size_t)chunk * TILE_B;
+        const char* g = w2g + (size_t)chunk * (GP_TN * 128);
         char* l = ring + slot * TILE_B + wave * 1024;
         dma16(g, l);
-        dma16(g + 8192, l + 8192);
+        dma16(g + 4096, l + 4096);
+        if (wave == (chunk & 3)) {
+            const int cn = (chunk + 1 < NKC) ? chunk + 1 : 0;
+            dma16(w1g + (size_t)cn * 1024, ring + slot * TILE_B + W2_B);
+        }
     };
 
     float b2v[2], ucv[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        b2v[nb] = a.b2[slice * GP_TN + ch * 64 + nb * 32 + l31];
-        ucv[nb] = a.ucol[slice * GP_TN + ch * 64 + nb * 32 + l31];
+        b2v[nb] = a.b2[slice * SLW + nb * 32 + l31];
+        ucv[nb] = a.ucol[slice * SLW + nb * 32 + l31];
     }
     // per-input-slot constants: bound weights max_k|W1b[k][d]| and column un-scales 2^-u_d
     float wmx8[8], fcol8[8];
@@ -115,22 +114,20 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
         fcol8[d] = a.fcol[d];
     }
     const int sw = (l31 >> 1) & 7;
-    const int rowb = (ch * 64 + l31) * 128;                       // byte offset of this lane's W2 row
+    const int rowb = l31 * 128;                                   // byte offset of this lane's W2 row
     const int boff0 = rowb + (((0 + h) ^ sw) << 4);
     const int boff1 = rowb + (((2 + h) ^ sw) << 4);
 
     // ---- per-tile side loads (unconditional, clamped: exact VMEM op counts) ----------------------------
-    // stage A (iteration 0):  edge id of the NEXT tile (1 load) + source nodes of THIS tile's rows
-    //                         this wave stages (4 loads)
-    // stage B (iteration K1): attributes of the NEXT tile (8 loads) + this tile's x_j rows, the
-    //                         wave's half (4 DMA)
+    // stage A (pair 0):   edge id of the NEXT tile (1 load) + source nodes of THIS tile's rows (8)
+    // stage B (pair KP1): attributes of the NEXT tile (8 loads) + this tile's x_j rows (8 DMA)
     const int e_clamp = max(e_hi - 1, 0);
-    int perm_n = 0, sidx[4];
+    int perm_n = 0, sidx[8];
     float attr_n[8];
     auto load_perm = [&](int e0n) { perm_n = a.perm[min(e0n + l31, e_clamp)]; };
     auto load_sidx = [&](int e0c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sidx[i] = a.src[min(e0c + (lane >> 4) + 4 * (ch * 4 + i), e_clamp)];
+        for (int i = 0; i < 8; ++i) sidx[i] = a.src[min(e0c + (lane >> 4) + 4 * i, e_clamp)];
     };
     auto load_attr = [&]() {
         const float* ap = a.attr + (size_t)perm_n * a.k0;
@@ -139,14 +136,15 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
     };
     auto issue_x = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            dma16(a.x + (size_t)sidx[i] * GP_W + (lane & 15) * 4, Xs + (ch * 4 + i) * 4 * GP_W);
+        for (int i = 0; i < 8; ++i)
+            dma16(a.x + (size_t)sidx[i] * GP_W + (lane & 15) * 4, Xs + i * 4 * GP_W);
     };
     const int NP = NKC / 2;                         // chunk pairs per tile (NKC is even)
     const int KP1 = NP >= 3 ? 1 : NP - 1;           // pair that issues stage B
 
     issue_w2(0, 0);
     issue_w2(1, 1);
+    if (wave == 0) dma16(w1g, (void*)w1c0);
     load_perm(ea);
     load_attr();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -162,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
     int cur = -1;
 
     auto flush = [&](int node) {
-        float* zrow = a.zbuf + ((size_t)(node - a.nc0) * GP_W) * a.K2P + slice * GP_TN + ch * 64 + l31;
+        float* zrow = a.zbuf + ((size_t)(node - a.nc0) * GP_W) * a.K2P + slice * SLW + l31;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -193,19 +191,12 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
     };
 
     int g = 0;
-#ifdef GPDE_V3_TIMING
-    long long tm_pro = 0, tm_loop = 0, tm_post = 0, tm0 = clock64(), tm1;
-#define TM_MARK(acc) do { tm1 = clock64(); acc += tm1 - tm0; tm0 = tm1; } while (0)
-#else
-#define TM_MARK(acc) do { } while (0)
-#endif
     for (int t = 0; t < maxtiles; ++t) {
         const int e0 = ea + t * GP_TE;
         const int e_end = min(e0 + GP_TE, eb);
 
         // ---- attributes of this lane's edge: validity, bias slot, per-edge scale, f16 split --------
         h8 B1, B2;          // H1 MFMA operands: B1 = h ? attr_lo : attr_hi ; B2 = h ? 0 : attr_hi
-        [[maybe_unused]] float dbg_attr[8];
         {
             const bool valid = (e0 + l31) < eb;
             float bnd = 0.f;
@@ -223,7 +214,6 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             if (h == 0) Es[l31] = isc;
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
-                dbg_attr[d] = attr_n[d] * sc;
                 const float s = attr_n[d] * fcol8[d] * sc;
                 const _Float16 hi = (_Float16)s;
                 const _Float16 lo = (_Float16)(s - (float)hi);
@@ -231,17 +221,8 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                 B2[d] = h ? (_Float16)0.f : hi;
             }
         }
-        auto h1gen = [&](int chunk) {
-#ifdef GPDE_V3_H1F32   // debugging aid: H1 on fp32 MFMA straight from the fp32 packed W1
-            {
-                const f32x4 w1f = *(const f32x4*)&a.w1[((size_t)(chunk * GP_BK + l31) * 2 + h) * 4];
-                f32x16 dd;
-                for (int r = 0; r < 16; ++r) dd[r] = 0.f;
-                for (int s_ = 0; s_ < 4; ++s_) dd = mfma32(w1f[s_], dbg_attr[2 * s_ + h], dd);
-                return dd;
-            }
-#endif
-            const char* wp = w1s + (size_t)(chunk * GP_BK + l31) * 32;
+        auto h1gen = [&](const char* w1rows) {
+            const char* wp = w1rows + (size_t)l31 * 32;
             const h8 A1 = *(const h8*)wp, A2 = *(const h8*)(wp + 16);
             f32x16 d;
 #pragma unroll
@@ -257,13 +238,11 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[nb][r] = 0.f;
 
-        h8 ahi[2][2], alo[2][2];      // two operand buffers: chunk parity (NKC is even: a tile starts at 0)
-        f32x16 d;                     // raw H1 of the chunk after the current one (loop carried)
+        h8 ahi[2], alo[2];
         {
-            const f32x16 a0 = h1gen(0);
-            d = h1gen(1);
+            const f32x16 a0 = h1gen(w1c0);
 #pragma unroll
-            for (int p_ = 0; p_ < 8; ++p_) conv_to(a0, p_, ahi[0], alo[0]);
+            for (int p_ = 0; p_ < 8; ++p_) conv_to(a0, p_, ahi, alo);
         }
         const int e0n = e0 + GP_TE;
         // destination of the tile's first / last edge (scalar loads issued now, used after the K
@@ -275,7 +254,6 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
         // thing in the loop, scripts/ubench/kloop_model_v3.hip).  Pair G lives in ring slots
         // {2(G&1), 2(G&1)+1}; the next pair's 4 DMA are issued at the top of the iteration into the
         // other two slots (free since the previous barrier) and retired before the closing barrier.
-        TM_MARK(tm_pro);
         for (int kp = 0; kp < NP; ++kp, ++g) {
             const int sb = (g & 1) * 2;
             int cA = 2 * kp + 2, cB = 2 * kp + 3;
@@ -296,13 +274,10 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
                 const char* rb = ring + (sb + cc) * TILE_B;
-                int c2 = 2 * kp + cc + 2;
-                if (c2 >= NKC) c2 -= NKC;
-                // Conversion of the NEXT chunk's raw H1 (d, made one chunk ago; 40 VALU) into the
-                // OTHER operand buffer a[cc ^ 1], laid out between this chunk's 12 MFMAs by the
-                // sched_group_barrier pipeline below, then the 2 MFMAs of H1 chunk c + 2.  A long VALU
-                // burst of one wave starves its SIMD partner's MFMA issue (same issue port, age
-                // priority): cross-wave overlap alone hides nothing (scripts/v3_timing.py ablations).
+                // raw H1 of the NEXT chunk first (2 MFMAs): converted behind this chunk's MFMAs, in
+                // place, as soon as the operand registers of each k-half are free.  The partner wave
+                // on this SIMD runs its MFMAs under this wave's conversion VALU and vice versa.
+                f32x16 d = h1gen(rb + W2_B);                 // this slot carries the next chunk's (W1|b1) rows
                 h8 bhi[2], blo[2];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
@@ -312,33 +287,29 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                         bhi[nb] = *(const h8*)(rb + nb * 4096 + bo);
                         blo[nb] = *(const h8*)(rb + nb * 4096 + (bo ^ 64));
                     }
-                    // source order is pinned: MFMA, one conversion pair (5 VALU), MFMA, ...
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        const int nb = j & 1, t = j >> 1;
-                        acc1[nb] = mfma16(t == 2 ? alo[cc][m] : ahi[cc][m], t == 1 ? blo[nb] : bhi[nb], acc1[nb]);
+                    for (int nb = 0; nb < 2; ++nb) acc1[nb] = mfma16(ahi[m], bhi[nb], acc1[nb]);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) acc1[nb] = mfma16(ahi[m], blo[nb], acc1[nb]);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) acc1[nb] = mfma16(alo[m], bhi[nb], acc1[nb]);
+                    __builtin_amdgcn_sched_barrier(0);
 #ifndef GPDE_ABL_NOCONV
-                        if (j == 0 || j == 1 || j == 3 || j == 4) {
-                            conv_to(d, 4 * m + (j < 2 ? j : j - 1), ahi[cc ^ 1], alo[cc ^ 1]);
-                            asm volatile("" ::"v"(ahi[cc ^ 1][m]), "v"(alo[cc ^ 1][m]));
-                        }
+#pragma unroll
+                    for (int p_ = 0; p_ < 4; ++p_) conv_to(d, 4 * m + p_, ahi, alo);
+#else
+                    asm volatile("" ::"v"(d));
 #endif
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    asm volatile("" ::"v"(ahi[m]), "v"(alo[m]));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#ifdef GPDE_ABL_NOCONV
-                asm volatile("" ::"v"(d));
-#endif
-                d = h1gen(c2);
-                asm volatile("" ::"v"(d));
-                __builtin_amdgcn_sched_barrier(0);
             }
             // counted wait: everything up to and including this iteration's 4 W2 DMA is retired; only
-            // the side loads issued after them (5 at kp == 0, 12 at kp == KP1) may stay in flight
+            // the side loads issued after them (9 at kp == 0, 16 at kp == KP1) may stay in flight
 #ifndef GPDE_ABL_NOSTAGE
-            if (kp == 0 && KP1 == 0) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-            else if (kp == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else if (kp == KP1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            if (kp == 0 && KP1 == 0) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+            else if (kp == 0) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if (kp == KP1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 #ifndef GPDE_ABL_NOBARRIER
@@ -351,7 +322,6 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             __builtin_amdgcn_s_barrier();
         }
 
-        TM_MARK(tm_loop);
         // ---- undo the row (edge) and column scales, bias, ReLU ---------------------------------------
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -393,53 +363,33 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             e_seg = seg_end;
             if (e_seg < e_end) node = a.dst[e_seg];
         }
-        TM_MARK(tm_post);
     }
     if (cur >= 0) flush(cur);
-#ifdef GPDE_V3_TIMING
-    if (lane == 0) {
-        atomicAdd(&gpde_v3_tm[0], (unsigned long long)tm_pro);
-        atomicAdd(&gpde_v3_tm[1], (unsigned long long)tm_loop);
-        atomicAdd(&gpde_v3_tm[2], (unsigned long long)tm_post);
-        atomicAdd(&gpde_v3_tm[3], (unsigned long long)maxtiles);
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace
 
-static size_t v3_lds_bytes(int K1P) {
-    return (size_t)RING * TILE_B + (size_t)K1P * 32 + (size_t)NET * XS_TILE * 4 + 16 + NW * GP_TE * 4 + 64;
+static size_t v4_lds_bytes(int K1P) {
+    (void)K1P;
+    return (size_t)RING * TILE_B + (size_t)NET * XS_TILE * 4 + 16 + NW * GP_TE * 4 + 1024 + 64;
 }
 
-#ifdef GPDE_V3_TIMING
-// developer probe (scripts/v3_timing.py): cycles per phase summed over waves, and wave-tiles
-extern "C" int gpde_debug_v3_timing(unsigned long long* out4, int reset) {
-    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(gpde_v3_tm), 32) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[4] = {0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(gpde_v3_tm), z, 32) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
-
-bool gpde_fused_f16v3_supported(const GpdeFusedArgs& a) {
-    return a.K1P / GP_BK >= 2 && (a.K1P / GP_BK) % 2 == 0 && a.k0 + 1 <= 8 && v3_lds_bytes(a.K1P) <= 80 * 1024 * 2;
+bool gpde_fused_f16v4_supported(const GpdeFusedArgs& a) {
+    return a.K1P / GP_BK >= 2 && (a.K1P / GP_BK) % 2 == 0 && a.k0 + 1 <= 8 && v4_lds_bytes(a.K1P) <= 80 * 1024;
 }
 
-int gpde_launch_fused_f16v3(const GpdeFusedArgs& a, hipStream_t stream) {
-    const int ns = a.K2P / GP_TN;
-    const dim3 grid(a.n_groups * ns), block(512);
-    const size_t lds = v3_lds_bytes(a.K1P);
+int gpde_launch_fused_f16v4(const GpdeFusedArgs& a, hipStream_t stream) {
+    const int ns = a.K2P / SLW;
+    const dim3 grid(a.n_groups * ns), block(256);
+    const size_t lds = v4_lds_bytes(a.K1P);
     static size_t lds_set = 0;
     if (lds > lds_set) {
-        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v3_kernel,
+        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v4_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
-    hipLaunchKernelGGL(gpde_fused_f16v3_kernel, grid, block, lds, stream, a);
-    GP_LAUNCH_CHECK("gpde_fused_f16v3_kernel");
+    hipLaunchKernelGGL(gpde_fused_f16v4_kernel, grid, block, lds, stream, a);
+    GP_LAUNCH_CHECK("gpde_fused_f16v4_kernel");
     return GPDE_OK;
 }

@@ -45,7 +45,8 @@ enum {
     GPDE_FWD_F16SPLIT = 1, /* hidden k1 x k2 layer on f16 MFMA with two-term operand splitting
                               (x = hi + lo, 3 MFMAs, fp32 accumulate; per-product error < 2^-21,
                               DESIGN.md §3b); ignored for kernels without a hidden GEMM */
-    GPDE_FWD_F16SPLIT_4WAVE = 2 /* with F16SPLIT: use the one-wave-per-SIMD kernel (A/B, debugging) */
+    GPDE_FWD_F16SPLIT_4WAVE = 2, /* with F16SPLIT: use the one-wave-per-SIMD kernel (A/B, debugging) */
+    GPDE_FWD_F16SPLIT_2WG = 4    /* with F16SPLIT: two independent 4-wave workgroups per CU (A/B) */
 };
 
 #define GPDE_MAX_LAYERS 8
