@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=512, help="destination rows of the CPU sample")
     ap.add_argument("--cpu-threads", type=int, default=64, help="threads of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default=None, choices=["f32", "f16split", "f16split4w", "f16split2wg"],
+    ap.add_argument("--precision", default=None, choices=["f32", "f16split", "f16split4w", "f16split2wg", "f16splitq"],
                     help="arithmetic of the hidden layer (default: graph_pde_amd.ops.DEFAULT_PRECISION)")
     args = ap.parse_args()
 

@@ -101,6 +101,9 @@ int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws
             return GPDE_EWORKSPACE;
         }
         npc = (int64_t)((ws_bytes - fixed - 2 * kAlign) / (zrow + prow));
+        // the whole graph in one chunk whenever it fits exactly (the estimate above gives up two
+        // alignment units, which used to split a graph sized with the recommended workspace)
+        if (N > 0 && align_up((size_t)N * prow) + align_up((size_t)N * zrow) + fixed <= ws_bytes) npc = N;
         if (npc > N) npc = N;
         const int64_t min_nodes = N < 64 ? N : 64;
         if (npc < min_nodes || (N > 0 && npc < 1)) {
@@ -108,7 +111,7 @@ int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws
                            "(%zu bytes per node)", ws_bytes, (long long)npc, (long long)min_nodes, zrow + prow);
             return GPDE_EWORKSPACE;
         }
-        if (npc > 64) npc = npc / 64 * 64;
+        if (npc < N && npc > 64) npc = npc / 64 * 64;
     }
     if (npc < 1) npc = 1;
     P->nodes_per_chunk = npc;
@@ -226,7 +229,8 @@ extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edg
             {
                 ProfScope ps(0, stream);
                 const bool f16s = (flags & GPDE_FWD_F16SPLIT) != 0 && L.mode == 1;
-                if (f16s && (flags & GPDE_FWD_F16SPLIT_2WG) && gpde_fused_f16v4_supported(f)) rc = gpde_launch_fused_f16v4(f, stream);
+                if (f16s && (flags & GPDE_FWD_F16SPLIT_QUAD) && gpde_fused_f16v5_supported(f)) rc = gpde_launch_fused_f16v5(f, stream);
+                else if (f16s && (flags & GPDE_FWD_F16SPLIT_2WG) && gpde_fused_f16v4_supported(f)) rc = gpde_launch_fused_f16v4(f, stream);
                 else if (f16s && !(flags & GPDE_FWD_F16SPLIT_4WAVE) && gpde_fused_f16v3_supported(f)) rc = gpde_launch_fused_f16v3(f, stream);
                 else if (f16s && gpde_fused_f16_supported(f)) rc = gpde_launch_fused_f16(f, stream);
                 else rc = gpde_launch_fused(L.mode, f16s, f, stream);

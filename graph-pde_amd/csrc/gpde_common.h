@@ -103,6 +103,9 @@ int gpde_launch_fused_f16v3(const GpdeFusedArgs& a, hipStream_t stream);
 // two independent 4-wave workgroups per CU, 64-column slices (gpde_fused_f16v4.hip)
 bool gpde_fused_f16v4_supported(const GpdeFusedArgs& a);
 int gpde_launch_fused_f16v4(const GpdeFusedArgs& a, hipStream_t stream);
+// 8 edge tiles x one 64-column slice, 8-slot ring, one barrier per four chunks (gpde_fused_f16v5.hip)
+bool gpde_fused_f16v5_supported(const GpdeFusedArgs& a);
+int gpde_launch_fused_f16v5(const GpdeFusedArgs& a, hipStream_t stream);
 
 struct GpdeGemm3Args {
     const float* zbuf;     // [nn][64*K2P]

@@ -1,17 +1,14 @@
-// Fused edge kernel, f16-split, TWO WAVES PER SIMD (v3): 8 waves per workgroup, wave tile =
-// 32 edges x 64 hidden columns, H1 generated on f16 MFMA as well.
+// Fused edge kernel, f16-split, v5: 8 waves = 8 edge tiles on ONE 64-column slice, 8-slot ring,
+// one s_barrier per FOUR k chunks.
 //
-// Same contract and math as gpde_fused_f16_kernel (gpde_fused_f16.hip; replaces DenseNet.forward
-// hidden part, /root/reference/graph-neural-operator/utilities.py:223-227, NNConv_old.message,
-// nn_conv.py:273-275, and PyG's gather/scatter).  Why a second variant: a wave alone on its SIMD
-// hides only ~4 non-MFMA instructions per 32-cycle MFMA (scripts/ubench/mfma_valu_overlap.hip), so
-// in the 4-wave kernel MFMA time and issue time ADD (47 % matrix-pipe occupancy).  Halving the
-// wave tile to 64 columns brings the accumulators (32 + 64 registers) under the 256-register
-// budget of two waves per SIMD; the partner wave's MFMAs then run under this wave's VALU / LDS /
-// DMA issue.  The two waves of a pair (same 32 edges, column halves 0/1) both need H1, so its
-// generation must be cheap: (W1|b1) . attr is done as 2 f16 MFMAs (K = 16 holds [hi|hi] x [hi;lo]
-// and [lo|lo] x [hi;0]) instead of 4 fp32 ones, with per-input-slot column scales 2^u_d folded
-// into the attributes (pack_w1_f16split_kernel).
+// Same contract, math and arithmetic as gpde_fused_f16v3_kernel (gpde_fused_f16v3.hip; replaces
+// DenseNet.forward's hidden layer, /root/reference/graph-neural-operator/utilities.py:223-227,
+// NNConv_old.message, nn_conv.py:273-275, and PyG's gather/scatter).  scripts/v3_timing.py attributes
+// a third of v3's K-loop overhead to its s_barrier (one per two chunks) and another third to the
+// W2 staging.  Here a workgroup covers 8 edge tiles x 64 hidden columns instead of 4 x 128: the W2
+// image per chunk is 8 KiB (+1 KiB of (W1|b1) rows riding in the same slot), so an 8-slot ring
+// (72 KiB) holds two QUADS of chunks: one barrier and one DMA instruction per chunk per wave every
+// four chunks, half the L2->LDS bytes per unit of work, and no resident W1 image.
 #include "gpde_common.h"
 
 namespace {
@@ -43,39 +40,35 @@ __device__ __forceinline__ int lower_bound_node(const int32_t* __restrict__ rowp
     return lo;
 }
 
-constexpr int RING = 4;                    // W2 chunk images in LDS: two pairs of chunks
-#ifdef GPDE_V3_TIMING
-__device__ unsigned long long gpde_v3_tm[6];
-#endif
-constexpr int TILE_B = GP_TN * 128;        // 16 KiB per W2 chunk image
-constexpr int XS_TILE = GP_TE * GP_W;      // floats per edge-tile x stage (shared by a wave pair)
-constexpr int NW = 8;                      // waves per workgroup
-constexpr int NET = 4;                     // edge tiles per workgroup
+constexpr int RING = 8;                    // chunk images in LDS: two quads of chunks
+constexpr int SLW = 64;                    // hidden columns per workgroup slice
+constexpr int W2_B = SLW * 128;            // 8 KiB: W2 rows of the slice for one chunk
+constexpr int TILE_B = W2_B + 1024;        // + the (W1|b1) rows of chunk + 2: [32][hi 16 B | lo 16 B]
+constexpr int XS_TILE = GP_TE * GP_W;      // floats per wave x stage
+constexpr int NW = 8;                      // waves per workgroup = edge tiles per workgroup
+constexpr int NET = 8;
 
-__global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs a) {
+__global__ __launch_bounds__(512, 2) void gpde_fused_f16v5_kernel(GpdeFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ring = smem;                                               // [4][16 KiB]
-    char* w1s = smem + RING * TILE_B;                                // [K1P][hi 16 B | lo 16 B]
-    float* Xs_all = (float*)(w1s + (size_t)a.K1P * 32);              // [4 edge tiles][32][64]
-    int* red = (int*)(Xs_all + NET * XS_TILE);                       // [4]
-    float* Es_all = (float*)(red + 4);                               // [8][32]
+    char* ring = smem;                                               // [8][9 KiB]
+    float* Xs_all = (float*)(smem + RING * TILE_B);                  // [8 waves][32][64]
+    int* red = (int*)(Xs_all + NET * XS_TILE);                       // [8]
+    float* Es_all = (float*)(red + 8);                               // [8][32]
+    const char* w1c01 = (const char*)(Es_all + NW * GP_TE);          // (W1|b1) rows of chunks 0 and 1, resident
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int et = wave >> 1, ch = wave & 1;                         // edge tile, column half
-    const bool roleB = wave >= 4;                                    // SIMD partner of wave - 4
+    const int et = wave;                                             // one edge tile per wave
     const int l31 = lane & 31;
     const int h = lane >> 5;
     float* Es = Es_all + wave * GP_TE;
     float* Xs = Xs_all + et * XS_TILE;
 
-    const int ns = a.K2P / GP_TN;
-    const int slice = blockIdx.x % ns;
+    const int ns = a.K2P / SLW;
+    const int slice = blockIdx.x % ns;                               // 64-column slice
     const int group = blockIdx.x / ns;
     const int NKC = a.K1P / GP_BK;
-
-    for (int i = tid; i < a.K1P * 2; i += 512) ((f32x4*)w1s)[i] = ((const f32x4*)a.w1h)[i];
 
     // ---- node-aligned edge range of this wave PAIR -------------------------------------------------
     const int e_lo = a.rowptr[a.nc0], e_hi = a.rowptr[a.nc1];
@@ -88,25 +81,31 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                                                            e_lo + tot * (wg + 1) / nranges);
     const int ea = a.rowptr[na], eb = a.rowptr[nb_];
     const int ntiles = (eb - ea + GP_TE - 1) / GP_TE;
-    if (lane == 0 && ch == 0) red[et] = ntiles;
+    if (lane == 0) red[et] = ntiles;
     __syncthreads();
-    const int maxtiles = max(max(red[0], red[1]), max(red[2], red[3]));
+    const int maxtiles = max(max(max(red[0], red[1]), max(red[2], red[3])), max(max(red[4], red[5]), max(red[6], red[7])));
     if (maxtiles == 0) return;
 
-    // ---- W2 chunk DMA: 2 x 1 KiB per wave per chunk ---------------------------------------------------
-    const char* w2g = (const char*)a.w2h + (size_t)slice * NKC * TILE_B + wave * 1024 + lane * 16;
+    // ---- chunk DMA into a ring slot: this slice's 64 W2 rows of `chunk` (8 x 1 KiB pieces, one per
+    //      wave) and the (W1|b1) rows of chunk + 2 (one 1 KiB piece, issued by wave chunk & 7) ----------
+    const char* w2g = (const char*)a.w2h + (size_t)(slice >> 1) * NKC * (GP_TN * 128) + (slice & 1) * W2_B +
+                      wave * 1024 + lane * 16;
+    const char* w1g = (const char*)a.w1h + lane * 16;
     auto issue_w2 = [&](int chunk, int slot) {
-        const char* g = w2g + (size_t)chunk * TILE_B;
+        const char* g = w2g + (size_t)chunk * (GP_TN * 128);
         char* l = ring + slot * TILE_B + wave * 1024;
         dma16(g, l);
-        dma16(g + 8192, l + 8192);
+        if (wave == (chunk & 7)) {
+            const int cn = (chunk + 2 < NKC) ? chunk + 2 : chunk + 2 - NKC;
+            dma16(w1g + (size_t)cn * 1024, ring + slot * TILE_B + W2_B);
+        }
     };
 
     float b2v[2], ucv[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        b2v[nb] = a.b2[slice * GP_TN + ch * 64 + nb * 32 + l31];
-        ucv[nb] = a.ucol[slice * GP_TN + ch * 64 + nb * 32 + l31];
+        b2v[nb] = a.b2[slice * SLW + nb * 32 + l31];
+        ucv[nb] = a.ucol[slice * SLW + nb * 32 + l31];
     }
     // per-input-slot constants: bound weights max_k|W1b[k][d]| and column un-scales 2^-u_d
     float wmx8[8], fcol8[8];
@@ -116,22 +115,20 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
         fcol8[d] = a.fcol[d];
     }
     const int sw = (l31 >> 1) & 7;
-    const int rowb = (ch * 64 + l31) * 128;                       // byte offset of this lane's W2 row
+    const int rowb = l31 * 128;                                   // byte offset of this lane's W2 row
     const int boff0 = rowb + (((0 + h) ^ sw) << 4);
     const int boff1 = rowb + (((2 + h) ^ sw) << 4);
 
     // ---- per-tile side loads (unconditional, clamped: exact VMEM op counts) ----------------------------
-    // stage A (iteration 0):  edge id of the NEXT tile (1 load) + source nodes of THIS tile's rows
-    //                         this wave stages (4 loads)
-    // stage B (iteration K1): attributes of the NEXT tile (8 loads) + this tile's x_j rows, the
-    //                         wave's half (4 DMA)
+    // stage A (quad 0):   edge id of the NEXT tile (1 load) + source nodes of THIS tile's rows (8)
+    // stage B (quad KP1): attributes of the NEXT tile (8 loads) + this tile's x_j rows (8 DMA)
     const int e_clamp = max(e_hi - 1, 0);
-    int perm_n = 0, sidx[4];
+    int perm_n = 0, sidx[8];
     float attr_n[8];
     auto load_perm = [&](int e0n) { perm_n = a.perm[min(e0n + l31, e_clamp)]; };
     auto load_sidx = [&](int e0c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sidx[i] = a.src[min(e0c + (lane >> 4) + 4 * (ch * 4 + i), e_clamp)];
+        for (int i = 0; i < 8; ++i) sidx[i] = a.src[min(e0c + (lane >> 4) + 4 * i, e_clamp)];
     };
     auto load_attr = [&]() {
         const float* ap = a.attr + (size_t)perm_n * a.k0;
@@ -140,14 +137,15 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
     };
     auto issue_x = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            dma16(a.x + (size_t)sidx[i] * GP_W + (lane & 15) * 4, Xs + (ch * 4 + i) * 4 * GP_W);
+        for (int i = 0; i < 8; ++i)
+            dma16(a.x + (size_t)sidx[i] * GP_W + (lane & 15) * 4, Xs + i * 4 * GP_W);
     };
-    const int NP = NKC / 2;                         // chunk pairs per tile (NKC is even)
-    const int KP1 = NP >= 3 ? 1 : NP - 1;           // pair that issues stage B
+    const int NP = NKC / 4;                         // chunk quads per tile (NKC % 4 == 0)
+    const int KP1 = NP >= 3 ? 1 : NP - 1;           // quad that issues stage B
 
-    issue_w2(0, 0);
-    issue_w2(1, 1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) issue_w2(c, c);
+    if (wave < 2) dma16(w1g + wave * 1024, (void*)(w1c01 + wave * 1024));
     load_perm(ea);
     load_attr();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -163,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
     int cur = -1;
 
     auto flush = [&](int node) {
-        float* zrow = a.zbuf + ((size_t)(node - a.nc0) * GP_W) * a.K2P + slice * GP_TN + ch * 64 + l31;
+        float* zrow = a.zbuf + ((size_t)(node - a.nc0) * GP_W) * a.K2P + slice * SLW + l31;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -194,19 +192,12 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
     };
 
     int g = 0;
-#ifdef GPDE_V3_TIMING
-    long long tm_pro = 0, tm_loop = 0, tm_post = 0, tm_wait = 0, tm_bar = 0, tm0 = clock64(), tm1;
-#define TM_MARK(acc) do { tm1 = clock64(); acc += tm1 - tm0; tm0 = tm1; } while (0)
-#else
-#define TM_MARK(acc) do { } while (0)
-#endif
     for (int t = 0; t < maxtiles; ++t) {
         const int e0 = ea + t * GP_TE;
         const int e_end = min(e0 + GP_TE, eb);
 
         // ---- attributes of this lane's edge: validity, bias slot, per-edge scale, f16 split --------
         h8 B1, B2;          // H1 MFMA operands: B1 = h ? attr_lo : attr_hi ; B2 = h ? 0 : attr_hi
-        [[maybe_unused]] float dbg_attr[8];
         {
             const bool valid = (e0 + l31) < eb;
             float bnd = 0.f;
@@ -224,7 +215,6 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             if (h == 0) Es[l31] = isc;
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
-                dbg_attr[d] = attr_n[d] * sc;
                 const float s = attr_n[d] * fcol8[d] * sc;
                 const _Float16 hi = (_Float16)s;
                 const _Float16 lo = (_Float16)(s - (float)hi);
@@ -232,17 +222,8 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                 B2[d] = h ? (_Float16)0.f : hi;
             }
         }
-        auto h1gen = [&](int chunk) {
-#ifdef GPDE_V3_H1F32   // debugging aid: H1 on fp32 MFMA straight from the fp32 packed W1
-            {
-                const f32x4 w1f = *(const f32x4*)&a.w1[((size_t)(chunk * GP_BK + l31) * 2 + h) * 4];
-                f32x16 dd;
-                for (int r = 0; r < 16; ++r) dd[r] = 0.f;
-                for (int s_ = 0; s_ < 4; ++s_) dd = mfma32(w1f[s_], dbg_attr[2 * s_ + h], dd);
-                return dd;
-            }
-#endif
-            const char* wp = w1s + (size_t)(chunk * GP_BK + l31) * 32;
+        auto h1gen = [&](const char* w1rows) {
+            const char* wp = w1rows + (size_t)l31 * 32;
             const h8 A1 = *(const h8*)wp, A2 = *(const h8*)(wp + 16);
             f32x16 d;
 #pragma unroll
@@ -258,11 +239,11 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[nb][r] = 0.f;
 
-        h8 ahi[2][2], alo[2][2];      // two operand buffers: chunk parity (NKC is even: a tile starts at 0)
+        h8 ahi[2][2], alo[2][2];      // two operand buffers: chunk parity (a tile starts at parity 0)
         f32x16 d;                     // raw H1 of the chunk after the current one (loop carried)
         {
-            const f32x16 a0 = h1gen(0);
-            d = h1gen(1);
+            const f32x16 a0 = h1gen(w1c01);
+            d = h1gen(w1c01 + 1024);
 #pragma unroll
             for (int p_ = 0; p_ < 8; ++p_) conv_to(a0, p_, ahi[0], alo[0]);
         }
@@ -272,19 +253,19 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
         const int n_first = a.dst[min(e0, e_clamp)];
         const int n_last = a.dst[min(max(e_end - 1, e0), e_clamp)];
 
-        // K loop in PAIRS of chunks: one s_barrier per two chunks (the barrier is the most expensive
-        // thing in the loop, scripts/ubench/kloop_model_v3.hip).  Pair G lives in ring slots
-        // {2(G&1), 2(G&1)+1}; the next pair's 4 DMA are issued at the top of the iteration into the
-        // other two slots (free since the previous barrier) and retired before the closing barrier.
-        TM_MARK(tm_pro);
+        // K loop in QUADS of chunks, one s_barrier per quad.  Quad G lives in ring slots
+        // 4(G&1) .. 4(G&1)+3; the next quad's DMA (one per chunk per wave) are issued at the top of the
+        // iteration into the other four slots (free since the previous barrier) and retired before
+        // the closing barrier.
         for (int kp = 0; kp < NP; ++kp, ++g) {
-            const int sb = (g & 1) * 2;
-            int cA = 2 * kp + 2, cB = 2 * kp + 3;
-            if (cA >= NKC) cA -= NKC;
-            if (cB >= NKC) cB -= NKC;
+            const int sb = (g & 1) * 4;
 #ifndef GPDE_ABL_NOSTAGE
-            issue_w2(cA, sb ^ 2);
-            issue_w2(cB, (sb ^ 2) + 1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                int cn = 4 * kp + 4 + c;
+                if (cn >= NKC) cn -= NKC;
+                issue_w2(cn, (sb ^ 4) + c);
+            }
 #endif
             if (kp == 0) {
                 load_perm(e0n);
@@ -294,103 +275,57 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                 load_attr();
                 issue_x();
             }
-            // B fragments (W2 hi / lo units of this lane's two rows) are read ONE HALF-CHUNK AHEAD, in
-            // place: the lo units are consumed by the first two MFMAs of a half and re-loaded right
-            // after them, the hi units after the last four.  Only the first half of a pair (the DMA
-            // landed at the previous barrier) has its reads exposed.
-            h8 bhi[2], blo[2];
-            auto ld_lo = [&](const char* rbx, int m) {
-                const int bo = m ? boff1 : boff0;
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) blo[nb] = *(const h8*)(rbx + nb * 4096 + (bo ^ 64));
-            };
-            auto ld_hi = [&](const char* rbx, int m) {
-                const int bo = m ? boff1 : boff0;
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) bhi[nb] = *(const h8*)(rbx + nb * 4096 + bo);
-            };
-            ld_lo(ring + sb * TILE_B, 0);
-            ld_hi(ring + sb * TILE_B, 0);
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
+            for (int cc = 0; cc < 4; ++cc) {
                 const char* rb = ring + (sb + cc) * TILE_B;
-#ifndef GPDE_V3_NOPRIO
-                // The SIMD arbitrates its two waves by age: alternate the priority per chunk so that
-                // neither wave of a pair runs ahead and then idles at the barrier.
-                if ((cc == 0) != roleB) __builtin_amdgcn_s_setprio(1);
-                else __builtin_amdgcn_s_setprio(0);
-#endif
-                int c2 = 2 * kp + cc + 2;
-                if (c2 >= NKC) c2 -= NKC;
-                // (W1|b1) rows of chunk c + 2, read now, used by the two H1 MFMAs at the end of the chunk
-                const char* wp = w1s + (size_t)(c2 * GP_BK + l31) * 32;
-                const h8 A1 = *(const h8*)wp, A2 = *(const h8*)(wp + 16);
+                const int pc = cc & 1;            // operand buffer of this chunk
                 // MFMA, one conversion pair of the NEXT chunk's H1 (5 VALU, into the other operand
                 // buffer), MFMA, ... in pinned source order: a long VALU burst of one wave starves its
-                // SIMD partner's MFMA issue (same issue port), so cross-wave overlap alone hides
-                // nothing (scripts/v3_timing.py ablations).
+                // SIMD partner's MFMA issue, so the conversions are spread between the MFMAs
+                h8 bhi[2], blo[2];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
+                    const int bo = m ? boff1 : boff0;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        bhi[nb] = *(const h8*)(rb + nb * 4096 + bo);
+                        blo[nb] = *(const h8*)(rb + nb * 4096 + (bo ^ 64));
+                    }
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {
-                        const int nb = j & 1, t = j >> 1;       // t: 0 = hi x lo, 1 = hi x hi, 2 = lo x hi
-                        acc1[nb] = mfma16(t == 2 ? alo[cc][m] : ahi[cc][m], t == 0 ? blo[nb] : bhi[nb], acc1[nb]);
+                        const int nb = j & 1, t = j >> 1;
+                        acc1[nb] = mfma16(t == 2 ? alo[pc][m] : ahi[pc][m], t == 1 ? blo[nb] : bhi[nb], acc1[nb]);
 #ifndef GPDE_ABL_NOCONV
                         if (j == 0 || j == 1 || j == 3 || j == 4) {
-                            conv_to(d, 4 * m + (j < 2 ? j : j - 1), ahi[cc ^ 1], alo[cc ^ 1]);
-                            asm volatile("" ::"v"(ahi[cc ^ 1][m]), "v"(alo[cc ^ 1][m]));
+                            conv_to(d, 4 * m + (j < 2 ? j : j - 1), ahi[pc ^ 1], alo[pc ^ 1]);
+                            asm volatile("" ::"v"(ahi[pc ^ 1][m]), "v"(alo[pc ^ 1][m]));
                         }
 #endif
-                        if (j == 1) {
-                            if (m == 0) ld_lo(rb, 1);
-                            else if (cc == 0) ld_lo(rb + TILE_B, 0);
-                        }
-                        if (j == 5) {
-                            if (m == 0) ld_hi(rb, 1);
-                            else if (cc == 0) ld_hi(rb + TILE_B, 0);
-                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
 #ifdef GPDE_ABL_NOCONV
                 asm volatile("" ::"v"(d));
 #endif
-#pragma unroll
-                for (int r = 0; r < 16; ++r) d[r] = 0.f;
-                d = mfma16(A1, B1, d);
-                d = mfma16(A2, B2, d);
+                d = h1gen(rb + W2_B);             // this slot carries the (W1|b1) rows of chunk + 2
                 asm volatile("" ::"v"(d));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // counted wait: everything up to and including this iteration's 4 W2 DMA is retired; only
-            // the side loads issued after them (5 at kp == 0, 12 at kp == KP1) may stay in flight
-#ifdef GPDE_V3_TIMING
-            const long long tw0 = clock64();
-#endif
+            // counted wait: everything up to and including this iteration's W2 DMA is retired; only
+            // the side loads issued after them (9 at kp == 0, 16 at kp == KP1) may stay in flight
 #ifndef GPDE_ABL_NOSTAGE
-            if (kp == 0 && KP1 == 0) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-            else if (kp == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else if (kp == KP1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            if (kp == 0 && KP1 == 0) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+            else if (kp == 0) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if (kp == KP1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#ifdef GPDE_V3_TIMING
-            const long long tw1 = clock64();
 #endif
 #ifndef GPDE_ABL_NOBARRIER
             __builtin_amdgcn_s_barrier();
 #endif
-#ifdef GPDE_V3_TIMING
-            tm_wait += tw1 - tw0;
-            tm_bar += clock64() - tw1;
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (NP < 3) {      // the x_j rows were issued in the last pair: land them before the aggregation
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
+        if (NP < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // x_j rows issued in the last quad
 
-        TM_MARK(tm_loop);
         // ---- undo the row (edge) and column scales, bias, ReLU ---------------------------------------
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -432,55 +367,37 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             e_seg = seg_end;
             if (e_seg < e_end) node = a.dst[e_seg];
         }
-        TM_MARK(tm_post);
     }
     if (cur >= 0) flush(cur);
-#ifdef GPDE_V3_TIMING
-    if (lane == 0) {
-        atomicAdd(&gpde_v3_tm[0], (unsigned long long)tm_pro);
-        atomicAdd(&gpde_v3_tm[1], (unsigned long long)tm_loop);
-        atomicAdd(&gpde_v3_tm[2], (unsigned long long)tm_post);
-        atomicAdd(&gpde_v3_tm[3], (unsigned long long)maxtiles);
-        atomicAdd(&gpde_v3_tm[4], (unsigned long long)tm_wait);
-        atomicAdd(&gpde_v3_tm[5], (unsigned long long)tm_bar);
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace
 
-static size_t v3_lds_bytes(int K1P) {
-    return (size_t)RING * TILE_B + (size_t)K1P * 32 + (size_t)NET * XS_TILE * 4 + 16 + NW * GP_TE * 4 + 64;
+static size_t v5_lds_bytes(int K1P) {
+    (void)K1P;
+    return (size_t)RING * TILE_B + (size_t)NET * XS_TILE * 4 + 32 + NW * GP_TE * 4 + 2048 + 64;
 }
 
-#ifdef GPDE_V3_TIMING
-// developer probe (scripts/v3_timing.py): cycles per phase summed over waves, and wave-tiles
-extern "C" int gpde_debug_v3_timing(unsigned long long* out6, int reset) {
-    if (hipMemcpyFromSymbol(out6, HIP_SYMBOL(gpde_v3_tm), 48) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(gpde_v3_tm), z, 48) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
-
-bool gpde_fused_f16v3_supported(const GpdeFusedArgs& a) {
-    return a.K1P / GP_BK >= 2 && (a.K1P / GP_BK) % 2 == 0 && a.k0 + 1 <= 8 && v3_lds_bytes(a.K1P) <= 80 * 1024 * 2;
+bool gpde_fused_f16v5_supported(const GpdeFusedArgs& a) {
+    return a.K1P / GP_BK >= 4 && (a.K1P / GP_BK) % 4 == 0 && a.k0 + 1 <= 8 && v5_lds_bytes(a.K1P) <= 160 * 1024;
 }
 
-int gpde_launch_fused_f16v3(const GpdeFusedArgs& a, hipStream_t stream) {
-    const int ns = a.K2P / GP_TN;
+int gpde_launch_fused_f16v5(const GpdeFusedArgs& a0, hipStream_t stream) {
+    // the plan's n_groups counts workgroups per 128-column slice (4 edge tiles each); this kernel
+    // has twice the slices and 8 edge tiles per workgroup
+    GpdeFusedArgs a = a0;
+    a.n_groups = a0.n_groups > 1 ? a0.n_groups / 2 : 1;
+    const int ns = a.K2P / SLW;
     const dim3 grid(a.n_groups * ns), block(512);
-    const size_t lds = v3_lds_bytes(a.K1P);
+    const size_t lds = v5_lds_bytes(a.K1P);
     static size_t lds_set = 0;
     if (lds > lds_set) {
-        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v3_kernel,
+        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v5_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
-    hipLaunchKernelGGL(gpde_fused_f16v3_kernel, grid, block, lds, stream, a);
-    GP_LAUNCH_CHECK("gpde_fused_f16v3_kernel");
+    hipLaunchKernelGGL(gpde_fused_f16v5_kernel, grid, block, lds, stream, a);
+    GP_LAUNCH_CHECK("gpde_fused_f16v5_kernel");
     return GPDE_OK;
 }

@@ -200,7 +200,8 @@ _AGGR = {"add": _lib.GPDE_AGGR_ADD, "mean": _lib.GPDE_AGGR_MEAN}
 # arithmetic of the hidden k1 x k2 layer: "f32" = fp32 MFMA (exact fmaf chains); "f16split" = f16
 # MFMA on two-term split operands with fp32 accumulation (include/gpde.h GPDE_FWD_F16SPLIT)
 _PRECISION = {"f32": _lib.GPDE_FWD_DEFAULT, "f16split": _lib.GPDE_FWD_F16SPLIT,
-              "f16split2wg": _lib.GPDE_FWD_F16SPLIT | 4,   # 2wg: two 4-wave workgroups per CU (A/B)
+              "f16split2wg": _lib.GPDE_FWD_F16SPLIT | 4,
+              "f16splitq": _lib.GPDE_FWD_F16SPLIT | 8,     # q: 8 tiles x 64 columns, barrier per 4 chunks (A/B)   # 2wg: two 4-wave workgroups per CU (A/B)
               "f16split4w": _lib.GPDE_FWD_F16SPLIT | 2}     # 4w: one-wave-per-SIMD kernel (A/B)
 DEFAULT_PRECISION = os.environ.get("GPDE_PRECISION", "f16split")
 

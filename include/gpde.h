@@ -46,7 +46,8 @@ enum {
                               (x = hi + lo, 3 MFMAs, fp32 accumulate; per-product error < 2^-21,
                               DESIGN.md §3b); ignored for kernels without a hidden GEMM */
     GPDE_FWD_F16SPLIT_4WAVE = 2, /* with F16SPLIT: use the one-wave-per-SIMD kernel (A/B, debugging) */
-    GPDE_FWD_F16SPLIT_2WG = 4    /* with F16SPLIT: two independent 4-wave workgroups per CU (A/B) */
+    GPDE_FWD_F16SPLIT_2WG = 4,   /* with F16SPLIT: two independent 4-wave workgroups per CU (A/B) */
+    GPDE_FWD_F16SPLIT_QUAD = 8   /* with F16SPLIT: 8 edge tiles x 64 columns, one barrier per 4 chunks (A/B) */
 };
 
 #define GPDE_MAX_LAYERS 8

@@ -19,7 +19,7 @@ pm = ops.pack_mlp([l.weight for l in lin], [l.bias for l in lin])
 ws = torch.empty(ops.workspace_bytes(n, csr.n_edges, pm), dtype=torch.uint8, device=dev)
 out = torch.empty(n, 64, device=dev)
 lib = _lib.lib()
-buf = (ctypes.c_ulonglong * 4)()
+buf = (ctypes.c_ulonglong * 6)()
 for _ in range(2):
     ops.nnconv_forward_raw(x, csr, ea, pm, conv.root, conv.bias, "mean", out=out, ws=ws, precision="f16split")
 torch.cuda.synchronize()
@@ -27,7 +27,8 @@ lib.gpde_debug_v3_timing(buf, 1)
 ops.nnconv_forward_raw(x, csr, ea, pm, conv.root, conv.bias, "mean", out=out, ws=ws, precision="f16split")
 torch.cuda.synchronize()
 lib.gpde_debug_v3_timing(buf, 1)
-pro, loop, post, tiles = [int(v) for v in buf]
+pro, loop, post, tiles, wait, bar = [int(v) for v in buf]
 tot = pro + loop + post
 print(f"{cfg}: wave-tiles {tiles}  clock64 ticks per wave-tile: prologue {pro/tiles:.0f}  K-loop {loop/tiles:.0f}  post+GEMM2 {post/tiles:.0f}  total {tot/tiles:.0f}")
+print(f"inside the K loop, per wave-tile: vmcnt wait {wait/tiles:.0f}  s_barrier {bar/tiles:.0f}")
 print(f"shares: prologue {pro/tot:.3f}  K-loop {loop/tot:.3f}  post {post/tot:.3f}")

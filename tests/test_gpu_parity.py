@@ -167,20 +167,25 @@ def test_module_forward_drop_in():
             g["x"].to(d), g["edge_index"].to(d), g["edge_attr"].to(d))
 
 
+F16_VARIANTS = ["f16split", "f16split4w", "f16split2wg", "f16splitq"]   # default + the A/B kernels
+
+
+@pytest.mark.parametrize("variant", F16_VARIANTS)
 @pytest.mark.parametrize("name", ["ckpt_g16", "burgers_k4"])
-def test_f16split_hidden_layer_golden(name):
+def test_f16split_hidden_layer_golden(name, variant):
     """GPDE_FWD_F16SPLIT (hidden layer on f16 MFMA with two-term split operands, fp32 accumulate)
     against the reference vectors: same 1e-5 bar, and within a small factor of the fp32-MFMA path."""
     from tests.conftest import load_golden
     g = load_golden(name)
     args = (g["x"], g["edge_index"], g["edge_attr"], g["weights"], g["biases"], g["root"], g["bias"], g["aggr"])
-    y16 = run_native(*args, precision="f16split")
+    y16 = run_native(*args, precision=variant)
     y32 = run_native(*args, precision="f32")
     e16, e32 = rel_l2(y16, g["out_f64"]), rel_l2(y32, g["out_f64"])
-    assert e16 <= TOL and e16 <= 4 * e32 + 2e-7, (name, e16, e32)
+    assert e16 <= TOL and e16 <= 4 * e32 + 2e-7, (name, variant, e16, e32)
 
 
-def test_f16split_wide_dynamic_range():
+@pytest.mark.parametrize("variant", F16_VARIANTS)
+def test_f16split_wide_dynamic_range(variant):
     """Attributes and weights spanning many binades (per-edge and per-row power-of-two scaling)."""
     torch.manual_seed(11)
     n, e = 400, 8000
@@ -195,11 +200,11 @@ def test_f16split_wide_dynamic_range():
     ws_ = [l.weight.detach() for l in mlp if isinstance(l, torch.nn.Linear)]
     bs_ = [l.bias.detach() for l in mlp if isinstance(l, torch.nn.Linear)]
     y64 = nnconv_forward(x, ei, ea, ws_, bs_, None, None, aggr="mean", dtype=torch.float64)
-    y16 = run_native(x, ei, ea, ws_, bs_, None, None, "mean", precision="f16split")
+    y16 = run_native(x, ei, ea, ws_, bs_, None, None, "mean", precision=variant)
     y32 = run_native(x, ei, ea, ws_, bs_, None, None, "mean", precision="f32")
     e16, e32 = rel_l2(y16, y64), rel_l2(y32, y64)
     assert torch.isfinite(y16).all()
-    assert e16 <= TOL and e16 <= 4 * e32 + 2e-7, (e16, e32)
+    assert e16 <= TOL and e16 <= 4 * e32 + 2e-7, (variant, e16, e32)
 
 
 def _oracle_grads(x, ei, ea, ws_, bs_, root, bias, aggr, gout):
