@@ -1,6 +1,11 @@
 """`torch.autograd.Function` around the fused NNConv (libgpde.so): forward = one gpde_nnconv_fwd
 call, backward = one gpde_nnconv_bwd call (include/gpde.h).  Nothing but the inputs is saved: the
 backward recomputes the hidden activations chunk by chunk.
+
+Cross-depth reuse: `HiddenFunction` materialises the hidden
+activations H(edge_attr; hidden layers) once, `NNConvHiddenFunction` is the operator given H.  When a
+module is applied `depth` times with the same edge_attr and weights, all `depth` applications share
+one H node: autograd sums their dL/dH and `HiddenFunction.backward` runs the MLP backward once.
 """
 from __future__ import annotations
 
@@ -36,3 +41,58 @@ class NNConvFunction(torch.autograd.Function):
             x, ctx.csr, edge_attr, weights, biases, root, ctx.aggr, grad_out,
             need_root=root is not None, need_bias=ctx.has_bias)
         return (gx, None, None, groot, gbias if ctx.has_bias else None, None, None, *gW, *gb)
+
+
+class HiddenToken:
+    """Validity flag shared between a cached H and its autograd node: once the node's backward has
+    run, the graph behind H is gone and the cached tensor must not be reused for a new forward."""
+    __slots__ = ("valid",)
+
+    def __init__(self):
+        self.valid = True
+
+
+class HiddenFunction(torch.autograd.Function):
+    """H [E, K2P] = relu(L_{n-1}(... relu(L_1(edge_attr)))) in CSR row order (gpde_hidden_fwd)."""
+
+    @staticmethod
+    def forward(ctx, edge_attr, csr, pm, precision, token, n_hidden, *params):
+        weights = list(params[:n_hidden])
+        biases = list(params[n_hidden:])
+        h = ops.hidden_forward_raw(csr, edge_attr.detach(), pm, weights + [None], biases + [None], precision)
+        ctx.csr, ctx.dims, ctx.n_hidden, ctx.token = csr, tuple(pm.dims), n_hidden, token
+        ctx.attr_needs_grad = edge_attr.requires_grad
+        ctx.save_for_backward(edge_attr, *params)
+        return h
+
+    @staticmethod
+    def backward(ctx, grad_h):
+        if ctx.attr_needs_grad:
+            raise NotImplementedError(
+                "gradient with respect to edge_attr is not built (no reference script needs it)")
+        ctx.token.valid = False
+        edge_attr, *params = ctx.saved_tensors
+        n = ctx.n_hidden
+        gW, gb = ops.hidden_backward_raw(ctx.csr, edge_attr, ctx.dims, list(params[:n]), list(params[n:]), grad_h)
+        return (None, None, None, None, None, None, *gW, *gb)
+
+
+class NNConvHiddenFunction(torch.autograd.Function):
+    """The operator given H: aggregation of x_j (x) H_e, last Linear, update() (gpde_nnconv_fwd_hidden /
+    gpde_nnconv_bwd_hidden)."""
+
+    @staticmethod
+    def forward(ctx, x, hidden, csr, pm, w_last, b_last, root, bias, aggr):
+        out = ops.nnconv_forward_hidden_raw(x.detach(), csr, hidden.detach(), pm, root, bias, aggr)
+        ctx.csr, ctx.dims, ctx.aggr = csr, tuple(pm.dims), aggr
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, hidden, w_last, b_last, root)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, hidden, w_last, b_last, root = ctx.saved_tensors
+        gx, gh, gw, gb, groot, gbias = ops.nnconv_backward_hidden_raw(
+            x, ctx.csr, hidden, ctx.dims, w_last, b_last, root, ctx.aggr, grad_out,
+            need_root=root is not None, need_bias=ctx.has_bias)
+        return (gx, gh, None, None, gw, gb, groot, gbias if ctx.has_bias else None, None)

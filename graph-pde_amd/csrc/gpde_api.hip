@@ -73,7 +73,7 @@ int pick_splits(int64_t nn) {
 }
 
 int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws_bytes, bool sizing,
-              Plan* P, size_t* needed) {
+              Plan* P, size_t* needed, bool hidden_given = false) {
     int rc = gpde_pack_layout(n_layers, dims, &P->L);
     if (rc != GPDE_OK) return rc;
     const GpdePackLayout& L = P->L;
@@ -81,7 +81,7 @@ int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws
     const size_t prow = (size_t)64 * GP_W * sizeof(float);   // worst case: 64 splits
     size_t fixed = 0;
     P->h_floats = 0;
-    if (L.mode == 2) {
+    if (L.mode == 2 && !hidden_given) {
         int kmax = 0;
         for (int l = 1; l <= n_layers - 1; ++l) kmax = kmax > L.frontKP[l] ? kmax : L.frontKP[l];
         P->h_floats = (size_t)(E > 0 ? E : 1) * kmax;
@@ -120,8 +120,8 @@ int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws
     size_t off = 0;
     P->off_part = off; off += align_up((size_t)npc * prow);
     P->off_z = off;    off += align_up((size_t)npc * zrow);
-    P->off_ha = off;   off += (L.mode == 2) ? align_up(P->h_floats * sizeof(float)) : 0;
-    P->off_hb = off;   off += (L.mode == 2) ? align_up(P->h_floats * sizeof(float)) : 0;
+    P->off_ha = off;   off += (L.mode == 2 && !hidden_given) ? align_up(P->h_floats * sizeof(float)) : 0;
+    P->off_hb = off;   off += (L.mode == 2 && !hidden_given) ? align_up(P->h_floats * sizeof(float)) : 0;
     if (needed) *needed = off;
     // fused-kernel grid: ~one workgroup per CU, never more edge groups than 4-wave tile sets
     const int ns = L.K2P / GP_TN;
@@ -162,18 +162,15 @@ extern "C" int gpde_nnconv_fwd_plan(int64_t n_nodes, int64_t n_edges, int n_laye
     return GPDE_OK;
 }
 
-extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edge_attr,
-                               int64_t n_edges, const int32_t* rowptr, const int32_t* src,
-                               const int32_t* dst, const int32_t* perm, int n_layers,
-                               const int32_t* dims, const void* packed, const float* root,
-                               const float* bias, int aggr, uint32_t flags, float* out, void* ws,
-                               size_t ws_bytes, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (n_nodes < 0 || n_edges < 0 || !dims || !packed || !rowptr || (n_nodes > 0 && (!x || !out)) ||
-        (n_edges > 0 && (!edge_attr || !src || !dst || !perm))) {
-        gpde_set_error("gpde_nnconv_fwd: null/negative argument");
-        return GPDE_EINVAL;
-    }
+namespace {
+
+// `hidden` != nullptr: the last hidden activations are given ([CSR slot][K2P], gpde_hidden_fwd); only the
+// aggregation, the last Linear and update() run (gpde_nnconv_fwd_hidden)
+int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
+             const int32_t* rowptr, const int32_t* src, const int32_t* dst, const int32_t* perm,
+             int n_layers, const int32_t* dims, const void* packed, const float* root,
+             const float* bias, int aggr, uint32_t flags, const float* hidden, float* out, void* ws,
+             size_t ws_bytes, hipStream_t stream) {
     if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) {
         gpde_set_error("gpde_nnconv_fwd: aggr %d not implemented (add=0, mean=1)", aggr);
         return GPDE_EUNSUPPORTED;
@@ -181,9 +178,10 @@ extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edg
     if (n_nodes == 0) return GPDE_OK;
     if (!ws) { gpde_set_error("gpde_nnconv_fwd: workspace is null"); return GPDE_EWORKSPACE; }
     Plan P;
-    int rc = make_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P, nullptr);
+    int rc = make_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P, nullptr, hidden != nullptr);
     if (rc != GPDE_OK) return rc;
     const GpdePackLayout& L = P.L;
+    const int mode = hidden ? 2 : L.mode;
     const float* pk = (const float*)packed;
     char* w = (char*)ws;
     w = (char*)(((uintptr_t)w + kAlign - 1) / kAlign * kAlign);
@@ -192,8 +190,8 @@ extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edg
     float* ha = (float*)(w + P.off_ha);
     float* hb = (float*)(w + P.off_hb);
 
-    const float* hfinal = nullptr;
-    if (L.mode == 2 && n_edges > 0) {
+    const float* hfinal = hidden;
+    if (!hidden && L.mode == 2 && n_edges > 0) {
         // front layers over all edges (CSR order), ping-pong between ha / hb
         const float* in = edge_attr;
         int ldx = L.k0, kin = L.k0;
@@ -218,7 +216,7 @@ extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edg
         const int nn = (int)(nc1 - nc0);
         const int splits = pick_splits(nn);
         if (n_edges > 0) {
-            GpdeFusedArgs f;
+            GpdeFusedArgs f{};
             f.x = x; f.attr = edge_attr; f.rowptr = rowptr; f.src = src; f.dst = dst; f.perm = perm;
             f.w1 = pk + L.off_w1; f.w2t = pk + L.off_w2t; f.b2 = pk + L.off_b2;
             f.w2h = pk + L.off_w2h; f.ucol = pk + L.off_ucol;
@@ -228,12 +226,13 @@ extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edg
             f.nc0 = (int)nc0; f.nc1 = (int)nc1; f.e_chunk0 = 0; f.n_groups = P.n_groups;
             {
                 ProfScope ps(0, stream);
-                const bool f16s = (flags & GPDE_FWD_F16SPLIT) != 0 && L.mode == 1;
-                if (f16s && (flags & GPDE_FWD_F16SPLIT_QUAD) && gpde_fused_f16v5_supported(f)) rc = gpde_launch_fused_f16v5(f, stream);
+                const bool f16s = (flags & GPDE_FWD_F16SPLIT) != 0 && mode == 1;
+                if (hidden) rc = gpde_launch_zagg(f, stream);
+                else if (f16s && (flags & GPDE_FWD_F16SPLIT_QUAD) && gpde_fused_f16v5_supported(f)) rc = gpde_launch_fused_f16v5(f, stream);
                 else if (f16s && (flags & GPDE_FWD_F16SPLIT_2WG) && gpde_fused_f16v4_supported(f)) rc = gpde_launch_fused_f16v4(f, stream);
                 else if (f16s && !(flags & GPDE_FWD_F16SPLIT_4WAVE) && gpde_fused_f16v3_supported(f)) rc = gpde_launch_fused_f16v3(f, stream);
                 else if (f16s && gpde_fused_f16_supported(f)) rc = gpde_launch_fused_f16(f, stream);
-                else rc = gpde_launch_fused(L.mode, f16s, f, stream);
+                else rc = gpde_launch_fused(mode, f16s, f, stream);
             }
             if (rc != GPDE_OK) return rc;
             ProfScope ps1(1, stream);
@@ -252,6 +251,37 @@ extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edg
         if (rc != GPDE_OK) return rc;
     }
     return GPDE_OK;
+}
+
+}  // namespace
+
+extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edge_attr,
+                               int64_t n_edges, const int32_t* rowptr, const int32_t* src,
+                               const int32_t* dst, const int32_t* perm, int n_layers,
+                               const int32_t* dims, const void* packed, const float* root,
+                               const float* bias, int aggr, uint32_t flags, float* out, void* ws,
+                               size_t ws_bytes, void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || !dims || !packed || !rowptr || (n_nodes > 0 && (!x || !out)) ||
+        (n_edges > 0 && (!edge_attr || !src || !dst || !perm))) {
+        gpde_set_error("gpde_nnconv_fwd: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    return fwd_impl(x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, n_layers, dims, packed, root, bias,
+                    aggr, flags, nullptr, out, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+extern "C" int gpde_nnconv_fwd_hidden(const float* x, int64_t n_nodes, const float* hidden,
+                                      int64_t n_edges, const int32_t* rowptr, const int32_t* src,
+                                      const int32_t* dst, int n_layers, const int32_t* dims,
+                                      const void* packed, const float* root, const float* bias,
+                                      int aggr, float* out, void* ws, size_t ws_bytes, void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || !dims || !packed || !rowptr || (n_nodes > 0 && (!x || !out)) ||
+        (n_edges > 0 && (!hidden || !src || !dst))) {
+        gpde_set_error("gpde_nnconv_fwd_hidden: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    return fwd_impl(x, n_nodes, nullptr, n_edges, rowptr, src, dst, nullptr, n_layers, dims, packed, root, bias,
+                    aggr, 0, hidden, out, ws, ws_bytes, (hipStream_t)stream_);
 }
 
 extern "C" int gpde_profile_begin(void) {

@@ -295,20 +295,24 @@ extern "C" size_t gpde_nnconv_bwd_workspace_bytes(int64_t n_nodes, int64_t n_edg
     return P.total;
 }
 
-extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
-                               const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                               const int32_t* perm, const int32_t* rowptr_host, int n_layers,
-                               const int32_t* dims, const float* const* W, const float* const* b,
-                               const float* root, int aggr, const float* grad_out, float* grad_x,
-                               float* const* grad_W, float* const* grad_b, float* grad_root,
-                               float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
-    hipStream_t st = (hipStream_t)stream_;
-    if (n_nodes < 0 || n_edges < 0 || !dims || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws ||
-        (n_nodes > 0 && !x) || (n_edges > 0 && (!edge_attr || !src || !dst || !perm))) {
-        gpde_set_error("gpde_nnconv_bwd: null/negative argument");
-        return GPDE_EINVAL;
-    }
-    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
+namespace {
+
+// One implementation, three entry points (the cross-depth reuse of SURVEY.md §8 row f4 splits the
+// operator into hidden(edge_attr) -> H and conv(x, H)):
+//   BWD_FULL  gpde_nnconv_bwd         hidden chain recomputed per chunk, everything differentiated
+//   BWD_CONV  gpde_nnconv_bwd_hidden  H given ([CSR slot][K2P]); grads of x, W3, b3, root, bias and
+//                                     dL/dU of the last hidden layer ([CSR slot][K2P]) written out
+//   BWD_MLP   gpde_hidden_bwd         H and dL/dU given; grads of the hidden Linear layers
+enum BwdPhase { BWD_FULL = 0, BWD_CONV = 1, BWD_MLP = 2 };
+
+int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
+             const int32_t* rowptr, const int32_t* src, const int32_t* dst, const int32_t* perm,
+             const int32_t* rowptr_host, int n_layers, const int32_t* dims, const float* const* W,
+             const float* const* b, const float* root, int aggr, const float* grad_out, float* grad_x,
+             float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias,
+             const float* hidden, float* grad_hidden_out, const float* grad_hidden_in, void* ws,
+             size_t ws_bytes, hipStream_t st) {
+    const bool do_conv = phase != BWD_MLP, do_mlp = phase != BWD_CONV;
     BwdPlan P;
     int rc = make_bwd_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P);
     if (rc != GPDE_OK) return rc;
@@ -319,7 +323,7 @@ extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edg
     const int T = 256;
 
     // ---- padded weights, zeroed gradient accumulators --------------------------------------------------
-    for (int l = 1; l < n; ++l) {
+    for (int l = 1; l < n && do_mlp; ++l) {
         const size_t wn = (size_t)P.KP[l] * P.KP[l - 1];
         hipLaunchKernelGGL(k_pad_mat, dim3(nblk(wn)), dim3(T), 0, st, W[l - 1], dims[l], dims[l - 1], dims[l - 1],
                            P.KP[l], P.KP[l - 1], F(P.off_wp[l]));
@@ -329,18 +333,76 @@ extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edg
         GP_HIP_CHECK(hipMemsetAsync(F(P.off_dbp[l]), 0, (size_t)P.KP[l] * 4, st));
     }
     const size_t w3n = (size_t)GP_W * GP_W * K2P;
-    hipLaunchKernelGGL(k_pad_mat, dim3(nblk(w3n)), dim3(T), 0, st, W[n - 1], GP_W * GP_W, dims[n - 1], dims[n - 1],
-                       GP_W * GP_W, K2P, F(P.off_w3p));
-    if (b[n - 1]) GP_HIP_CHECK(hipMemcpyAsync(F(P.off_b3), b[n - 1], GP_W * GP_W * 4, hipMemcpyDeviceToDevice, st));
-    else GP_HIP_CHECK(hipMemsetAsync(F(P.off_b3), 0, GP_W * GP_W * 4, st));
-    GP_HIP_CHECK(hipMemsetAsync(F(P.off_dw3p), 0, w3n * 4, st));
-    GP_HIP_CHECK(hipMemsetAsync(F(P.off_db3), 0, GP_W * GP_W * 4, st));
-    if (grad_x) GP_HIP_CHECK(hipMemsetAsync(grad_x, 0, (size_t)N * GP_W * 4, st));
+    if (do_conv) {
+        hipLaunchKernelGGL(k_pad_mat, dim3(nblk(w3n)), dim3(T), 0, st, W[n - 1], GP_W * GP_W, dims[n - 1], dims[n - 1],
+                           GP_W * GP_W, K2P, F(P.off_w3p));
+        if (b[n - 1]) GP_HIP_CHECK(hipMemcpyAsync(F(P.off_b3), b[n - 1], GP_W * GP_W * 4, hipMemcpyDeviceToDevice, st));
+        else GP_HIP_CHECK(hipMemsetAsync(F(P.off_b3), 0, GP_W * GP_W * 4, st));
+        GP_HIP_CHECK(hipMemsetAsync(F(P.off_dw3p), 0, w3n * 4, st));
+        GP_HIP_CHECK(hipMemsetAsync(F(P.off_db3), 0, GP_W * GP_W * 4, st));
+        if (grad_x) GP_HIP_CHECK(hipMemsetAsync(grad_x, 0, (size_t)N * GP_W * 4, st));
+    }
     float* dx = grad_x;
+
+    // recompute of the hidden chain for rows [e0, e0 + rows): layers 1 .. last (inclusive)
+    auto recompute = [&](int e0, int rows, int last) -> int {
+        hipLaunchKernelGGL(k_gather_attr, dim3(nblk((size_t)rows * P.KP[0])), dim3(T), 0, st, edge_attr, perm, e0,
+                           rows, dims[0], P.KP[0], F(P.off_H[0]));
+        for (int l = 1; l <= last; ++l) {
+            GpdeGemmArgs g = gemm0();
+            g.A = F(P.off_H[l - 1]); g.lda = P.KP[l - 1]; g.B = F(P.off_wp[l]); g.ldb = P.KP[l - 1];
+            g.C = F(P.off_H[l]); g.ldc = P.KP[l]; g.M = rows; g.N = P.KP[l]; g.K = P.KP[l - 1];
+            g.bias = F(P.off_bp[l]); g.relu = 1;
+            int rc2 = gpde_launch_gemm(g, st);
+            if (rc2 != GPDE_OK) return rc2;
+        }
+        return GPDE_OK;
+    };
+    // MLP backward over rows [e0, e0 + rows): dU_last given (read only), activations H[0 .. n-2] in the
+    // workspace, H[n-1] = Hlast
+    auto mlp_backward = [&](const float* dUlast, int rows) -> int {
+        const float* dUc = dUlast;
+        float* bufs[2] = {F(P.off_dU[0]), F(P.off_dU[1])};
+        int nb_ = 0;
+        for (int l = n - 1; l >= 1; --l) {
+            const int Kl = P.KP[l], Kin = P.KP[l - 1];
+            int rc2;
+            if ((rc2 = gemm_tn_acc(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, F(P.off_dwp[l]), Kin,
+                                   F(P.off_part), P.part_floats, 1, st)) != GPDE_OK) return rc2;
+            {
+                int splits = 1; while (splits < 64 && (Kl / 64) * splits < 512 && rows / (splits * 2) >= 64) splits *= 2;
+                if ((size_t)splits * Kl > P.part_floats) splits = 1;
+                hipLaunchKernelGGL(k_colsum, dim3((Kl + 63) / 64, splits), dim3(T), 0, st, dUc, rows, Kl, Kl, splits, F(P.off_part));
+                if ((rc2 = gpde_launch_reduce_splits(F(P.off_part), Kl, splits, Kl, F(P.off_dbp[l]), 1, st)) != GPDE_OK) return rc2;
+            }
+            if (l > 1) {
+                float* dUo = bufs[nb_]; nb_ ^= 1;
+                GpdeGemmArgs g = gemm0();
+                g.A = dUc; g.lda = Kl; g.B = F(P.off_wp[l]); g.ldb = Kin; g.b_kcontig = 0;
+                g.C = dUo; g.ldc = Kin; g.M = rows; g.N = Kin; g.K = Kl;
+                g.mask = F(P.off_H[l - 1]); g.ldmask = Kin;
+                if ((rc2 = gpde_launch_gemm(g, st)) != GPDE_OK) return rc2;
+                dUc = dUo;
+            }
+        }
+        return GPDE_OK;
+    };
+
+    if (phase == BWD_MLP) {
+        // plain edge chunks: nothing here depends on the destination structure
+        for (int64_t e0 = 0; e0 < n_edges; e0 += P.Ec) {
+            const int rows = (int)((n_edges - e0) < P.Ec ? (n_edges - e0) : P.Ec);
+            if ((rc = recompute((int)e0, rows, n - 2)) != GPDE_OK) return rc;
+            // activations below the last hidden layer are recomputed; the last one is needed only as
+            // the ReLU mask, which the incoming dL/dU already carries
+            if ((rc = mlp_backward(grad_hidden_in + (size_t)e0 * K2P, rows)) != GPDE_OK) return rc;
+        }
+        GP_LAUNCH_CHECK("gpde_hidden_bwd kernels");
+    }
 
     // ---- node-aligned chunks ----------------------------------------------------------------------------------
     int na = 0;
-    while (na < N && n_edges > 0) {
+    while (do_conv && na < N && n_edges > 0) {
         // largest nb with (nb - na) <= Nc and edges <= Ec (at least one node)
         int lo = na + 1, hi = (int)((int64_t)na + P.Nc < N ? na + P.Nc : N);
         const int64_t ebase = rowptr_host[na];
@@ -359,17 +421,9 @@ extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edg
         float* Z = F(P.off_Z); float* dZ = F(P.off_dZ);
         hipLaunchKernelGGL(k_scale_g, dim3((nn + 3) / 4), dim3(T), 0, st, grad_out, rowptr, aggr, na, nn, gT);
         if (rows > 0) {
-            // forward recompute of the hidden chain for the chunk's edges
-            hipLaunchKernelGGL(k_gather_attr, dim3(nblk((size_t)rows * P.KP[0])), dim3(T), 0, st, edge_attr, perm, e0,
-                               rows, dims[0], P.KP[0], F(P.off_H[0]));
-            for (int l = 1; l < n; ++l) {
-                GpdeGemmArgs g = gemm0();
-                g.A = F(P.off_H[l - 1]); g.lda = P.KP[l - 1]; g.B = F(P.off_wp[l]); g.ldb = P.KP[l - 1];
-                g.C = F(P.off_H[l]); g.ldc = P.KP[l]; g.M = rows; g.N = P.KP[l]; g.K = P.KP[l - 1];
-                g.bias = F(P.off_bp[l]); g.relu = 1;
-                if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
-            }
-            const float* Hlast = F(P.off_H[n - 1]);
+            // hidden activations of the chunk's edges: recomputed, or rows of the given cache
+            if (phase == BWD_FULL) { if ((rc = recompute(e0, rows, n - 1)) != GPDE_OK) return rc; }
+            const float* Hlast = phase == BWD_FULL ? F(P.off_H[n - 1]) : hidden + (size_t)e0 * K2P;
             // Z of the chunk's nodes from the recomputed activations (mode-2 fused kernel)
             GP_HIP_CHECK(hipMemsetAsync(Z, 0, (size_t)nn * GP_W * K2P * 4, st));
             {
@@ -378,10 +432,10 @@ extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edg
                 f.hbuf = Hlast; f.zbuf = Z; f.k0 = dims[0]; f.K1P = 32; f.K2P = K2P;
                 f.nc0 = na; f.nc1 = nb; f.e_chunk0 = e0;
                 const int ns = K2P / GP_TN;
-                int groups = gpde_num_cus() * 2 / ns; if (groups < 1) groups = 1;
+                int groups = gpde_num_cus() / ns; if (groups < 1) groups = 1;
                 const int gcap = (rows / GP_TE + GP_WAVES) / GP_WAVES; if (groups > gcap) groups = gcap;
                 f.n_groups = groups;
-                if ((rc = gpde_launch_fused(2, false, f, st)) != GPDE_OK) return rc;
+                if ((rc = gpde_launch_zagg(f, st)) != GPDE_OK) return rc;
             }
             hipLaunchKernelGGL(k_nbr_sum, dim3((nn + 3) / 4), dim3(T), 0, st, x, rowptr, src, na, nn, S);
             // db3[c][o] += S^T gT ;  dW3[c][o][k] += gT^T Z[:, c, :]
@@ -406,7 +460,7 @@ extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edg
                 if ((rc = gpde_launch_gemm(s2, st)) != GPDE_OK) return rc;
             }
             // per-edge backward through the aggregation -> dU_{n-1}, dx_j
-            float* dUc = F(P.off_dU[0]); float* dUo = F(P.off_dU[1]);
+            float* dUc = phase == BWD_FULL ? F(P.off_dU[0]) : grad_hidden_out + (size_t)e0 * K2P;
             {
                 EdgeBwdArgs ea{x, rowptr, src, dst, dZ, dS, Hlast, dUc, dx, e0, e1, na, K2P};
                 const size_t lds = (size_t)4 * (32 * EB_XS + 32 * EB_HS) * 4;
@@ -416,57 +470,173 @@ extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edg
                 else { gpde_set_error("gpde_nnconv_bwd: grad_x must be provided"); return GPDE_EINVAL; }
             }
             // MLP backward over the chunk's edges
-            for (int l = n - 1; l >= 1; --l) {
-                const int Kl = P.KP[l], Kin = P.KP[l - 1];
-                if ((rc = gemm_tn_acc(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, F(P.off_dwp[l]), Kin,
-                                      F(P.off_part), P.part_floats, 1, st)) != GPDE_OK) return rc;
-                {
-                    int splits = 1; while (splits < 64 && (Kl / 64) * splits < 512 && rows / (splits * 2) >= 64) splits *= 2;
-                    if ((size_t)splits * Kl > P.part_floats) splits = 1;
-                    hipLaunchKernelGGL(k_colsum, dim3((Kl + 63) / 64, splits), dim3(T), 0, st, dUc, rows, Kl, Kl, splits, F(P.off_part));
-                    if ((rc = gpde_launch_reduce_splits(F(P.off_part), Kl, splits, Kl, F(P.off_dbp[l]), 1, st)) != GPDE_OK) return rc;
-                }
-                if (l > 1) {
-                    GpdeGemmArgs g = gemm0();
-                    g.A = dUc; g.lda = Kl; g.B = F(P.off_wp[l]); g.ldb = Kin; g.b_kcontig = 0;
-                    g.C = dUo; g.ldc = Kin; g.M = rows; g.N = Kin; g.K = Kl;
-                    g.mask = F(P.off_H[l - 1]); g.ldmask = Kin;
-                    if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
-                    float* t = dUc; dUc = dUo; dUo = t;
-                }
-            }
+            if (phase == BWD_FULL) { if ((rc = mlp_backward(dUc, rows)) != GPDE_OK) return rc; }
         }
         na = nb;
     }
     GP_LAUNCH_CHECK("gpde_nnconv_bwd kernels");
 
     // ---- node-side terms of update(): dx += g root^T, droot = X^T g, dbias = colsum g ----------------------
-    if (root && dx) {
+    if (do_conv && root && dx) {
         GpdeGemmArgs g = gemm0();
         g.A = grad_out; g.lda = GP_W; g.B = root; g.ldb = GP_W; g.C = dx; g.ldc = GP_W;
         g.M = N; g.N = GP_W; g.K = GP_W; g.accumulate = 1;
         if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
     }
-    if (grad_root)
+    if (do_conv && grad_root)
         if ((rc = gemm_tn_acc(x, GP_W, GP_W, grad_out, GP_W, GP_W, N, grad_root, GP_W, F(P.off_part), P.part_floats, 0, st)) != GPDE_OK) return rc;
-    if (grad_bias) {
+    if (do_conv && grad_bias) {
         int splits = 1; while (splits < 64 && N / (splits * 2) >= 64) splits *= 2;
         hipLaunchKernelGGL(k_colsum, dim3(1, splits), dim3(T), 0, st, grad_out, N, GP_W, GP_W, splits, F(P.off_part));
         if ((rc = gpde_launch_reduce_splits(F(P.off_part), GP_W, splits, GP_W, grad_bias, 0, st)) != GPDE_OK) return rc;
     }
     // ---- un-pad the weight gradients into torch layout -------------------------------------------------------
-    for (int l = 1; l < n; ++l) {
+    for (int l = 1; l < n && do_mlp; ++l) {
         if (grad_W && grad_W[l - 1])
             hipLaunchKernelGGL(k_unpad_mat, dim3(nblk((size_t)dims[l] * dims[l - 1])), dim3(T), 0, st, F(P.off_dwp[l]),
                                dims[l], dims[l - 1], P.KP[l - 1], grad_W[l - 1]);
         if (grad_b && grad_b[l - 1])
             GP_HIP_CHECK(hipMemcpyAsync(grad_b[l - 1], F(P.off_dbp[l]), (size_t)dims[l] * 4, hipMemcpyDeviceToDevice, st));
     }
-    if (grad_W && grad_W[n - 1])
+    if (do_conv && grad_W && grad_W[n - 1])
         hipLaunchKernelGGL(k_unpad_mat, dim3(nblk((size_t)GP_W * GP_W * dims[n - 1])), dim3(T), 0, st, F(P.off_dw3p),
                            GP_W * GP_W, dims[n - 1], K2P, grad_W[n - 1]);
-    if (grad_b && grad_b[n - 1])
+    if (do_conv && grad_b && grad_b[n - 1])
         GP_HIP_CHECK(hipMemcpyAsync(grad_b[n - 1], F(P.off_db3), GP_W * GP_W * 4, hipMemcpyDeviceToDevice, st));
     GP_LAUNCH_CHECK("gpde_nnconv_bwd epilogue kernels");
+    return GPDE_OK;
+}
+
+}  // namespace
+
+extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
+                               const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                               const int32_t* perm, const int32_t* rowptr_host, int n_layers,
+                               const int32_t* dims, const float* const* W, const float* const* b,
+                               const float* root, int aggr, const float* grad_out, float* grad_x,
+                               float* const* grad_W, float* const* grad_b, float* grad_root,
+                               float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || !dims || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws ||
+        (n_nodes > 0 && !x) || (n_edges > 0 && (!edge_attr || !src || !dst || !perm))) {
+        gpde_set_error("gpde_nnconv_bwd: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
+    return bwd_impl(BWD_FULL, x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims,
+                    W, b, root, aggr, grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, nullptr, nullptr,
+                    nullptr, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+extern "C" int gpde_nnconv_bwd_hidden(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
+                                      const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                                      const int32_t* rowptr_host, int n_layers, const int32_t* dims,
+                                      const float* w_last, const float* b_last, const float* root, int aggr,
+                                      const float* grad_out, float* grad_x, float* grad_hidden,
+                                      float* grad_w_last, float* grad_b_last, float* grad_root,
+                                      float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || !dims || !w_last || !grad_out || !rowptr || !rowptr_host || !ws ||
+        n_layers < 2 || n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x || !grad_x)) ||
+        (n_edges > 0 && (!hidden || !grad_hidden || !src || !dst))) {
+        gpde_set_error("gpde_nnconv_bwd_hidden: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_hidden: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
+    const float* W[GPDE_MAX_LAYERS] = {};
+    const float* b[GPDE_MAX_LAYERS] = {};
+    float* gW[GPDE_MAX_LAYERS] = {};
+    float* gb[GPDE_MAX_LAYERS] = {};
+    W[n_layers - 1] = w_last; b[n_layers - 1] = b_last;
+    gW[n_layers - 1] = grad_w_last; gb[n_layers - 1] = grad_b_last;
+    return bwd_impl(BWD_CONV, x, n_nodes, nullptr, n_edges, rowptr, src, dst, nullptr, rowptr_host, n_layers, dims,
+                    W, b, root, aggr, grad_out, grad_x, gW, gb, grad_root, grad_bias, hidden, grad_hidden, nullptr,
+                    ws, ws_bytes, (hipStream_t)stream_);
+}
+
+extern "C" int gpde_hidden_bwd(const float* edge_attr, int64_t n_edges, const int32_t* perm, int n_layers,
+                               const int32_t* dims, const float* const* W, const float* const* b,
+                               const float* grad_hidden, float* const* grad_W, float* const* grad_b, void* ws,
+                               size_t ws_bytes, void* stream_) {
+    if (n_edges < 0 || !dims || !W || !b || !ws || !grad_W || !grad_b ||
+        (n_edges > 0 && (!edge_attr || !perm || !grad_hidden))) {
+        gpde_set_error("gpde_hidden_bwd: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    return bwd_impl(BWD_MLP, nullptr, 0, edge_attr, n_edges, nullptr, nullptr, nullptr, perm, nullptr, n_layers, dims,
+                    W, b, nullptr, GPDE_AGGR_ADD, nullptr, nullptr, grad_W, grad_b, nullptr, nullptr, nullptr, nullptr,
+                    grad_hidden, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+
+// ---- cross-depth reuse: the hidden activations as a tensor -------------------------
+// `conv1` is applied depth x with the same edge_attr and weights
+// (/root/reference/graph-neural-operator/UAI1_full_resolution.py:29-30; the MGKN V-cycle,
+// multipole-graph-neural-operator/MGKN_general_darcy2d.py:76-90): H_e = relu(L_{n-1}(...relu(L_1(attr_e))))
+// is identical in all of them.  gpde_hidden_fwd writes it once ([CSR slot][K2P] fp32), the *_hidden
+// entry points consume it.
+extern "C" size_t gpde_hidden_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims) {
+    BwdPlan P;
+    if (!dims || n_edges < 0) return 0;
+    if (make_bwd_plan(1, n_edges, n_layers, dims, 0, true, &P) != GPDE_OK) return 0;
+    return P.total;
+}
+
+extern "C" int gpde_hidden_fwd(const float* edge_attr, int64_t n_edges, const int32_t* rowptr, int64_t n_nodes,
+                               const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
+                               const float* const* W, const float* const* b, uint32_t flags, float* hidden,
+                               void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    if (n_edges < 0 || n_nodes < 0 || !dims || (n_edges > 0 && (!edge_attr || !perm || !hidden || !rowptr))) {
+        gpde_set_error("gpde_hidden_fwd: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (n_edges == 0) return GPDE_OK;
+    GpdePackLayout L;
+    int rc = gpde_pack_layout(n_layers, dims, &L);
+    if (rc != GPDE_OK) return rc;
+    // fast path: the f16-split fused kernel with a store epilogue instead of the aggregation
+    if (packed && (flags & GPDE_FWD_F16SPLIT) && L.mode == 1) {
+        const float* pk = (const float*)packed;
+        GpdeFusedArgs f{};
+        f.attr = edge_attr; f.rowptr = rowptr; f.perm = perm;
+        f.w1 = pk + L.off_w1; f.w2t = pk + L.off_w2t; f.b2 = pk + L.off_b2;
+        f.w2h = pk + L.off_w2h; f.ucol = pk + L.off_ucol; f.w1h = pk + L.off_w1h; f.fcol = pk + L.off_fcol;
+        f.hout = hidden; f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
+        f.nc0 = 0; f.nc1 = (int)n_nodes; f.e_chunk0 = 0;
+        const int ns = L.K2P / GP_TN;
+        int groups = gpde_num_cus() / ns; if (groups < 1) groups = 1;
+        const int64_t gcap = ((n_edges + GP_TE - 1) / GP_TE + GP_WAVES - 1) / GP_WAVES;
+        if (groups > gcap) groups = (int)gcap;
+        f.n_groups = groups;
+        if (gpde_fused_f16v3_supported(f)) return gpde_launch_fused_f16v3(f, st);
+    }
+    // general path (any layer count, exact fp32): chunks of edges through the dense GEMM
+    if (!W || !b || !ws) { gpde_set_error("gpde_hidden_fwd: weights / workspace needed for the general path"); return GPDE_EINVAL; }
+    BwdPlan P;
+    rc = make_bwd_plan(1, n_edges, n_layers, dims, ws_bytes, false, &P);
+    if (rc != GPDE_OK) return rc;
+    const int n = n_layers, K2P = P.K2P, T = 256;
+    char* w = (char*)(((uintptr_t)ws + 255) / 256 * 256);
+    auto F = [&](size_t off) { return (float*)(w + off); };
+    for (int l = 1; l < n; ++l) {
+        const size_t wn = (size_t)P.KP[l] * P.KP[l - 1];
+        hipLaunchKernelGGL(k_pad_mat, dim3(nblk(wn)), dim3(T), 0, st, W[l - 1], dims[l], dims[l - 1], dims[l - 1],
+                           P.KP[l], P.KP[l - 1], F(P.off_wp[l]));
+        if (b[l - 1]) hipLaunchKernelGGL(k_pad_mat, dim3(nblk(P.KP[l])), dim3(T), 0, st, b[l - 1], 1, dims[l], dims[l], 1, P.KP[l], F(P.off_bp[l]));
+        else GP_HIP_CHECK(hipMemsetAsync(F(P.off_bp[l]), 0, (size_t)P.KP[l] * 4, st));
+    }
+    for (int64_t e0 = 0; e0 < n_edges; e0 += P.Ec) {
+        const int rows = (int)((n_edges - e0) < P.Ec ? (n_edges - e0) : P.Ec);
+        hipLaunchKernelGGL(k_gather_attr, dim3(nblk((size_t)rows * P.KP[0])), dim3(T), 0, st, edge_attr, perm, (int)e0,
+                           rows, dims[0], P.KP[0], F(P.off_H[0]));
+        for (int l = 1; l < n; ++l) {
+            GpdeGemmArgs g = gemm0();
+            g.A = F(P.off_H[l - 1]); g.lda = P.KP[l - 1]; g.B = F(P.off_wp[l]); g.ldb = P.KP[l - 1];
+            g.C = (l == n - 1) ? hidden + (size_t)e0 * K2P : F(P.off_H[l]);
+            g.ldc = P.KP[l]; g.M = rows; g.N = P.KP[l]; g.K = P.KP[l - 1];
+            g.bias = F(P.off_bp[l]); g.relu = 1;
+            if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
+        }
+    }
+    GP_LAUNCH_CHECK("gpde_hidden_fwd kernels");
     return GPDE_OK;
 }

@@ -88,12 +88,17 @@ struct GpdeFusedArgs {
     const float* fcol;     // [8] per-input-slot 2^-u_d
     const float* hbuf;     // mode 2: [edges of chunk][K2P] in CSR order, relu already applied
     float* zbuf;           // [nc1-nc0][64][K2P]
+    float* hout;           // f16v3 only: when set, write the hidden activations [slot - e_chunk0][K2P]
+                           // instead of aggregating (gpde_hidden_fwd)
     int k0, K1P, K2P;
     int nc0, nc1;          // destination-node chunk
     int e_chunk0;          // rowptr[nc0] (mode 2: first row of hbuf)
     int n_groups;          // edge groups (workgroups per slice)
 };
 int gpde_launch_fused(int mode, bool f16split, const GpdeFusedArgs& a, hipStream_t stream);
+// Z = sum x_j (x) H_e from given hidden activations a.hbuf (gpde_zagg.hip); uses x, rowptr, src, dst,
+// hbuf, zbuf, K2P, nc0, nc1, e_chunk0, n_groups
+int gpde_launch_zagg(const GpdeFusedArgs& a, hipStream_t stream);
 // f16-split + LDS-DMA variant (gpde_fused_f16.hip); supported for 3 <= K1P/32 and K1P <= ~1000
 bool gpde_fused_f16_supported(const GpdeFusedArgs& a);
 int gpde_launch_fused_f16(const GpdeFusedArgs& a, hipStream_t stream);

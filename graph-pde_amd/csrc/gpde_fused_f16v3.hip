@@ -52,6 +52,9 @@ constexpr int XS_TILE = GP_TE * GP_W;      // floats per edge-tile x stage (shar
 constexpr int NW = 8;                      // waves per workgroup
 constexpr int NET = 4;                     // edge tiles per workgroup
 
+// WRITE_H: store the hidden activations [CSR slot][K2P] (a.hout) instead of aggregating them
+// (gpde_hidden_fwd: the cross-depth cache of SURVEY.md §8 row f4); no x_j staging, no Z.
+template <bool WRITE_H>
 __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;                                               // [4][16 KiB]
@@ -153,21 +156,24 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    f32x16 Z[2][2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Z[cb][nb][r] = 0.f;
-    int cur = -1;
-
-    auto flush = [&](int node) {
-        float* zrow = a.zbuf + ((size_t)(node - a.nc0) * GP_W) * a.K2P + slice * GP_TN + ch * 64 + l31;
+    f32x16 Z[WRITE_H ? 1 : 2][WRITE_H ? 1 : 2];
+    if constexpr (!WRITE_H) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Z[cb][nb][r] = 0.f;
+    }
+    int cur = -1;
+
+    auto flush = [&](int node) {
+        if constexpr (WRITE_H) return;
+        float* zrow = a.zbuf + ((size_t)(node - a.nc0) * GP_W) * a.K2P + slice * GP_TN + ch * 64 + l31;
+#pragma unroll
+        for (int cb = 0; cb < (WRITE_H ? 1 : 2); ++cb)
+#pragma unroll
+            for (int nb = 0; nb < (WRITE_H ? 1 : 2); ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -269,8 +275,8 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
         const int e0n = e0 + GP_TE;
         // destination of the tile's first / last edge (scalar loads issued now, used after the K
         // loop): a tile inside one destination node needs no further index loads
-        const int n_first = a.dst[min(e0, e_clamp)];
-        const int n_last = a.dst[min(max(e_end - 1, e0), e_clamp)];
+        const int n_first = WRITE_H ? 0 : a.dst[min(e0, e_clamp)];
+        const int n_last = WRITE_H ? 0 : a.dst[min(max(e_end - 1, e0), e_clamp)];
 
         // K loop in PAIRS of chunks: one s_barrier per two chunks (the barrier is the most expensive
         // thing in the loop, scripts/ubench/kloop_model_v3.hip).  Pair G lives in ring slots
@@ -288,11 +294,11 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
 #endif
             if (kp == 0) {
                 load_perm(e0n);
-                load_sidx(e0);
+                if constexpr (!WRITE_H) load_sidx(e0);
             }
             if (kp == KP1) {
                 load_attr();
-                issue_x();
+                if constexpr (!WRITE_H) issue_x();
             }
             // B fragments (W2 hi / lo units of this lane's two rows) are read ONE HALF-CHUNK AHEAD, in
             // place: the lo units are consumed by the first two MFMAs of a half and re-loaded right
@@ -368,10 +374,17 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             const long long tw0 = clock64();
 #endif
 #ifndef GPDE_ABL_NOSTAGE
-            if (kp == 0 && KP1 == 0) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-            else if (kp == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else if (kp == KP1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (WRITE_H) {       // no source-index loads (4) / x_j DMA (4)
+                if (kp == 0 && KP1 == 0) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                else if (kp == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else if (kp == KP1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (kp == 0 && KP1 == 0) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+                else if (kp == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else if (kp == KP1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
 #endif
 #ifdef GPDE_V3_TIMING
             const long long tw1 = clock64();
@@ -400,6 +413,19 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                 acc1[nb][r] = relu1(fmaf(acc1[nb][r], ie * ucv[nb], b2v[nb]));
         }
 
+        if constexpr (WRITE_H) {
+            // hidden activations of this tile: row = CSR slot, 128-byte runs along the columns
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int e = e0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (e < eb) {
+                    float* hp = a.hout + (size_t)(e - a.e_chunk0) * a.K2P + slice * GP_TN + ch * 64 + l31;
+                    hp[0] = acc1[0][r];
+                    hp[32] = acc1[1][r];
+                }
+            }
+            continue;
+        }
         // ---- GEMM2 with destination segments (fp32 MFMA) ----------------------------------------------
         int e_seg = e0;
 #ifdef GPDE_ABL_NOGEMM2
@@ -424,9 +450,9 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                 av0 = m ? av0 : 0.f;
                 av1 = m ? av1 : 0.f;
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
+                for (int nb = 0; nb < (WRITE_H ? 0 : 2); ++nb) {
                     Z[0][nb] = mfma32(av0, acc1[nb][r], Z[0][nb]);
-                    Z[1][nb] = mfma32(av1, acc1[nb][r], Z[1][nb]);
+                    Z[WRITE_H ? 0 : 1][nb] = mfma32(av1, acc1[nb][r], Z[WRITE_H ? 0 : 1][nb]);
                 }
             }
             e_seg = seg_end;
@@ -476,11 +502,14 @@ int gpde_launch_fused_f16v3(const GpdeFusedArgs& a, hipStream_t stream) {
     const size_t lds = v3_lds_bytes(a.K1P);
     static size_t lds_set = 0;
     if (lds > lds_set) {
-        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v3_kernel,
+        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v3_kernel<false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v3_kernel<true>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
-    hipLaunchKernelGGL(gpde_fused_f16v3_kernel, grid, block, lds, stream, a);
+    if (a.hout) hipLaunchKernelGGL(gpde_fused_f16v3_kernel<true>, grid, block, lds, stream, a);
+    else hipLaunchKernelGGL(gpde_fused_f16v3_kernel<false>, grid, block, lds, stream, a);
     GP_LAUNCH_CHECK("gpde_fused_f16v3_kernel");
     return GPDE_OK;
 }

@@ -1,0 +1,107 @@
+"""Cross-depth reuse of the kernel-MLP hidden activations.
+
+The reference applies one NNConv module `depth` times per forward with the same `edge_attr` and
+the same weights (/root/reference/graph-neural-operator/UAI1_full_resolution.py:29-30; the MGKN
+V-cycle, multipole-graph-neural-operator/MGKN_general_darcy2d.py:76-90), so
+H = relu(L_{n-1}(... relu(L_1(edge_attr)))) -- 94 % of the operator's FLOPs at [6,1024,1024,4096] -- is
+the same tensor in every one of those calls.  This module decides, per NNConv instance, when to
+materialise H (one `HiddenFunction` node) and serve the remaining calls from it
+(`NNConvHiddenFunction`): the hidden layer and its backward then run once per step.
+
+Policy (`GPDE_HIDDEN_CACHE` = auto | on | off, default auto; budget `GPDE_HIDDEN_CACHE_GB`, default 32):
+  * a call whose (edge_attr memory + version, CSR, hidden-layer parameter versions, precision, grad
+    mode) matches the cached H is a hit;
+  * "auto" materialises H only for a module that has been SEEN repeating a key (the second call of
+    the first forward, then the first call of every later forward); a module that stops repeating
+    goes back to the direct fused path.  "on" always materialises, "off" never does;
+  * H is E x K2P x 4 bytes; larger than the budget -> direct path (G241 at k2 = 1024 needs 391 GB).
+The entry holds `edge_attr` (so its memory cannot be recycled for other data while the key is
+alive) and is invalidated when the backward of its H node has run.  Nothing is stored on the
+module itself: modules pickle as before.
+"""
+from __future__ import annotations
+
+import os
+import weakref
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .autograd import HiddenFunction, HiddenToken
+
+MODE = os.environ.get("GPDE_HIDDEN_CACHE", "auto")
+BUDGET_BYTES = int(float(os.environ.get("GPDE_HIDDEN_CACHE_GB", "32")) * (1 << 30))
+
+stats = {"hits": 0, "builds": 0, "direct": 0}       # counters for tests / bench
+
+
+class _Entry:
+    __slots__ = ("key", "hidden", "token", "attr_ref", "csr", "last_key", "repeats", "hits_on_hidden")
+
+    def __init__(self):
+        self.key = None
+        self.hidden = None
+        self.token = None
+        self.attr_ref = None        # strong reference: pins the memory behind `key`
+        self.csr = None
+        self.last_key = None
+        self.repeats = False        # this module has been seen repeating a key
+        self.hits_on_hidden = 0
+
+
+_entries: "weakref.WeakKeyDictionary[torch.nn.Module, _Entry]" = weakref.WeakKeyDictionary()
+
+
+def clear():
+    _entries.clear()
+    for k in stats:
+        stats[k] = 0
+
+
+def _key(edge_attr: torch.Tensor, csr, hidden_params: List[Optional[torch.Tensor]], precision: str):
+    st = edge_attr.untyped_storage()
+    grad = torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in hidden_params)
+    return (str(edge_attr.device), st.data_ptr(), edge_attr.storage_offset(), tuple(edge_attr.shape),
+            tuple(edge_attr.stride()), edge_attr._version, id(csr),
+            tuple((0, 0) if p is None else (p.data_ptr(), p._version) for p in hidden_params),
+            precision, grad)
+
+
+def lookup(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, biases,
+           precision: Optional[str] = None, mode: Optional[str] = None) -> Optional[torch.Tensor]:
+    """Returns H for this call (cached or freshly built), or None when the direct fused path
+    should run."""
+    mode = MODE if mode is None else mode
+    if mode == "off":
+        stats["direct"] += 1
+        return None
+    precision = ops.DEFAULT_PRECISION if precision is None else precision
+    hw, hb = list(weights[:-1]), list(biases[:-1])
+    key = _key(edge_attr, csr, hw + hb, precision)
+    ent = _entries.get(module)
+    if ent is None:
+        ent = _entries[module] = _Entry()
+    if ent.hidden is not None and ent.key == key and ent.token.valid:
+        ent.hits_on_hidden += 1
+        stats["hits"] += 1
+        return ent.hidden
+    repeated = ent.last_key == key
+    if repeated:
+        ent.repeats = True
+    elif ent.hidden is not None and ent.key != key and ent.hits_on_hidden == 0:
+        ent.repeats = False          # the last H was built and never reused: stop speculating
+    ent.last_key = key
+    nbytes = csr.n_edges * ops.hidden_width(pm.dims) * 4
+    want = mode == "on" or (mode == "auto" and ent.repeats)
+    if not want or nbytes > BUDGET_BYTES or csr.n_edges == 0 or edge_attr.requires_grad:
+        ent.hidden, ent.key, ent.token, ent.attr_ref, ent.csr = None, None, None, None, None
+        stats["direct"] += 1
+        return None
+    token = HiddenToken()
+    ent.hidden = None                # release the previous H before allocating the next one
+    hidden = HiddenFunction.apply(edge_attr, csr, pm, precision, token, len(hw), *hw, *hb)
+    ent.key, ent.hidden, ent.token, ent.attr_ref, ent.csr = key, hidden, token, edge_attr, csr
+    ent.hits_on_hidden = 0
+    stats["builds"] += 1
+    return hidden

@@ -19,8 +19,8 @@ from typing import Optional
 import torch
 from torch.nn import Parameter
 
-from . import ops
-from .autograd import NNConvFunction
+from . import hidden_cache, ops
+from .autograd import NNConvFunction, NNConvHiddenFunction
 
 
 def _reset(nn):
@@ -88,6 +88,16 @@ class NNConv_old(torch.nn.Module):
         lin = ops.mlp_linears(self.nn)
         weights = [l.weight for l in lin]
         biases = [l.bias for l in lin]
+        # cross-depth reuse (hidden_cache.py): this module applied again with the same edge_attr and
+        # weights shares one hidden-activation tensor with the earlier applications
+        if hidden_cache.MODE != "off" and x.is_cuda and self.aggr in ("add", "mean") and \
+                pseudo.dtype == torch.float32 and x.dtype == torch.float32:
+            csr = ops.csr_for(edge_index, x.size(0))
+            pm = ops.pack_mlp(weights, biases)
+            hidden = hidden_cache.lookup(self, pseudo, csr, pm, weights, biases)
+            if hidden is not None:
+                return NNConvHiddenFunction.apply(x, hidden, csr, pm, weights[-1], biases[-1],
+                                                  self.root, self.bias, self.aggr)
         return NNConvFunction.apply(x, edge_index, pseudo, self.root, self.bias, self.aggr,
                                     len(weights), *weights, *biases)
 

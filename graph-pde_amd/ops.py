@@ -200,8 +200,8 @@ _AGGR = {"add": _lib.GPDE_AGGR_ADD, "mean": _lib.GPDE_AGGR_MEAN}
 # arithmetic of the hidden k1 x k2 layer: "f32" = fp32 MFMA (exact fmaf chains); "f16split" = f16
 # MFMA on two-term split operands with fp32 accumulation (include/gpde.h GPDE_FWD_F16SPLIT)
 _PRECISION = {"f32": _lib.GPDE_FWD_DEFAULT, "f16split": _lib.GPDE_FWD_F16SPLIT,
-              "f16split2wg": _lib.GPDE_FWD_F16SPLIT | 4,
-              "f16splitq": _lib.GPDE_FWD_F16SPLIT | 8,     # q: 8 tiles x 64 columns, barrier per 4 chunks (A/B)   # 2wg: two 4-wave workgroups per CU (A/B)
+              "f16split2wg": _lib.GPDE_FWD_F16SPLIT | 4,   # 2wg: two 4-wave workgroups per CU (A/B)
+              "f16splitq": _lib.GPDE_FWD_F16SPLIT | 8,     # q: 8 tiles x 64 columns, barrier per 4 chunks (A/B)
               "f16split4w": _lib.GPDE_FWD_F16SPLIT | 2}     # 4w: one-wave-per-SIMD kernel (A/B)
 DEFAULT_PRECISION = os.environ.get("GPDE_PRECISION", "f16split")
 
@@ -316,6 +316,159 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
     _lib.check(rc, "gpde_nnconv_bwd")
     _lib.n_native_calls += 1
     return gx, gW, gb, groot, gbias
+
+
+# ----------------------------------------------------------------------------------------------
+# cross-depth reuse of the hidden activations (include/gpde.h gpde_hidden_*)
+# ----------------------------------------------------------------------------------------------
+def hidden_width(dims: Sequence[int]) -> int:
+    """K2P: padded width of the last hidden layer (row stride of the hidden-activation tensor)."""
+    return (int(dims[-2]) + 127) // 128 * 128
+
+
+def _ptr_array(ts):
+    P = ctypes.c_void_p
+    return (P * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+def hidden_forward_raw(csr: Csr, edge_attr: torch.Tensor, pm: PackedMlp,
+                       weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
+                       precision: Optional[str] = None) -> torch.Tensor:
+    """gpde_hidden_fwd: H [E, K2P] (rows in CSR order) = all Linear+ReLU layers but the last one."""
+    lib = _lib.lib()
+    _require_cuda(edge_attr, "edge_attr")
+    precision = DEFAULT_PRECISION if precision is None else precision
+    if precision not in _PRECISION:
+        raise ValueError(f"precision must be one of {sorted(_PRECISION)}, got {precision!r}")
+    e, dev = csr.n_edges, edge_attr.device
+    if edge_attr.dtype != torch.float32 or edge_attr.dim() != 2 or edge_attr.size(0) != e or \
+            edge_attr.size(1) != pm.dims[0]:
+        raise ValueError(f"edge_attr must be float32 [{e},{pm.dims[0]}], got {edge_attr.dtype} {tuple(edge_attr.shape)}")
+    edge_attr = edge_attr.detach().contiguous()
+    nl = len(pm.dims) - 1
+    ws_ = [None if w is None else w.detach().contiguous() for w in weights]    # last entry unused
+    bs_ = [None if b is None else b.detach().contiguous() for b in biases]
+    hidden = torch.empty(e, hidden_width(pm.dims), dtype=torch.float32, device=dev)
+    nbytes = int(lib.gpde_hidden_workspace_bytes(e, nl, pm.dims_c))
+    fast = (_PRECISION[precision] & _lib.GPDE_FWD_F16SPLIT) and nl == 3
+    ws = torch.empty(1 if fast else max(nbytes, 1), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gpde_hidden_fwd(edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), csr.n_nodes,
+                                 csr.perm.data_ptr(), nl, pm.dims_c, pm.packed.data_ptr(),
+                                 _ptr_array(ws_), _ptr_array(bs_), _PRECISION[precision],
+                                 hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+        if rc in (-1, -3) and fast:    # shape not covered by the fused kernel: the general path needs ws
+            ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+            rc = lib.gpde_hidden_fwd(edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), csr.n_nodes,
+                                     csr.perm.data_ptr(), nl, pm.dims_c, pm.packed.data_ptr(),
+                                     _ptr_array(ws_), _ptr_array(bs_), _PRECISION[precision],
+                                     hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "gpde_hidden_fwd")
+    _lib.n_native_calls += 1
+    return hidden
+
+
+def nnconv_forward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, pm: PackedMlp,
+                              root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,
+                              out: Optional[torch.Tensor] = None,
+                              ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gpde_nnconv_fwd_hidden: aggregation + last Linear + update() from given hidden activations."""
+    lib = _lib.lib()
+    _require_cuda(x, "x")
+    _require_cuda(hidden, "hidden")
+    if aggr not in _AGGR:
+        raise NotImplementedError(f"aggr={aggr!r}: 'add' and 'mean' only")
+    n, e = csr.n_nodes, csr.n_edges
+    if x.dtype != torch.float32 or x.dim() != 2 or x.size(1) != WIDTH or x.size(0) != n:
+        raise ValueError(f"x must be float32 [{n},{WIDTH}], got {x.dtype} {tuple(x.shape)}")
+    if hidden.dtype != torch.float32 or tuple(hidden.shape) != (e, hidden_width(pm.dims)) or \
+            not hidden.is_contiguous():
+        raise ValueError(f"hidden must be contiguous float32 [{e},{hidden_width(pm.dims)}]")
+    x = x.contiguous()
+    root_c = None if root is None else root.detach().contiguous()
+    bias_c = None if bias is None else bias.detach().contiguous()
+    if out is None:
+        out = torch.empty(n, WIDTH, dtype=torch.float32, device=x.device)
+    if ws is None:
+        ws = torch.empty(max(workspace_bytes(n, e, pm), 1), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.gpde_nnconv_fwd_hidden(x.data_ptr(), n, hidden.data_ptr(), e, csr.rowptr.data_ptr(),
+                                        csr.src.data_ptr(), csr.dst.data_ptr(), len(pm.dims) - 1,
+                                        pm.dims_c, pm.packed.data_ptr(),
+                                        None if root_c is None else root_c.data_ptr(),
+                                        None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
+                                        out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
+    _lib.check(rc, "gpde_nnconv_fwd_hidden")
+    _lib.n_native_calls += 1
+    return out
+
+
+def nnconv_backward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, dims: Sequence[int],
+                               w_last: torch.Tensor, b_last: Optional[torch.Tensor],
+                               root: Optional[torch.Tensor], aggr: str, grad_out: torch.Tensor,
+                               need_root: bool = True, need_bias: bool = True):
+    """gpde_nnconv_bwd_hidden.  Returns (grad_x, grad_hidden [E,K2P], grad_w_last, grad_b_last or None,
+    grad_root or None, grad_bias or None)."""
+    lib = _lib.lib()
+    n, e, dev = csr.n_nodes, csr.n_edges, x.device
+    nl = len(dims) - 1
+    dims_c = _lib.dims_array(dims)
+    x = x.detach().contiguous()
+    grad_out = grad_out.detach().contiguous().float()
+    w_last = w_last.detach().contiguous()
+    b_c = None if b_last is None else b_last.detach().contiguous()
+    root_c = None if root is None else root.detach().contiguous()
+    gx = torch.empty(n, WIDTH, dtype=torch.float32, device=dev)
+    gh = torch.empty_like(hidden)
+    gw = torch.empty_like(w_last)
+    gb = None if b_c is None else torch.empty_like(b_c)
+    groot = torch.empty(WIDTH, WIDTH, dtype=torch.float32, device=dev) if (need_root and root is not None) else None
+    gbias = torch.empty(WIDTH, dtype=torch.float32, device=dev) if need_bias else None
+    nbytes = int(lib.gpde_nnconv_bwd_workspace_bytes(n, e, nl, dims_c))
+    if nbytes == 0:
+        _lib.check(-2, "gpde_nnconv_bwd_workspace_bytes")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    p = lambda t: None if t is None else t.data_ptr()
+    with torch.cuda.device(dev):
+        rc = lib.gpde_nnconv_bwd_hidden(x.data_ptr(), n, hidden.data_ptr(), e, csr.rowptr.data_ptr(),
+                                        csr.src.data_ptr(), csr.dst.data_ptr(), csr.rowptr_host.data_ptr(),
+                                        nl, dims_c, w_last.data_ptr(), p(b_c), p(root_c), _AGGR[aggr],
+                                        grad_out.data_ptr(), gx.data_ptr(), gh.data_ptr(), gw.data_ptr(),
+                                        p(gb), p(groot), p(gbias), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "gpde_nnconv_bwd_hidden")
+    _lib.n_native_calls += 1
+    return gx, gh, gw, gb, groot, gbias
+
+
+def hidden_backward_raw(csr: Csr, edge_attr: torch.Tensor, dims: Sequence[int],
+                        weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
+                        grad_hidden: torch.Tensor):
+    """gpde_hidden_bwd: gradients of the hidden Linear layers from the summed dL/dU of the last hidden
+    layer.  `weights` / `biases`: the hidden layers only (all but the last Linear); `dims`: all layer
+    widths.  Returns ([grad_W_l], [grad_b_l or None]) for the hidden layers."""
+    lib = _lib.lib()
+    e, dev = csr.n_edges, edge_attr.device
+    nl = len(dims) - 1
+    if len(weights) != nl - 1:
+        raise ValueError("hidden_backward_raw takes the hidden layers only")
+    dims_c = _lib.dims_array(dims)
+    edge_attr = edge_attr.detach().contiguous()
+    grad_hidden = grad_hidden.detach().contiguous()
+    ws_ = [w.detach().contiguous() for w in weights] + [None]
+    bs_ = [None if b is None else b.detach().contiguous() for b in biases] + [None]
+    gW = [torch.empty_like(w) for w in ws_[:-1]] + [None]
+    gb = [None if b is None else torch.empty_like(b) for b in bs_[:-1]] + [None]
+    nbytes = int(lib.gpde_nnconv_bwd_workspace_bytes(0, e, nl, dims_c))
+    if nbytes == 0:
+        _lib.check(-2, "gpde_nnconv_bwd_workspace_bytes")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gpde_hidden_bwd(edge_attr.data_ptr(), e, csr.perm.data_ptr(), nl, dims_c,
+                                 _ptr_array(ws_), _ptr_array(bs_), grad_hidden.data_ptr(),
+                                 _ptr_array(gW), _ptr_array(gb), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "gpde_hidden_bwd")
+    _lib.n_native_calls += 1
+    return gW[:-1], gb[:-1]
 
 
 # ----------------------------------------------------------------------------------------------

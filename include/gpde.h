@@ -143,6 +143,55 @@ int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int
                     void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Cross-depth reuse of the kernel MLP.  The reference applies ONE NNConv
+ * module `depth` times per forward with the same edge_attr and the same weights
+ * (UAI1_full_resolution.py:29-30 `for k in range(self.depth): x = F.relu(self.conv1(x, ...))`;
+ * MGKN_general_darcy2d.py:76-90, MGKN_orthogonal_burgers1d.py:65-82), so the hidden activation
+ *   H_e = relu(L_{n-1}(... relu(L_1(edge_attr_e))))     (DenseNet.forward, utilities.py:223-227,
+ *                                                         all but the last Linear)
+ * is identical in every one of those calls.  The operator splits into
+ *   gpde_hidden_fwd:         edge_attr -> H            [E][K2P] fp32, rows in CSR (destination-sorted)
+ *                            order, K2P = dims[n_layers-1] rounded up to 128, padding columns zero
+ *   gpde_nnconv_fwd_hidden:  (x, H) -> out             aggregation + last Linear + update()
+ * and, for training, their backward halves
+ *   gpde_nnconv_bwd_hidden:  grad_out -> grad_x, grad of the last Linear / root / bias, and
+ *                            grad_hidden = dL/dU of the last hidden layer (already multiplied by the
+ *                            ReLU mask H > 0), [E][K2P], overwritten
+ *   gpde_hidden_bwd:         grad_hidden (summed over the `depth` uses by the caller's autograd)
+ *                            -> gradients of the hidden Linear layers 0 .. n_layers-2 (grad_W / grad_b
+ *                            entries of the last layer are ignored)
+ * so the k1 x k2 layer (94 % of the FLOPs) and its backward run once per step instead of `depth`
+ * times.  The caller owns H (E * K2P * 4 bytes) and decides whether it fits.
+ *
+ * gpde_hidden_fwd: with flags & GPDE_FWD_F16SPLIT, `packed` (gpde_mlp_pack) and a 3-Linear MLP the
+ * fused f16-split kernel computes H (same arithmetic as gpde_nnconv_fwd); otherwise the layers run
+ * as fp32-MFMA GEMMs over chunks of edges and W, b (HOST arrays of device pointers, torch layouts)
+ * and ws (gpde_hidden_workspace_bytes) are required.  Workspaces of the *_hidden entry points:
+ * gpde_nnconv_fwd_workspace_bytes / gpde_nnconv_bwd_workspace_bytes; gpde_hidden_bwd:
+ * gpde_nnconv_bwd_workspace_bytes(0, E, ...). */
+size_t gpde_hidden_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims);
+int gpde_hidden_fwd(const float* edge_attr, int64_t n_edges, const int32_t* rowptr, int64_t n_nodes,
+                    const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
+                    const float* const* W, const float* const* b, uint32_t flags, float* hidden,
+                    void* ws, size_t ws_bytes, void* stream);
+int gpde_nnconv_fwd_hidden(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
+                           const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                           int n_layers, const int32_t* dims, const void* packed, const float* root,
+                           const float* bias, int aggr, float* out, void* ws, size_t ws_bytes,
+                           void* stream);
+int gpde_nnconv_bwd_hidden(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
+                           const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                           const int32_t* rowptr_host, int n_layers, const int32_t* dims,
+                           const float* w_last, const float* b_last, const float* root, int aggr,
+                           const float* grad_out, float* grad_x, float* grad_hidden,
+                           float* grad_w_last, float* grad_b_last, float* grad_root, float* grad_bias,
+                           void* ws, size_t ws_bytes, void* stream);
+int gpde_hidden_bwd(const float* edge_attr, int64_t n_edges, const int32_t* perm, int n_layers,
+                    const int32_t* dims, const float* const* W, const float* const* b,
+                    const float* grad_hidden, float* const* grad_W, float* const* grad_b, void* ws,
+                    size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Radius graph on the GPU.  Replaces SquareMeshGenerator / RandomMeshGenerator.ball_connectivity
  * (utilities.py:250-255, 362-368: dense float64 pairwise_distances + np.where).  pos [n][dim]
  * float64 (dim 1..3).  Pass 1 writes the out-degree of every source; the caller forms the
