@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=512, help="destination rows of the CPU sample")
     ap.add_argument("--cpu-threads", type=int, default=64, help="threads of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reuse-probe", action="store_true",
+                    help="skip the depth x module probe of the cross-depth hidden-activation reuse")
     ap.add_argument("--precision", default=None, choices=["f32", "f16split", "f16split4w", "f16split2wg", "f16splitq"],
                     help="arithmetic of the hidden layer (default: graph_pde_amd.ops.DEFAULT_PRECISION)")
     args = ap.parse_args()
@@ -275,6 +277,61 @@ def main():
         rel = rel_l2(out[rows.to(dev)].cpu(), y_cpu[rows])
         log(f"[bench] CPU oracle sample: {es} edges in {tcpu:.2f}s; rel-L2 GPU vs CPU rows = {rel:.3e}")
 
+    # ---- cross-depth reuse: depth applications of ONE module, as KernelNN.forward does
+    #      (UAI1_full_resolution.py:29-30), on the reference's own training resolution s=61 r=0.10 -- the
+    #      headline graph's hidden activations (E x 4 KiB = 391 GB) do not fit one GPU.  Not part of `value`.
+    reuse = None
+    if not args.no_reuse_probe and world == 1:
+        from graph_pde_amd import hidden_cache
+        del ws
+        torch.cuda.empty_cache()
+        ei6, ea6, n6 = synth.darcy_graph(61, 0.1, device=dev, seed=0)
+        x6 = torch.randn(n6, 64, device=dev)
+        depth = 6
+
+        def model_fwd(xin):
+            hcur = xin
+            for _ in range(depth):
+                hcur = torch.relu(conv(hcur, ei6, ea6))
+            return hcur
+
+        def tm(fn, reps=5):
+            fn(); fn()
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - tq) / reps
+
+        def fwd_only():
+            with torch.no_grad():
+                return model_fwd(x6)
+
+        def fwd_bwd():
+            conv.zero_grad(set_to_none=True)
+            for p_ in conv.parameters():
+                p_.data.mul_(1.0)                       # new weight version: as after an optimiser step
+            model_fwd(x6).square().mean().backward()
+        res = {}
+        mode0 = hidden_cache.MODE
+        for mode in ("off", "auto"):
+            hidden_cache.MODE = mode
+            hidden_cache.clear()
+            y6 = fwd_only()
+            res[mode] = (tm(fwd_only), tm(fwd_bwd, 3), y6)
+        hidden_cache.MODE = mode0
+        d6 = float((res["off"][2].double() - res["auto"][2].double()).norm() / res["off"][2].double().norm())
+        e6 = int(ei6.shape[1])
+        reuse = {"graph": "g61 (N=%d, E=%d)" % (n6, e6), "depth": depth,
+                 "forward_ms": {"direct": round(1e3 * res["off"][0], 3), "reuse": round(1e3 * res["auto"][0], 3)},
+                 "forward_backward_ms": {"direct": round(1e3 * res["off"][1], 3), "reuse": round(1e3 * res["auto"][1], 3)},
+                 "forward_M_edge_applications_per_s": {"direct": round(depth * e6 / res["off"][0] / 1e6, 1),
+                                                       "reuse": round(depth * e6 / res["auto"][0] / 1e6, 1)},
+                 "rel_l2_between_paths": d6,
+                 "note": "forward: fixed weights, H built once and reused by all later calls; "
+                         "forward_backward: new weight version every step, H rebuilt once per step"}
+
     line = {
         "metric": "M-edges/s through fused NNConv fwd (width=64)",
         "value": round(value, 3), "unit": "M-edges/s", "n_gpus": world, "steps": args.steps,
@@ -289,6 +346,7 @@ def main():
                    "plan": plan},
         "rel_l2_sample": rel,
         "alt_precision": alt,
+        "depth_reuse": reuse,
         "roofline": roofline,
         "cpu_baseline": cpu,
     }

@@ -239,11 +239,14 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     // per-chunk buffers: per edge (hsum + 2*kmax) floats, per node (2*64*K2P + 3*64) floats
     const size_t per_edge = (hsum + 2 * (size_t)kmax) * 4, per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4;
     int64_t Ec, Nc;
+    const size_t slack = 64 * 256;       // alignment of the per-chunk buffers below
     if (sizing) {
         Ec = (int64_t)(((size_t)6 << 30) / per_edge); Nc = (int64_t)(((size_t)4 << 30) / per_node);
+    } else if (ws_bytes >= fixed + (size_t)(E > 0 ? E : 1) * per_edge + (size_t)(N > 0 ? N : 1) * per_node + slack) {
+        Ec = E; Nc = N;                  // everything in one chunk
     } else {
         if (ws_bytes < fixed + (1 << 20)) { gpde_set_error("gpde_nnconv_bwd: workspace %zu bytes too small (%zu fixed)", ws_bytes, fixed); return GPDE_EWORKSPACE; }
-        const size_t avail = ws_bytes - fixed - 64 * 256;
+        const size_t avail = ws_bytes - fixed - slack;
         Ec = (int64_t)(avail * 6 / 10 / per_edge); Nc = (int64_t)(avail * 4 / 10 / per_node);
     }
     if (Ec > E) Ec = E;
@@ -256,7 +259,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     P->off_dU[0] = take((size_t)Ec * kmax); P->off_dU[1] = take((size_t)Ec * kmax);
     P->off_Z = take((size_t)Nc * GP_W * P->K2P); P->off_dZ = take((size_t)Nc * GP_W * P->K2P);
     P->off_gT = take((size_t)Nc * GP_W); P->off_S = take((size_t)Nc * GP_W); P->off_dS = take((size_t)Nc * GP_W);
-    P->total = off + 256;
+    P->total = off + 256 + (sizing ? slack : 0);
     if (!sizing && P->total > ws_bytes) { gpde_set_error("gpde_nnconv_bwd: internal plan %zu > workspace %zu", P->total, ws_bytes); return GPDE_EWORKSPACE; }
     return GPDE_OK;
 }
