@@ -92,13 +92,14 @@ __global__ void k_colsum(const float* __restrict__ M, int rows, int cols, int ld
 //   dx[j][c] += sum_n dZ_i[c][n] H[e][n] + dS_i[c]                       (fp32 atomics)
 // One wave per tile of 32 CSR slots; destination segments inside a tile are handled by masking,
 // exactly like the forward aggregation.  dZ: [nodes of chunk][64][K2P].
-constexpr int EB_XS = 65, EB_HS = 129;
+constexpr int EB_XS = 65, EB_HS = 65, EB_NC = 64;   // 64-column chunks: 66 KiB of LDS per workgroup,
+                                                       // two workgroups (two waves per SIMD) per CU
 struct EdgeBwdArgs {
     const float* x; const int32_t* rowptr; const int32_t* src; const int32_t* dst;
     const float* dZ; const float* dS; const float* H; float* dU; float* dx;
     int e0, e1, n0, K2P;
 };
-__global__ __launch_bounds__(256) void gpde_edge_bwd_kernel(EdgeBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void gpde_edge_bwd_kernel(EdgeBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -123,19 +124,19 @@ __global__ __launch_bounds__(256) void gpde_edge_bwd_kernel(EdgeBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dxa[cb][r] = 0.f;
 
-    for (int nc = 0; nc < a.K2P; nc += 128) {
-        // H tile [32][128] -> LDS
+    for (int nc = 0; nc < a.K2P; nc += EB_NC) {
+        // H tile [32][64] -> LDS
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int f = i * 64 + lane, er = f >> 5, q4 = f & 31, e = t0 + er;
+        for (int i = 0; i < 8; ++i) {
+            const int f = i * 64 + lane, er = f >> 4, q4 = f & 15, e = t0 + er;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (e < t1) v = *(const f32x4*)&a.H[(size_t)(e - a.e0) * a.K2P + nc + q4 * 4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) Hs[er * EB_HS + q4 * 4 + q] = v[q];
         }
-        f32x16 dh[4];
+        f32x16 dh[2];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dh[nb][r] = 0.f;
 
@@ -154,11 +155,11 @@ __global__ __launch_bounds__(256) void gpde_edge_bwd_kernel(EdgeBwdArgs a) {
                     const float av = mine ? Xs[l31 * EB_XS + c] : 0.f;
                     const float* zp = dZi + (size_t)c * a.K2P + l31;
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) dh[nb] = mfma32(av, zp[nb * 32], dh[nb]);
+                    for (int nb = 0; nb < 2; ++nb) dh[nb] = mfma32(av, zp[nb * 32], dh[nb]);
                 }
             // dXg^T[c][e] += sum_n dZ_i[c][n] H[e][n]   (A = dZ_i rows c, B = H^T from LDS)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
+            for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void gpde_edge_bwd_kernel(EdgeBwdArgs a) {
         }
         // dU = dH * (H > 0)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int er = (r & 3) + 8 * (r >> 2) + 4 * h, e = t0 + er;
@@ -241,7 +242,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     int64_t Ec, Nc;
     const size_t slack = 64 * 256;       // alignment of the per-chunk buffers below
     if (sizing) {
-        Ec = (int64_t)(((size_t)6 << 30) / per_edge); Nc = (int64_t)(((size_t)4 << 30) / per_node);
+        Ec = (int64_t)(((size_t)12 << 30) / per_edge); Nc = (int64_t)(((size_t)8 << 30) / per_node);
     } else if (ws_bytes >= fixed + (size_t)(E > 0 ? E : 1) * per_edge + (size_t)(N > 0 ? N : 1) * per_node + slack) {
         Ec = E; Nc = N;                  // everything in one chunk
     } else {
@@ -409,6 +410,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         // largest nb with (nb - na) <= Nc and edges <= Ec (at least one node)
         int lo = na + 1, hi = (int)((int64_t)na + P.Nc < N ? na + P.Nc : N);
         const int64_t ebase = rowptr_host[na];
+        if (phase == BWD_CONV) P.Ec = n_edges;       // H and dU live outside the workspace: no edge limit
         if (rowptr_host[lo] - ebase > P.Ec) {
             gpde_set_error("gpde_nnconv_bwd: node %d has in-degree %d > %lld edges per chunk; give more workspace",
                            na, (int)(rowptr_host[lo] - ebase), (long long)P.Ec);
