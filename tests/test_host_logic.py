@@ -88,3 +88,42 @@ def test_synthetic_graphs_have_reference_shape():
     g = synth.burgers_multipole_graphs(8192)
     assert [x[0].shape[1] for x in g][:4] == [16384, 24570, 12282, 6138]
     assert sum(x[0].shape[1] for x in g) == 65462
+
+
+def test_hidden_cache_key_and_policy_bookkeeping(monkeypatch):
+    """hidden_cache.py host logic (SURVEY.md §8 f4): the key pins memory + version + parameter versions;
+    `off` never builds; `auto` goes direct on the first sight of a key and wants to build on the
+    second -- which, without a GPU, must fail loudly inside the native path, not compute on the CPU."""
+    from graph_pde_amd import hidden_cache, ops
+
+    class FakeCsr:
+        n_edges, n_nodes = 3, 5
+    class FakePm:
+        dims = (6, 8, 4096)
+    conv = gp.NNConv_old(64, 64, DenseNet([6, 8, 4096], torch.nn.ReLU), aggr="mean")
+    lin = ops.mlp_linears(conv.nn)
+    w, b = [l.weight for l in lin], [l.bias for l in lin]
+    ea, csr, pm = torch.randn(3, 6), FakeCsr(), FakePm()
+    k1 = hidden_cache._key(ea, csr, w[:-1] + b[:-1], "f16split")
+    assert k1 == hidden_cache._key(ea, csr, w[:-1] + b[:-1], "f16split")
+    assert k1 != hidden_cache._key(ea[1:], csr, w[:-1] + b[:-1], "f16split")          # other view
+    assert k1 != hidden_cache._key(ea, csr, w[:-1] + b[:-1], "f32")
+    ea.mul_(1.0)
+    assert k1 != hidden_cache._key(ea, csr, w[:-1] + b[:-1], "f16split")              # version counter
+    k2 = hidden_cache._key(ea, csr, w[:-1] + b[:-1], "f16split")
+    with torch.no_grad():
+        w[0].add_(0.0)
+    assert k2 != hidden_cache._key(ea, csr, w[:-1] + b[:-1], "f16split")              # weights touched
+    with torch.no_grad():
+        assert k2[-1] is True and hidden_cache._key(ea, csr, w[:-1] + b[:-1], "f16split")[-1] is False
+
+    hidden_cache.clear()
+    assert hidden_cache.lookup(conv, ea, csr, pm, w, b, mode="off") is None
+    assert hidden_cache.lookup(conv, ea, csr, pm, w, b, mode="auto") is None           # first sight: direct
+    assert hidden_cache.stats["direct"] == 2 and hidden_cache.stats["builds"] == 0
+    with pytest.raises(RuntimeError):                                                  # second: wants H -> native
+        hidden_cache.lookup(conv, ea, csr, pm, w, b, mode="auto")
+    monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", 16)
+    assert hidden_cache.lookup(conv, ea, csr, pm, w, b, mode="on") is None             # over budget: direct
+    buf = io.BytesIO()
+    torch.save(conv, buf)                                                              # nothing rides on the module
