@@ -23,6 +23,7 @@
 // Weight-gradient reductions use ordered split partials (deterministic); dx_j uses fp32 atomics
 // (as the reference's scatter backward does on a GPU).
 #include "gpde_common.h"
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -194,6 +195,163 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd_kernel(EdgeBwdArgs a) {
                 const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 atomicAdd(&a.dx[(size_t)j * GP_W + c], dxa[cb][r] + ds[c]);
             }
+    }
+}
+
+// ---- per-edge backward, staged version (graphs with in-degree >= ~32) --------------------------------------
+// Same two products as gpde_edge_bwd_kernel, but nothing is fetched per MFMA.  A workgroup owns 128
+// consecutive CSR slots (4 tiles of 32, one per wave); in a radius graph these almost always belong
+// to ONE destination node, so the dZ_i chunk is staged ONCE per workgroup and shared:
+//   * hidden columns in chunks of 32; per chunk the dZ rows of up to two destination nodes
+//     ([2][64 c][32 n], 16 KiB, by all four waves) and each wave's H tile ([32 e][32 n], 4 KiB) come
+//     global -> LDS by DMA, double-buffered, one s_barrier per chunk (64 fp32 MFMAs = 4096 cycles);
+//     16-byte units are XOR-swizzled by (row & 7) on the way in (a DMA lane may fetch any unit), so
+//     ds_read_b128 along a row and ds_read_b32 down a column are both conflict-free without padding;
+//   * x_j rows are the A operand of product (1) for every chunk: 32 registers per lane, loaded once;
+//   * product (1)  dH[e][n] = sum_c x[e][c] dZ[c][n]   A = x (registers), B = dZs (ds_read_b32)
+//     product (2)  dXg[e][c] = sum_n H[e][n] dZ[c][n]   A = Hs, B = dZs, both ds_read_b128 with the k
+//     permutation n = 8q + 4h + t;  D rows = edges in both, so dU rows are written as 128-byte runs and
+//     the dx atomics of one edge are 32 consecutive floats;
+//   * a 128-slot group spanning more than two destinations repeats the chunk loop per node pair (rare
+//     at in-degree >= 32; low-degree graphs use gpde_edge_bwd_kernel).
+constexpr int EB2_NC = 32;                          // hidden columns per chunk
+constexpr int EB2_DZ = 2 * 64 * EB2_NC;             // floats per dZ buffer (two nodes)
+constexpr int EB2_H = 32 * EB2_NC;                  // floats per wave H buffer
+
+__device__ __forceinline__ void eb2_dma16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void gpde_edge_bwd2_kernel(EdgeBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dZs = smem;                                      // [2 buf][2 node][64][32]
+    float* Hs_all = smem + 2 * EB2_DZ;                      // [4 waves][2 buf][32][32]
+    int* idx_all = (int*)(Hs_all + 4 * 2 * EB2_H);          // [4 waves][src 32 | dst 32]
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* Hs = Hs_all + wave * 2 * EB2_H;
+    int* src_s = idx_all + wave * 64;
+    int* dst_s = src_s + 32;
+
+    const int g0 = a.e0 + blockIdx.x * 128;                 // first slot of the group
+    const int g1 = min(g0 + 128, a.e1);
+    const int t0 = g0 + wave * 32;                          // this wave's tile (may be empty)
+    const int e_last = a.e1 - 1;
+    const int nA0 = a.dst[g0], nB0 = a.dst[g1 - 1];         // destination range of the group
+
+    // lane-as-edge data (A operands): destination and x_j row of edge t0 + l31
+    const int eL = t0 + l31;
+    const bool vL = eL < a.e1;
+    const int nodeL = vL ? a.dst[eL] : -1;
+    const int srcL = vL ? a.src[eL] : 0;
+    if (h == 0) { src_s[l31] = srcL; dst_s[l31] = nodeL; }
+    f32x4 xr[8];                                            // x[e = l31][c = 8q + 4h + t]
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vL) v = *(const f32x4*)&a.x[(size_t)srcL * GP_W + 8 * q + 4 * h];
+        xr[q] = v;
+    }
+    f32x16 dxa[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dxa[cb][r] = 0.f;
+
+    const int NCH = a.K2P / EB2_NC;
+    const int npass = (nB0 - nA0) / 2 + 1;
+    const int nit = npass * NCH;
+    // DMA lane roles: one instruction = 8 rows x 8 units of 16 B; LDS position (rr, p) holds unit p ^ rr
+    const int rr = lane >> 3, uq = (lane & 7) ^ rr;
+    auto issue = [&](int it) {
+        const int pass = it / NCH, nc = (it - pass * NCH) * EB2_NC, buf = it & 1;
+        const int nodeA = nA0 + 2 * pass;
+#pragma unroll
+        for (int nd = 0; nd < 2; ++nd) {
+            const int node = min(nodeA + nd, nB0);          // a missing second node re-reads the first
+            const float* g = a.dZ + ((size_t)(node - a.n0) * GP_W) * a.K2P + nc + uq * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int blk = wave * 2 + i;               // rows 8 blk .. 8 blk + 7
+                eb2_dma16(g + (size_t)(blk * 8 + rr) * a.K2P, dZs + buf * EB2_DZ + nd * 64 * EB2_NC + blk * 256);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = min(t0 + i * 8 + rr, e_last);
+            eb2_dma16(a.H + (size_t)(e - a.e0) * a.K2P + nc + uq * 4, Hs + buf * EB2_H + i * 256);
+        }
+    };
+
+    issue(0);
+    for (int it = 0; it < nit; ++it) {
+        const int pass = it / NCH, nc = (it - pass * NCH) * EB2_NC, buf = it & 1;
+        const int nodeA = nA0 + 2 * pass, nodeB = nodeA + 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it + 1 < nit) issue(it + 1);
+        const bool inA = nodeL == nodeA, inB = nodeL == nodeB;
+        const bool anyA = __builtin_amdgcn_ballot_w64(inA) != 0, anyB = __builtin_amdgcn_ballot_w64(inB) != 0;
+        if (!anyA && !anyB) continue;
+        const float* hb = Hs + buf * EB2_H;
+        // H of lane-as-edge (A operand of product 2): units 2q' + h of row l31
+        f32x4 hv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv[q] = *(const f32x4*)&hb[l31 * EB2_NC + (((2 * q + h) ^ (l31 & 7)) << 2)];
+        f32x16 dh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+#pragma unroll
+        for (int nd = 0; nd < 2; ++nd) {
+            if (nd == 0 ? !anyA : !anyB) continue;
+            const bool in = nd == 0 ? inA : inB;
+            const float* zb = dZs + buf * EB2_DZ + nd * 64 * EB2_NC;
+            // product (1): k = c = 8q + 4h + t
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int c = 8 * q + 4 * h + t;
+                    const float bv = zb[c * EB2_NC + ((((l31 >> 2) ^ (c & 7)) << 2) | (l31 & 3))];
+                    dh = mfma32(in ? xr[q][t] : 0.f, bv, dh);
+                }
+            // product (2): k = n = 8q + 4h + t, B row c = l31 (+32)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int c = cb * 32 + l31;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 zv = *(const f32x4*)&zb[c * EB2_NC + (((2 * q + h) ^ (c & 7)) << 2)];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dxa[cb] = mfma32(in ? hv[q][t] : 0.f, zv[t], dxa[cb]);
+                }
+            }
+        }
+        // dU rows of this pass's nodes: dH * (H > 0); lane = column nc + l31, rows (r, h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int er = (r & 3) + 8 * (r >> 2) + 4 * h, e = t0 + er;
+            const int nd_e = dst_s[er];
+            if (e < a.e1 && (nd_e == nodeA || nd_e == nodeB)) {
+                const float hval = hb[er * EB2_NC + ((((l31 >> 2) ^ (er & 7)) << 2) | (l31 & 3))];
+                a.dU[(size_t)(e - a.e0) * a.K2P + nc + l31] = hval > 0.f ? dh[r] : 0.f;
+            }
+        }
+    }
+    // dx_j += dXg + dS_i : lane = channel c = l31 (+32), rows = edges
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int er = (r & 3) + 8 * (r >> 2) + 4 * h, e = t0 + er;
+        if (e < a.e1) {
+            const int j = src_s[er], node = dst_s[er];
+            const float* ds = a.dS + (size_t)(node - a.n0) * GP_W;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int c = cb * 32 + l31;
+                atomicAdd(&a.dx[(size_t)j * GP_W + c], dxa[cb][r] + ds[c]);
+            }
+        }
     }
 }
 
@@ -469,10 +627,20 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             {
                 EdgeBwdArgs ea{x, rowptr, src, dst, dZ, dS, Hlast, dUc, dx, e0, e1, na, K2P};
                 const size_t lds = (size_t)4 * (32 * EB_XS + 32 * EB_HS) * 4;
+                const size_t lds2 = (size_t)(2 * EB2_DZ + 4 * 2 * EB2_H) * 4 + 4 * 64 * 4;
                 static bool set = false;
-                if (!set) { GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_edge_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
-                if (dx) hipLaunchKernelGGL(gpde_edge_bwd_kernel, dim3((rows + 127) / 128), dim3(T), lds, st, ea);
-                else { gpde_set_error("gpde_nnconv_bwd: grad_x must be provided"); return GPDE_EINVAL; }
+                if (!set) {
+                    GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_edge_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_edge_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                    set = true;
+                }
+                if (!dx) { gpde_set_error("gpde_nnconv_bwd: grad_x must be provided"); return GPDE_EINVAL; }
+                // staged kernel where a 128-slot group rarely spans more than two destinations
+                const char* fe = getenv("GPDE_EDGE_BWD");          // "1" / "2": force a variant (tests, A/B)
+                const int force = fe ? atoi(fe) : 0;
+                const bool staged = force ? force == 2 : (int64_t)rows >= (int64_t)32 * nn;
+                if (staged) hipLaunchKernelGGL(gpde_edge_bwd2_kernel, dim3((rows + 127) / 128), dim3(T), lds2, st, ea);
+                else hipLaunchKernelGGL(gpde_edge_bwd_kernel, dim3((rows + 127) / 128), dim3(T), lds, st, ea);
             }
             // MLP backward over the chunk's edges
             if (phase == BWD_FULL) { if ((rc = mlp_backward(dUc, rows)) != GPDE_OK) return rc; }
