@@ -61,7 +61,7 @@ struct Plan {
     int64_t nodes_per_chunk;
     int n_chunks;
     int n_groups;        // fused-kernel edge groups (workgroups per hidden slice)
-    size_t off_part, off_z, off_ha, off_hb;
+    size_t off_part, off_z, off_ha, off_hb, off_xs, off_scal;
     size_t h_floats;     // mode 2: floats per ping-pong activation buffer
 };
 
@@ -81,12 +81,15 @@ int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws
     const size_t prow = (size_t)64 * GP_W * sizeof(float);   // worst case: 64 splits
     size_t fixed = 0;
     P->h_floats = 0;
+    // f16-split aggregation (mode 1): x as split f16 words [N][64] + two scalars (gpde_prep.hip)
+    const size_t xs_bytes = (L.mode == 1 && !hidden_given) ? align_up((size_t)(N > 0 ? N : 1) * GP_W * 4) + kAlign : 0;
     if (L.mode == 2 && !hidden_given) {
         int kmax = 0;
         for (int l = 1; l <= n_layers - 1; ++l) kmax = kmax > L.frontKP[l] ? kmax : L.frontKP[l];
         P->h_floats = (size_t)(E > 0 ? E : 1) * kmax;
         fixed = 2 * align_up(P->h_floats * sizeof(float));
     }
+    fixed += xs_bytes;
     int64_t npc;
     if (sizing) {
         // recommended: all nodes if Z fits 4 GiB, else 4 GiB worth of nodes (at least one tile)
@@ -122,6 +125,8 @@ int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws
     P->off_z = off;    off += align_up((size_t)npc * zrow);
     P->off_ha = off;   off += (L.mode == 2 && !hidden_given) ? align_up(P->h_floats * sizeof(float)) : 0;
     P->off_hb = off;   off += (L.mode == 2 && !hidden_given) ? align_up(P->h_floats * sizeof(float)) : 0;
+    P->off_xs = off;   off += xs_bytes ? xs_bytes - kAlign : 0;
+    P->off_scal = off; off += xs_bytes ? kAlign : 0;
     if (needed) *needed = off;
     // fused-kernel grid: ~one workgroup per CU, never more edge groups than 4-wave tile sets
     const int ns = L.K2P / GP_TN;
@@ -211,6 +216,23 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
         hfinal = in;
     }
 
+    // f16-split aggregation inside the fused kernel: worth its three tiny pre-pass launches from a few
+    // ten thousand edges on; GPDE_FWD_AGG_F16 / GPDE_FWD_AGG_F32 force it on / off
+    const unsigned* xs = nullptr;
+    const unsigned* scal = nullptr;
+    if (!hidden && mode == 1 && (flags & GPDE_FWD_F16SPLIT) && !(flags & (GPDE_FWD_F16SPLIT_4WAVE | GPDE_FWD_F16SPLIT_2WG | GPDE_FWD_F16SPLIT_QUAD)) &&
+        !(flags & GPDE_FWD_AGG_F32) && n_edges > 0 && ((flags & GPDE_FWD_AGG_F16) || n_edges >= 32768)) {
+        GpdeFusedArgs probe{};
+        probe.k0 = L.k0; probe.K1P = L.K1P; probe.K2P = L.K2P;
+        if (gpde_fused_f16v3_supported(probe)) {
+            rc = gpde_launch_g2_prep(x, n_nodes, edge_attr, n_edges, L.k0, pk + L.off_w1 + (size_t)L.K1P * 8,
+                                     (unsigned*)(w + P.off_scal), (unsigned*)(w + P.off_xs), stream);
+            if (rc != GPDE_OK) return rc;
+            xs = (const unsigned*)(w + P.off_xs);
+            scal = (const unsigned*)(w + P.off_scal);
+        }
+    }
+
     for (int64_t nc0 = 0; nc0 < n_nodes; nc0 += P.nodes_per_chunk) {
         const int64_t nc1 = (nc0 + P.nodes_per_chunk < n_nodes) ? nc0 + P.nodes_per_chunk : n_nodes;
         const int nn = (int)(nc1 - nc0);
@@ -221,7 +243,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
             f.w1 = pk + L.off_w1; f.w2t = pk + L.off_w2t; f.b2 = pk + L.off_b2;
             f.w2h = pk + L.off_w2h; f.ucol = pk + L.off_ucol;
             f.w1h = pk + L.off_w1h; f.fcol = pk + L.off_fcol;
-            f.hbuf = hfinal; f.zbuf = zbuf;
+            f.hbuf = hfinal; f.zbuf = zbuf; f.xs = xs; f.scal = scal;
             f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
             f.nc0 = (int)nc0; f.nc1 = (int)nc1; f.e_chunk0 = 0; f.n_groups = P.n_groups;
             {

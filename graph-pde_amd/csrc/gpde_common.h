@@ -90,12 +90,25 @@ struct GpdeFusedArgs {
     float* zbuf;           // [nc1-nc0][64][K2P]
     float* hout;           // f16v3 only: when set, write the hidden activations [slot - e_chunk0][K2P]
                            // instead of aggregating (gpde_hidden_fwd)
+    const unsigned* xs;    // f16v3, f16-split aggregation: x as (lo16 << 16 | hi16) words, globally scaled
+    const unsigned* scal;  // [0] bits of max |x|, [1] bits of max_e B_e   (gpde_prep.hip)
     int k0, K1P, K2P;
     int nc0, nc1;          // destination-node chunk
     int e_chunk0;          // rowptr[nc0] (mode 2: first row of hbuf)
     int n_groups;          // edge groups (workgroups per slice)
 };
 int gpde_launch_fused(int mode, bool f16split, const GpdeFusedArgs& a, hipStream_t stream);
+// pre-passes of the f16-split aggregation (gpde_prep.hip): scal[0..1], xs [n_nodes][64]
+int gpde_launch_g2_prep(const float* x, int64_t n_nodes, const float* attr, int64_t n_edges, int k0,
+                        const float* wmax8, unsigned* scal, unsigned* xs, hipStream_t stream);
+// 2^(13 - floor(log2 v)) for v in the normal range, else 1: puts a maximum v into [2^13, 2^14)
+__host__ __device__ static inline float gpde_pow2_to_2p13(float v) {
+    union { float f; unsigned u; } a; a.f = v;
+    const int eb = (int)((a.u >> 23) & 0xff);
+    if (eb < 20 || eb > 230) return 1.f;
+    a.u = (unsigned)(267 - eb) << 23;
+    return a.f;
+}
 // Z = sum x_j (x) H_e from given hidden activations a.hbuf (gpde_zagg.hip); uses x, rowptr, src, dst,
 // hbuf, zbuf, K2P, nc0, nc1, e_chunk0, n_groups
 int gpde_launch_zagg(const GpdeFusedArgs& a, hipStream_t stream);

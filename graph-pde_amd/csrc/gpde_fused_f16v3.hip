@@ -54,7 +54,11 @@ constexpr int NET = 4;                     // edge tiles per workgroup
 
 // WRITE_H: store the hidden activations [CSR slot][K2P] (a.hout) instead of aggregating them
 // (gpde_hidden_fwd: the cross-depth cache of SURVEY.md §8 row f4); no x_j staging, no Z.
-template <bool WRITE_H>
+// G2F16: the aggregation Z += x_j (x) h_e on f16 MFMA with the same two-term operand split as the
+// hidden layer (3 x v_mfma_f32_32x32x16_f16 instead of 8 x v_mfma_f32_32x32x2_f32 per 16 edges).  The
+// contraction runs over edges, so the operands carry GLOBAL power-of-two scales: x comes pre-split
+// from gpde_prep.hip (a.xs, scaled by max |x|), h is scaled by an a-priori bound.
+template <bool WRITE_H, bool G2F16>
 __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;                                               // [4][16 KiB]
@@ -111,6 +115,16 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
         b2v[nb] = a.b2[slice * GP_TN + ch * 64 + nb * 32 + l31];
         ucv[nb] = a.ucol[slice * GP_TN + ch * 64 + nb * 32 + l31];
     }
+    float z_unscale = 1.f;
+    if constexpr (G2F16) {
+        // h_e[k] <= max|b2| + max_k ||W2_k||_1 * max_e B_e  (pack-time constants in fcol[8..9])
+        const float sx = gpde_pow2_to_2p13(__uint_as_float(a.scal[0]));
+        const float hb = a.fcol[8] + a.fcol[9] * __uint_as_float(a.scal[1]);
+        const float sh = gpde_pow2_to_2p13(hb);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) { b2v[nb] *= sh; ucv[nb] *= sh; }       // exact: sh is a power of two
+        z_unscale = 1.f / (sx * sh);
+    }
     // per-input-slot constants: bound weights max_k|W1b[k][d]| and column un-scales 2^-u_d
     float wmx8[8], fcol8[8];
 #pragma unroll
@@ -144,7 +158,8 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
     auto issue_x = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            dma16(a.x + (size_t)sidx[i] * GP_W + (lane & 15) * 4, Xs + (ch * 4 + i) * 4 * GP_W);
+            dma16((G2F16 ? (const float*)a.xs : a.x) + (size_t)sidx[i] * GP_W + (lane & 15) * 4,
+                  Xs + (ch * 4 + i) * 4 * GP_W);
     };
     const int NP = NKC / 2;                         // chunk pairs per tile (NKC is even)
     const int KP1 = NP >= 3 ? 1 : NP - 1;           // pair that issues stage B
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    zrow[(size_t)c * a.K2P + nb * 32] = Z[cb][nb][r];
+                    zrow[(size_t)c * a.K2P + nb * 32] = G2F16 ? Z[cb][nb][r] * z_unscale : Z[cb][nb][r];
                     Z[cb][nb][r] = 0.f;
                 }
     };
@@ -410,7 +425,8 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             const float ie = Es[(r & 3) + 8 * (r >> 2) + 4 * h];
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
-                acc1[nb][r] = relu1(fmaf(acc1[nb][r], ie * ucv[nb], b2v[nb]));
+                acc1[nb][r] = G2F16 ? fmaf(acc1[nb][r], ie * ucv[nb], b2v[nb])      // ReLU in the split below
+                                    : relu1(fmaf(acc1[nb][r], ie * ucv[nb], b2v[nb]));
         }
 
         if constexpr (WRITE_H) {
@@ -427,6 +443,15 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             continue;
         }
         // ---- GEMM2 with destination segments (fp32 MFMA) ----------------------------------------------
+        // f16-split aggregation: B operands = the tile's h values, k slot (h, t) of MFMA m <-> edge
+        // er(8m + t) + 4h, i.e. registers 8m .. 8m+7 of the accumulator, as they are
+        h8 g2hi[2][2], g2lo[2][2];
+        if constexpr (G2F16) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int p_ = 0; p_ < 8; ++p_) conv_to(acc1[nb], p_, g2hi[nb], g2lo[nb]);
+        }
         int e_seg = e0;
 #ifdef GPDE_ABL_NOGEMM2
 #pragma unroll
@@ -441,6 +466,34 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                 cur = node;
             }
             const int lo = e_seg - e0 - 4 * h, hi = seg_end - e0 - 4 * h;
+            if constexpr (G2F16) {
+                const unsigned* xu = (const unsigned*)Xs;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        unsigned w[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const int er = ((8 * m + t) & 3) + 8 * ((8 * m + t) >> 2);
+                            const unsigned v = xu[(er + 4 * h) * GP_W + cb * 32 + l31];
+                            w[t] = (er >= lo && er < hi) ? v : 0u;
+                        }
+                        u4 ah, al;
+#pragma unroll
+                        for (int jp = 0; jp < 4; ++jp) {
+                            ah[jp] = __builtin_amdgcn_perm(w[2 * jp + 1], w[2 * jp], 0x05040100u);
+                            al[jp] = __builtin_amdgcn_perm(w[2 * jp + 1], w[2 * jp], 0x07060302u);
+                        }
+                        const h8 xhi = __builtin_bit_cast(h8, ah), xlo = __builtin_bit_cast(h8, al);
+#pragma unroll
+                        for (int nb = 0; nb < (WRITE_H ? 0 : 2); ++nb) {
+                            Z[WRITE_H ? 0 : cb][nb] = mfma16(xhi, g2hi[nb][m], Z[WRITE_H ? 0 : cb][nb]);
+                            Z[WRITE_H ? 0 : cb][nb] = mfma16(xhi, g2lo[nb][m], Z[WRITE_H ? 0 : cb][nb]);
+                            Z[WRITE_H ? 0 : cb][nb] = mfma16(xlo, g2hi[nb][m], Z[WRITE_H ? 0 : cb][nb]);
+                        }
+                    }
+            } else
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int er = (r & 3) + 8 * (r >> 2);
@@ -502,14 +555,17 @@ int gpde_launch_fused_f16v3(const GpdeFusedArgs& a, hipStream_t stream) {
     const size_t lds = v3_lds_bytes(a.K1P);
     static size_t lds_set = 0;
     if (lds > lds_set) {
-        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v3_kernel<false>,
+        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v3_kernel<false, false>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v3_kernel<true>,
+        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v3_kernel<false, true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v3_kernel<true, false>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
-    if (a.hout) hipLaunchKernelGGL(gpde_fused_f16v3_kernel<true>, grid, block, lds, stream, a);
-    else hipLaunchKernelGGL(gpde_fused_f16v3_kernel<false>, grid, block, lds, stream, a);
+    if (a.hout) hipLaunchKernelGGL((gpde_fused_f16v3_kernel<true, false>), grid, block, lds, stream, a);
+    else if (a.xs) hipLaunchKernelGGL((gpde_fused_f16v3_kernel<false, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((gpde_fused_f16v3_kernel<false, false>), grid, block, lds, stream, a);
     GP_LAUNCH_CHECK("gpde_fused_f16v3_kernel");
     return GPDE_OK;
 }

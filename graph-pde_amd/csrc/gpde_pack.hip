@@ -38,7 +38,7 @@ int gpde_pack_layout(int n_layers, const int32_t* dims, GpdePackLayout* L) {
         L->off_w2h = take((size_t)L->K2P * L->K1P);
         L->off_ucol = take((size_t)L->K2P);
         L->off_w1h = take((size_t)L->K1P * 8);
-        L->off_fcol = take(8);
+        L->off_fcol = take(16);      // [0..7] 2^-u_d ; [8] max_k |b2_k| ; [9] max_k sum_j |W2[k][j]|
     } else {
         // front layers 0 .. n_layers-2 as dense layers; widths padded to 128 (inputs of layer 0: 32)
         L->frontKP[0] = gp_round_up(dims[0], 32);
@@ -194,6 +194,30 @@ __global__ void pack_w3_kernel(const float* __restrict__ W3, int k2, int K2P, fl
     out[i] = (k < k2) ? W3[((size_t)c * GP_W + o) * k2 + k] : 0.f;
 }
 
+// a-priori bound of the last hidden layer for the f16-split aggregation (gpde_fused_f16v3.hip):
+// h_e[k] <= |b2_k| + (sum_j |W2[k][j]|) * max_j H1_e[j];  out[0] = max_k |b2_k|, out[1] = max_k ||W2_k||_1
+__global__ void pack_g2_consts_kernel(const float* __restrict__ W2, const float* __restrict__ b2, int k2,
+                                      int k1, float* __restrict__ out) {
+    __shared__ float sb[256], sl[256];
+    float mb = 0.f, ml = 0.f;
+    for (int k = threadIdx.x; k < k2; k += blockDim.x) {
+        float l1 = 0.f;
+        for (int j = 0; j < k1; ++j) l1 += fabsf(W2[(size_t)k * k1 + j]);
+        ml = fmaxf(ml, l1);
+        if (b2) mb = fmaxf(mb, fabsf(b2[k]));
+    }
+    sb[threadIdx.x] = mb; sl[threadIdx.x] = ml;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sb[threadIdx.x] = fmaxf(sb[threadIdx.x], sb[threadIdx.x + s]);
+            sl[threadIdx.x] = fmaxf(sl[threadIdx.x], sl[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = sb[0]; out[1] = sl[0]; }
+}
+
 }  // namespace
 
 extern "C" size_t gpde_mlp_pack_bytes(int n_layers, const int32_t* dims) {
@@ -236,6 +260,8 @@ extern "C" int gpde_mlp_pack(int n_layers, const int32_t* dims, const float* con
                            P + L.off_w1, L.K1P, (_Float16*)(P + L.off_w1h), P + L.off_fcol);
         hipLaunchKernelGGL(pack_w2_f16split_kernel, dim3(L.K2P), dim3(256), 0, stream, W[1], dims[2],
                            dims[1], L.K2P, L.K1P, (_Float16*)(P + L.off_w2h), P + L.off_ucol);
+        hipLaunchKernelGGL(pack_g2_consts_kernel, dim3(1), dim3(256), 0, stream, W[1], b[1], dims[2], dims[1],
+                           P + L.off_fcol + 8);
     } else {
         for (int l = 0; l < n_layers - 1; ++l) {
             hipLaunchKernelGGL(pack_pad_mat_kernel,

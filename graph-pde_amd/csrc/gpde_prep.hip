@@ -1,0 +1,63 @@
+// Pre-passes of the f16-split aggregation inside gpde_fused_f16v3_kernel<false, true>:
+// the aggregation Z_i[c][k] = sum_e x_j[c] h_e[k] (NNConv_old.message + scatter,
+// /root/reference/graph-neural-operator/nn_conv.py:273-275) contracts over EDGES, so its operands
+// can only carry scales that are constant along the contraction: one global power of two for x
+// (from max |x|) and one for h (from an a-priori bound that needs max_e B_e, B_e = the per-edge bound
+// of the first hidden layer).  Three tiny kernels per forward call:
+//   k_absmax_x      scal[0] = max |x|            (atomicMax on the bit pattern; scal zeroed by memset)
+//   k_attr_bound    scal[1] = max_e sum_d max_k|W1b[k][d]| |attr_e[d]|   (bias slot d = k0 counts as 1)
+//   k_split_x       xs[i][c] = (lo16 << 16) | hi16 of x[i][c] * 2^sx,  hi = rtz16, lo = rn16(rest)
+#include "gpde_common.h"
+
+namespace {
+
+__global__ void k_absmax_x(const float* __restrict__ x, size_t n, unsigned* __restrict__ scal) {
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(scal, m);
+}
+
+__global__ void k_attr_bound(const float* __restrict__ attr, int64_t E, int k0, const float* __restrict__ wmax8,
+                             unsigned* __restrict__ scal) {
+    float w[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) w[d] = wmax8[(d & 1) * 4 + (d >> 1)];      // packed [2][4] order (gpde_pack.hip)
+    float m = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        float bnd = w[k0 < 8 ? k0 : 7];                                     // bias slot
+        for (int d = 0; d < k0 && d < 8; ++d) bnd = fmaf(w[d], fabsf(attr[(size_t)e * k0 + d]), bnd);
+        m = fmaxf(m, bnd);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(scal + 1, __float_as_uint(m));
+}
+
+__global__ void k_split_x(const float* __restrict__ x, size_t n, const unsigned* __restrict__ scal,
+                          unsigned* __restrict__ xs) {
+    const float sc = gpde_pow2_to_2p13(__uint_as_float(scal[0]));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float y = x[i] * sc;
+        const _Float16 hi = (_Float16)__builtin_amdgcn_cvt_pkrtz(y, 0.f)[0];
+        const _Float16 lo = (_Float16)(y - (float)hi);
+        xs[i] = ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16) | __builtin_bit_cast(unsigned short, hi);
+    }
+}
+
+}  // namespace
+
+int gpde_launch_g2_prep(const float* x, int64_t n_nodes, const float* attr, int64_t n_edges, int k0,
+                        const float* wmax8, unsigned* scal, unsigned* xs, hipStream_t stream) {
+    GP_HIP_CHECK(hipMemsetAsync(scal, 0, 8, stream));
+    const size_t n = (size_t)n_nodes * GP_W;
+    const unsigned gx = (unsigned)((n + 1023) / 1024 < 1024 ? (n + 1023) / 1024 : 1024);
+    const unsigned ge = (unsigned)((n_edges + 1023) / 1024 < 2048 ? (n_edges + 1023) / 1024 : 2048);
+    hipLaunchKernelGGL(k_absmax_x, dim3(gx ? gx : 1), dim3(256), 0, stream, x, n, scal);
+    hipLaunchKernelGGL(k_attr_bound, dim3(ge ? ge : 1), dim3(256), 0, stream, attr, n_edges, k0, wmax8, scal);
+    hipLaunchKernelGGL(k_split_x, dim3(gx ? gx : 1), dim3(256), 0, stream, x, n, scal, xs);
+    GP_LAUNCH_CHECK("gpde_g2_prep kernels");
+    return GPDE_OK;
+}

@@ -202,7 +202,9 @@ _AGGR = {"add": _lib.GPDE_AGGR_ADD, "mean": _lib.GPDE_AGGR_MEAN}
 _PRECISION = {"f32": _lib.GPDE_FWD_DEFAULT, "f16split": _lib.GPDE_FWD_F16SPLIT,
               "f16split2wg": _lib.GPDE_FWD_F16SPLIT | 4,   # 2wg: two 4-wave workgroups per CU (A/B)
               "f16splitq": _lib.GPDE_FWD_F16SPLIT | 8,     # q: 8 tiles x 64 columns, barrier per 4 chunks (A/B)
-              "f16split4w": _lib.GPDE_FWD_F16SPLIT | 2}     # 4w: one-wave-per-SIMD kernel (A/B)
+              "f16split4w": _lib.GPDE_FWD_F16SPLIT | 2,     # 4w: one-wave-per-SIMD kernel (A/B)
+              "f16split_agg16": _lib.GPDE_FWD_F16SPLIT | 16,  # aggregation on split f16 regardless of size
+              "f16split_agg32": _lib.GPDE_FWD_F16SPLIT | 32}  # aggregation on fp32 MFMA regardless of size
 DEFAULT_PRECISION = os.environ.get("GPDE_PRECISION", "f16split")
 
 

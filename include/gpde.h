@@ -47,7 +47,10 @@ enum {
                               DESIGN.md §3b); ignored for kernels without a hidden GEMM */
     GPDE_FWD_F16SPLIT_4WAVE = 2, /* with F16SPLIT: use the one-wave-per-SIMD kernel (A/B, debugging) */
     GPDE_FWD_F16SPLIT_2WG = 4,   /* with F16SPLIT: two independent 4-wave workgroups per CU (A/B) */
-    GPDE_FWD_F16SPLIT_QUAD = 8   /* with F16SPLIT: 8 edge tiles x 64 columns, one barrier per 4 chunks (A/B) */
+    GPDE_FWD_F16SPLIT_QUAD = 8,  /* with F16SPLIT: 8 edge tiles x 64 columns, one barrier per 4 chunks (A/B) */
+    GPDE_FWD_AGG_F16 = 16,       /* with F16SPLIT: aggregation x_j (x) h_e on split-f16 MFMA too, also for small
+                                    graphs (default: from 32768 edges on; three tiny pre-pass launches) */
+    GPDE_FWD_AGG_F32 = 32        /* with F16SPLIT: keep the aggregation on fp32 MFMA (A/B) */
 };
 
 #define GPDE_MAX_LAYERS 8
