@@ -364,7 +364,7 @@ struct BwdPlan {
     int K2P;
     int64_t Ec, Nc;                   // edges / nodes per chunk
     size_t off_wp[GPDE_MAX_LAYERS], off_bp[GPDE_MAX_LAYERS], off_dwp[GPDE_MAX_LAYERS], off_dbp[GPDE_MAX_LAYERS];
-    size_t off_w3p, off_dw3p, off_b3, off_db3, off_part, part_floats;
+    size_t off_w3p, off_dw3p, off_b3, off_db3, off_part, part_floats, off_pack, pack_bytes;
     size_t off_H[GPDE_MAX_LAYERS + 1], off_dU[2], off_Z, off_dZ, off_gT, off_S, off_dS;
     size_t total;
 };
@@ -394,6 +394,9 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     const int max_splits = 16;
     P->part_floats = (size_t)max_splits * (wmax > 4096 ? wmax : 4096);
     P->off_part = take(P->part_floats);
+    // packed MLP image for the fused f16-split recompute of the last hidden layer (3-Linear kernels)
+    P->pack_bytes = (n_layers == 3 && dims[0] + 1 <= 8) ? gpde_mlp_pack_bytes(n_layers, dims) : 0;
+    P->off_pack = take(P->pack_bytes / 4);
     const size_t fixed = off;
     // per-chunk buffers: per edge (hsum + 2*kmax) floats, per node (2*64*K2P + 3*64) floats
     const size_t per_edge = (hsum + 2 * (size_t)kmax) * 4, per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4;
@@ -506,10 +509,41 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     }
     float* dx = grad_x;
 
-    // recompute of the hidden chain for rows [e0, e0 + rows): layers 1 .. last (inclusive)
+    // FULL phase, 3-Linear kernels: the expensive last hidden layer of the recompute runs on the forward's
+    // fused f16-split kernel with the store epilogue (3x the fp32 GEMM's rate); the first hidden layer is
+    // still needed in memory (dW_2 = dU_2^T H_1) and comes from the GEMM below
+    GpdePackLayout PL;
+    bool fast_last = false;
+    if (phase == BWD_FULL && P.pack_bytes && rowptr && !getenv("GPDE_BWD_RECOMPUTE_F32") &&
+        gpde_pack_layout(n, dims, &PL) == GPDE_OK && PL.mode == 1) {
+        GpdeFusedArgs probe{};
+        probe.k0 = PL.k0; probe.K1P = PL.K1P; probe.K2P = PL.K2P;
+        if (gpde_fused_f16v3_supported(probe)) {
+            if ((rc = gpde_mlp_pack(n, dims, W, b, F(P.off_pack), P.pack_bytes, st)) != GPDE_OK) return rc;
+            fast_last = true;
+        }
+    }
+    // recompute of the hidden chain for rows [e0, e0 + rows) = in-edges of nodes [na_, nb_): layers 1 .. last
+    int rc_na = 0, rc_nb = 0;
     auto recompute = [&](int e0, int rows, int last) -> int {
         hipLaunchKernelGGL(k_gather_attr, dim3(nblk((size_t)rows * P.KP[0])), dim3(T), 0, st, edge_attr, perm, e0,
                            rows, dims[0], P.KP[0], F(P.off_H[0]));
+        if (fast_last && last == n - 1) {
+            const float* pk = F(P.off_pack);
+            GpdeFusedArgs f{};
+            f.attr = edge_attr; f.rowptr = rowptr; f.perm = perm;
+            f.w1 = pk + PL.off_w1; f.w2t = pk + PL.off_w2t; f.b2 = pk + PL.off_b2;
+            f.w2h = pk + PL.off_w2h; f.ucol = pk + PL.off_ucol; f.w1h = pk + PL.off_w1h; f.fcol = pk + PL.off_fcol;
+            f.hout = F(P.off_H[n - 1]); f.k0 = PL.k0; f.K1P = PL.K1P; f.K2P = PL.K2P;
+            f.nc0 = rc_na; f.nc1 = rc_nb; f.e_chunk0 = e0;
+            const int ns = PL.K2P / GP_TN;
+            int groups = gpde_num_cus() / ns; if (groups < 1) groups = 1;
+            const int gcap = (rows / GP_TE + GP_WAVES) / GP_WAVES; if (groups > gcap) groups = gcap;
+            f.n_groups = groups;
+            int rc2 = gpde_launch_fused_f16v3(f, st);
+            if (rc2 != GPDE_OK) return rc2;
+            last = n - 2;
+        }
         for (int l = 1; l <= last; ++l) {
             GpdeGemmArgs g = gemm0();
             g.A = F(P.off_H[l - 1]); g.lda = P.KP[l - 1]; g.B = F(P.off_wp[l]); g.ldb = P.KP[l - 1];
@@ -585,7 +619,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         hipLaunchKernelGGL(k_scale_g, dim3((nn + 3) / 4), dim3(T), 0, st, grad_out, rowptr, aggr, na, nn, gT);
         if (rows > 0) {
             // hidden activations of the chunk's edges: recomputed, or rows of the given cache
-            if (phase == BWD_FULL) { if ((rc = recompute(e0, rows, n - 1)) != GPDE_OK) return rc; }
+            if (phase == BWD_FULL) { rc_na = na; rc_nb = nb; if ((rc = recompute(e0, rows, n - 1)) != GPDE_OK) return rc; }
             const float* Hlast = phase == BWD_FULL ? F(P.off_H[n - 1]) : hidden + (size_t)e0 * K2P;
             // Z of the chunk's nodes from the recomputed activations (mode-2 fused kernel)
             GP_HIP_CHECK(hipMemsetAsync(Z, 0, (size_t)nn * GP_W * K2P * 4, st));

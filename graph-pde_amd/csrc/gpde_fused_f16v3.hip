@@ -101,12 +101,19 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
     if (maxtiles == 0) return;
 
     // ---- W2 chunk DMA: 2 x 1 KiB per wave per chunk ---------------------------------------------------
-    const char* w2g = (const char*)a.w2h + (size_t)slice * NKC * TILE_B + wave * 1024 + lane * 16;
+    // The address is rebuilt from a SCALAR base at every issue (one 64-bit add per DMA).  Left to
+    // itself the compiler keeps four running per-lane pointers in VGPR pairs, spills them, and every
+    // DMA of the steady-state loop then waits for a scratch load (~130 cycles each, 4 per iteration).
+    const unsigned long long w2base = (unsigned long long)a.w2h + (size_t)slice * NKC * TILE_B + wave * 1024;
+    const unsigned lane16 = lane * 16;
     auto issue_w2 = [&](int chunk, int slot) {
-        const char* g = w2g + (size_t)chunk * TILE_B;
+        unsigned long long gb = w2base + (size_t)chunk * TILE_B;
+        asm volatile("" : "+s"(gb));
         char* l = ring + slot * TILE_B + wave * 1024;
-        dma16(g, l);
-        dma16(g + 8192, l + 8192);
+        dma16((const char*)(gb + lane16), l);
+        unsigned long long gb2 = gb + 8192;
+        asm volatile("" : "+s"(gb2));
+        dma16((const char*)(gb2 + lane16), l + 8192);
     };
 
     float b2v[2], ucv[2];
