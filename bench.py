@@ -81,7 +81,11 @@ def executed_flops_per_edge(dims, w=64, precision="f32"):
     if precision == "f16split4w":            # 4-wave kernel: H1 on fp32 MFMA per 128-column slice
         return (2 * 8 * k1p * (k2p // 128) + agg, 3 * hidden)
     # default 8-wave kernel: H1 as 2 f16 MFMAs (K = 16) per 32-row chunk and 64-column wave tile
-    return (agg, 3 * hidden + 2 * 2 * 16 * k1p * (k2p // 64))
+    h1 = 2 * 2 * 16 * k1p * (k2p // 64)
+    if precision == "f16split_agg32":        # aggregation kept on fp32 MFMA
+        return (agg, 3 * hidden + h1)
+    # aggregation on split f16 as well (default from 32768 edges on)
+    return (0, 3 * hidden + h1 + 3 * agg)
 
 
 def main():
