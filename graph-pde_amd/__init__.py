@@ -8,5 +8,6 @@ neuraloperator/graph-pde — hand-written HIP for gfx950 behind the reference's 
 """
 from . import _lib, ops, synth          # noqa: F401
 from .nn_conv import ECConv, NNConv, NNConv_old   # noqa: F401
+from .ops import NodeAttr                           # noqa: F401  (opt-in: edge attributes from node data)
 
-__all__ = ["NNConv_old", "NNConv", "ECConv", "ops", "synth"]
+__all__ = ["NNConv_old", "NNConv", "ECConv", "NodeAttr", "ops", "synth"]

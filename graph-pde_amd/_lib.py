@@ -56,6 +56,12 @@ SIGNATURES = {
                                        ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_size_t, ctypes.c_void_p]),
+    "gpde_nnconv_fwd_nodeattr": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32,
+                                                c_i32p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                                ctypes.c_void_p]),
     "gpde_hidden_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, c_i32p]),
     "gpde_hidden_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                        ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.c_void_p,

@@ -171,11 +171,13 @@ namespace {
 
 // `hidden` != nullptr: the last hidden activations are given ([CSR slot][K2P], gpde_hidden_fwd); only the
 // aggregation, the last Linear and update() run (gpde_nnconv_fwd_hidden)
+// `kt` != 0: edge_attr is a NODE table [n_nodes][kt] and slot d of an edge's attribute is
+// table[(sel[d] >> 8 ? dst : src)][sel[d] & 255] (gpde_nnconv_fwd_nodeattr)
 int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
              const int32_t* rowptr, const int32_t* src, const int32_t* dst, const int32_t* perm,
              int n_layers, const int32_t* dims, const void* packed, const float* root,
              const float* bias, int aggr, uint32_t flags, const float* hidden, float* out, void* ws,
-             size_t ws_bytes, hipStream_t stream) {
+             size_t ws_bytes, hipStream_t stream, int kt = 0, const int* sel = nullptr) {
     if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) {
         gpde_set_error("gpde_nnconv_fwd: aggr %d not implemented (add=0, mean=1)", aggr);
         return GPDE_EUNSUPPORTED;
@@ -220,13 +222,22 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
     // ten thousand edges on; GPDE_FWD_AGG_F16 / GPDE_FWD_AGG_F32 force it on / off
     const unsigned* xs = nullptr;
     const unsigned* scal = nullptr;
+    if (kt) {
+        GpdeFusedArgs probe{};
+        probe.k0 = L.k0; probe.K1P = L.K1P; probe.K2P = L.K2P;
+        if (mode != 1 || !(flags & GPDE_FWD_F16SPLIT) || (flags & (GPDE_FWD_F16SPLIT_4WAVE | GPDE_FWD_F16SPLIT_2WG | GPDE_FWD_F16SPLIT_QUAD)) ||
+            !gpde_fused_f16v3_supported(probe)) {
+            gpde_set_error("gpde_nnconv_fwd_nodeattr: built for 3-Linear kernel MLPs on the default f16-split kernel only");
+            return GPDE_EUNSUPPORTED;
+        }
+    }
     if (!hidden && mode == 1 && (flags & GPDE_FWD_F16SPLIT) && !(flags & (GPDE_FWD_F16SPLIT_4WAVE | GPDE_FWD_F16SPLIT_2WG | GPDE_FWD_F16SPLIT_QUAD)) &&
         !(flags & GPDE_FWD_AGG_F32) && n_edges > 0 && ((flags & GPDE_FWD_AGG_F16) || n_edges >= 32768)) {
         GpdeFusedArgs probe{};
         probe.k0 = L.k0; probe.K1P = L.K1P; probe.K2P = L.K2P;
         if (gpde_fused_f16v3_supported(probe)) {
             rc = gpde_launch_g2_prep(x, n_nodes, edge_attr, n_edges, L.k0, pk + L.off_w1 + (size_t)L.K1P * 8,
-                                     (unsigned*)(w + P.off_scal), (unsigned*)(w + P.off_xs), stream);
+                                     (unsigned*)(w + P.off_scal), (unsigned*)(w + P.off_xs), stream, kt, sel, src, dst);
             if (rc != GPDE_OK) return rc;
             xs = (const unsigned*)(w + P.off_xs);
             scal = (const unsigned*)(w + P.off_scal);
@@ -244,6 +255,8 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
             f.w2h = pk + L.off_w2h; f.ucol = pk + L.off_ucol;
             f.w1h = pk + L.off_w1h; f.fcol = pk + L.off_fcol;
             f.hbuf = hfinal; f.zbuf = zbuf; f.xs = xs; f.scal = scal;
+            f.kt = kt;
+            for (int d = 0; d < 8; ++d) f.sel[d] = (kt && sel) ? sel[d < L.k0 ? d : L.k0 - 1] : 0;
             f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
             f.nc0 = (int)nc0; f.nc1 = (int)nc1; f.e_chunk0 = 0; f.n_groups = P.n_groups;
             {
@@ -290,6 +303,30 @@ extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edg
     }
     return fwd_impl(x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, n_layers, dims, packed, root, bias,
                     aggr, flags, nullptr, out, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+extern "C" int gpde_nnconv_fwd_nodeattr(const float* x, int64_t n_nodes, const float* node_table, int32_t table_stride,
+                                        const int32_t* attr_sel, int64_t n_edges, const int32_t* rowptr,
+                                        const int32_t* src, const int32_t* dst, int n_layers,
+                                        const int32_t* dims, const void* packed, const float* root,
+                                        const float* bias, int aggr, uint32_t flags, float* out, void* ws,
+                                        size_t ws_bytes, void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || !dims || !packed || !rowptr || !attr_sel || table_stride < 1 ||
+        (n_nodes > 0 && (!x || !out || !node_table)) || (n_edges > 0 && (!src || !dst))) {
+        gpde_set_error("gpde_nnconv_fwd_nodeattr: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (dims[0] < 1 || dims[0] > 7) { gpde_set_error("gpde_nnconv_fwd_nodeattr: 1..7 attribute slots, got %d", dims[0]); return GPDE_EUNSUPPORTED; }
+    int sel[8];
+    for (int d = 0; d < 8; ++d) {
+        sel[d] = attr_sel[d < dims[0] ? d : dims[0] - 1];
+        if ((sel[d] >> 8) < 0 || (sel[d] >> 8) > 1 || (sel[d] & 255) >= table_stride) {
+            gpde_set_error("gpde_nnconv_fwd_nodeattr: attr_sel[%d] = 0x%x (endpoint << 8 | column, column < %d)", d, sel[d], table_stride);
+            return GPDE_EINVAL;
+        }
+    }
+    return fwd_impl(x, n_nodes, node_table, n_edges, rowptr, src, dst, nullptr, n_layers, dims, packed, root, bias,
+                    aggr, flags, nullptr, out, ws, ws_bytes, (hipStream_t)stream_, table_stride, sel);
 }
 
 extern "C" int gpde_nnconv_fwd_hidden(const float* x, int64_t n_nodes, const float* hidden,

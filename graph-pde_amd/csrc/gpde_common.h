@@ -92,6 +92,8 @@ struct GpdeFusedArgs {
                            // instead of aggregating (gpde_hidden_fwd)
     const unsigned* xs;    // f16v3, f16-split aggregation: x as (lo16 << 16 | hi16) words, globally scaled
     const unsigned* scal;  // [0] bits of max |x|, [1] bits of max_e B_e   (gpde_prep.hip)
+    int kt;                // f16v3, attributes from a node table (row f3): table row stride, 0 = edge_attr tensor
+    int sel[8];            // slot d of an edge's attribute = attr[(sel[d] >> 8 ? dst : src) * kt + (sel[d] & 255)]
     int k0, K1P, K2P;
     int nc0, nc1;          // destination-node chunk
     int e_chunk0;          // rowptr[nc0] (mode 2: first row of hbuf)
@@ -100,7 +102,9 @@ struct GpdeFusedArgs {
 int gpde_launch_fused(int mode, bool f16split, const GpdeFusedArgs& a, hipStream_t stream);
 // pre-passes of the f16-split aggregation (gpde_prep.hip): scal[0..1], xs [n_nodes][64]
 int gpde_launch_g2_prep(const float* x, int64_t n_nodes, const float* attr, int64_t n_edges, int k0,
-                        const float* wmax8, unsigned* scal, unsigned* xs, hipStream_t stream);
+                        const float* wmax8, unsigned* scal, unsigned* xs, hipStream_t stream,
+                        int kt = 0, const int* sel = nullptr, const int32_t* src = nullptr,
+                        const int32_t* dst = nullptr);
 // 2^(13 - floor(log2 v)) for v in the normal range, else 1: puts a maximum v into [2^13, 2^14)
 __host__ __device__ static inline float gpde_pow2_to_2p13(float v) {
     union { float f; unsigned u; } a; a.f = v;

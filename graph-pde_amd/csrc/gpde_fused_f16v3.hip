@@ -58,7 +58,10 @@ constexpr int NET = 4;                     // edge tiles per workgroup
 // hidden layer (3 x v_mfma_f32_32x32x16_f16 instead of 8 x v_mfma_f32_32x32x2_f32 per 16 edges).  The
 // contraction runs over edges, so the operands carry GLOBAL power-of-two scales: x comes pre-split
 // from gpde_prep.hip (a.xs, scaled by max |x|), h is scaled by an a-priori bound.
-template <bool WRITE_H, bool G2F16>
+// NODEATTR (opt-in): no [E][k0] attribute tensor; slot d of an edge's attribute is
+// read from a node table, a.attr[(sel_d >> 8 ? dst_e : src_e) * a.kt + (sel_d & 255)] -- the reference
+// builds edge_attr exactly so, [pos_src, pos_dst, a_src, a_dst] (graph-neural-operator/utilities.py:274-277).
+template <bool WRITE_H, bool G2F16, bool NODEATTR>
 __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;                                               // [4][16 KiB]
@@ -150,14 +153,28 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
     // stage B (iteration K1): attributes of the NEXT tile (8 loads) + this tile's x_j rows, the
     //                         wave's half (4 DMA)
     const int e_clamp = max(e_hi - 1, 0);
-    int perm_n = 0, sidx[4];
+    int perm_n = 0, dstn_n = 0, sidx[4];
     float attr_n[8];
-    auto load_perm = [&](int e0n) { perm_n = a.perm[min(e0n + l31, e_clamp)]; };
+    auto load_perm = [&](int e0n) {
+        const int e = min(e0n + l31, e_clamp);
+        if constexpr (NODEATTR) { perm_n = a.src[e]; dstn_n = a.dst[e]; }
+        else perm_n = a.perm[e];
+    };
+    constexpr int A_CNT = (WRITE_H ? 0 : 4) + 1 + (NODEATTR ? 1 : 0);     // stage A VMEM ops after the W2 DMA
+    constexpr int B_CNT = (WRITE_H ? 0 : 4) + 8;                          // stage B
     auto load_sidx = [&](int e0c) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) sidx[i] = a.src[min(e0c + (lane >> 4) + 4 * (ch * 4 + i), e_clamp)];
     };
     auto load_attr = [&]() {
+        if constexpr (NODEATTR) {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const int sel = a.sel[min(d, a.k0 - 1)];
+                attr_n[d] = a.attr[(size_t)((sel >> 8) ? dstn_n : perm_n) * a.kt + (sel & 255)];
+            }
+            return;
+        }
         const float* ap = a.attr + (size_t)perm_n * a.k0;
 #pragma unroll
         for (int d = 0; d < 8; ++d) attr_n[d] = ap[min(d, a.k0 - 1)];
@@ -342,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
                 const char* rb = ring + (sb + cc) * TILE_B;
-#ifndef GPDE_V3_NOPRIO
+#if !defined(GPDE_V3_NOPRIO) && !defined(GPDE_V3_PRIO_HALF)
                 // The SIMD arbitrates its two waves by age: alternate the priority per chunk so that
                 // neither wave of a pair runs ahead and then idles at the barrier.
                 if ((cc == 0) != roleB) __builtin_amdgcn_s_setprio(1);
@@ -359,6 +376,10 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                 // nothing (scripts/v3_timing.py ablations).
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
+#ifdef GPDE_V3_PRIO_HALF
+                    if (((m == 0) != (cc == 0)) != roleB) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {
                         const int nb = j & 1, t = j >> 1;       // t: 0 = hi x lo, 1 = hi x hi, 2 = lo x hi
@@ -396,17 +417,10 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             const long long tw0 = clock64();
 #endif
 #ifndef GPDE_ABL_NOSTAGE
-            if constexpr (WRITE_H) {       // no source-index loads (4) / x_j DMA (4)
-                if (kp == 0 && KP1 == 0) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                else if (kp == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                else if (kp == KP1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                if (kp == 0 && KP1 == 0) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-                else if (kp == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else if (kp == KP1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            if (kp == 0 && KP1 == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_CNT + B_CNT) : "memory");
+            else if (kp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_CNT) : "memory");
+            else if (kp == KP1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_CNT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 #ifdef GPDE_V3_TIMING
             const long long tw1 = clock64();
@@ -562,17 +576,23 @@ int gpde_launch_fused_f16v3(const GpdeFusedArgs& a, hipStream_t stream) {
     const size_t lds = v3_lds_bytes(a.K1P);
     static size_t lds_set = 0;
     if (lds > lds_set) {
-        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v3_kernel<false, false>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v3_kernel<false, true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v3_kernel<true, false>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const void* fns[5] = {(const void*)gpde_fused_f16v3_kernel<false, false, false>,
+                              (const void*)gpde_fused_f16v3_kernel<false, true, false>,
+                              (const void*)gpde_fused_f16v3_kernel<true, false, false>,
+                              (const void*)gpde_fused_f16v3_kernel<false, false, true>,
+                              (const void*)gpde_fused_f16v3_kernel<false, true, true>};
+        for (const void* f : fns)
+            GP_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
-    if (a.hout) hipLaunchKernelGGL((gpde_fused_f16v3_kernel<true, false>), grid, block, lds, stream, a);
-    else if (a.xs) hipLaunchKernelGGL((gpde_fused_f16v3_kernel<false, true>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((gpde_fused_f16v3_kernel<false, false>), grid, block, lds, stream, a);
+    if (a.hout) {
+        if (a.kt) { gpde_set_error("hidden-activation output from node-table attributes is not built"); return GPDE_EUNSUPPORTED; }
+        hipLaunchKernelGGL((gpde_fused_f16v3_kernel<true, false, false>), grid, block, lds, stream, a);
+    } else if (a.kt) {
+        if (a.xs) hipLaunchKernelGGL((gpde_fused_f16v3_kernel<false, true, true>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((gpde_fused_f16v3_kernel<false, false, true>), grid, block, lds, stream, a);
+    } else if (a.xs) hipLaunchKernelGGL((gpde_fused_f16v3_kernel<false, true, false>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((gpde_fused_f16v3_kernel<false, false, false>), grid, block, lds, stream, a);
     GP_LAUNCH_CHECK("gpde_fused_f16v3_kernel");
     return GPDE_OK;
 }

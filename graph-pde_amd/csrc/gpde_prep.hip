@@ -36,6 +36,27 @@ __global__ void k_attr_bound(const float* __restrict__ attr, int64_t E, int k0, 
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(scal + 1, __float_as_uint(m));
 }
 
+// the same bound with the attributes read from a node table (row f3), edges in CSR order
+struct SelArr { int v[8]; };
+__global__ void k_attr_bound_nodes(const float* __restrict__ table, int kt, SelArr sel, const int32_t* __restrict__ src,
+                                   const int32_t* __restrict__ dst, int64_t E, int k0,
+                                   const float* __restrict__ wmax8, unsigned* __restrict__ scal) {
+    float w[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) w[d] = wmax8[(d & 1) * 4 + (d >> 1)];
+    float m = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int s_ = src[e], t_ = dst[e];
+        float bnd = w[k0 < 8 ? k0 : 7];
+        for (int d = 0; d < k0 && d < 8; ++d)
+            bnd = fmaf(w[d], fabsf(table[(size_t)((sel.v[d] >> 8) ? t_ : s_) * kt + (sel.v[d] & 255)]), bnd);
+        m = fmaxf(m, bnd);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(scal + 1, __float_as_uint(m));
+}
+
 __global__ void k_split_x(const float* __restrict__ x, size_t n, const unsigned* __restrict__ scal,
                           unsigned* __restrict__ xs) {
     const float sc = gpde_pow2_to_2p13(__uint_as_float(scal[0]));
@@ -50,13 +71,21 @@ __global__ void k_split_x(const float* __restrict__ x, size_t n, const unsigned*
 }  // namespace
 
 int gpde_launch_g2_prep(const float* x, int64_t n_nodes, const float* attr, int64_t n_edges, int k0,
-                        const float* wmax8, unsigned* scal, unsigned* xs, hipStream_t stream) {
+                        const float* wmax8, unsigned* scal, unsigned* xs, hipStream_t stream, int kt,
+                        const int* sel, const int32_t* src, const int32_t* dst) {
     GP_HIP_CHECK(hipMemsetAsync(scal, 0, 8, stream));
     const size_t n = (size_t)n_nodes * GP_W;
     const unsigned gx = (unsigned)((n + 1023) / 1024 < 1024 ? (n + 1023) / 1024 : 1024);
     const unsigned ge = (unsigned)((n_edges + 1023) / 1024 < 2048 ? (n_edges + 1023) / 1024 : 2048);
     hipLaunchKernelGGL(k_absmax_x, dim3(gx ? gx : 1), dim3(256), 0, stream, x, n, scal);
-    hipLaunchKernelGGL(k_attr_bound, dim3(ge ? ge : 1), dim3(256), 0, stream, attr, n_edges, k0, wmax8, scal);
+    if (kt) {
+        SelArr sa;
+        for (int d = 0; d < 8; ++d) sa.v[d] = sel[d];
+        hipLaunchKernelGGL(k_attr_bound_nodes, dim3(ge ? ge : 1), dim3(256), 0, stream, attr, kt, sa, src, dst,
+                           n_edges, k0, wmax8, scal);
+    } else {
+        hipLaunchKernelGGL(k_attr_bound, dim3(ge ? ge : 1), dim3(256), 0, stream, attr, n_edges, k0, wmax8, scal);
+    }
     hipLaunchKernelGGL(k_split_x, dim3(gx ? gx : 1), dim3(256), 0, stream, x, n, scal, xs);
     GP_LAUNCH_CHECK("gpde_g2_prep kernels");
     return GPDE_OK;

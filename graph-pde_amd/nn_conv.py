@@ -80,6 +80,17 @@ class NNConv_old(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_attr):      # nn_conv.py:267-271
         x = x.unsqueeze(-1) if x.dim() == 1 else x
+        if isinstance(edge_attr, ops.NodeAttr):
+            # opt-in: attributes read from node data inside the kernel.  Inference on
+            # the default f16-split kernel; anything else takes the tensor the reference would build.
+            lin = ops.mlp_linears(self.nn)
+            needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+            if not needs_grad and len(lin) == 3 and ops.DEFAULT_PRECISION == "f16split" and \
+                    self.in_channels == ops.WIDTH and self.out_channels == ops.WIDTH:
+                csr = ops.csr_for(edge_index, x.size(0))
+                pm = ops.pack_mlp([l.weight for l in lin], [l.bias for l in lin])
+                return ops.nnconv_forward_nodeattr_raw(x, csr, edge_attr, pm, self.root, self.bias, self.aggr)
+            edge_attr = edge_attr.materialize(edge_index)
         pseudo = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
         if self.in_channels != ops.WIDTH or self.out_channels != ops.WIDTH:
             raise NotImplementedError(

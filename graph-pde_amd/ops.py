@@ -257,6 +257,77 @@ def nnconv_forward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor, pm: P
     return out
 
 
+class NodeAttr:
+    """Edge attributes described by node data instead of an [E, k0] tensor (SURVEY.md §8 row f3,
+    opt-in): slot d of edge (j -> i) is table[(i if endpoint_d else j), column_d].
+    `NodeAttr.darcy(pos, a)` is the reference's recipe edge_attr = [pos_src, pos_dst, a_src, a_dst]
+    (graph-neural-operator/utilities.py:274-277)."""
+
+    def __init__(self, table: torch.Tensor, sel: Sequence[Tuple[int, int]]):
+        if table.dim() != 2 or table.dtype != torch.float32:
+            raise ValueError("node table must be float32 [N, columns]")
+        if not 1 <= len(sel) <= 7:
+            raise NotImplementedError("1..7 attribute slots")
+        for ep, col in sel:
+            if ep not in (0, 1) or not 0 <= col < table.size(1) or col > 255:
+                raise ValueError(f"slot ({ep}, {col}): endpoint 0 = source / 1 = target, column < {table.size(1)}")
+        self.table = table.contiguous()
+        self.sel = [(int(ep), int(col)) for ep, col in sel]
+
+    @staticmethod
+    def darcy(pos: torch.Tensor, a: torch.Tensor) -> "NodeAttr":
+        d = pos.size(1)
+        table = torch.cat([pos.float(), a.float().reshape(-1, 1)], dim=1)
+        sel = [(0, c) for c in range(d)] + [(1, c) for c in range(d)] + [(0, d), (1, d)]
+        return NodeAttr(table, sel)
+
+    @property
+    def k0(self) -> int:
+        return len(self.sel)
+
+    def materialize(self, edge_index: torch.Tensor) -> torch.Tensor:
+        """The [E, k0] tensor the reference would have built (torch gather; for training / checks)."""
+        cols = [self.table[edge_index[ep].long(), col] for ep, col in self.sel]
+        return torch.stack(cols, dim=1)
+
+
+def nnconv_forward_nodeattr_raw(x: torch.Tensor, csr: Csr, na: NodeAttr, pm: PackedMlp,
+                                root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,
+                                out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
+                                precision: Optional[str] = None) -> torch.Tensor:
+    """One gpde_nnconv_fwd_nodeattr call: the forward with edge attributes read from a node table."""
+    lib = _lib.lib()
+    _require_cuda(x, "x")
+    _require_cuda(na.table, "node table")
+    if aggr not in _AGGR:
+        raise NotImplementedError(f"aggr={aggr!r}: 'add' and 'mean' only")
+    precision = DEFAULT_PRECISION if precision is None else precision
+    n, e = csr.n_nodes, csr.n_edges
+    if x.dtype != torch.float32 or x.dim() != 2 or x.size(1) != WIDTH or x.size(0) != n:
+        raise ValueError(f"x must be float32 [{n},{WIDTH}]")
+    if na.table.size(0) != n or na.k0 != pm.dims[0]:
+        raise ValueError(f"node table must have {n} rows and {pm.dims[0]} slots, got {na.table.size(0)} / {na.k0}")
+    x = x.contiguous()
+    sel_c = (ctypes.c_int32 * na.k0)(*[(ep << 8) | col for ep, col in na.sel])
+    root_c = None if root is None else root.detach().contiguous()
+    bias_c = None if bias is None else bias.detach().contiguous()
+    if out is None:
+        out = torch.empty(n, WIDTH, dtype=torch.float32, device=x.device)
+    if ws is None:
+        ws = torch.empty(max(workspace_bytes(n, e, pm), 1), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.gpde_nnconv_fwd_nodeattr(x.data_ptr(), n, na.table.data_ptr(), na.table.size(1), sel_c, e,
+                                          csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(),
+                                          len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(),
+                                          None if root_c is None else root_c.data_ptr(),
+                                          None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
+                                          _PRECISION[precision], out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          _stream_ptr(x.device))
+    _lib.check(rc, "gpde_nnconv_fwd_nodeattr")
+    _lib.n_native_calls += 1
+    return out
+
+
 def launch_plan(n_nodes: int, n_edges: int, pm: PackedMlp, ws_bytes: int):
     lib = _lib.lib()
     nch, npc, wgs, mode = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()

@@ -195,6 +195,25 @@ int gpde_hidden_bwd(const float* edge_attr, int64_t n_edges, const int32_t* perm
                     size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Edge attributes on the fly (opt-in).  The reference materialises
+ * edge_attr[e] = [pos_src(2), pos_dst(2), a_src, a_dst] from node data (SquareMeshGenerator.attributes,
+ * utilities.py:274-277; multi_pole_grid1d, multipole utilities.py:1771-1777): 24 of the 40
+ * algorithmic bytes per edge and a 2.3 GB tensor on the 241^2 graph.  Here the fused kernel reads
+ * them from a node table instead: slot d of edge (j -> i) is
+ *     node_table[(attr_sel[d] >> 8 ? i : j) * table_stride + (attr_sel[d] & 255)]
+ * attr_sel: HOST array of dims[0] ints (endpoint << 8 | column; endpoint 0 = source j, 1 = target i).
+ * Same result as gpde_nnconv_fwd on the materialised tensor (bitwise: the attribute values are the
+ * same floats).  Built for 3-Linear kernel MLPs on the default GPDE_FWD_F16SPLIT kernel; anything
+ * else returns GPDE_EUNSUPPORTED.  `perm` is not needed.  Forward only (training takes the
+ * materialised tensor). */
+int gpde_nnconv_fwd_nodeattr(const float* x, int64_t n_nodes, const float* node_table,
+                             int32_t table_stride, const int32_t* attr_sel, int64_t n_edges,
+                             const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                             int n_layers, const int32_t* dims, const void* packed, const float* root,
+                             const float* bias, int aggr, uint32_t flags, float* out, void* ws,
+                             size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Radius graph on the GPU.  Replaces SquareMeshGenerator / RandomMeshGenerator.ball_connectivity
  * (utilities.py:250-255, 362-368: dense float64 pairwise_distances + np.where).  pos [n][dim]
  * float64 (dim 1..3).  Pass 1 writes the out-degree of every source; the caller forms the

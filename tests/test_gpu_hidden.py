@@ -201,3 +201,49 @@ def test_budget_and_off(monkeypatch):
     with torch.no_grad():
         conv(x, eid, ead)
     assert hidden_cache.stats["builds"] == 0
+
+
+def test_edge_attr_from_node_table_matches_materialised_tensor():
+    """edge_attr = [pos_src, pos_dst, a_src, a_dst]
+    (graph-neural-operator/utilities.py:274-277) read from node data inside the fused kernel; same
+    output as the forward on the materialised [E,6] tensor, and within 1e-5 of the oracle."""
+    from tests.test_host_logic import DenseNet
+    d = dev()
+    torch.manual_seed(9)
+    s, r = 24, 0.15
+    ei = synth.lattice_radius_graph(s, r, d)
+    pos = synth.lattice_positions(s, d)
+    a = synth.darcy_coefficient(s, 3).to(d)
+    ea = synth.darcy_edge_attr(ei, pos, a)
+    n = s * s
+    na = gp.NodeAttr.darcy(pos, a)
+    assert torch.equal(na.materialize(ei), ea)                       # the recipe, slot for slot
+    x = torch.randn(n, 64, device=d)
+    for dims in ([6, 64, 128, 4096], [6, 128, 256, 4096]):
+        conv = gp.NNConv_old(64, 64, DenseNet(dims, torch.nn.ReLU), aggr="mean").to(d)
+        lin = ops.mlp_linears(conv.nn)
+        pm = ops.pack_mlp([l.weight for l in lin], [l.bias for l in lin])
+        csr = ops.csr_for(ei, n)
+        for prec in ("f16split_agg32", "f16split_agg16"):
+            calls = _lib.n_native_calls
+            y_t = ops.nnconv_forward_raw(x, csr, ea, pm, conv.root, conv.bias, "mean", precision=prec)
+            y_n = ops.nnconv_forward_nodeattr_raw(x, csr, na, pm, conv.root, conv.bias, "mean", precision=prec)
+            torch.cuda.synchronize()
+            assert _lib.n_native_calls == calls + 2
+            assert torch.equal(y_t, y_n), (dims, prec, rel_l2(y_n.cpu(), y_t.cpu()))
+        y64 = nnconv_forward(x.cpu(), ei.cpu(), ea.cpu(), [l.weight.detach().cpu() for l in lin],
+                             [l.bias.detach().cpu() for l in lin], conv.root.detach().cpu(),
+                             conv.bias.detach().cpu(), aggr="mean", dtype=torch.float64)
+        with torch.no_grad():
+            y_mod = conv(x, ei, na)                                   # module surface, inference
+        assert rel_l2(y_mod.cpu(), y64) <= TOL
+        # training through the module takes the materialised tensor: gradients flow as usual
+        out = conv(x, ei, na)
+        out.square().mean().backward()
+        assert conv.root.grad is not None and torch.isfinite(conv.root.grad).all()
+    # anything but the default f16-split kernel on a 3-Linear MLP is refused, not silently rerouted
+    conv2 = gp.NNConv_old(64, 64, DenseNet([6, 64, 4096], torch.nn.ReLU), aggr="mean").to(d)
+    lin2 = ops.mlp_linears(conv2.nn)
+    pm2 = ops.pack_mlp([l.weight for l in lin2], [l.bias for l in lin2])
+    with pytest.raises(NotImplementedError):
+        ops.nnconv_forward_nodeattr_raw(x, ops.csr_for(ei, n), na, pm2, conv2.root, conv2.bias, "mean")

@@ -127,3 +127,21 @@ def test_hidden_cache_key_and_policy_bookkeeping(monkeypatch):
     assert hidden_cache.lookup(conv, ea, csr, pm, w, b, mode="on") is None             # over budget: direct
     buf = io.BytesIO()
     torch.save(conv, buf)                                                              # nothing rides on the module
+
+
+def test_node_attr_recipe_is_the_reference_edge_attr():
+    """NodeAttr.darcy(pos, a).materialize(edge_index) == [pos_src, pos_dst, a_src, a_dst]
+    (SquareMeshGenerator.attributes, graph-neural-operator/utilities.py:274-277) -- host side of row f3."""
+    ei = synth.lattice_radius_graph(8, 0.3)
+    pos = synth.lattice_positions(8)
+    a = synth.darcy_coefficient(8, 1)
+    na = gp.NodeAttr.darcy(pos, a)
+    assert na.k0 == 6 and na.sel == [(0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (1, 2)]
+    assert torch.equal(na.materialize(ei), synth.darcy_edge_attr(ei, pos, a))
+    with pytest.raises(ValueError):
+        gp.NodeAttr(torch.zeros(4, 3), [(2, 0)])
+    with pytest.raises(NotImplementedError):
+        gp.NodeAttr(torch.zeros(4, 3), [(0, 0)] * 8)
+    conv = gp.NNConv_old(64, 64, DenseNet([6, 8, 16, 4096], torch.nn.ReLU), aggr="mean")
+    with pytest.raises(RuntimeError, match="no CPU"):       # still no CPU execution path
+        conv(torch.randn(64, 64), ei, na)
