@@ -130,6 +130,7 @@ def test_hidden_cache_key_and_policy_bookkeeping(monkeypatch):
 
 
 def test_node_attr_recipe_is_the_reference_edge_attr():
+    from graph_pde_amd import synth
     """NodeAttr.darcy(pos, a).materialize(edge_index) == [pos_src, pos_dst, a_src, a_dst]
     (SquareMeshGenerator.attributes, graph-neural-operator/utilities.py:274-277) -- host side of row f3."""
     ei = synth.lattice_radius_graph(8, 0.3)
