@@ -46,10 +46,11 @@ class NNConvFunction(torch.autograd.Function):
 class HiddenToken:
     """Validity flag shared between a cached H and its autograd node: once the node's backward has
     run, the graph behind H is gone and the cached tensor must not be reused for a new forward."""
-    __slots__ = ("valid",)
+    __slots__ = ("valid", "hmax")
 
     def __init__(self):
         self.valid = True
+        self.hmax = None        # device scalar max |H| when the fused kernel recorded it
 
 
 class HiddenFunction(torch.autograd.Function):
@@ -59,7 +60,8 @@ class HiddenFunction(torch.autograd.Function):
     def forward(ctx, edge_attr, csr, pm, precision, token, n_hidden, *params):
         weights = list(params[:n_hidden])
         biases = list(params[n_hidden:])
-        h = ops.hidden_forward_raw(csr, edge_attr.detach(), pm, weights + [None], biases + [None], precision)
+        h, token.hmax = ops.hidden_forward_raw(csr, edge_attr.detach(), pm, weights + [None], biases + [None],
+                                               precision)
         ctx.csr, ctx.dims, ctx.n_hidden, ctx.token = csr, tuple(pm.dims), n_hidden, token
         ctx.attr_needs_grad = edge_attr.requires_grad
         ctx.save_for_backward(edge_attr, *params)
@@ -82,8 +84,8 @@ class NNConvHiddenFunction(torch.autograd.Function):
     gpde_nnconv_bwd_hidden)."""
 
     @staticmethod
-    def forward(ctx, x, hidden, csr, pm, w_last, b_last, root, bias, aggr):
-        out = ops.nnconv_forward_hidden_raw(x.detach(), csr, hidden.detach(), pm, root, bias, aggr)
+    def forward(ctx, x, hidden, csr, pm, w_last, b_last, root, bias, aggr, hmax=None):
+        out = ops.nnconv_forward_hidden_raw(x.detach(), csr, hidden.detach(), pm, root, bias, aggr, hmax=hmax)
         ctx.csr, ctx.dims, ctx.aggr = csr, tuple(pm.dims), aggr
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, hidden, w_last, b_last, root)
@@ -95,4 +97,4 @@ class NNConvHiddenFunction(torch.autograd.Function):
         gx, gh, gw, gb, groot, gbias = ops.nnconv_backward_hidden_raw(
             x, ctx.csr, hidden, ctx.dims, w_last, b_last, root, ctx.aggr, grad_out,
             need_root=root is not None, need_bias=ctx.has_bias)
-        return (gx, gh, None, None, gw, gb, groot, gbias if ctx.has_bias else None, None)
+        return (gx, gh, None, None, gw, gb, groot, gbias if ctx.has_bias else None, None, None)

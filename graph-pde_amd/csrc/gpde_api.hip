@@ -82,7 +82,7 @@ int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws
     size_t fixed = 0;
     P->h_floats = 0;
     // f16-split aggregation (mode 1): x as split f16 words [N][64] + two scalars (gpde_prep.hip)
-    const size_t xs_bytes = (L.mode == 1 && !hidden_given) ? align_up((size_t)(N > 0 ? N : 1) * GP_W * 4) + kAlign : 0;
+    const size_t xs_bytes = (L.mode == 1 || hidden_given) ? align_up((size_t)(N > 0 ? N : 1) * GP_W * 4) + kAlign : 0;
     if (L.mode == 2 && !hidden_given) {
         int kmax = 0;
         for (int l = 1; l <= n_layers - 1; ++l) kmax = kmax > L.frontKP[l] ? kmax : L.frontKP[l];
@@ -177,7 +177,8 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
              const int32_t* rowptr, const int32_t* src, const int32_t* dst, const int32_t* perm,
              int n_layers, const int32_t* dims, const void* packed, const float* root,
              const float* bias, int aggr, uint32_t flags, const float* hidden, float* out, void* ws,
-             size_t ws_bytes, hipStream_t stream, int kt = 0, const int* sel = nullptr) {
+             size_t ws_bytes, hipStream_t stream, int kt = 0, const int* sel = nullptr,
+             const float* hidden_absmax = nullptr) {
     if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) {
         gpde_set_error("gpde_nnconv_fwd: aggr %d not implemented (add=0, mean=1)", aggr);
         return GPDE_EUNSUPPORTED;
@@ -244,6 +245,15 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
         }
     }
 
+    // hidden activations given together with their maximum: the streaming aggregation on split f16
+    if (hidden && hidden_absmax && n_edges >= 32768 && !(flags & GPDE_FWD_AGG_F32)) {
+        rc = gpde_launch_g2_prep(x, n_nodes, nullptr, 0, 0, nullptr, (unsigned*)(w + P.off_scal),
+                                 (unsigned*)(w + P.off_xs), stream);
+        if (rc != GPDE_OK) return rc;
+        xs = (const unsigned*)(w + P.off_xs);
+        scal = (const unsigned*)(w + P.off_scal);
+    }
+
     for (int64_t nc0 = 0; nc0 < n_nodes; nc0 += P.nodes_per_chunk) {
         const int64_t nc1 = (nc0 + P.nodes_per_chunk < n_nodes) ? nc0 + P.nodes_per_chunk : n_nodes;
         const int nn = (int)(nc1 - nc0);
@@ -255,7 +265,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
             f.w2h = pk + L.off_w2h; f.ucol = pk + L.off_ucol;
             f.w1h = pk + L.off_w1h; f.fcol = pk + L.off_fcol;
             f.hbuf = hfinal; f.zbuf = zbuf; f.xs = xs; f.scal = scal;
-            f.kt = kt;
+            f.kt = kt; f.hmax = (hidden && xs) ? (const unsigned*)hidden_absmax : nullptr;
             for (int d = 0; d < 8; ++d) f.sel[d] = (kt && sel) ? sel[d < L.k0 ? d : L.k0 - 1] : 0;
             f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
             f.nc0 = (int)nc0; f.nc1 = (int)nc1; f.e_chunk0 = 0; f.n_groups = P.n_groups;
@@ -330,7 +340,7 @@ extern "C" int gpde_nnconv_fwd_nodeattr(const float* x, int64_t n_nodes, const f
 }
 
 extern "C" int gpde_nnconv_fwd_hidden(const float* x, int64_t n_nodes, const float* hidden,
-                                      int64_t n_edges, const int32_t* rowptr, const int32_t* src,
+                                      const float* hidden_absmax, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
                                       const int32_t* dst, int n_layers, const int32_t* dims,
                                       const void* packed, const float* root, const float* bias,
                                       int aggr, float* out, void* ws, size_t ws_bytes, void* stream_) {
@@ -340,7 +350,7 @@ extern "C" int gpde_nnconv_fwd_hidden(const float* x, int64_t n_nodes, const flo
         return GPDE_EINVAL;
     }
     return fwd_impl(x, n_nodes, nullptr, n_edges, rowptr, src, dst, nullptr, n_layers, dims, packed, root, bias,
-                    aggr, 0, hidden, out, ws, ws_bytes, (hipStream_t)stream_);
+                    aggr, 0, hidden, out, ws, ws_bytes, (hipStream_t)stream_, 0, nullptr, hidden_absmax);
 }
 
 extern "C" int gpde_profile_begin(void) {

@@ -790,8 +790,11 @@ extern "C" size_t gpde_hidden_workspace_bytes(int64_t n_edges, int n_layers, con
 extern "C" int gpde_hidden_fwd(const float* edge_attr, int64_t n_edges, const int32_t* rowptr, int64_t n_nodes,
                                const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
                                const float* const* W, const float* const* b, uint32_t flags, float* hidden,
-                               void* ws, size_t ws_bytes, void* stream_) {
+                               float* hidden_absmax, void* ws, size_t ws_bytes, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
+    // hidden_absmax (nullable, one float): max |H|, recorded by the fused path only (0 = not recorded);
+    // it lets gpde_nnconv_fwd_hidden run the aggregation on split-f16 MFMA
+    if (hidden_absmax) GP_HIP_CHECK(hipMemsetAsync(hidden_absmax, 0, sizeof(float), st));
     if (n_edges < 0 || n_nodes < 0 || !dims || (n_edges > 0 && (!edge_attr || !perm || !hidden || !rowptr))) {
         gpde_set_error("gpde_hidden_fwd: null/negative argument");
         return GPDE_EINVAL;
@@ -807,7 +810,7 @@ extern "C" int gpde_hidden_fwd(const float* edge_attr, int64_t n_edges, const in
         f.attr = edge_attr; f.rowptr = rowptr; f.perm = perm;
         f.w1 = pk + L.off_w1; f.w2t = pk + L.off_w2t; f.b2 = pk + L.off_b2;
         f.w2h = pk + L.off_w2h; f.ucol = pk + L.off_ucol; f.w1h = pk + L.off_w1h; f.fcol = pk + L.off_fcol;
-        f.hout = hidden; f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
+        f.hout = hidden; f.hmax_out = (unsigned*)hidden_absmax; f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
         f.nc0 = 0; f.nc1 = (int)n_nodes; f.e_chunk0 = 0;
         const int ns = L.K2P / GP_TN;
         int groups = gpde_num_cus() / ns; if (groups < 1) groups = 1;

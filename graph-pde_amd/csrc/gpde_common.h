@@ -92,6 +92,8 @@ struct GpdeFusedArgs {
                            // instead of aggregating (gpde_hidden_fwd)
     const unsigned* xs;    // f16v3, f16-split aggregation: x as (lo16 << 16 | hi16) words, globally scaled
     const unsigned* scal;  // [0] bits of max |x|, [1] bits of max_e B_e   (gpde_prep.hip)
+    const unsigned* hmax;  // zagg f16: bits of max |H| (recorded by gpde_hidden_fwd)
+    unsigned* hmax_out;    // f16v3 WRITE_H: atomicMax target for the bits of max |H| (nullable)
     int kt;                // f16v3, attributes from a node table (row f3): table row stride, 0 = edge_attr tensor
     int sel[8];            // slot d of an edge's attribute = attr[(sel[d] >> 8 ? dst : src) * kt + (sel[d] & 255)]
     int k0, K1P, K2P;

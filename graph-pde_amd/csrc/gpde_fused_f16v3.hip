@@ -238,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
         lo[m] = __builtin_bit_cast(h8, lv);
     };
 
+    [[maybe_unused]] float hmax_run = 0.f;      // WRITE_H: running max of the written activations (>= 0)
     int g = 0;
 #ifdef GPDE_V3_TIMING
     long long tm_pro = 0, tm_loop = 0, tm_post = 0, tm_wait = 0, tm_bar = 0, tm0 = clock64(), tm1;
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                     float* hp = a.hout + (size_t)(e - a.e_chunk0) * a.K2P + slice * GP_TN + ch * 64 + l31;
                     hp[0] = acc1[0][r];
                     hp[32] = acc1[1][r];
+                    hmax_run = fmaxf(hmax_run, fmaxf(acc1[0][r], acc1[1][r]));
                 }
             }
             continue;
@@ -535,6 +537,13 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
         TM_MARK(tm_post);
     }
     if (cur >= 0) flush(cur);
+    if constexpr (WRITE_H) {
+        if (a.hmax_out) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) hmax_run = fmaxf(hmax_run, __shfl_xor(hmax_run, o));
+            if (lane == 0 && hmax_run > 0.f) atomicMax(a.hmax_out, __float_as_uint(hmax_run));
+        }
+    }
 #ifdef GPDE_V3_TIMING
     if (lane == 0) {
         atomicAdd(&gpde_v3_tm[0], (unsigned long long)tm_pro);

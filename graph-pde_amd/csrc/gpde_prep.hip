@@ -78,7 +78,9 @@ int gpde_launch_g2_prep(const float* x, int64_t n_nodes, const float* attr, int6
     const unsigned gx = (unsigned)((n + 1023) / 1024 < 1024 ? (n + 1023) / 1024 : 1024);
     const unsigned ge = (unsigned)((n_edges + 1023) / 1024 < 2048 ? (n_edges + 1023) / 1024 : 2048);
     hipLaunchKernelGGL(k_absmax_x, dim3(gx ? gx : 1), dim3(256), 0, stream, x, n, scal);
-    if (kt) {
+    if (n_edges == 0 || !wmax8) {
+        // no attributes to bound (aggregation from given hidden activations: scal[1] stays 0)
+    } else if (kt) {
         SelArr sa;
         for (int d = 0; d < 8; ++d) sa.v[d] = sel[d];
         hipLaunchKernelGGL(k_attr_bound_nodes, dim3(ge ? ge : 1), dim3(256), 0, stream, attr, kt, sa, src, dst,

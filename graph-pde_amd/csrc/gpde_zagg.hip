@@ -19,9 +19,20 @@
 //     the next tile, a full tile (~3.5 us of MFMA) after issue;
 //   * destination segments inside a tile by masking the A operand, one plain-store flush of the
 //     64 x 128 accumulator per destination node: deterministic, no atomics.
+//
+// F16 variant (from 32768 edges on, when max |H| is known): the same products on
+// v_mfma_f32_32x32x16_f16 with two-term split operands (3 MFMAs per 16 edges instead of 8 fp32 ones),
+// global power-of-two scales from max |x| (x pre-split by gpde_prep.hip) and max |H| (recorded when H
+// was built); H is converted tile by tile in registers.  The kernel is then bound by the H stream.
 #include "gpde_common.h"
 
 namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -41,6 +52,7 @@ __device__ __forceinline__ int lower_bound_node(const int32_t* __restrict__ rowp
 
 constexpr int XS_TILE = GP_TE * GP_W;      // floats per x stage
 
+template <bool F16>
 __global__ __launch_bounds__(256, 1) void gpde_zagg_kernel(GpdeFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // [4 waves][2][32][64]
     const int tid = threadIdx.x;
@@ -82,7 +94,8 @@ __global__ __launch_bounds__(256, 1) void gpde_zagg_kernel(GpdeFusedArgs a) {
     };
     auto issue_x = [&](float* Xs) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dma16(a.x + (size_t)sidx[i] * GP_W + (lane & 15) * 4, Xs + i * 4 * GP_W);
+        for (int i = 0; i < 8; ++i)
+            dma16((F16 ? (const float*)a.xs : a.x) + (size_t)sidx[i] * GP_W + (lane & 15) * 4, Xs + i * 4 * GP_W);
     };
 
     f32x16 Z[2][4];
@@ -93,6 +106,12 @@ __global__ __launch_bounds__(256, 1) void gpde_zagg_kernel(GpdeFusedArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) Z[cb][nb][r] = 0.f;
     int cur = -1;
+    float sh = 1.f, z_unscale = 1.f;
+    if constexpr (F16) {
+        const float sx = gpde_pow2_to_2p13(__uint_as_float(a.scal[0]));
+        sh = gpde_pow2_to_2p13(__uint_as_float(a.hmax[0]));
+        z_unscale = 1.f / (sx * sh);
+    }
     auto flush = [&](int node) {
         float* zrow = a.zbuf + ((size_t)(node - a.nc0) * GP_W) * a.K2P + slice * GP_TN + 4 * l31;
 #pragma unroll
@@ -101,6 +120,7 @@ __global__ __launch_bounds__(256, 1) void gpde_zagg_kernel(GpdeFusedArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 f32x4 v = {Z[cb][0][r], Z[cb][1][r], Z[cb][2][r], Z[cb][3][r]};
+                if constexpr (F16) v *= z_unscale;
                 *(f32x4*)(zrow + (size_t)c * a.K2P) = v;
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) Z[cb][nb][r] = 0.f;
@@ -131,6 +151,28 @@ __global__ __launch_bounds__(256, 1) void gpde_zagg_kernel(GpdeFusedArgs a) {
         load_sidx(e0 + 2 * GP_TE);
         __builtin_amdgcn_sched_barrier(0);
 
+        // F16: B operands of MFMA m, column q: edges er(8m + t) + 4h, t = 0..7 = registers hc[8m + t][q]
+        h8 bhi[2][4], blo[2][4];
+        if constexpr (F16) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u4 hv, lv;
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) {
+                        const float y0 = hc[8 * m + 2 * jp][q] * sh, y1 = hc[8 * m + 2 * jp + 1][q] * sh;
+                        const unsigned ph = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(y0, y1));
+                        unsigned pl;
+                        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(pl) : "v"(y0), "v"(ph));
+                        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(pl) : "v"(y1), "v"(ph));
+                        hv[jp] = ph;
+                        lv[jp] = pl;
+                    }
+                    bhi[m][q] = __builtin_bit_cast(h8, hv);
+                    blo[m][q] = __builtin_bit_cast(h8, lv);
+                }
+        }
         int e_seg = e0;
         int node = n_first;
         while (e_seg < e_end) {
@@ -140,6 +182,34 @@ __global__ __launch_bounds__(256, 1) void gpde_zagg_kernel(GpdeFusedArgs a) {
                 cur = node;
             }
             const int lo = e_seg - e0 - 4 * h, hi = seg_end - e0 - 4 * h;
+            if constexpr (F16) {
+                const unsigned* xu = (const unsigned*)Xs;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        unsigned w[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const int er = ((8 * m + t) & 3) + 8 * ((8 * m + t) >> 2);
+                            const unsigned v = xu[(er + 4 * h) * GP_W + cb * 32 + l31];
+                            w[t] = (er >= lo && er < hi) ? v : 0u;
+                        }
+                        u4 ah, al;
+#pragma unroll
+                        for (int jp = 0; jp < 4; ++jp) {
+                            ah[jp] = __builtin_amdgcn_perm(w[2 * jp + 1], w[2 * jp], 0x05040100u);
+                            al[jp] = __builtin_amdgcn_perm(w[2 * jp + 1], w[2 * jp], 0x07060302u);
+                        }
+                        const h8 xhi = __builtin_bit_cast(h8, ah), xlo = __builtin_bit_cast(h8, al);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            Z[cb][q] = mfma16(xhi, bhi[m][q], Z[cb][q]);
+                            Z[cb][q] = mfma16(xhi, blo[m][q], Z[cb][q]);
+                            Z[cb][q] = mfma16(xlo, bhi[m][q], Z[cb][q]);
+                        }
+                    }
+            } else
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int er = (r & 3) + 8 * (r >> 2);
@@ -170,10 +240,12 @@ int gpde_launch_zagg(const GpdeFusedArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)GP_WAVES * 2 * XS_TILE * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_zagg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_zagg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_zagg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gpde_zagg_kernel, grid, block, lds, stream, a);
+    if (a.xs && a.hmax) hipLaunchKernelGGL(gpde_zagg_kernel<true>, grid, block, lds, stream, a);
+    else hipLaunchKernelGGL(gpde_zagg_kernel<false>, grid, block, lds, stream, a);
     GP_LAUNCH_CHECK("gpde_zagg_kernel");
     return GPDE_OK;
 }

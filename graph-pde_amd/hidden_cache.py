@@ -69,9 +69,9 @@ def _key(edge_attr: torch.Tensor, csr, hidden_params: List[Optional[torch.Tensor
 
 
 def lookup(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, biases,
-           precision: Optional[str] = None, mode: Optional[str] = None) -> Optional[torch.Tensor]:
-    """Returns H for this call (cached or freshly built), or None when the direct fused path
-    should run."""
+           precision: Optional[str] = None, mode: Optional[str] = None):
+    """Returns (H, hmax) for this call (cached or freshly built; hmax = device scalar max |H| or None),
+    or None when the direct fused path should run."""
     mode = MODE if mode is None else mode
     if mode == "off":
         stats["direct"] += 1
@@ -85,7 +85,7 @@ def lookup(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, b
     if ent.hidden is not None and ent.key == key and ent.token.valid:
         ent.hits_on_hidden += 1
         stats["hits"] += 1
-        return ent.hidden
+        return ent.hidden, ent.token.hmax
     repeated = ent.last_key == key
     if repeated:
         ent.repeats = True
@@ -104,4 +104,4 @@ def lookup(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, b
     ent.key, ent.hidden, ent.token, ent.attr_ref, ent.csr = key, hidden, token, edge_attr, csr
     ent.hits_on_hidden = 0
     stats["builds"] += 1
-    return hidden
+    return hidden, token.hmax

@@ -105,10 +105,11 @@ class NNConv_old(torch.nn.Module):
                 pseudo.dtype == torch.float32 and x.dtype == torch.float32:
             csr = ops.csr_for(edge_index, x.size(0))
             pm = ops.pack_mlp(weights, biases)
-            hidden = hidden_cache.lookup(self, pseudo, csr, pm, weights, biases)
-            if hidden is not None:
+            hit = hidden_cache.lookup(self, pseudo, csr, pm, weights, biases)
+            if hit is not None:
+                hidden, hmax = hit
                 return NNConvHiddenFunction.apply(x, hidden, csr, pm, weights[-1], biases[-1],
-                                                  self.root, self.bias, self.aggr)
+                                                  self.root, self.bias, self.aggr, hmax)
         return NNConvFunction.apply(x, edge_index, pseudo, self.root, self.bias, self.aggr,
                                     len(weights), *weights, *biases)
 

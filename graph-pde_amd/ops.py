@@ -407,7 +407,8 @@ def _ptr_array(ts):
 def hidden_forward_raw(csr: Csr, edge_attr: torch.Tensor, pm: PackedMlp,
                        weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
                        precision: Optional[str] = None) -> torch.Tensor:
-    """gpde_hidden_fwd: H [E, K2P] (rows in CSR order) = all Linear+ReLU layers but the last one."""
+    """gpde_hidden_fwd: H [E, K2P] (rows in CSR order) = all Linear+ReLU layers but the last one.
+    Returns (H, hmax): hmax = device scalar max |H| when the fused kernel recorded it, else None."""
     lib = _lib.lib()
     _require_cuda(edge_attr, "edge_attr")
     precision = DEFAULT_PRECISION if precision is None else precision
@@ -425,27 +426,31 @@ def hidden_forward_raw(csr: Csr, edge_attr: torch.Tensor, pm: PackedMlp,
     nbytes = int(lib.gpde_hidden_workspace_bytes(e, nl, pm.dims_c))
     fast = (_PRECISION[precision] & _lib.GPDE_FWD_F16SPLIT) and nl == 3
     ws = torch.empty(1 if fast else max(nbytes, 1), dtype=torch.uint8, device=dev)
+    hmax = torch.zeros(1, dtype=torch.float32, device=dev) if fast else None
     with torch.cuda.device(dev):
         rc = lib.gpde_hidden_fwd(edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), csr.n_nodes,
                                  csr.perm.data_ptr(), nl, pm.dims_c, pm.packed.data_ptr(),
                                  _ptr_array(ws_), _ptr_array(bs_), _PRECISION[precision],
-                                 hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+                                 hidden.data_ptr(), None if hmax is None else hmax.data_ptr(),
+                                 ws.data_ptr(), ws.numel(), _stream_ptr(dev))
         if rc in (-1, -3) and fast:    # shape not covered by the fused kernel: the general path needs ws
             ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+            hmax = None                # ... and does not record max |H|
             rc = lib.gpde_hidden_fwd(edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), csr.n_nodes,
                                      csr.perm.data_ptr(), nl, pm.dims_c, pm.packed.data_ptr(),
                                      _ptr_array(ws_), _ptr_array(bs_), _PRECISION[precision],
-                                     hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+                                     hidden.data_ptr(), None, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
     _lib.check(rc, "gpde_hidden_fwd")
     _lib.n_native_calls += 1
-    return hidden
+    return hidden, hmax
 
 
 def nnconv_forward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, pm: PackedMlp,
                               root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,
-                              out: Optional[torch.Tensor] = None,
-                              ws: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """gpde_nnconv_fwd_hidden: aggregation + last Linear + update() from given hidden activations."""
+                              out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
+                              hmax: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gpde_nnconv_fwd_hidden: aggregation + last Linear + update() from given hidden activations
+    (`hmax`: the max |H| scalar hidden_forward_raw returned; enables the split-f16 aggregation)."""
     lib = _lib.lib()
     _require_cuda(x, "x")
     _require_cuda(hidden, "hidden")
@@ -465,7 +470,8 @@ def nnconv_forward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, p
     if ws is None:
         ws = torch.empty(max(workspace_bytes(n, e, pm), 1), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        rc = lib.gpde_nnconv_fwd_hidden(x.data_ptr(), n, hidden.data_ptr(), e, csr.rowptr.data_ptr(),
+        rc = lib.gpde_nnconv_fwd_hidden(x.data_ptr(), n, hidden.data_ptr(),
+                                        None if hmax is None else hmax.data_ptr(), e, csr.rowptr.data_ptr(),
                                         csr.src.data_ptr(), csr.dst.data_ptr(), len(pm.dims) - 1,
                                         pm.dims_c, pm.packed.data_ptr(),
                                         None if root_c is None else root_c.data_ptr(),

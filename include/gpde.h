@@ -171,13 +171,17 @@ int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int
  * as fp32-MFMA GEMMs over chunks of edges and W, b (HOST arrays of device pointers, torch layouts)
  * and ws (gpde_hidden_workspace_bytes) are required.  Workspaces of the *_hidden entry points:
  * gpde_nnconv_fwd_workspace_bytes / gpde_nnconv_bwd_workspace_bytes; gpde_hidden_bwd:
- * gpde_nnconv_bwd_workspace_bytes(0, E, ...). */
+ * gpde_nnconv_bwd_workspace_bytes(0, E, ...).
+ * hidden_absmax (nullable, one device float): gpde_hidden_fwd records max |H| there when the fused
+ * path computed H (else 0); given back to gpde_nnconv_fwd_hidden it lets the aggregation run on
+ * split-f16 MFMA from 32768 edges on (NULL or 0: fp32 MFMA). */
 size_t gpde_hidden_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims);
 int gpde_hidden_fwd(const float* edge_attr, int64_t n_edges, const int32_t* rowptr, int64_t n_nodes,
                     const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
                     const float* const* W, const float* const* b, uint32_t flags, float* hidden,
-                    void* ws, size_t ws_bytes, void* stream);
-int gpde_nnconv_fwd_hidden(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
+                    float* hidden_absmax, void* ws, size_t ws_bytes, void* stream);
+int gpde_nnconv_fwd_hidden(const float* x, int64_t n_nodes, const float* hidden,
+                           const float* hidden_absmax, int64_t n_edges,
                            const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                            int n_layers, const int32_t* dims, const void* packed, const float* root,
                            const float* bias, int aggr, float* out, void* ws, size_t ws_bytes,

@@ -49,8 +49,10 @@ def test_hidden_forward_and_conv_from_hidden(dims, precision):
     wd, bd = [w.to(d) for w in ws_], [b.to(d) for b in bs_]
     pm = ops.pack_mlp(wd, bd)
     calls = _lib.n_native_calls
-    H = ops.hidden_forward_raw(csr, ea.to(d), pm, wd, bd, precision=precision)
-    y = ops.nnconv_forward_hidden_raw(x.to(d), csr, H, pm, root.to(d), bias.to(d), "mean")
+    H, hmax = ops.hidden_forward_raw(csr, ea.to(d), pm, wd, bd, precision=precision)
+    y = ops.nnconv_forward_hidden_raw(x.to(d), csr, H, pm, root.to(d), bias.to(d), "mean", hmax=hmax)
+    if hmax is not None:
+        assert float(hmax) == float(H.max())                       # recorded by the fused kernel
     torch.cuda.synchronize()
     assert _lib.n_native_calls == calls + 2
     # H against the oracle's hidden chain (float64), rows permuted into CSR order
@@ -247,3 +249,28 @@ def test_edge_attr_from_node_table_matches_materialised_tensor():
     pm2 = ops.pack_mlp([l.weight for l in lin2], [l.bias for l in lin2])
     with pytest.raises(NotImplementedError):
         ops.nnconv_forward_nodeattr_raw(x, ops.csr_for(ei, n), na, pm2, conv2.root, conv2.bias, "mean")
+
+
+def test_streaming_aggregation_on_split_f16_from_32768_edges():
+    """gpde_nnconv_fwd_hidden with the recorded max |H|: above 32768 edges the aggregation kernel runs on
+    split-f16 MFMA (global scales from max |x| and max |H|); against the float64 oracle and against the
+    fp32-MFMA aggregation (hmax withheld)."""
+    d = dev()
+    torch.manual_seed(17)
+    ei, ea, n = synth.darcy_graph(32, 0.13)
+    assert ei.shape[1] >= 32768
+    dims = [6, 64, 128, 4096]
+    ws_, bs_ = _params(_mlp(dims))
+    root, bias = torch.empty(64, 64).uniform_(-0.125, 0.125), torch.empty(64).uniform_(-0.125, 0.125)
+    x = torch.randn(n, 64) * torch.logspace(-2, 2, n).unsqueeze(1)       # rows from 1e-2 to 1e2
+    csr = ops.build_csr(ei.to(d), n)
+    wd, bd = [w.to(d) for w in ws_], [b.to(d) for b in bs_]
+    pm = ops.pack_mlp(wd, bd)
+    H, hmax = ops.hidden_forward_raw(csr, ea.to(d), pm, wd, bd, precision="f16split")
+    assert hmax is not None and float(hmax) == float(H.max()) > 0
+    y16 = ops.nnconv_forward_hidden_raw(x.to(d), csr, H, pm, root.to(d), bias.to(d), "mean", hmax=hmax)
+    y32 = ops.nnconv_forward_hidden_raw(x.to(d), csr, H, pm, root.to(d), bias.to(d), "mean", hmax=None)
+    y64 = nnconv_forward(x, ei, ea, ws_, bs_, root, bias, aggr="mean", dtype=torch.float64)
+    e16, e32 = rel_l2(y16.cpu(), y64), rel_l2(y32.cpu(), y64)
+    assert not torch.equal(y16, y32)                                     # two different arithmetics ran
+    assert e16 <= TOL and e16 <= 4 * e32 + 2e-7, (e16, e32)
