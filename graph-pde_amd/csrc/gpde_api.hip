@@ -82,7 +82,8 @@ int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws
     size_t fixed = 0;
     P->h_floats = 0;
     // f16-split aggregation (mode 1): x as split f16 words [N][64] + two scalars (gpde_prep.hip)
-    const size_t xs_bytes = (L.mode == 1 || hidden_given) ? align_up((size_t)(N > 0 ? N : 1) * GP_W * 4) + kAlign : 0;
+    // (sized for every kernel shape: gpde_nnconv_fwd_hidden uses it whatever the MLP looks like)
+    const size_t xs_bytes = (L.mode == 1 || hidden_given || sizing) ? align_up((size_t)(N > 0 ? N : 1) * GP_W * 4) + kAlign : 0;
     if (L.mode == 2 && !hidden_given) {
         int kmax = 0;
         for (int l = 1; l <= n_layers - 1; ++l) kmax = kmax > L.frontKP[l] ? kmax : L.frontKP[l];

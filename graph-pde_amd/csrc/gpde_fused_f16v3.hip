@@ -1,17 +1,33 @@
-// Fused edge kernel, f16-split, TWO WAVES PER SIMD (v3): 8 waves per workgroup, wave tile =
-// 32 edges x 64 hidden columns, H1 generated on f16 MFMA as well.
+// Fused edge kernel, f16-split, TWO WAVES PER SIMD (v3, the default): 8 waves per workgroup, wave
+// tile = 32 edges x 64 hidden columns, H1 generated on f16 MFMA as well.
 //
 // Same contract and math as gpde_fused_f16_kernel (gpde_fused_f16.hip; replaces DenseNet.forward
 // hidden part, /root/reference/graph-neural-operator/utilities.py:223-227, NNConv_old.message,
-// nn_conv.py:273-275, and PyG's gather/scatter).  Why a second variant: a wave alone on its SIMD
-// hides only ~4 non-MFMA instructions per 32-cycle MFMA (scripts/ubench/mfma_valu_overlap.hip), so
-// in the 4-wave kernel MFMA time and issue time ADD (47 % matrix-pipe occupancy).  Halving the
-// wave tile to 64 columns brings the accumulators (32 + 64 registers) under the 256-register
-// budget of two waves per SIMD; the partner wave's MFMAs then run under this wave's VALU / LDS /
-// DMA issue.  The two waves of a pair (same 32 edges, column halves 0/1) both need H1, so its
+// nn_conv.py:273-275, and PyG's gather/scatter).  Why this shape: a wave alone on its SIMD hides
+// only ~4 non-MFMA instructions per 32-cycle MFMA (scripts/ubench/mfma_valu_overlap.hip), so in the
+// 4-wave kernel MFMA time and issue time ADD (47 % matrix-pipe occupancy).  Halving the wave tile to
+// 64 columns brings the accumulators (32 + 64 registers) under the 256-register budget of two waves
+// per SIMD.  The two waves of a pair (same 32 edges, column halves 0/1) both need H1, so its
 // generation must be cheap: (W1|b1) . attr is done as 2 f16 MFMAs (K = 16 holds [hi|hi] x [hi;lo]
 // and [lo|lo] x [hi;0]) instead of 4 fp32 ones, with per-input-slot column scales 2^u_d folded
 // into the attributes (pack_w1_f16split_kernel).
+//
+// What the K loop looks like now, and why (in-kernel phase timing: -DGPDE_V3_TIMING +
+// scripts/v3_timing.py; the story with numbers is DESIGN.md §3b):
+//   * chunks of 32 k in PAIRS, one s_barrier per pair; pair G lives in ring slots {2(G&1), 2(G&1)+1},
+//     the next pair's four 1-KiB DMA per wave are issued at the top of the iteration and retired by a
+//     counted s_waitcnt before the closing barrier;
+//   * per chunk: [MFMA, one conversion pair of the NEXT chunk's H1 (5 VALU, into the other operand
+//     buffer)] x 12 in pinned source order, then the 2 H1 MFMAs of chunk + 2.  A long VALU burst of one
+//     wave starves its SIMD partner's MFMA issue (same issue port, age priority): cross-wave overlap
+//     alone hides nothing;
+//   * W2 fragments are read half a chunk ahead, into the registers the previous MFMAs just released;
+//   * s_setprio alternates per chunk between the two waves of a SIMD (w and w + 4) so that neither
+//     runs ahead and then idles at the barrier;
+//   * side loads (next tile's edge ids / attributes, this tile's x_j rows by DMA) at fixed iterations,
+//     unconditional and clamped, so the wait counts are exact;
+//   * after the loop: un-scale + bias + ReLU, then the aggregation Z += x_j (x) h_e per destination
+//     segment (fp32 MFMA, or split f16 with global scales: G2F16), one plain-store flush per node.
 #include "gpde_common.h"
 
 namespace {
