@@ -208,6 +208,15 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
     issue_w2(1, 1);
     load_perm(ea);
     load_attr();
+#ifdef GPDE_V3_LDSSYNC
+    // Experiment (A/B build): per-wave progress counters in LDS instead of the workgroup barrier --
+    // bounded skew (one pair) instead of lock-step.  prog[w] = pairs whose DMA pieces of wave w have
+    // landed, prog[8 + w] = pairs wave w has finished reading.  Needs NP >= 4 (x_j staging analysis).
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    volatile int* prog = (volatile int*)(Es_all + NW * GP_TE);
+    const bool flagsync = NP >= 4;
+    if (tid < 16) prog[tid] = tid < 8 ? 1 : 0;
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -344,6 +353,21 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             int cA = 2 * kp + 2, cB = 2 * kp + 3;
             if (cA >= NKC) cA -= NKC;
             if (cB >= NKC) cB -= NKC;
+#ifdef GPDE_V3_LDSSYNC
+            if (flagsync) {
+                // pair g must have landed everywhere (RAW) and pair g - 1 must have been read by everyone
+                // before its slots are refilled (WAR)
+                for (int spin = 0; spin < (1 << 22); ++spin) {      // bounded: a protocol bug must not hang the GPU
+                    const volatile i4v* pv = (const volatile i4v*)prog;
+                    const i4v l0 = pv[0], l1 = pv[1], d0 = pv[2], d1 = pv[3];
+                    const int ml = min(min(min(l0[0], l0[1]), min(l0[2], l0[3])), min(min(l1[0], l1[1]), min(l1[2], l1[3])));
+                    const int md = min(min(min(d0[0], d0[1]), min(d0[2], d0[3])), min(min(d1[0], d1[1]), min(d1[2], d1[3])));
+                    if (__builtin_amdgcn_readfirstlane((ml >= g + 1 && md >= g) ? 1 : 0)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+            }
+#endif
 #ifndef GPDE_ABL_NOSTAGE
             issue_w2(cA, sb ^ 2);
             issue_w2(cB, (sb ^ 2) + 1);
@@ -441,6 +465,13 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
 #endif
 #ifdef GPDE_V3_TIMING
             const long long tw1 = clock64();
+#endif
+#ifdef GPDE_V3_LDSSYNC
+            if (flagsync) {
+                asm volatile("" ::: "memory");
+                if (lane == 0) { prog[wave] = g + 2; prog[8 + wave] = g + 1; }
+                asm volatile("" ::: "memory");
+            } else
 #endif
 #ifndef GPDE_ABL_NOBARRIER
             __builtin_amdgcn_s_barrier();
@@ -576,7 +607,7 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
 }  // namespace
 
 static size_t v3_lds_bytes(int K1P) {
-    return (size_t)RING * TILE_B + (size_t)K1P * 32 + (size_t)NET * XS_TILE * 4 + 16 + NW * GP_TE * 4 + 64;
+    return (size_t)RING * TILE_B + (size_t)K1P * 32 + (size_t)NET * XS_TILE * 4 + 16 + NW * GP_TE * 4 + 64 + 64;
 }
 
 #ifdef GPDE_V3_TIMING
