@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                 asm volatile("" ::: "memory");
             }
 #endif
-#ifndef GPDE_ABL_NOSTAGE
+#if !defined(GPDE_ABL_NOSTAGE) && !defined(GPDE_V3_DMASPREAD)
             issue_w2(cA, sb ^ 2);
             issue_w2(cB, (sb ^ 2) + 1);
 #endif
@@ -439,6 +439,15 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                             if (m == 0) ld_hi(rb, 1);
                             else if (cc == 0) ld_hi(rb + TILE_B, 0);
                         }
+#ifdef GPDE_V3_DMASPREAD
+                        // Experiment: the 8 waves used to issue their 4 DMA each right after the barrier --
+                        // 32 KiB through the CU's one address pipe at 64 B/clk = 512 cycles of queueing.
+                        // Wave w now issues its four after its (w + 1)-th MFMA of the pair's first chunk.
+                        if (cc == 0 && m * 6 + j == wave) {
+                            issue_w2(cA, sb ^ 2);
+                            issue_w2(cB, (sb ^ 2) + 1);
+                        }
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -457,7 +466,9 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
 #ifdef GPDE_V3_TIMING
             const long long tw0 = clock64();
 #endif
-#ifndef GPDE_ABL_NOSTAGE
+#ifdef GPDE_V3_DMASPREAD
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the W2 DMA are the youngest VMEM ops now
+#elif !defined(GPDE_ABL_NOSTAGE) && !defined(GPDE_ABL_NOWAIT)
             if (kp == 0 && KP1 == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_CNT + B_CNT) : "memory");
             else if (kp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_CNT) : "memory");
             else if (kp == KP1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_CNT) : "memory");
