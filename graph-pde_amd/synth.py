@@ -63,7 +63,9 @@ def lattice_radius_graph(s: int, r: float, device="cpu") -> torch.Tensor:
 
 def lattice_positions(s: int, device="cpu") -> torch.Tensor:
     """float64 [N, 2] positions (x, y), node id = iy*s + ix (meshgrid 'xy')."""
-    lin = torch.linspace(0.0, 1.0, s, dtype=torch.float64, device=device)
+    # numpy's linspace, as the reference's SquareMeshGenerator uses (utilities.py:242): torch.linspace
+    # differs from it in the last bit of some float64 values
+    lin = torch.from_numpy(np.linspace(0.0, 1.0, s)).to(device)
     node = torch.arange(s * s, device=device)
     return torch.stack([lin[node % s], lin[node // s]], dim=1)
 

@@ -213,6 +213,23 @@ def main():
     x = torch.randn(n, 64)
     _save("mlp5_g16", conv, x, ei, ea, *_run(conv, x, ei, ea))
 
+    # 6. graph + attribute construction by the reference's own SquareMeshGenerator
+    #    (utilities.py:228-285: meshgrid 'xy' grid, sklearn pairwise_distances <= r, np.where order,
+    #    attributes(theta=a) = [pos_src, pos_dst, a_src, a_dst]) -- pins rows f2 / f3: the native radius
+    #    graph must emit exactly this edge_index, NodeAttr.darcy exactly this edge_attr.  r = 0.21 on the
+    #    12 x 12 lattice has no pair at distance exactly r (r^2/h^2 = 5.34), so the reference's
+    #    float-rounding asymmetry does not enter.
+    s_, r_ = 12, 0.21
+    mesh = ref_util.SquareMeshGenerator([[0, 1], [0, 1]], [s_, s_])
+    ei_ref = mesh.ball_connectivity(r_)
+    a64 = synth.darcy_coefficient(s_, 5).double().numpy()
+    ea_ref = mesh.attributes(theta=a64)
+    path = os.path.join(HERE, "mesh_s12.npz")
+    np.savez_compressed(path, s=np.int64(s_), r=np.float64(r_), grid=mesh.grid.astype(np.float64),
+                        grid_f32=mesh.get_grid().numpy(), a=a64, edge_index=ei_ref.numpy(),
+                        edge_attr=ea_ref.numpy())
+    print(f"mesh_s12: N={mesh.n} E={ei_ref.shape[1]} -> {os.path.getsize(path)} B")
+
 
 if __name__ == "__main__":
     main()

@@ -401,6 +401,12 @@ def test_native_radius_graph_matches_reference_construction():
         ref = np.vstack(np.where(pwd <= r))                              # the reference's lines
         ei = ops.radius_graph(torch.from_numpy(pos).to(d), r).cpu().numpy()
         assert ei.shape == ref.shape and (ei == ref).all(), (n, dim, ei.shape, ref.shape)
+    # the reference's own SquareMeshGenerator output (tests/golden/mesh_s12.npz), edge order included
+    import os
+    from tests.conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "mesh_s12.npz"))
+    ei = ops.radius_graph(torch.from_numpy(g["grid"]).to(d), float(g["r"])).cpu().numpy()
+    assert np.array_equal(ei, g["edge_index"])
     # exact-arithmetic lattice (synth) == native builder with a radius safely between lattice shells
     s = 31
     ei_lat = synth.lattice_radius_graph(s, 0.10)

@@ -43,3 +43,26 @@ def test_oracle_1d_inputs_and_isolated_nodes():
     assert y.shape == (n, 1)
     iso = torch.arange(5, n)
     assert torch.allclose(y[iso, 0], x[iso] * root[0, 0] + bias[0])
+
+
+def test_mesh_fixture_pins_graph_and_attribute_construction():
+    """tests/golden/mesh_s12.npz was produced by the reference's own SquareMeshGenerator
+    (graph-neural-operator/utilities.py:228-285).  Our restatements of it must reproduce it exactly:
+    the lattice positions, the radius graph in np.where order, and the edge-attribute recipe that
+    NodeAttr.darcy (row f3) reads from node data."""
+    import os
+    import numpy as np
+    import graph_pde_amd as gp
+    from graph_pde_amd import synth
+    from tests.conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "mesh_s12.npz"))
+    s, r = int(g["s"]), float(g["r"])
+    pos = synth.lattice_positions(s)
+    assert np.array_equal(pos.numpy(), g["grid"])
+    assert np.array_equal(pos.float().numpy(), g["grid_f32"])
+    ei = synth.lattice_radius_graph(s, r)
+    assert np.array_equal(ei.numpy(), g["edge_index"])
+    a = torch.from_numpy(g["a"])
+    assert np.array_equal(synth.darcy_edge_attr(ei, pos, a.float()).numpy(), g["edge_attr"])
+    na = gp.NodeAttr.darcy(pos, a)
+    assert np.array_equal(na.materialize(ei).numpy(), g["edge_attr"])
