@@ -102,6 +102,15 @@ def darcy_graph(s: int, r: float, device="cpu", seed: int = 0
     return ei, darcy_edge_attr(ei, pos, a), s * s
 
 
+def burgers_coefficient(s: int, seed: int = 0) -> np.ndarray:
+    """float32 [s]: a smooth periodic Gaussian random field, normalised (stands in for the Burgers
+    initial condition `a` of burgers_data_R10.mat)."""
+    rng = np.random.default_rng(seed)
+    from scipy.ndimage import gaussian_filter1d
+    a0 = gaussian_filter1d(rng.standard_normal(s), sigma=s / 32.0, mode="wrap")
+    return ((a0 - a0.mean()) / (a0.std() + 1e-5)).astype(np.float32)
+
+
 def burgers_multipole_graphs(s: int, device="cpu", seed: int = 0, periodic: bool = True):
     """1-D multipole graphs of the MGKN-orthogonal shape — a vectorised restatement of
     `multi_pole_grid1d` + `get_edge_attr`
@@ -115,10 +124,7 @@ def burgers_multipole_graphs(s: int, device="cpu", seed: int = 0, periodic: bool
     order (by x_i, then by offset); edge_index[0] = x_i, edge_index[1] = x_j.
     Returns [(edge_index [2,E], edge_attr [E,4] = [grid[x_i], grid[x_j], a[x_i], a[x_j]], s_l)].
     """
-    rng = np.random.default_rng(seed)
-    from scipy.ndimage import gaussian_filter1d
-    a0 = gaussian_filter1d(rng.standard_normal(s), sigma=s / 32.0, mode="wrap")
-    a0 = ((a0 - a0.mean()) / (a0.std() + 1e-5)).astype(np.float32)
+    a0 = burgers_coefficient(s, seed)
     level = int(np.log2(s) - 1)
     graphs = []
 
@@ -152,7 +158,8 @@ def burgers_multipole_graphs(s: int, device="cpu", seed: int = 0, periodic: bool
     return graphs
 
 
-def sampled_multilevel_graphs(s: int, m, radii_inner, radii_inter, device="cpu", seed: int = 0):
+def sampled_multilevel_graphs(s: int, m, radii_inner, radii_inter, device="cpu", seed: int = 0,
+                              idx=None, a_all=None):
     """Multi-level sampled radius graphs of the MGKN-general shape
     (/root/reference/multipole-graph-neural-operator/utilities.py:546-712
     `RandomMultiMeshGenerator`, restated): level l holds m[l] points sampled without replacement
@@ -162,16 +169,22 @@ def sampled_multilevel_graphs(s: int, m, radii_inner, radii_inter, device="cpu",
 
     Returns dict with per-level inner graphs and inter graphs as
     (edge_index [2,E] (local node ids), edge_attr [E,6], n_src_nodes, n_dst_nodes).
+    `idx` (per-level lattice indices) / `a_all` (coefficient on the lattice) override the sampling --
+    used to pin this restatement against the reference's own generator (tests/golden).
     """
-    rng = np.random.default_rng(seed)
     n = s * s
     pos_all = lattice_positions(s).numpy()
-    a_all = darcy_coefficient(s, seed).numpy()
-    perm = rng.permutation(n)
-    idx, off = [], 0
-    for ml in m:
-        idx.append(np.sort(perm[off:off + ml]))
-        off += ml
+    if a_all is None:
+        a_all = darcy_coefficient(s, seed).numpy()
+    a_all = np.asarray(a_all)
+    if idx is None:
+        # consecutive slices of one random permutation, unsorted, as RandomMultiMeshGenerator.sample does
+        perm = np.random.default_rng(seed).permutation(n)
+        idx, off = [], 0
+        for ml in m:
+            idx.append(perm[off:off + ml])
+            off += ml
+    idx = [np.asarray(i) for i in idx]
     from sklearn.metrics import pairwise_distances
 
     def attrs(pi, pj, ai, aj, src, dst):

@@ -230,6 +230,56 @@ def main():
                         edge_attr=ea_ref.numpy())
     print(f"mesh_s12: N={mesh.n} E={ei_ref.shape[1]} -> {os.path.getsize(path)} B")
 
+    # 7. the MGKN-orthogonal graph family by the reference's own multi_pole_grid1d + get_edge_attr
+    #    (multipole-graph-neural-operator/utilities.py:1702-1777, called with is_periodic=True at
+    #    MGKN_orthogonal_burgers1d.py:165).  The function calls .cuda() on its index tensors; there is
+    #    no GPU here, so Tensor.cuda is the identity while it runs.  Pins synth.burgers_multipole_graphs.
+    import contextlib, io
+    ref_mg = _load("mg_utilities", os.path.join(os.path.dirname(REF), "multipole-graph-neural-operator", "utilities.py"))
+    s7 = 64
+    a7 = synth.burgers_coefficient(s7, 0)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            grids, thetas, eis, _ = ref_mg.multi_pole_grid1d(a7.reshape(1, s7, 1).astype(np.float64), 1, s7, 1,
+                                                             is_periodic=True)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    out = {"s": np.int64(s7), "a": a7, "n_graphs": np.int64(len(eis))}
+    level = len(grids)
+    for gi, ei_g in enumerate(eis):
+        lvl = 0 if gi == 0 else gi - 1                       # graph 0 = NN on the finest level, then one per level
+        ea_g = ref_mg.get_edge_attr(grids[lvl], thetas[lvl][0, :, 0], ei_g)
+        out[f"ei{gi}"] = ei_g.numpy()
+        out[f"ea{gi}"] = ea_g.numpy()
+        out[f"n{gi}"] = np.int64(grids[lvl].shape[0])
+    path = os.path.join(HERE, "burgers_graphs_s64.npz")
+    np.savez_compressed(path, **out)
+    print(f"burgers_graphs_s64: {len(eis)} graphs over {level} levels -> {os.path.getsize(path)} B")
+
+    # 8. the MGKN-general graph family by the reference's own RandomMultiMeshGenerator
+    #    (multipole-graph-neural-operator/utilities.py:546-712): sample(), ball_connectivity(),
+    #    attributes(theta).  Pins synth.sampled_multilevel_graphs (given the same sampled indices).
+    s8, m8 = 20, [100, 40, 10]
+    rin, rint = [0.18, 0.3, 0.6], [0.2, 0.4]
+    torch.manual_seed(8)
+    gen = ref_mg.RandomMultiMeshGenerator([[0, 1], [0, 1]], [s8, s8], level=3, sample_sizes=m8)
+    idx8, idx_all8 = gen.sample()
+    e_in, e_dn, e_up = gen.ball_connectivity(rin, rint)
+    r_in, r_dn, r_up = gen.get_edge_index_range()
+    a8 = synth.darcy_coefficient(s8, 2).double().numpy()
+    ea_in, ea_dn, ea_up = gen.attributes(theta=a8)
+    out = {"s": np.int64(s8), "m": np.array(m8), "radii_inner": np.array(rin), "radii_inter": np.array(rint),
+           "a": a8, "edge_index": e_in.numpy(), "edge_index_down": e_dn.numpy(), "edge_index_up": e_up.numpy(),
+           "range": r_in.numpy(), "range_down": r_dn.numpy(), "range_up": r_up.numpy(),
+           "edge_attr": ea_in.numpy(), "edge_attr_down": ea_dn.numpy(), "edge_attr_up": ea_up.numpy()}
+    for l in range(3):
+        out[f"idx{l}"] = idx8[l].numpy()
+    path = os.path.join(HERE, "mgkn_graphs_s20.npz")
+    np.savez_compressed(path, **out)
+    print(f"mgkn_graphs_s20: inner {e_in.shape[1]} / down {e_dn.shape[1]} edges -> {os.path.getsize(path)} B")
+
 
 if __name__ == "__main__":
     main()

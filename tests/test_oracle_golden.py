@@ -66,3 +66,55 @@ def test_mesh_fixture_pins_graph_and_attribute_construction():
     assert np.array_equal(synth.darcy_edge_attr(ei, pos, a.float()).numpy(), g["edge_attr"])
     na = gp.NodeAttr.darcy(pos, a)
     assert np.array_equal(na.materialize(ei).numpy(), g["edge_attr"])
+
+
+def test_burgers_graph_fixture_pins_the_multipole_graph_family():
+    """tests/golden/burgers_graphs_s64.npz: the reference's own multi_pole_grid1d + get_edge_attr
+    (multipole-graph-neural-operator/utilities.py:1702-1777, is_periodic=True).  The vectorised
+    restatement in synth.burgers_multipole_graphs (BASELINE config 3's graph family) must reproduce every
+    graph: edges in the reference's loop order and the [grid_i, grid_j, a_i, a_j] attributes."""
+    import os
+    import numpy as np
+    from graph_pde_amd import synth
+    from tests.conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "burgers_graphs_s64.npz"))
+    s = int(g["s"])
+    assert np.array_equal(synth.burgers_coefficient(s, 0), g["a"])
+    graphs = synth.burgers_multipole_graphs(s, seed=0, periodic=True)
+    assert len(graphs) == int(g["n_graphs"])
+    for i, (ei, ea, n) in enumerate(graphs):
+        assert n == int(g[f"n{i}"]), i
+        assert np.array_equal(ei.numpy(), g[f"ei{i}"]), i
+        assert np.array_equal(ea.numpy(), g[f"ea{i}"]), i
+
+
+def test_mgkn_graph_fixture_pins_the_sampled_multilevel_family():
+    """tests/golden/mgkn_graphs_s20.npz: the reference's own RandomMultiMeshGenerator
+    (multipole-graph-neural-operator/utilities.py:546-712: sample, ball_connectivity, attributes(theta)).
+    Given the same sampled lattice indices, synth.sampled_multilevel_graphs (BASELINE config 4's graph
+    family) must reproduce the inner / down / up graphs and their [pos_src, pos_dst, a_src, a_dst]
+    attributes, edge order included (the reference numbers nodes globally, level after level)."""
+    import os
+    import numpy as np
+    from graph_pde_amd import synth
+    from tests.conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "mgkn_graphs_s20.npz"))
+    m = [int(v) for v in g["m"]]
+    idx = [g[f"idx{l}"] for l in range(len(m))]
+    out = synth.sampled_multilevel_graphs(int(g["s"]), m, list(g["radii_inner"]), list(g["radii_inter"]),
+                                          idx=idx, a_all=g["a"])
+    offs = np.concatenate([[0], np.cumsum(m)])
+    for l in range(len(m)):
+        lo, hi = g["range"][l]
+        ei, ea, ns, nd = out["inner"][l]
+        assert (ns, nd) == (m[l], m[l])
+        assert np.array_equal(ei.numpy() + offs[l], g["edge_index"][:, lo:hi]), l
+        assert np.array_equal(ea.numpy(), g["edge_attr"][lo:hi]), l
+    for l in range(len(m) - 1):
+        lo, hi = g["range_down"][l]
+        ei, ea, ns, nd = out["down"][l]
+        assert np.array_equal(ei.numpy() + np.array([[offs[l]], [offs[l + 1]]]), g["edge_index_down"][:, lo:hi]), l
+        assert np.array_equal(ea.numpy(), g["edge_attr_down"][lo:hi]), l
+        ei, ea, ns, nd = out["up"][l]
+        assert np.array_equal(ei.numpy() + np.array([[offs[l + 1]], [offs[l]]]), g["edge_index_up"][:, lo:hi]), l
+        assert np.array_equal(ea.numpy(), g["edge_attr_up"][lo:hi]), l
