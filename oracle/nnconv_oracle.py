@@ -114,6 +114,37 @@ def nnconv_forward(x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.T
     return out
 
 
+def nnconv_grads(x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor,
+                 weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
+                 root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,
+                 grad_out: torch.Tensor):
+    """float64 autograd through the restated operator = the reference's `loss.backward()`
+    (UAI1_full_resolution.py:266) for loss = sum(out * grad_out).  Pinned against autograd through
+    the reference's own module by tests/golden/*_grad.npz.
+    Returns (grad_x, [grad_W], [grad_b], grad_root or None, grad_bias or None)."""
+    n = x.shape[0]
+    xs = x.double().requires_grad_(True)
+    Ws = [w.double().requires_grad_(True) for w in weights]
+    Bs = [b.double().requires_grad_(True) for b in biases]
+    r = None if root is None else root.double().requires_grad_(True)
+    bb = None if bias is None else bias.double().requires_grad_(True)
+    src, dst = edge_index[0], edge_index[1]
+    h = densenet_forward(edge_attr.double(), Ws, Bs)
+    m = torch.matmul(xs[src].unsqueeze(1), h.view(-1, xs.shape[1], h.shape[1] // xs.shape[1])).squeeze(1)
+    out = torch.zeros(n, m.shape[1], dtype=torch.float64).index_add(0, dst, m)
+    if aggr == "mean":
+        out = out / torch.bincount(dst, minlength=n).clamp(min=1).double().unsqueeze(1)
+    elif aggr != "add":
+        raise ValueError(aggr)
+    if r is not None:
+        out = out + xs @ r
+    if bb is not None:
+        out = out + bb
+    (out * grad_out.double()).sum().backward()
+    return (xs.grad, [w.grad for w in Ws], [b.grad for b in Bs], None if r is None else r.grad,
+            None if bb is None else bb.grad)
+
+
 def rel_l2(y: torch.Tensor, y_ref: torch.Tensor) -> float:
     """Relative L2 over the whole output, the `LpLoss.rel` formula for one sample
     (/root/reference/graph-neural-operator/utilities.py:184-196)."""

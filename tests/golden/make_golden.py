@@ -130,6 +130,31 @@ def _run(conv, x, ei, ea):
     return y32, y64
 
 
+def _save_grads(name, conv, x, ei, ea, seed):
+    """Gradients of sum(out * gout) by torch autograd THROUGH the reference's own module in float64
+    (what `loss.backward()` computes in the reference, UAI1_full_resolution.py:266).  The inputs are
+    those of tests/golden/<name>.npz; only gout and the gradients are stored (<name>_grad.npz)."""
+    gout = torch.randn(x.shape[0], 64, generator=torch.Generator().manual_seed(seed))
+    conv64 = conv.double()
+    conv64.zero_grad()
+    x64 = x.double().requires_grad_(True)
+    out = conv64(x64, ei, ea.double())
+    (out * gout.double()).sum().backward()
+    layers = [l for l in conv64.nn.layers if isinstance(l, torch.nn.Linear)]
+    d = {"gout": gout.numpy(), "gx": x64.grad.numpy()}
+    for i, l in enumerate(layers):
+        d[f"gW{i}"] = l.weight.grad.numpy()
+        d[f"gb{i}"] = l.bias.grad.numpy()
+    if conv64.root is not None:
+        d["groot"] = conv64.root.grad.numpy()
+    if conv64.bias is not None:
+        d["gbias"] = conv64.bias.grad.numpy()
+    conv.float()
+    path = os.path.join(HERE, name + "_grad.npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}_grad: |gx|={float(x64.grad.norm()):.4f} -> {os.path.getsize(path)} B")
+
+
 def _save(name, conv, x, ei, ea, y32, y64):
     layers = [l for l in conv.nn.layers if isinstance(l, torch.nn.Linear)]
     d = {
@@ -181,6 +206,7 @@ def main():
     ea = torch.randn(e, 6, generator=g)
     x = torch.randn(n, 64, generator=g)
     _save("ragged_add", conv, x, ei, ea, *_run(conv, x, ei, ea))
+    _save_grads("ragged_add", conv, x, ei, ea, 21)
 
     # 3. 2-layer MLP (MGKN inter-level shape), root_weight=False, bias=False, aggr='mean',
     #    bipartite-like "down" graph given on a shared index space
@@ -194,6 +220,7 @@ def main():
     ea = torch.rand(e, 6, generator=g)
     x = torch.randn(n, 64, generator=g)
     _save("mlp2_mean_noroot", conv, x, ei, ea, *_run(conv, x, ei, ea))
+    _save_grads("mlp2_mean_noroot", conv, x, ei, ea, 22)
 
     # 4. Burgers shape: k0 = 4, periodic 1-D interactive-neighbour graph (level with 512 nodes)
     torch.manual_seed(3)
@@ -203,6 +230,7 @@ def main():
     ei, ea, n = graphs[1]
     x = torch.randn(n, 64)
     _save("burgers_k4", conv, x, ei, ea, *_run(conv, x, ei, ea))
+    _save_grads("burgers_k4", conv, x, ei, ea, 23)
 
     # 5. 5-layer MLP (UAI8_kernel.py:21 shape, narrow) on the s=16 lattice, 1-D x promoted
     torch.manual_seed(4)

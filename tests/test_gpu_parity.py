@@ -208,7 +208,8 @@ def test_f16split_wide_dynamic_range(variant):
 
 
 def _oracle_grads(x, ei, ea, ws_, bs_, root, bias, aggr, gout):
-    """float64 autograd through the CPU oracle = the reference's backward."""
+    """float64 autograd through the CPU oracle = the reference's backward (same as
+    oracle.nnconv_oracle.nnconv_grads, which tests/golden/*_grad.npz pin to the reference module)."""
     xs = x.double().requires_grad_(True)
     Ws = [w.double().requires_grad_(True) for w in ws_]
     Bs = [b.double().requires_grad_(True) for b in bs_]
@@ -269,6 +270,32 @@ def test_backward_against_reference_autograd(dims, aggr, use_root, use_bias, edg
         assert rel_l2(groot.cpu(), rroot) <= tol
     if use_bias:
         assert rel_l2(gbias.cpu(), rbias) <= tol
+
+
+@pytest.mark.parametrize("name", ["ragged_add", "mlp2_mean_noroot", "burgers_k4"])
+def test_backward_against_reference_module_gradients(name):
+    """gpde_nnconv_bwd against tests/golden/<name>_grad.npz: float64 autograd through the reference's OWN
+    NNConv_old / DenseNet classes (make_golden.py) on the golden inputs."""
+    from tests.conftest import load_golden
+    from tests.test_oracle_golden import load_golden_grads
+    d = dev()
+    g, r = load_golden(name), load_golden_grads(name)
+    n = g["x"].shape[0]
+    csr = ops.build_csr(g["edge_index"].to(d), n)
+    gx, gW, gb, groot, gbias = ops.nnconv_backward_raw(
+        g["x"].to(d), csr, g["edge_attr"].to(d), [w.to(d) for w in g["weights"]], [b.to(d) for b in g["biases"]],
+        None if g["root"] is None else g["root"].to(d), g["aggr"], r["gout"].to(d),
+        need_root=g["root"] is not None, need_bias=g["bias"] is not None)
+    torch.cuda.synchronize()
+    tol = 2e-5
+    assert rel_l2(gx.cpu(), r["gx"]) <= tol, rel_l2(gx.cpu(), r["gx"])
+    for l in range(len(gW)):
+        assert rel_l2(gW[l].cpu(), r["gW"][l]) <= tol, (l, rel_l2(gW[l].cpu(), r["gW"][l]))
+        assert rel_l2(gb[l].cpu(), r["gb"][l]) <= tol, l
+    if r["groot"] is not None:
+        assert rel_l2(groot.cpu(), r["groot"]) <= tol
+    if r["gbias"] is not None:
+        assert rel_l2(gbias.cpu(), r["gbias"]) <= tol
 
 
 def test_module_training_step_matches_reference():

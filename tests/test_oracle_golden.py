@@ -2,6 +2,7 @@
 
 The vectors were produced by the reference's own NNConv_old + DenseNet classes
 (tests/golden/make_golden.py); the oracle must reproduce them — that is what pins it."""
+import pytest
 import torch
 
 from oracle.nnconv_oracle import nnconv_forward, rel_l2
@@ -118,3 +119,40 @@ def test_mgkn_graph_fixture_pins_the_sampled_multilevel_family():
         ei, ea, ns, nd = out["up"][l]
         assert np.array_equal(ei.numpy() + np.array([[offs[l + 1]], [offs[l]]]), g["edge_index_up"][:, lo:hi]), l
         assert np.array_equal(ea.numpy(), g["edge_attr_up"][lo:hi]), l
+
+
+GRAD_CASES = ["ragged_add", "mlp2_mean_noroot", "burgers_k4"]
+
+
+def load_golden_grads(name):
+    import os
+    import numpy as np
+    from tests.conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, name + "_grad.npz"))
+    n = sum(1 for k in z.files if k.startswith("gW"))
+    return {"gout": torch.from_numpy(z["gout"]), "gx": torch.from_numpy(z["gx"]),
+            "gW": [torch.from_numpy(z[f"gW{i}"]) for i in range(n)],
+            "gb": [torch.from_numpy(z[f"gb{i}"]) for i in range(n)],
+            "groot": torch.from_numpy(z["groot"]) if "groot" in z.files else None,
+            "gbias": torch.from_numpy(z["gbias"]) if "gbias" in z.files else None}
+
+
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_oracle_gradients_match_autograd_through_the_reference_module(name):
+    """tests/golden/<name>_grad.npz: float64 autograd through the reference's own NNConv_old / DenseNet
+    (make_golden.py).  The restated operator's autograd (oracle.nnconv_grads, the checker of the native
+    backward) must give the same gradients."""
+    from oracle.nnconv_oracle import nnconv_grads
+    from tests.conftest import load_golden
+    g, r = load_golden(name), load_golden_grads(name)
+    gx, gW, gb, groot, gbias = nnconv_grads(g["x"], g["edge_index"], g["edge_attr"], g["weights"], g["biases"],
+                                            g["root"], g["bias"], g["aggr"], r["gout"])
+    tol = 1e-12
+    assert rel_l2(gx, r["gx"]) <= tol
+    for l in range(len(gW)):
+        assert rel_l2(gW[l], r["gW"][l]) <= tol and rel_l2(gb[l], r["gb"][l]) <= tol, l
+    assert (groot is None) == (r["groot"] is None) and (gbias is None) == (r["gbias"] is None)
+    if groot is not None:
+        assert rel_l2(groot, r["groot"]) <= tol
+    if gbias is not None:
+        assert rel_l2(gbias, r["gbias"]) <= tol
