@@ -341,7 +341,7 @@ def main():
         "value": round(value, 3), "unit": "M-edges/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if precision == "f32" else "f32 (hidden GEMM: 2-term f16-split MFMA, f32 accumulate)",
+        "dtype": "f32" if precision == "f32" else "f32 (hidden layer + aggregation: 2-term f16-split MFMA, f32 accumulate)",
         "precision": precision, "data": "synthetic",
         "config": {"workload": f"GKN Darcy-2D {s}x{s} lattice radius graph r={r} "
                                f"(N={n}, E={e} per sample), NNConv_old fwd width=64, kernel MLP "
