@@ -172,9 +172,10 @@ int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int
  * and ws (gpde_hidden_workspace_bytes) are required.  Workspaces of the *_hidden entry points:
  * gpde_nnconv_fwd_workspace_bytes / gpde_nnconv_bwd_workspace_bytes; gpde_hidden_bwd:
  * gpde_nnconv_bwd_workspace_bytes(0, E, ...).
- * hidden_absmax (nullable, one device float): gpde_hidden_fwd records max |H| there when the fused
- * path computed H (else 0); given back to gpde_nnconv_fwd_hidden it lets the aggregation run on
- * split-f16 MFMA from 32768 edges on (NULL or 0: fp32 MFMA). */
+ * hidden_absmax (nullable, one device float): gpde_hidden_fwd records max |H| there when its fused
+ * path computed H (the general path leaves 0: the value is then NOT a maximum and must not be
+ * passed on).  Given back to gpde_nnconv_fwd_hidden it lets the aggregation run on split-f16 MFMA
+ * from 32768 edges on; NULL: fp32 MFMA. */
 size_t gpde_hidden_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims);
 int gpde_hidden_fwd(const float* edge_attr, int64_t n_edges, const int32_t* rowptr, int64_t n_nodes,
                     const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
