@@ -74,6 +74,12 @@ SIGNATURES = {
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                               ctypes.c_void_p]),
+    "gpde_nnconv_fwd_mixed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                             c_i32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_size_t, ctypes.c_void_p]),
     "gpde_nnconv_bwd_hidden": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                               ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p,

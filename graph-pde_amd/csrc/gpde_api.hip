@@ -179,7 +179,11 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
              int n_layers, const int32_t* dims, const void* packed, const float* root,
              const float* bias, int aggr, uint32_t flags, const float* hidden, float* out, void* ws,
              size_t ws_bytes, hipStream_t stream, int kt = 0, const int* sel = nullptr,
-             const float* hidden_absmax = nullptr) {
+             const float* hidden_absmax = nullptr, int64_t hidden_nodes = -1) {
+    // hidden_nodes in [0, n_nodes): MIXED call (gpde_nnconv_fwd_mixed) -- `hidden` covers the in-edges of
+    // nodes [0, hidden_nodes) only (a graph whose H does not fit memory, e.g. 391 GB at the 241^2 graph);
+    // those nodes aggregate from it, the others run the fused kernel on edge_attr
+    const bool mixed = hidden && hidden_nodes >= 0 && hidden_nodes < n_nodes;
     if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) {
         gpde_set_error("gpde_nnconv_fwd: aggr %d not implemented (add=0, mean=1)", aggr);
         return GPDE_EUNSUPPORTED;
@@ -187,10 +191,11 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
     if (n_nodes == 0) return GPDE_OK;
     if (!ws) { gpde_set_error("gpde_nnconv_fwd: workspace is null"); return GPDE_EWORKSPACE; }
     Plan P;
-    int rc = make_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P, nullptr, hidden != nullptr);
+    int rc = make_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P, nullptr, hidden != nullptr && !mixed);
     if (rc != GPDE_OK) return rc;
     const GpdePackLayout& L = P.L;
-    const int mode = hidden ? 2 : L.mode;
+    const int mode = (hidden && !mixed) ? 2 : L.mode;
+    if (mixed && L.mode != 1) { gpde_set_error("gpde_nnconv_fwd_mixed: built for 3-Linear kernel MLPs"); return GPDE_EUNSUPPORTED; }
     const float* pk = (const float*)packed;
     char* w = (char*)ws;
     w = (char*)(((uintptr_t)w + kAlign - 1) / kAlign * kAlign);
@@ -200,7 +205,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
     float* hb = (float*)(w + P.off_hb);
 
     const float* hfinal = hidden;
-    if (!hidden && L.mode == 2 && n_edges > 0) {
+    if (!hidden && L.mode == 2 && n_edges > 0) {   // (a mixed call has L.mode == 1)
         // front layers over all edges (CSR order), ping-pong between ha / hb
         const float* in = edge_attr;
         int ldx = L.k0, kin = L.k0;
@@ -233,7 +238,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
             return GPDE_EUNSUPPORTED;
         }
     }
-    if (!hidden && mode == 1 && (flags & GPDE_FWD_F16SPLIT) && !(flags & (GPDE_FWD_F16SPLIT_4WAVE | GPDE_FWD_F16SPLIT_2WG | GPDE_FWD_F16SPLIT_QUAD)) &&
+    if ((!hidden || mixed) && mode == 1 && (flags & GPDE_FWD_F16SPLIT) && !(flags & (GPDE_FWD_F16SPLIT_4WAVE | GPDE_FWD_F16SPLIT_2WG | GPDE_FWD_F16SPLIT_QUAD)) &&
         !(flags & GPDE_FWD_AGG_F32) && n_edges > 0 && ((flags & GPDE_FWD_AGG_F16) || n_edges >= 32768)) {
         GpdeFusedArgs probe{};
         probe.k0 = L.k0; probe.K1P = L.K1P; probe.K2P = L.K2P;
@@ -247,7 +252,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
     }
 
     // hidden activations given together with their maximum: the streaming aggregation on split f16
-    if (hidden && hidden_absmax && n_edges >= 32768 && !(flags & GPDE_FWD_AGG_F32)) {
+    if (hidden && !mixed && hidden_absmax && n_edges >= 32768 && !(flags & GPDE_FWD_AGG_F32)) {
         rc = gpde_launch_g2_prep(x, n_nodes, nullptr, 0, 0, nullptr, (unsigned*)(w + P.off_scal),
                                  (unsigned*)(w + P.off_xs), stream);
         if (rc != GPDE_OK) return rc;
@@ -255,8 +260,11 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
         scal = (const unsigned*)(w + P.off_scal);
     }
 
-    for (int64_t nc0 = 0; nc0 < n_nodes; nc0 += P.nodes_per_chunk) {
-        const int64_t nc1 = (nc0 + P.nodes_per_chunk < n_nodes) ? nc0 + P.nodes_per_chunk : n_nodes;
+    const int64_t hn = mixed ? hidden_nodes : (hidden ? n_nodes : 0);     // nodes served from `hidden`
+    for (int64_t nc0 = 0, nc1 = 0; nc0 < n_nodes; nc0 = nc1) {
+        const int64_t lim = nc0 < hn ? hn : n_nodes;                       // a chunk never straddles hn
+        nc1 = (nc0 + P.nodes_per_chunk < lim) ? nc0 + P.nodes_per_chunk : lim;
+        const bool from_h = nc0 < hn;
         const int nn = (int)(nc1 - nc0);
         const int splits = pick_splits(nn);
         if (n_edges > 0) {
@@ -266,14 +274,14 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
             f.w2h = pk + L.off_w2h; f.ucol = pk + L.off_ucol;
             f.w1h = pk + L.off_w1h; f.fcol = pk + L.off_fcol;
             f.hbuf = hfinal; f.zbuf = zbuf; f.xs = xs; f.scal = scal;
-            f.kt = kt; f.hmax = (hidden && xs) ? (const unsigned*)hidden_absmax : nullptr;
+            f.kt = kt; f.hmax = (from_h && xs) ? (const unsigned*)hidden_absmax : nullptr;
             for (int d = 0; d < 8; ++d) f.sel[d] = (kt && sel) ? sel[d < L.k0 ? d : L.k0 - 1] : 0;
             f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
             f.nc0 = (int)nc0; f.nc1 = (int)nc1; f.e_chunk0 = 0; f.n_groups = P.n_groups;
             {
                 ProfScope ps(0, stream);
                 const bool f16s = (flags & GPDE_FWD_F16SPLIT) != 0 && mode == 1;
-                if (hidden) rc = gpde_launch_zagg(f, stream);
+                if (from_h) rc = gpde_launch_zagg(f, stream);
                 else if (f16s && (flags & GPDE_FWD_F16SPLIT_QUAD) && gpde_fused_f16v5_supported(f)) rc = gpde_launch_fused_f16v5(f, stream);
                 else if (f16s && (flags & GPDE_FWD_F16SPLIT_2WG) && gpde_fused_f16v4_supported(f)) rc = gpde_launch_fused_f16v4(f, stream);
                 else if (f16s && !(flags & GPDE_FWD_F16SPLIT_4WAVE) && gpde_fused_f16v3_supported(f)) rc = gpde_launch_fused_f16v3(f, stream);
@@ -338,6 +346,26 @@ extern "C" int gpde_nnconv_fwd_nodeattr(const float* x, int64_t n_nodes, const f
     }
     return fwd_impl(x, n_nodes, node_table, n_edges, rowptr, src, dst, nullptr, n_layers, dims, packed, root, bias,
                     aggr, flags, nullptr, out, ws, ws_bytes, (hipStream_t)stream_, table_stride, sel);
+}
+
+extern "C" int gpde_nnconv_fwd_mixed(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
+                                     const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges,
+                                     const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                                     const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
+                                     const float* root, const float* bias, int aggr, uint32_t flags, float* out,
+                                     void* ws, size_t ws_bytes, void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || !dims || !packed || !rowptr || (n_nodes > 0 && (!x || !out)) ||
+        (n_edges > 0 && (!edge_attr || !src || !dst || !perm)) || hidden_nodes < 0 || hidden_nodes > n_nodes ||
+        (hidden_nodes > 0 && !hidden)) {
+        gpde_set_error("gpde_nnconv_fwd_mixed: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (hidden_nodes == 0)
+        return fwd_impl(x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, n_layers, dims, packed, root, bias,
+                        aggr, flags, nullptr, out, ws, ws_bytes, (hipStream_t)stream_);
+    return fwd_impl(x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, n_layers, dims, packed, root, bias,
+                    aggr, flags, hidden, out, ws, ws_bytes, (hipStream_t)stream_, 0, nullptr, hidden_absmax,
+                    hidden_nodes);
 }
 
 extern "C" int gpde_nnconv_fwd_hidden(const float* x, int64_t n_nodes, const float* hidden,

@@ -14,7 +14,10 @@ Policy (`GPDE_HIDDEN_CACHE` = auto | on | off, default auto; budget `GPDE_HIDDEN
   * "auto" materialises H only for a module that has been SEEN repeating a key (the second call of
     the first forward, then the first call of every later forward); a module that stops repeating
     goes back to the direct fused path.  "on" always materialises, "off" never does;
-  * H is E x K2P x 4 bytes; larger than the budget -> direct path (G241 at k2 = 1024 needs 391 GB).
+  * H is E x K2P x 4 bytes; larger than the budget -> direct path, or, for inference
+    (`GPDE_HIDDEN_CACHE_PARTIAL`, default on), a PARTIAL H: the in-edges of the first `hn` nodes that fit
+    the budget are cached and served by the mixed forward (gpde_nnconv_fwd_mixed), the other nodes run
+    the fused kernel.  G241 at k2 = 1024 needs 391 GB for the full H.
 The entry holds `edge_attr` (so its memory cannot be recycled for other data while the key is
 alive) and is invalidated when the backward of its H node has run.  Nothing is stored on the
 module itself: modules pickle as before.
@@ -32,12 +35,13 @@ from .autograd import HiddenFunction, HiddenToken
 
 MODE = os.environ.get("GPDE_HIDDEN_CACHE", "auto")
 BUDGET_BYTES = int(float(os.environ.get("GPDE_HIDDEN_CACHE_GB", "32")) * (1 << 30))
+PARTIAL = os.environ.get("GPDE_HIDDEN_CACHE_PARTIAL", "1") != "0"
 
 stats = {"hits": 0, "builds": 0, "direct": 0}       # counters for tests / bench
 
 
 class _Entry:
-    __slots__ = ("key", "hidden", "token", "attr_ref", "csr", "last_key", "repeats", "hits_on_hidden")
+    __slots__ = ("key", "hidden", "token", "attr_ref", "csr", "last_key", "repeats", "hits_on_hidden", "hn")
 
     def __init__(self):
         self.key = None
@@ -48,6 +52,7 @@ class _Entry:
         self.last_key = None
         self.repeats = False        # this module has been seen repeating a key
         self.hits_on_hidden = 0
+        self.hn = 0                 # nodes whose in-edges the cached H covers (all of them unless partial)
 
 
 _entries: "weakref.WeakKeyDictionary[torch.nn.Module, _Entry]" = weakref.WeakKeyDictionary()
@@ -69,9 +74,10 @@ def _key(edge_attr: torch.Tensor, csr, hidden_params: List[Optional[torch.Tensor
 
 
 def lookup(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, biases,
-           precision: Optional[str] = None, mode: Optional[str] = None):
-    """Returns (H, hmax) for this call (cached or freshly built; hmax = device scalar max |H| or None),
-    or None when the direct fused path should run."""
+           precision: Optional[str] = None, mode: Optional[str] = None, allow_partial: bool = False):
+    """Returns (H, hmax, hn) for this call (cached or freshly built; hmax = device scalar max |H| or None;
+    hn = number of leading nodes whose in-edges H covers, = N unless partial), or None when the direct
+    fused path should run.  `allow_partial`: the caller needs no gradient at all."""
     mode = MODE if mode is None else mode
     if mode == "off":
         stats["direct"] += 1
@@ -84,24 +90,37 @@ def lookup(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, b
         ent = _entries[module] = _Entry()
     if ent.hidden is not None and ent.key == key and ent.token.valid:
         ent.hits_on_hidden += 1
-        stats["hits"] += 1
-        return ent.hidden, ent.token.hmax
+        if ent.hn == csr.n_nodes or allow_partial:
+            stats["hits"] += 1
+            return ent.hidden, ent.token.hmax, ent.hn
     repeated = ent.last_key == key
     if repeated:
         ent.repeats = True
     elif ent.hidden is not None and ent.key != key and ent.hits_on_hidden == 0:
         ent.repeats = False          # the last H was built and never reused: stop speculating
     ent.last_key = key
-    nbytes = csr.n_edges * ops.hidden_width(pm.dims) * 4
+    row_bytes = ops.hidden_width(pm.dims) * 4
+    nbytes = csr.n_edges * row_bytes
     want = mode == "on" or (mode == "auto" and ent.repeats)
+    hn = csr.n_nodes
+    if want and nbytes > BUDGET_BYTES and PARTIAL and allow_partial and len(pm.dims) == 4:
+        # the leading nodes whose in-edges fit the budget, in whole 64-node tiles; worth it from 1/8 on
+        rp = csr.rowptr_host
+        hn = int(torch.searchsorted(rp.to(torch.int64), torch.tensor(BUDGET_BYTES // row_bytes), right=True)) - 1
+        hn = hn // 64 * 64
+        nbytes = int(rp[hn]) * row_bytes if hn >= csr.n_nodes // 8 and hn > 0 else BUDGET_BYTES + 1
     if not want or nbytes > BUDGET_BYTES or csr.n_edges == 0 or edge_attr.requires_grad:
         ent.hidden, ent.key, ent.token, ent.attr_ref, ent.csr = None, None, None, None, None
         stats["direct"] += 1
         return None
     token = HiddenToken()
     ent.hidden = None                # release the previous H before allocating the next one
-    hidden = HiddenFunction.apply(edge_attr, csr, pm, precision, token, len(hw), *hw, *hb)
-    ent.key, ent.hidden, ent.token, ent.attr_ref, ent.csr = key, hidden, token, edge_attr, csr
+    if hn < csr.n_nodes:             # partial: inference only, no autograd node
+        hidden, token.hmax = ops.hidden_forward_raw(csr, edge_attr.detach(), pm, list(weights[:-1]) + [None],
+                                                    list(biases[:-1]) + [None], precision, n_nodes_limit=hn)
+    else:
+        hidden = HiddenFunction.apply(edge_attr, csr, pm, precision, token, len(hw), *hw, *hb)
+    ent.key, ent.hidden, ent.token, ent.attr_ref, ent.csr, ent.hn = key, hidden, token, edge_attr, csr, hn
     ent.hits_on_hidden = 0
     stats["builds"] += 1
-    return hidden, token.hmax
+    return hidden, token.hmax, hn

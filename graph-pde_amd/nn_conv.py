@@ -105,9 +105,14 @@ class NNConv_old(torch.nn.Module):
                 pseudo.dtype == torch.float32 and x.dtype == torch.float32:
             csr = ops.csr_for(edge_index, x.size(0))
             pm = ops.pack_mlp(weights, biases)
-            hit = hidden_cache.lookup(self, pseudo, csr, pm, weights, biases)
+            no_grad = not (torch.is_grad_enabled() and
+                           (x.requires_grad or any(p.requires_grad for p in self.parameters())))
+            hit = hidden_cache.lookup(self, pseudo, csr, pm, weights, biases, allow_partial=no_grad)
             if hit is not None:
-                hidden, hmax = hit
+                hidden, hmax, hn = hit
+                if hn < csr.n_nodes:        # H of the leading nodes only: mixed forward (inference)
+                    return ops.nnconv_forward_mixed_raw(x, csr, pseudo, hidden, hmax, hn, pm, self.root,
+                                                        self.bias, self.aggr)
                 return NNConvHiddenFunction.apply(x, hidden, csr, pm, weights[-1], biases[-1],
                                                   self.root, self.bias, self.aggr, hmax)
         return NNConvFunction.apply(x, edge_index, pseudo, self.root, self.bias, self.aggr,

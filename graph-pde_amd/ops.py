@@ -406,7 +406,7 @@ def _ptr_array(ts):
 
 def hidden_forward_raw(csr: Csr, edge_attr: torch.Tensor, pm: PackedMlp,
                        weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
-                       precision: Optional[str] = None) -> torch.Tensor:
+                       precision: Optional[str] = None, n_nodes_limit: Optional[int] = None) -> torch.Tensor:
     """gpde_hidden_fwd: H [E, K2P] (rows in CSR order) = all Linear+ReLU layers but the last one.
     Returns (H, hmax): hmax = device scalar max |H| when the fused kernel recorded it, else None."""
     lib = _lib.lib()
@@ -419,6 +419,10 @@ def hidden_forward_raw(csr: Csr, edge_attr: torch.Tensor, pm: PackedMlp,
             edge_attr.size(1) != pm.dims[0]:
         raise ValueError(f"edge_attr must be float32 [{e},{pm.dims[0]}], got {edge_attr.dtype} {tuple(edge_attr.shape)}")
     edge_attr = edge_attr.detach().contiguous()
+    n_lim = csr.n_nodes
+    if n_nodes_limit is not None:           # H of the in-edges of nodes [0, n_nodes_limit) only (mixed forward)
+        n_lim = int(n_nodes_limit)
+        e = int(csr.rowptr_host[n_lim])
     nl = len(pm.dims) - 1
     ws_ = [None if w is None else w.detach().contiguous() for w in weights]    # last entry unused
     bs_ = [None if b is None else b.detach().contiguous() for b in biases]
@@ -428,7 +432,7 @@ def hidden_forward_raw(csr: Csr, edge_attr: torch.Tensor, pm: PackedMlp,
     ws = torch.empty(1 if fast else max(nbytes, 1), dtype=torch.uint8, device=dev)
     hmax = torch.zeros(1, dtype=torch.float32, device=dev) if fast else None
     with torch.cuda.device(dev):
-        rc = lib.gpde_hidden_fwd(edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), csr.n_nodes,
+        rc = lib.gpde_hidden_fwd(edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), n_lim,
                                  csr.perm.data_ptr(), nl, pm.dims_c, pm.packed.data_ptr(),
                                  _ptr_array(ws_), _ptr_array(bs_), _PRECISION[precision],
                                  hidden.data_ptr(), None if hmax is None else hmax.data_ptr(),
@@ -436,7 +440,7 @@ def hidden_forward_raw(csr: Csr, edge_attr: torch.Tensor, pm: PackedMlp,
         if rc in (-1, -3) and fast:    # shape not covered by the fused kernel: the general path needs ws
             ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
             hmax = None                # ... and does not record max |H|
-            rc = lib.gpde_hidden_fwd(edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), csr.n_nodes,
+            rc = lib.gpde_hidden_fwd(edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), n_lim,
                                      csr.perm.data_ptr(), nl, pm.dims_c, pm.packed.data_ptr(),
                                      _ptr_array(ws_), _ptr_array(bs_), _PRECISION[precision],
                                      hidden.data_ptr(), None, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
@@ -478,6 +482,39 @@ def nnconv_forward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, p
                                         None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
                                         out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
     _lib.check(rc, "gpde_nnconv_fwd_hidden")
+    _lib.n_native_calls += 1
+    return out
+
+
+def nnconv_forward_mixed_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor, hidden: torch.Tensor,
+                             hmax: Optional[torch.Tensor], hidden_nodes: int, pm: PackedMlp,
+                             root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,
+                             precision: Optional[str] = None) -> torch.Tensor:
+    """gpde_nnconv_fwd_mixed: nodes [0, hidden_nodes) aggregate from `hidden` (their in-edges' rows), the
+    rest run the fused kernel -- for graphs whose full H does not fit memory.  Forward only."""
+    lib = _lib.lib()
+    _require_cuda(x, "x")
+    precision = DEFAULT_PRECISION if precision is None else precision
+    n, e = csr.n_nodes, csr.n_edges
+    eh = int(csr.rowptr_host[hidden_nodes])
+    if tuple(hidden.shape) != (eh, hidden_width(pm.dims)) or not hidden.is_contiguous():
+        raise ValueError(f"hidden must be contiguous float32 [{eh},{hidden_width(pm.dims)}]")
+    x = x.contiguous()
+    edge_attr = edge_attr.detach().contiguous()
+    root_c = None if root is None else root.detach().contiguous()
+    bias_c = None if bias is None else bias.detach().contiguous()
+    out = torch.empty(n, WIDTH, dtype=torch.float32, device=x.device)
+    ws = torch.empty(max(workspace_bytes(n, e, pm), 1), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.gpde_nnconv_fwd_mixed(x.data_ptr(), n, edge_attr.data_ptr(), hidden.data_ptr(),
+                                       None if hmax is None else hmax.data_ptr(), hidden_nodes, e,
+                                       csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(),
+                                       csr.perm.data_ptr(), len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(),
+                                       None if root_c is None else root_c.data_ptr(),
+                                       None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
+                                       _PRECISION[precision], out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       _stream_ptr(x.device))
+    _lib.check(rc, "gpde_nnconv_fwd_mixed")
     _lib.n_native_calls += 1
     return out
 

@@ -187,6 +187,17 @@ int gpde_nnconv_fwd_hidden(const float* x, int64_t n_nodes, const float* hidden,
                            int n_layers, const int32_t* dims, const void* packed, const float* root,
                            const float* bias, int aggr, float* out, void* ws, size_t ws_bytes,
                            void* stream);
+/* Mixed call for graphs whose H does not fit memory (E * K2P * 4 bytes: 391 GB at the 241^2 graph):
+ * `hidden` holds the rows of the in-edges of nodes [0, hidden_nodes) only (CSR slots
+ * [0, rowptr[hidden_nodes]); build it with gpde_hidden_fwd(..., n_edges = rowptr[hidden_nodes],
+ * n_nodes = hidden_nodes)); those nodes aggregate from it, all others run the fused kernel on
+ * edge_attr.  Same result as gpde_nnconv_fwd.  3-Linear kernel MLPs; forward only. */
+int gpde_nnconv_fwd_mixed(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
+                          const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges,
+                          const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                          const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
+                          const float* root, const float* bias, int aggr, uint32_t flags, float* out,
+                          void* ws, size_t ws_bytes, void* stream);
 int gpde_nnconv_bwd_hidden(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
                            const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                            const int32_t* rowptr_host, int n_layers, const int32_t* dims,

@@ -8,7 +8,8 @@ from graph_pde_amd import ops, synth, hidden_cache
 cfg = sys.argv[1] if len(sys.argv) > 1 else "g61"
 depth = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 kw = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
-s, r = {"g121": (121, 0.1), "g61": (61, 0.1), "g31": (31, 0.12), "g16": (16, 0.15)}[cfg]
+s, r = {"g241": (241, 0.1), "g121": (121, 0.1), "g61": (61, 0.1), "g31": (31, 0.12), "g16": (16, 0.15)}[cfg]
+FWD_ONLY = os.environ.get("FWD_ONLY", "0") == "1"       # skip the training step (G241: 41 s per step)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 mlp = torch.nn.Sequential(torch.nn.Linear(6, kw), torch.nn.ReLU(), torch.nn.Linear(kw, kw), torch.nn.ReLU(), torch.nn.Linear(kw, 4096))
@@ -24,7 +25,11 @@ def model(xin):
     return h
 
 def timeit(fn, reps=3):
-    fn(); fn()
+    if FWD_ONLY:
+        reps = 2
+        fn()
+    else:
+        fn(); fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -48,7 +53,7 @@ for mode in os.environ.get("MODES", "off,auto").split(","):
     ops.clear_caches()
     y = fwd()
     tf = timeit(fwd)
-    ts = timeit(step)
+    ts = float("nan") if FWD_ONLY else timeit(step)
     res[mode] = (tf, ts, y)
     print(f"{cfg} E={e} depth={depth} k={kw} hidden_cache={mode}: forward {1e3*tf:.2f} ms "
           f"({depth*e/tf/1e6:.1f} M-edge-applications/s), training step {1e3*ts:.2f} ms "

@@ -274,3 +274,47 @@ def test_streaming_aggregation_on_split_f16_from_32768_edges():
     e16, e32 = rel_l2(y16.cpu(), y64), rel_l2(y32.cpu(), y64)
     assert not torch.equal(y16, y32)                                     # two different arithmetics ran
     assert e16 <= TOL and e16 <= 4 * e32 + 2e-7, (e16, e32)
+
+
+def test_partial_hidden_cache_and_mixed_forward(monkeypatch):
+    """H larger than the budget (391 GB at the 241^2 graph): for inference the in-edges of the leading
+    nodes that fit are cached and gpde_nnconv_fwd_mixed serves those nodes from H, the rest through the
+    fused kernel.  Same output class as the direct path; a call that needs gradients does not use it."""
+    from tests.test_host_logic import DenseNet
+    d = dev()
+    torch.manual_seed(23)
+    ei, ea, n = synth.darcy_graph(32, 0.13)
+    conv = gp.NNConv_old(64, 64, DenseNet([6, 64, 128, 4096], torch.nn.ReLU), aggr="mean").to(d)
+    eid, ead, x = ei.to(d), ea.to(d), torch.randn(n, 64, device=d)
+    lin = ops.mlp_linears(conv.nn)
+    y64 = nnconv_forward(x.cpu(), ei, ea, [l.weight.detach().cpu() for l in lin],
+                         [l.bias.detach().cpu() for l in lin], conv.root.detach().cpu(),
+                         conv.bias.detach().cpu(), aggr="mean", dtype=torch.float64)
+    full_bytes = ei.shape[1] * 128 * 4
+    monkeypatch.setattr(hidden_cache, "MODE", "on")
+    monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", full_bytes // 2)
+    hidden_cache.clear()
+    with torch.no_grad():
+        y1 = conv(x, eid, ead)
+        ent = hidden_cache._entries[conv]
+        assert 0 < ent.hn < n and ent.hn % 64 == 0
+        assert ent.hidden.shape[0] == int(ops.csr_for(eid, n).rowptr_host[ent.hn])
+        assert ent.hidden.numel() * 4 <= full_bytes // 2
+        y2 = conv(x, eid, ead)
+    assert hidden_cache.stats["builds"] == 1 and hidden_cache.stats["hits"] == 1
+    assert torch.equal(y1, y2)
+    assert rel_l2(y1.cpu(), y64) <= TOL
+    # raw entry point, arbitrary split (not a multiple of the node chunk), against the direct forward
+    csr = ops.csr_for(eid, n)
+    pm = ops.pack_mlp([l.weight for l in lin], [l.bias for l in lin])
+    wd, bd = [l.weight.detach() for l in lin], [l.bias.detach() for l in lin]
+    y_dir = ops.nnconv_forward_raw(x, csr, ead, pm, conv.root, conv.bias, "mean")
+    for hn in (1, 333, n - 1):
+        H, hmax = ops.hidden_forward_raw(csr, ead, pm, wd, bd, n_nodes_limit=hn)
+        y_mix = ops.nnconv_forward_mixed_raw(x, csr, ead, H, hmax, hn, pm, conv.root, conv.bias, "mean")
+        assert rel_l2(y_mix.cpu(), y64) <= TOL and rel_l2(y_mix.cpu(), y_dir.cpu()) <= 1e-6, hn
+    # gradients needed -> no partial cache: the direct path runs and differentiates
+    hidden_cache.clear()
+    out = conv(x, eid, ead)
+    out.square().mean().backward()
+    assert hidden_cache.stats["builds"] == 0 and conv.root.grad is not None
