@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
         const float sh = gpde_pow2_to_2p13(hb);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) { b2v[nb] *= sh; ucv[nb] *= sh; }       // exact: sh is a power of two
-        z_unscale = 1.f / (sx * sh);
+        z_unscale = (1.f / sx) * (1.f / sh);      // two exact reciprocals: sx * sh may exceed the float range
     }
     // per-input-slot constants: bound weights max_k|W1b[k][d]| and column un-scales 2^-u_d
     float wmx8[8], fcol8[8];

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 1) void gpde_zagg_kernel(GpdeFusedArgs a) {
     if constexpr (F16) {
         const float sx = gpde_pow2_to_2p13(__uint_as_float(a.scal[0]));
         sh = gpde_pow2_to_2p13(__uint_as_float(a.hmax[0]));
-        z_unscale = 1.f / (sx * sh);
+        z_unscale = (1.f / sx) * (1.f / sh);      // two exact reciprocals: sx * sh may exceed the float range
     }
     auto flush = [&](int node) {
         float* zrow = a.zbuf + ((size_t)(node - a.nc0) * GP_W) * a.K2P + slice * GP_TN + 4 * l31;
