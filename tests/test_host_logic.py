@@ -146,3 +146,45 @@ def test_node_attr_recipe_is_the_reference_edge_attr():
     conv = gp.NNConv_old(64, 64, DenseNet([6, 8, 16, 4096], torch.nn.ReLU), aggr="mean")
     with pytest.raises(RuntimeError, match="no CPU"):       # still no CPU execution path
         conv(torch.randn(64, 64), ei, na)
+
+
+def test_partial_hidden_cache_split_point(monkeypatch):
+    """hidden_cache.py host logic for graphs whose H exceeds the budget: the split node hn is the largest
+    multiple of 64 whose in-edges fit, partial caching needs a gradient-free caller and at least an eighth
+    of the nodes, and the native builder is asked for exactly those nodes."""
+    from graph_pde_amd import hidden_cache, ops
+
+    class FakeCsr:
+        n_nodes, deg = 1024, 10
+        n_edges = n_nodes * deg
+        rowptr_host = torch.arange(0, (n_nodes + 1) * deg, deg, dtype=torch.int32)
+    class FakePm:
+        dims = (6, 8, 100, 4096)                 # K2P = 128 -> 512 B per row
+    conv = gp.NNConv_old(64, 64, DenseNet([6, 8, 100, 4096], torch.nn.ReLU), aggr="mean")
+    lin = ops.mlp_linears(conv.nn)
+    w, b = [l.weight for l in lin], [l.bias for l in lin]
+    ea, csr, pm = torch.randn(FakeCsr.n_edges, 6), FakeCsr(), FakePm()
+    calls = []
+
+    def fake_hidden(csr_, attr, pm_, ws_, bs_, precision, n_nodes_limit=None):
+        calls.append(n_nodes_limit)
+        return torch.zeros(int(csr_.rowptr_host[n_nodes_limit]), 128), None
+    monkeypatch.setattr(ops, "hidden_forward_raw", fake_hidden)
+    row = 128 * 4
+    monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", 500 * 10 * row)      # 500 nodes' worth of rows
+    hidden_cache.clear()
+    with torch.no_grad():
+        hit = hidden_cache.lookup(conv, ea, csr, pm, w, b, mode="on", allow_partial=True)
+    assert hit is not None and hit[2] == 448 and calls == [448]            # 500 -> 448 = 7 * 64
+    assert hit[0].shape[0] == 448 * 10
+    # a caller that needs gradients never gets a partial H
+    assert hidden_cache.lookup(conv, ea, csr, pm, w, b, mode="on", allow_partial=False) is None
+    # less than an eighth of the nodes fits: not worth it
+    monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", 100 * 10 * row)
+    hidden_cache.clear()
+    with torch.no_grad():
+        assert hidden_cache.lookup(conv, ea, csr, pm, w, b, mode="on", allow_partial=True) is None
+    monkeypatch.setattr(hidden_cache, "PARTIAL", False)
+    monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", 500 * 10 * row)
+    with torch.no_grad():
+        assert hidden_cache.lookup(conv, ea, csr, pm, w, b, mode="on", allow_partial=True) is None
