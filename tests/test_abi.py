@@ -87,6 +87,21 @@ def test_argument_validation_without_gpu():
     assert rc == -1
     rc = l.gpde_mlp_pack(2, d, None, None, None, 0, None)
     assert rc == -1
+    # the split operator, the mixed forward and the node-table forward validate before touching the device
+    d3 = _lib.dims_array([6, 16, 32, 4096])
+    sel = (ctypes.c_int32 * 6)(0, 1, 256, 257, 2, 258)
+    assert l.gpde_hidden_fwd(None, 8, None, 4, None, 3, d3, None, None, None, 1, None, None, None, 0, None) == -1
+    assert l.gpde_hidden_fwd(None, 0, None, 4, None, 3, d3, None, None, None, 1, None, None, None, 0, None) == 0   # no edges
+    assert l.gpde_nnconv_fwd_hidden(None, 4, None, None, 8, None, None, None, 3, d3, None, None, None, 1,
+                                    None, None, 0, None) == -1
+    assert l.gpde_nnconv_fwd_mixed(None, 4, None, None, None, 9, 8, None, None, None, None, 3, d3, None, None,
+                                   None, 1, 1, None, None, 0, None) == -1
+    assert l.gpde_nnconv_bwd_hidden(None, 4, None, 8, None, None, None, None, 3, d3, None, None, None, 1, None,
+                                    None, None, None, None, None, None, None, 0, None) == -1
+    assert l.gpde_hidden_bwd(None, 8, None, 3, d3, None, None, None, None, None, None, 0, None) == -1
+    assert l.gpde_nnconv_fwd_nodeattr(None, 4, None, 3, sel, 8, None, None, None, 3, d3, None, None, None, 1, 1,
+                                      None, None, 0, None) == -1
+    assert l.gpde_hidden_workspace_bytes(1000, 3, d3) > 0 and l.gpde_hidden_workspace_bytes(-1, 3, d3) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):
