@@ -188,3 +188,21 @@ def test_partial_hidden_cache_split_point(monkeypatch):
     monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", 500 * 10 * row)
     with torch.no_grad():
         assert hidden_cache.lookup(conv, ea, csr, pm, w, b, mode="on", allow_partial=True) is None
+
+
+def test_bench_flop_accounting_matches_survey():
+    """bench.py's roofline inputs: the reference formulation's FLOPs per edge and what the
+    kernels execute."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.algorithmic_flops_per_edge([6, 1024, 1024, 4096]) == 10506304
+    assert bench.algorithmic_flops_per_edge([6, 256, 256, 4096]) == 2239552
+    f32, f16 = bench.executed_flops_per_edge([6, 1024, 1024, 4096], precision="f32")
+    assert (f32, f16) == (2 * 8 * 1024 * 8 + 2 * 64 * 1024 + 2 * 1024 * 1024, 0)
+    f32, f16 = bench.executed_flops_per_edge([6, 1024, 1024, 4096], precision="f16split")
+    assert f32 == 0 and f16 == 3 * 2 * 1024 * 1024 + 2 * 2 * 16 * 1024 * 16 + 3 * 2 * 64 * 1024 == 7733248
+    f32, f16 = bench.executed_flops_per_edge([6, 1024, 1024, 4096], precision="f16split_agg32")
+    assert f32 == 131072 and f16 == 7340032
