@@ -18,8 +18,10 @@
 //
 // Edges are processed in node-aligned chunks (host partition from rowptr_host) so that the hidden
 // activations of a chunk ([edges][k], recomputed, never saved by the forward) fit the workspace;
-// all contractions run on fp32 MFMA: gpde_gemm (dense layers, weight gradients), the mode-2 fused
-// kernel of gpde_fused.hip (Z of the chunk from the recomputed H) and gpde_edge_bwd_kernel below.
+// all contractions run on fp32 MFMA: gpde_gemm (dense layers, weight gradients), gpde_zagg_kernel
+// (Z of the chunk from the recomputed or given H) and the two edge kernels below -- except the recompute
+// of the last hidden layer of 3-Linear kernels, which reuses the forward's fused f16-split kernel with
+// its store epilogue (gpde_fused_f16v3_kernel<true, ...>).
 // Weight-gradient reductions use ordered split partials (deterministic); dx_j uses fp32 atomics
 // (as the reference's scatter backward does on a GPU).
 #include "gpde_common.h"
