@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reuse-probe", action="store_true",
                     help="skip the depth x module probe of the cross-depth hidden-activation reuse")
-    ap.add_argument("--precision", default=None, choices=["f32", "f16split", "f16split4w", "f16split2wg", "f16splitq", "f16split_agg16", "f16split_agg32"],
+    ap.add_argument("--precision", default=None, choices=["f32", "f16split", "f16split_8wave", "f16split_agg16", "f16split_agg32"],
                     help="arithmetic of the hidden layer (default: graph_pde_amd.ops.DEFAULT_PRECISION)")
     args = ap.parse_args()
 

@@ -140,9 +140,38 @@ int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws
     return GPDE_OK;
 }
 
+// Which fused edge kernel serves a forward call -- ONE place, used by fwd_impl and by the query
+// gpde_nnconv_fwd_kernel (bench.py / tests key profiles and expectations on the kernel symbol).
+enum FusedKind { FK_GENERIC = 0, FK_V3 = 1, FK_V6 = 2 };
+struct FusedChoice { FusedKind kind; bool g2f16; };
+FusedChoice choose_fused(const GpdePackLayout& L, int mode, uint32_t flags, int64_t n_edges, int kt) {
+    FusedChoice c{FK_GENERIC, false};
+    if (mode != 1 || !(flags & GPDE_FWD_F16SPLIT)) return c;
+    GpdeFusedArgs probe{};
+    probe.k0 = L.k0; probe.K1P = L.K1P; probe.K2P = L.K2P; probe.kt = kt;
+    if (!gpde_fused_f16v3_supported(probe)) return c;
+    c.kind = FK_V3;
+    // f16-split aggregation inside the fused kernel: worth its three tiny pre-pass launches from a few ten
+    // thousand edges on; GPDE_FWD_AGG_F16 / GPDE_FWD_AGG_F32 force it on / off
+    c.g2f16 = !(flags & GPDE_FWD_AGG_F32) && n_edges > 0 && ((flags & GPDE_FWD_AGG_F16) || n_edges >= 32768);
+    probe.xs = c.g2f16 ? (const unsigned*)(uintptr_t)8 : nullptr;      // "will be present"
+    if (c.g2f16 && !(flags & GPDE_FWD_F16SPLIT_8WAVE) && gpde_fused_f16v6_supported(probe)) c.kind = FK_V6;
+    return c;
+}
+
 }  // namespace
 
 int gpde_num_cus() { return num_cus_impl(); }
+
+extern "C" const char* gpde_nnconv_fwd_kernel(int64_t n_edges, int n_layers, const int32_t* dims, uint32_t flags) {
+    GpdePackLayout L;
+    if (!dims || gpde_pack_layout(n_layers, dims, &L) != GPDE_OK) return "";
+    switch (choose_fused(L, L.mode, flags, n_edges, 0).kind) {
+        case FK_V6: return "gpde_fused_f16v6_kernel";
+        case FK_V3: return "gpde_fused_f16v3_kernel";
+        default: return "gpde_fused_kernel";
+    }
+}
 
 extern "C" size_t gpde_nnconv_fwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers,
                                                   const int32_t* dims) {
@@ -225,30 +254,19 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
         hfinal = in;
     }
 
-    // f16-split aggregation inside the fused kernel: worth its three tiny pre-pass launches from a few
-    // ten thousand edges on; GPDE_FWD_AGG_F16 / GPDE_FWD_AGG_F32 force it on / off
     const unsigned* xs = nullptr;
     const unsigned* scal = nullptr;
-    if (kt) {
-        GpdeFusedArgs probe{};
-        probe.k0 = L.k0; probe.K1P = L.K1P; probe.K2P = L.K2P;
-        if (mode != 1 || !(flags & GPDE_FWD_F16SPLIT) || (flags & (GPDE_FWD_F16SPLIT_4WAVE | GPDE_FWD_F16SPLIT_2WG | GPDE_FWD_F16SPLIT_QUAD)) ||
-            !gpde_fused_f16v3_supported(probe)) {
-            gpde_set_error("gpde_nnconv_fwd_nodeattr: built for 3-Linear kernel MLPs on the default f16-split kernel only");
-            return GPDE_EUNSUPPORTED;
-        }
+    const FusedChoice fc = choose_fused(L, mode, flags, n_edges, kt);
+    if (kt && fc.kind == FK_GENERIC) {
+        gpde_set_error("gpde_nnconv_fwd_nodeattr: built for 3-Linear kernel MLPs on the f16-split kernel only");
+        return GPDE_EUNSUPPORTED;
     }
-    if ((!hidden || mixed) && mode == 1 && (flags & GPDE_FWD_F16SPLIT) && !(flags & (GPDE_FWD_F16SPLIT_4WAVE | GPDE_FWD_F16SPLIT_2WG | GPDE_FWD_F16SPLIT_QUAD)) &&
-        !(flags & GPDE_FWD_AGG_F32) && n_edges > 0 && ((flags & GPDE_FWD_AGG_F16) || n_edges >= 32768)) {
-        GpdeFusedArgs probe{};
-        probe.k0 = L.k0; probe.K1P = L.K1P; probe.K2P = L.K2P;
-        if (gpde_fused_f16v3_supported(probe)) {
-            rc = gpde_launch_g2_prep(x, n_nodes, edge_attr, n_edges, L.k0, pk + L.off_w1 + (size_t)L.K1P * 8,
-                                     (unsigned*)(w + P.off_scal), (unsigned*)(w + P.off_xs), stream, kt, sel, src, dst);
-            if (rc != GPDE_OK) return rc;
-            xs = (const unsigned*)(w + P.off_xs);
-            scal = (const unsigned*)(w + P.off_scal);
-        }
+    if ((!hidden || mixed) && fc.g2f16) {
+        rc = gpde_launch_g2_prep(x, n_nodes, edge_attr, n_edges, L.k0, pk + L.off_w1 + (size_t)L.K1P * 8,
+                                 (unsigned*)(w + P.off_scal), (unsigned*)(w + P.off_xs), stream, kt, sel, src, dst);
+        if (rc != GPDE_OK) return rc;
+        xs = (const unsigned*)(w + P.off_xs);
+        scal = (const unsigned*)(w + P.off_scal);
     }
 
     // hidden activations given together with their maximum: the streaming aggregation on split f16
@@ -280,13 +298,10 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
             f.nc0 = (int)nc0; f.nc1 = (int)nc1; f.e_chunk0 = 0; f.n_groups = P.n_groups;
             {
                 ProfScope ps(0, stream);
-                const bool f16s = (flags & GPDE_FWD_F16SPLIT) != 0 && mode == 1;
                 if (from_h) rc = gpde_launch_zagg(f, stream);
-                else if (f16s && (flags & GPDE_FWD_F16SPLIT_QUAD) && gpde_fused_f16v5_supported(f)) rc = gpde_launch_fused_f16v5(f, stream);
-                else if (f16s && (flags & GPDE_FWD_F16SPLIT_2WG) && gpde_fused_f16v4_supported(f)) rc = gpde_launch_fused_f16v4(f, stream);
-                else if (f16s && !(flags & GPDE_FWD_F16SPLIT_4WAVE) && gpde_fused_f16v3_supported(f)) rc = gpde_launch_fused_f16v3(f, stream);
-                else if (f16s && gpde_fused_f16_supported(f)) rc = gpde_launch_fused_f16(f, stream);
-                else rc = gpde_launch_fused(mode, f16s, f, stream);
+                else if (fc.kind == FK_V6) rc = gpde_launch_fused_f16v6(f, stream);
+                else if (fc.kind == FK_V3) rc = gpde_launch_fused_f16v3(f, stream);
+                else rc = gpde_launch_fused(mode, (flags & GPDE_FWD_F16SPLIT) != 0 && mode == 1, f, stream);
             }
             if (rc != GPDE_OK) return rc;
             ProfScope ps1(1, stream);

@@ -118,18 +118,12 @@ __host__ __device__ static inline float gpde_pow2_to_2p13(float v) {
 // Z = sum x_j (x) H_e from given hidden activations a.hbuf (gpde_zagg.hip); uses x, rowptr, src, dst,
 // hbuf, zbuf, K2P, nc0, nc1, e_chunk0, n_groups
 int gpde_launch_zagg(const GpdeFusedArgs& a, hipStream_t stream);
-// f16-split + LDS-DMA variant (gpde_fused_f16.hip); supported for 3 <= K1P/32 and K1P <= ~1000
-bool gpde_fused_f16_supported(const GpdeFusedArgs& a);
-int gpde_launch_fused_f16(const GpdeFusedArgs& a, hipStream_t stream);
 // 8-wave (two per SIMD) variant with f16 H1 generation (gpde_fused_f16v3.hip)
 bool gpde_fused_f16v3_supported(const GpdeFusedArgs& a);
 int gpde_launch_fused_f16v3(const GpdeFusedArgs& a, hipStream_t stream);
-// two independent 4-wave workgroups per CU, 64-column slices (gpde_fused_f16v4.hip)
-bool gpde_fused_f16v4_supported(const GpdeFusedArgs& a);
-int gpde_launch_fused_f16v4(const GpdeFusedArgs& a, hipStream_t stream);
-// 8 edge tiles x one 64-column slice, 8-slot ring, one barrier per four chunks (gpde_fused_f16v5.hip)
-bool gpde_fused_f16v5_supported(const GpdeFusedArgs& a);
-int gpde_launch_fused_f16v5(const GpdeFusedArgs& a, hipStream_t stream);
+// one wave per SIMD, 64 x 128 wave tile, 512 registers (gpde_fused_f16v6.hip): the default from 32768 edges on
+bool gpde_fused_f16v6_supported(const GpdeFusedArgs& a);
+int gpde_launch_fused_f16v6(const GpdeFusedArgs& a, hipStream_t stream);
 
 struct GpdeGemm3Args {
     const float* zbuf;     // [nn][64*K2P]

@@ -1,9 +1,10 @@
-// Fused edge kernel, f16-split, TWO WAVES PER SIMD (v3, the default): 8 waves per workgroup, wave
-// tile = 32 edges x 64 hidden columns, H1 generated on f16 MFMA as well.
+// Fused edge kernel, f16-split, TWO WAVES PER SIMD (v3): 8 waves per workgroup, wave tile = 32 edges x
+// 64 hidden columns, H1 generated on f16 MFMA as well.  Since round 2 the big-graph default is
+// gpde_fused_f16v6_kernel (gpde_fused_f16v6.hip); this kernel serves graphs below 32,768 edges (fp32
+// aggregation, no pre-pass launches), node-table attributes (NODEATTR) and gpde_hidden_fwd (WRITE_H).
 //
-// Same contract and math as gpde_fused_f16_kernel (gpde_fused_f16.hip; replaces DenseNet.forward
-// hidden part, /root/reference/graph-neural-operator/utilities.py:223-227, NNConv_old.message,
-// nn_conv.py:273-275, and PyG's gather/scatter).  Why this shape: a wave alone on its SIMD hides
+// Replaces the hidden part of DenseNet.forward (/root/reference/graph-neural-operator/utilities.py:223-227),
+// NNConv_old.message (nn_conv.py:273-275) and PyG's gather / scatter.  Why this shape: a wave alone on its SIMD hides
 // only ~4 non-MFMA instructions per 32-cycle MFMA (scripts/ubench/mfma_valu_overlap.hip), so in the
 // 4-wave kernel MFMA time and issue time ADD (47 % matrix-pipe occupancy).  Halving the wave tile to
 // 64 columns brings the accumulators (32 + 64 registers) under the 256-register budget of two waves
@@ -12,8 +13,7 @@
 // and [lo|lo] x [hi;0]) instead of 4 fp32 ones, with per-input-slot column scales 2^u_d folded
 // into the attributes (pack_w1_f16split_kernel).
 //
-// What the K loop looks like now, and why (in-kernel phase timing: -DGPDE_V3_TIMING +
-// scripts/v3_timing.py; the story with numbers is DESIGN.md §3b):
+// What the K loop looks like, and why (the story with numbers is DESIGN.md §3b):
 //   * chunks of 32 k in PAIRS, one s_barrier per pair; pair G lives in ring slots {2(G&1), 2(G&1)+1},
 //     the next pair's four 1-KiB DMA per wave are issued at the top of the iteration and retired by a
 //     counted s_waitcnt before the closing barrier;
@@ -60,9 +60,6 @@ __device__ __forceinline__ int lower_bound_node(const int32_t* __restrict__ rowp
 }
 
 constexpr int RING = 4;                    // W2 chunk images in LDS: two pairs of chunks
-#ifdef GPDE_V3_TIMING
-__device__ unsigned long long gpde_v3_tm[6];
-#endif
 constexpr int TILE_B = GP_TN * 128;        // 16 KiB per W2 chunk image
 constexpr int XS_TILE = GP_TE * GP_W;      // floats per edge-tile x stage (shared by a wave pair)
 constexpr int NW = 8;                      // waves per workgroup
@@ -208,15 +205,6 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
     issue_w2(1, 1);
     load_perm(ea);
     load_attr();
-#ifdef GPDE_V3_LDSSYNC
-    // Experiment (A/B build): per-wave progress counters in LDS instead of the workgroup barrier --
-    // bounded skew (one pair) instead of lock-step.  prog[w] = pairs whose DMA pieces of wave w have
-    // landed, prog[8 + w] = pairs wave w has finished reading.  Needs NP >= 4 (x_j staging analysis).
-    typedef int i4v __attribute__((ext_vector_type(4)));
-    volatile int* prog = (volatile int*)(Es_all + NW * GP_TE);
-    const bool flagsync = NP >= 4;
-    if (tid < 16) prog[tid] = tid < 8 ? 1 : 0;
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -265,19 +253,12 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
 
     [[maybe_unused]] float hmax_run = 0.f;      // WRITE_H: running max of the written activations (>= 0)
     int g = 0;
-#ifdef GPDE_V3_TIMING
-    long long tm_pro = 0, tm_loop = 0, tm_post = 0, tm_wait = 0, tm_bar = 0, tm0 = clock64(), tm1;
-#define TM_MARK(acc) do { tm1 = clock64(); acc += tm1 - tm0; tm0 = tm1; } while (0)
-#else
-#define TM_MARK(acc) do { } while (0)
-#endif
     for (int t = 0; t < maxtiles; ++t) {
         const int e0 = ea + t * GP_TE;
         const int e_end = min(e0 + GP_TE, eb);
 
         // ---- attributes of this lane's edge: validity, bias slot, per-edge scale, f16 split --------
         h8 B1, B2;          // H1 MFMA operands: B1 = h ? attr_lo : attr_hi ; B2 = h ? 0 : attr_hi
-        [[maybe_unused]] float dbg_attr[8];
         {
             const bool valid = (e0 + l31) < eb;
             float bnd = 0.f;
@@ -295,7 +276,6 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             if (h == 0) Es[l31] = isc;
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
-                dbg_attr[d] = attr_n[d] * sc;
                 const float s = attr_n[d] * fcol8[d] * sc;
                 const _Float16 hi = (_Float16)s;
                 const _Float16 lo = (_Float16)(s - (float)hi);
@@ -304,15 +284,6 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             }
         }
         auto h1gen = [&](int chunk) {
-#ifdef GPDE_V3_H1F32   // debugging aid: H1 on fp32 MFMA straight from the fp32 packed W1
-            {
-                const f32x4 w1f = *(const f32x4*)&a.w1[((size_t)(chunk * GP_BK + l31) * 2 + h) * 4];
-                f32x16 dd;
-                for (int r = 0; r < 16; ++r) dd[r] = 0.f;
-                for (int s_ = 0; s_ < 4; ++s_) dd = mfma32(w1f[s_], dbg_attr[2 * s_ + h], dd);
-                return dd;
-            }
-#endif
             const char* wp = w1s + (size_t)(chunk * GP_BK + l31) * 32;
             const h8 A1 = *(const h8*)wp, A2 = *(const h8*)(wp + 16);
             f32x16 d;
@@ -347,31 +318,13 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
         // thing in the loop, scripts/ubench/kloop_model_v3.hip).  Pair G lives in ring slots
         // {2(G&1), 2(G&1)+1}; the next pair's 4 DMA are issued at the top of the iteration into the
         // other two slots (free since the previous barrier) and retired before the closing barrier.
-        TM_MARK(tm_pro);
         for (int kp = 0; kp < NP; ++kp, ++g) {
             const int sb = (g & 1) * 2;
             int cA = 2 * kp + 2, cB = 2 * kp + 3;
             if (cA >= NKC) cA -= NKC;
             if (cB >= NKC) cB -= NKC;
-#ifdef GPDE_V3_LDSSYNC
-            if (flagsync) {
-                // pair g must have landed everywhere (RAW) and pair g - 1 must have been read by everyone
-                // before its slots are refilled (WAR)
-                for (int spin = 0; spin < (1 << 22); ++spin) {      // bounded: a protocol bug must not hang the GPU
-                    const volatile i4v* pv = (const volatile i4v*)prog;
-                    const i4v l0 = pv[0], l1 = pv[1], d0 = pv[2], d1 = pv[3];
-                    const int ml = min(min(min(l0[0], l0[1]), min(l0[2], l0[3])), min(min(l1[0], l1[1]), min(l1[2], l1[3])));
-                    const int md = min(min(min(d0[0], d0[1]), min(d0[2], d0[3])), min(min(d1[0], d1[1]), min(d1[2], d1[3])));
-                    if (__builtin_amdgcn_readfirstlane((ml >= g + 1 && md >= g) ? 1 : 0)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                asm volatile("" ::: "memory");
-            }
-#endif
-#if !defined(GPDE_ABL_NOSTAGE) && !defined(GPDE_V3_DMASPREAD)
             issue_w2(cA, sb ^ 2);
             issue_w2(cB, (sb ^ 2) + 1);
-#endif
             if (kp == 0) {
                 load_perm(e0n);
                 if constexpr (!WRITE_H) load_sidx(e0);
@@ -400,12 +353,10 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
                 const char* rb = ring + (sb + cc) * TILE_B;
-#if !defined(GPDE_V3_NOPRIO) && !defined(GPDE_V3_PRIO_HALF)
                 // The SIMD arbitrates its two waves by age: alternate the priority per chunk so that
                 // neither wave of a pair runs ahead and then idles at the barrier.
                 if ((cc == 0) != roleB) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
-#endif
                 int c2 = 2 * kp + cc + 2;
                 if (c2 >= NKC) c2 -= NKC;
                 // (W1|b1) rows of chunk c + 2, read now, used by the two H1 MFMAs at the end of the chunk
@@ -417,20 +368,14 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                 // nothing (scripts/v3_timing.py ablations).
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-#ifdef GPDE_V3_PRIO_HALF
-                    if (((m == 0) != (cc == 0)) != roleB) __builtin_amdgcn_s_setprio(1);
-                    else __builtin_amdgcn_s_setprio(0);
-#endif
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {
                         const int nb = j & 1, t = j >> 1;       // t: 0 = hi x lo, 1 = hi x hi, 2 = lo x hi
                         acc1[nb] = mfma16(t == 2 ? alo[cc][m] : ahi[cc][m], t == 0 ? blo[nb] : bhi[nb], acc1[nb]);
-#ifndef GPDE_ABL_NOCONV
                         if (j == 0 || j == 1 || j == 3 || j == 4) {
                             conv_to(d, 4 * m + (j < 2 ? j : j - 1), ahi[cc ^ 1], alo[cc ^ 1]);
                             asm volatile("" ::"v"(ahi[cc ^ 1][m]), "v"(alo[cc ^ 1][m]));
                         }
-#endif
                         if (j == 1) {
                             if (m == 0) ld_lo(rb, 1);
                             else if (cc == 0) ld_lo(rb + TILE_B, 0);
@@ -439,21 +384,9 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                             if (m == 0) ld_hi(rb, 1);
                             else if (cc == 0) ld_hi(rb + TILE_B, 0);
                         }
-#ifdef GPDE_V3_DMASPREAD
-                        // Experiment: the 8 waves used to issue their 4 DMA each right after the barrier --
-                        // 32 KiB through the CU's one address pipe at 64 B/clk = 512 cycles of queueing.
-                        // Wave w now issues its four after its (w + 1)-th MFMA of the pair's first chunk.
-                        if (cc == 0 && m * 6 + j == wave) {
-                            issue_w2(cA, sb ^ 2);
-                            issue_w2(cB, (sb ^ 2) + 1);
-                        }
-#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-#ifdef GPDE_ABL_NOCONV
-                asm volatile("" ::"v"(d));
-#endif
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d[r] = 0.f;
                 d = mfma16(A1, B1, d);
@@ -463,42 +396,17 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             }
             // counted wait: everything up to and including this iteration's 4 W2 DMA is retired; only
             // the side loads issued after them (5 at kp == 0, 12 at kp == KP1) may stay in flight
-#ifdef GPDE_V3_TIMING
-            const long long tw0 = clock64();
-#endif
-#ifdef GPDE_V3_DMASPREAD
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the W2 DMA are the youngest VMEM ops now
-#elif !defined(GPDE_ABL_NOSTAGE) && !defined(GPDE_ABL_NOWAIT)
             if (kp == 0 && KP1 == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_CNT + B_CNT) : "memory");
             else if (kp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_CNT) : "memory");
             else if (kp == KP1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_CNT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#ifdef GPDE_V3_TIMING
-            const long long tw1 = clock64();
-#endif
-#ifdef GPDE_V3_LDSSYNC
-            if (flagsync) {
-                asm volatile("" ::: "memory");
-                if (lane == 0) { prog[wave] = g + 2; prog[8 + wave] = g + 1; }
-                asm volatile("" ::: "memory");
-            } else
-#endif
-#ifndef GPDE_ABL_NOBARRIER
             __builtin_amdgcn_s_barrier();
-#endif
-#ifdef GPDE_V3_TIMING
-            tm_wait += tw1 - tw0;
-            tm_bar += clock64() - tw1;
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         if (NP < 3) {      // the x_j rows were issued in the last pair: land them before the aggregation
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-
-        TM_MARK(tm_loop);
         // ---- undo the row (edge) and column scales, bias, ReLU ---------------------------------------
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -534,11 +442,6 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
                 for (int p_ = 0; p_ < 8; ++p_) conv_to(acc1[nb], p_, g2hi[nb], g2lo[nb]);
         }
         int e_seg = e0;
-#ifdef GPDE_ABL_NOGEMM2
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) asm volatile("" ::"v"(acc1[nb]));
-        e_seg = e_end;
-#endif
         int node = n_first;
         while (e_seg < e_end) {
             const int seg_end = (node == n_last) ? e_end : min(a.rowptr[node + 1], e_end);
@@ -592,7 +495,6 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             e_seg = seg_end;
             if (e_seg < e_end) node = a.dst[e_seg];
         }
-        TM_MARK(tm_post);
     }
     if (cur >= 0) flush(cur);
     if constexpr (WRITE_H) {
@@ -602,16 +504,6 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             if (lane == 0 && hmax_run > 0.f) atomicMax(a.hmax_out, __float_as_uint(hmax_run));
         }
     }
-#ifdef GPDE_V3_TIMING
-    if (lane == 0) {
-        atomicAdd(&gpde_v3_tm[0], (unsigned long long)tm_pro);
-        atomicAdd(&gpde_v3_tm[1], (unsigned long long)tm_loop);
-        atomicAdd(&gpde_v3_tm[2], (unsigned long long)tm_post);
-        atomicAdd(&gpde_v3_tm[3], (unsigned long long)maxtiles);
-        atomicAdd(&gpde_v3_tm[4], (unsigned long long)tm_wait);
-        atomicAdd(&gpde_v3_tm[5], (unsigned long long)tm_bar);
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -621,17 +513,6 @@ static size_t v3_lds_bytes(int K1P) {
     return (size_t)RING * TILE_B + (size_t)K1P * 32 + (size_t)NET * XS_TILE * 4 + 16 + NW * GP_TE * 4 + 64 + 64;
 }
 
-#ifdef GPDE_V3_TIMING
-// developer probe (scripts/v3_timing.py): cycles per phase summed over waves, and wave-tiles
-extern "C" int gpde_debug_v3_timing(unsigned long long* out6, int reset) {
-    if (hipMemcpyFromSymbol(out6, HIP_SYMBOL(gpde_v3_tm), 48) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(gpde_v3_tm), z, 48) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 bool gpde_fused_f16v3_supported(const GpdeFusedArgs& a) {
     return a.K1P / GP_BK >= 2 && (a.K1P / GP_BK) % 2 == 0 && a.k0 + 1 <= 8 && v3_lds_bytes(a.K1P) <= 80 * 1024 * 2;
@@ -641,17 +522,12 @@ int gpde_launch_fused_f16v3(const GpdeFusedArgs& a, hipStream_t stream) {
     const int ns = a.K2P / GP_TN;
     const dim3 grid(a.n_groups * ns), block(512);
     const size_t lds = v3_lds_bytes(a.K1P);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        const void* fns[5] = {(const void*)gpde_fused_f16v3_kernel<false, false, false>,
-                              (const void*)gpde_fused_f16v3_kernel<false, true, false>,
-                              (const void*)gpde_fused_f16v3_kernel<true, false, false>,
-                              (const void*)gpde_fused_f16v3_kernel<false, false, true>,
-                              (const void*)gpde_fused_f16v3_kernel<false, true, true>};
-        for (const void* f : fns)
-            GP_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
+    // set per launch: the attribute is per device, a process-wide "done" flag would be wrong for a second GPU
+    // and racy between threads (include/gpde.h promises re-entrancy)
+    const void* fn = a.hout ? (const void*)gpde_fused_f16v3_kernel<true, false, false>
+                   : a.kt ? (a.xs ? (const void*)gpde_fused_f16v3_kernel<false, true, true> : (const void*)gpde_fused_f16v3_kernel<false, false, true>)
+                   : (a.xs ? (const void*)gpde_fused_f16v3_kernel<false, true, false> : (const void*)gpde_fused_f16v3_kernel<false, false, false>);
+    GP_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (a.hout) {
         if (a.kt) { gpde_set_error("hidden-activation output from node-table attributes is not built"); return GPDE_EUNSUPPORTED; }
         hipLaunchKernelGGL((gpde_fused_f16v3_kernel<true, false, false>), grid, block, lds, stream, a);

@@ -1,0 +1,571 @@
+// Fused edge kernel, f16-split, ONE WAVE PER SIMD with a 512-register budget (v6, the default for
+// graphs from 32,768 edges on): 4 waves per workgroup, wave tile = 64 edges x 128 hidden columns.
+//
+// Same contract and math as gpde_fused_f16v3_kernel<false, true, false> (gpde_fused_f16v3.hip; replaces
+// the hidden part of DenseNet.forward, /root/reference/graph-neural-operator/utilities.py:223-227,
+// NNConv_old.message, nn_conv.py:273-275, and PyG's gather / scatter): per edge
+//   H1 = relu((W1|b1) . attr)  ->  H2 = relu(W2 . H1 + b2)  ->  Z_dst[c][k] += x_src[c] * H2[k]
+// with the k1 x k2 layer and the aggregation on 2-term split f16 MFMA, fp32 accumulation.
+//
+// Why this shape (scripts/ubench/kloop_model_v6.hip, measured on MI355X: the K loop below runs at 85 %
+// matrix-pipe occupancy = 1.73 PFLOP/s chip-wide, which is what a bare MFMA stream sustains under the
+// chip's power limit; the 8-wave v3 kernel sits at 51 %):
+//   * the v3 kernel's two waves per SIMD both convert the same H1 tile, share the SIMD's issue port and
+//     lose ~40 % of the loop to conversions, barrier waits and staging.  One wave per SIMD with a wave
+//     tile twice as tall halves conversions, W2 fragment reads, DMA pieces and barriers per MFMA
+//     (2.9 non-MFMA instructions per MFMA, spread so that no gap holds more than 4);
+//   * 512 registers: accumulators (128) and Z (128) live in AGPRs for the whole kernel, nothing spills
+//     (v3: 256 registers, 50 spilled);
+//   * MFMA order is pinned by an empty asm on the accumulator ("+a") after every MFMA plus
+//     sched_barrier(0): hipcc otherwise sinks the MFMAs of a step below its conversions;
+//   * H1 is produced by an asm MFMA with a VGPR destination (the builtin lands in AGPRs in a 512-register
+//     kernel: one v_accvgpr_read per value) and converted by asm pairs (relu, rtz16 hi, rn16 lo) - hipcc
+//     pads no hazards for asm operands, so the producer is placed >= 2 MFMAs before the first consumer;
+//   * W2 chunk images (16 KiB, pre-swizzled) stream through a 3-slot LDS ring by LDS-DMA: chunk c + 2 is
+//     issued during chunk c (4 pieces per wave, one address + immediate offsets), retired by the
+//     s_waitcnt vmcnt(0) + s_barrier that ends chunk c; fragments are read half a chunk ahead, in place.
+#include "gpde_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+#define GPDE_GLDS(g, l, off)                                                                       \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),         \
+                                     (__attribute__((address_space(3))) void*)(l), 16, off, 0)
+
+__device__ __forceinline__ int lower_bound_node(const int32_t* __restrict__ rowptr, int lo, int hi, long target) {
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if ((long)rowptr[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+#ifdef GPDE_V6_TIMING      // developer probe (scripts/v6_timing.py): cycles per phase summed over waves, wave-tiles
+__device__ unsigned long long gpde_v6_tm[4];
+#define TM_MARK(acc) do { const long long tm1_ = clock64(); acc += tm1_ - tm0_; tm0_ = tm1_; } while (0)
+#else
+#define TM_MARK(acc) do { } while (0)
+#endif
+
+constexpr int NS = 3;                      // W2 ring slots
+constexpr int TILE_B = GP_TN * 128;        // 16 KiB per W2 chunk image: [128 columns][hi 64 B | lo 64 B]
+constexpr int TE = 64;                     // edges per wave tile (two MFMA row blocks)
+constexpr int NW = 4;                      // waves per workgroup
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // ONE LDS object (cdna guide, glds trap a)
+    char* ring = smem;                                               // [3][16 KiB]
+    char* w1s = smem + NS * TILE_B;                                  // [K1P][hi 16 B | lo 16 B]
+    unsigned* Xs_all = (unsigned*)(w1s + (size_t)a.K1P * 32);        // [4 waves][64 rows][64 words]
+    float* Es_all = (float*)(Xs_all + NW * TE * GP_W);               // [4][64]
+    int* red = (int*)(Es_all + NW * TE);                             // [4]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+    float* Es = Es_all + wave * TE;
+    unsigned* Xs = Xs_all + wave * TE * GP_W;
+
+    const int ns = a.K2P / GP_TN;
+    const int slice = blockIdx.x % ns;
+    const int group = blockIdx.x / ns;
+    const int NKC = a.K1P / GP_BK;
+
+    for (int i = tid; i < a.K1P * 2; i += 256) ((f32x4*)w1s)[i] = ((const f32x4*)a.w1h)[i];
+
+    // ---- node-aligned edge range of this wave --------------------------------------------------------
+    const int e_lo = a.rowptr[a.nc0], e_hi = a.rowptr[a.nc1];
+    const long tot = (long)e_hi - e_lo;
+    const int nranges = a.n_groups * NW;
+    const int wg = group * NW + wave;
+    const int na = lower_bound_node(a.rowptr, a.nc0, a.nc1, e_lo + tot * wg / nranges);
+    const int nb_ = (wg == nranges - 1) ? a.nc1
+                                        : lower_bound_node(a.rowptr, a.nc0, a.nc1, e_lo + tot * (wg + 1) / nranges);
+    const int ea = a.rowptr[na], eb = a.rowptr[nb_];
+    const int ntiles = (eb - ea + TE - 1) / TE;
+    if (lane == 0) red[wave] = ntiles;
+    __syncthreads();
+    const int maxtiles = max(max(red[0], red[1]), max(red[2], red[3]));
+    if (maxtiles == 0) return;
+
+    // ---- W2 chunk DMA: 4 x 1 KiB per wave per chunk, one address, immediate offsets on both sides -----
+    const unsigned long long w2base = (unsigned long long)a.w2h + (size_t)slice * NKC * TILE_B + wave * 4096;
+    const unsigned lane16 = lane * 16;
+    auto w2_src = [&](int chunk) {
+        unsigned long long gb = w2base + (size_t)chunk * TILE_B;
+        asm volatile("" : "+s"(gb));
+        return (const char*)(gb + lane16);
+    };
+
+    // constants of the un-scaling: h <= max|b2| + max_k ||W2_k||_1 * max_e B_e (pack-time constants in fcol[8..9])
+    float b2v[4], ucv[4];
+    float z_unscale;
+    {
+        const float sx = gpde_pow2_to_2p13(__uint_as_float(a.scal[0]));
+        const float hb = a.fcol[8] + a.fcol[9] * __uint_as_float(a.scal[1]);
+        const float sh = gpde_pow2_to_2p13(hb);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            b2v[nb] = a.b2[slice * GP_TN + nb * 32 + l31] * sh;          // exact: sh is a power of two
+            ucv[nb] = a.ucol[slice * GP_TN + nb * 32 + l31] * sh;
+        }
+        z_unscale = (1.f / sx) * (1.f / sh);      // two exact reciprocals: sx * sh may exceed the float range
+    }
+    float wmx8[8], fcol8[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        wmx8[d] = a.w1[(size_t)a.K1P * 8 + (d & 1) * 4 + (d >> 1)];
+        fcol8[d] = a.fcol[d];
+    }
+    const int sw = (l31 >> 1) & 7;
+    const int boff[2] = {l31 * 128 + (((0 + h) ^ sw) << 4), l31 * 128 + (((2 + h) ^ sw) << 4)};
+
+    // ---- per-tile side loads ----------------------------------------------------------------------------
+    const int e_clamp = max(e_hi - 1, 0);
+    // lane l owns edge (tile start + l): its edge id, source node and 8 attribute slots; the MFMA operand
+    // layout needs edge 32 b + (l & 31) in BOTH lane halves - exchanged by v_permlane32_swap in the prologue
+    int perm_n = 0;
+    int src_l = 0;                      // source node of edge (tile start + lane), for the x_j row DMA
+    float attr_n[8];
+    auto load_perm = [&](int e0n) { perm_n = a.perm[min(e0n + lane, e_clamp)]; };
+    auto load_attr = [&]() {
+        const float* ap = a.attr + (size_t)perm_n * a.k0;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) attr_n[d] = ap[min(d, a.k0 - 1)];
+    };
+    // x_j rows of this tile: piece i = rows 4i .. 4i+3 (lane >> 4 picks the row, lane & 15 its 16-byte unit).
+    // The source node comes from the lane that loaded that edge's src (ds_bpermute) at the START of a chunk,
+    // the four DMA are issued at its END, behind the chunk's W2 pieces (see the K loop).
+    int xsidx[4];
+    auto x_addr = [&](int i0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xsidx[i] = __builtin_amdgcn_ds_bpermute((4 * (i0 + i) + (lane >> 4)) * 4, src_l);
+    };
+    auto x_issue = [&](int i0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            GPDE_GLDS(a.xs + (size_t)xsidx[i] * GP_W + (lane & 15) * 4, Xs + (i0 + i) * 4 * GP_W, 0);
+    };
+
+    // ---- conversions and H1 generation (asm: see the header) ----------------------------------------------
+    auto conv_a = [&](float v0, float v1, unsigned& ph, unsigned& t0_, unsigned& t1_) {
+        asm("v_max_i32 %1, 0, %3\n\t"
+            "v_max_i32 %2, 0, %4\n\t"
+            "v_cvt_pkrtz_f16_f32 %0, %1, %2"
+            : "=&v"(ph), "=&v"(t0_), "=&v"(t1_) : "v"(v0), "v"(v1));
+    };
+    auto conv_b = [&](unsigned ph, unsigned t0_, unsigned t1_, unsigned& pl) {
+        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(pl) : "v"(t0_), "v"(t1_), "v"(ph));
+    };
+    auto conv_pair = [&](float v0, float v1, unsigned& ph, unsigned& pl) {      // both parts (outside the K loop)
+        unsigned t0_, t1_;
+        conv_a(v0, v1, ph, t0_, t1_);
+        conv_b(ph, t0_, t1_, pl);
+    };
+    // the leading s_nop covers a VALU write of an operand right in front of the statement
+    auto h1gen = [&](f32x16& dd, h8 a1, h8 a2, h8 b1, h8 b2) {
+        asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(dd) : "v"(a1), "v"(b1));
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(dd) : "v"(a2), "v"(b2));
+    };
+
+    // ---- prologue: chunks 0 and 1 of the W2 slice, the first tile's edges and attributes ---------------
+    {
+        const char* g0 = w2_src(0);
+        char* l0 = ring + wave * 4096;
+        GPDE_GLDS(g0, l0, 0); GPDE_GLDS(g0, l0, 1024); GPDE_GLDS(g0, l0, 2048); GPDE_GLDS(g0, l0, 3072);
+        const char* g1 = w2_src(1);
+        char* l1 = ring + TILE_B + wave * 4096;
+        GPDE_GLDS(g1, l1, 0); GPDE_GLDS(g1, l1, 1024); GPDE_GLDS(g1, l1, 2048); GPDE_GLDS(g1, l1, 3072);
+    }
+    load_perm(ea);
+    load_attr();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 acc[2][4], Z[2][4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[e][nb][r] = 0.f; Z[e][nb][r] = 0.f; }
+    int cur = -1;
+
+    // one plain-store flush per (node, slice): the row base is wave-uniform (scalar address arithmetic), the lane
+    // part of the address is ONE tile-invariant offset - 32 per-row vector addresses would be hoisted out of the
+    // tile loop and spilled
+    const int z_loff = 4 * h * a.K2P + l31;
+    auto flush = [&](int node) {
+        float* zb = a.zbuf + ((size_t)(node - a.nc0) * GP_W) * a.K2P + slice * GP_TN;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) asm volatile("" : "+a"(Z[cb][nb]));
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* rp = zb + (size_t)(cb * 32 + (r & 3) + 8 * (r >> 2)) * a.K2P;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    rp[z_loff + nb * 32] = Z[cb][nb][r] * z_unscale;
+                    Z[cb][nb][r] = 0.f;
+                }
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // 16 values in flight, not 128
+            }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) asm volatile("" : "+a"(Z[cb][nb]));
+    };
+
+    int slot = 0;           // ring slot of the current chunk
+
+#ifdef GPDE_V6_TIMING
+    long long tm_pro = 0, tm_loop = 0, tm_post = 0, tm0_ = clock64();
+#endif
+    for (int t = 0; t < maxtiles; ++t) {
+        const int e0 = ea + t * TE;
+        const int e_end = min(e0 + TE, eb);
+
+        // ---- attributes of this lane's two edges: validity, bias slot, per-edge scale, f16 split ------------
+        h8 B1[2], B2[2];        // H1 MFMA operands: B1 = h ? attr_lo : attr_hi ; B2 = h ? 0 : attr_hi
+        {
+            float av[2][8];     // [edge block][slot]: attributes of edge 32 b + l31 in both lane halves
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(attr_n[d]), __float_as_uint(attr_n[d]), false, false);
+                av[0][d] = __uint_as_float(r2[0]);      // [lower | lower]
+                av[1][d] = __uint_as_float(r2[1]);      // [upper | upper]
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const bool valid = (e0 + 32 * b + l31) < eb;
+                float v[8];
+                float bnd = 0.f;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    float q = (valid && d < a.k0) ? av[b][d] : 0.f;
+                    if (valid && d == a.k0) q = 1.f;
+                    v[d] = q;
+                    bnd = fmaf(wmx8[d], fabsf(q), bnd);
+                }
+                const int ebits = (__float_as_int(bnd) >> 23) & 0xff;
+                const bool okb = (ebits >= 20) && (ebits <= 230);
+                const float sc = okb ? __int_as_float((267 - ebits) << 23) : 1.f;     // 2^(13 - E(B))
+                const float isc = okb ? __int_as_float((ebits - 13) << 23) : 1.f;
+                if (h == 0) Es[32 * b + l31] = isc;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    const float s_ = v[d] * fcol8[d] * sc;
+                    const _Float16 hi = (_Float16)s_;
+                    const _Float16 lo = (_Float16)(s_ - (float)hi);
+                    B1[b][d] = h ? lo : hi;
+                    B2[b][d] = h ? (_Float16)0.f : hi;
+                }
+            }
+        }
+        // W2 fragments of step (0, 0) (within the tile they are read half a chunk ahead, in place; not carried
+        // across the aggregation phase: 32 registers)
+        h8 bhi[4], blo[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            bhi[nb] = *(const h8*)(ring + slot * TILE_B + nb * 4096 + boff[0]);
+            blo[nb] = *(const h8*)(ring + slot * TILE_B + nb * 4096 + (boff[0] ^ 64));
+        }
+        // ---- raw H1 of chunk 0 and the operands of step (0, 0) -------------------------------------------
+        f32x16 d[2];
+        u4 ahi[2][2], alo[2][2];          // [operand buffer = step parity][edge block]
+        {
+            const char* wp = w1s + (size_t)l31 * 32;
+            const h8 A1 = *(const h8*)wp, A2 = *(const h8*)(wp + 16);
+            h1gen(d[0], A1, A2, B1[0], B2[0]);
+            h1gen(d[1], A1, A2, B1[1], B2[1]);
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // MFMA result -> VALU read (asm operands are not padded)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    unsigned ph, pl;
+                    conv_pair(d[e][2 * jp], d[e][2 * jp + 1], ph, pl);
+                    ahi[0][e][jp] = ph;
+                    alo[0][e][jp] = pl;
+                }
+        }
+        // destination of the first / last edge of the two 32-edge halves: loaded with the other side loads at the
+        // end of chunk 0 (all lanes the same address), made scalar after the K loop
+        int nf_v[2] = {0, 0}, nl_v[2] = {0, 0};
+        const int e0n = e0 + TE;
+        unsigned cph = 0, ct0 = 0, ct1 = 0;
+        h8 A1, A2;
+        {
+            const char* wp = w1s + (size_t)(GP_BK + l31) * 32;           // (W1|b1) rows of chunk 1
+            A1 = *(const h8*)wp;
+            A2 = *(const h8*)(wp + 16);
+        }
+
+        // One k1 chunk.  The first seven chunks of a tile are peeled (PH = compile-time phase) so that the side
+        // loads are straight-line code: inside a runtime `if (c == ..)` hipcc copies the loaded registers into
+        // their loop-carried homes and waits vmcnt(0) for them right behind the load (measured: one exposed
+        // memory round trip per chunk, ~40 % of the tile).  Side loads are issued at the END of a chunk, BEHIND
+        // its four W2 pieces, and the closing wait is vmcnt(<side loads of this chunk>): the W2 pieces are
+        // retired, the side loads fly for a whole chunk and are retired by the next chunk's closing wait.
+        //   PH 0: next tile's edge ids, this tile's source nodes, 4 segment-end nodes (6 loads)   -> vmcnt(6)
+        //   PH 1: nothing (the three loads land)                                                   -> vmcnt(0)
+        //   PH 2: next tile's attributes (8 loads) + x_j rows 0..15 (4 DMA)                        -> vmcnt(12)
+        //   PH 3/4/5: x_j rows 16..31 / 32..47 / 48..63 (4 DMA each)                               -> vmcnt(4)
+        //   PH 6: steady state                                                                     -> vmcnt(0)
+        TM_MARK(tm_pro);
+        auto chunk = [&](auto ph_tag, int c) {
+            constexpr int PH = decltype(ph_tag)::value;
+            asm volatile("" : "+s"(c));         // opaque: keeps the peeled chunks' addresses from being hoisted out of
+                                                // the tile loop (and spilled)
+            const int slot1 = slot + 1 == NS ? 0 : slot + 1;
+            const int slot2 = slot1 + 1 == NS ? 0 : slot1 + 1;
+            int c2 = c + 2;
+            if (c2 >= NKC) c2 -= NKC;
+            const char* gsrc = w2_src(c2);
+            char* ldst = ring + slot2 * TILE_B + wave * 4096;
+            const char* rb0 = ring + slot * TILE_B;
+            const char* rb1 = ring + slot1 * TILE_B;
+            int c1 = c + 2;                                               // (W1|b1) rows read in this chunk: chunk c + 2
+            if (c1 >= NKC) c1 -= NKC;
+            const char* w1n = w1s + (size_t)(c1 * GP_BK + l31) * 32;
+            if constexpr (PH >= 2 && PH <= 5) x_addr(4 * (PH - 2));      // consumes src_l (loaded two chunks ago)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int cbuf = m;                                       // operand buffer of this step
+                const char* rn = (m == 0) ? rb0 : rb1;                    // where the NEXT step's fragments live
+                const int bo = boff[m ^ 1];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const int tt = j >> 1, e = j & 1;                 // tt: 0 = hi x lo, 1 = hi x hi, 2 = lo x hi
+                        const int i = nb * 6 + j;
+                        acc[e][nb] = mfma16(__builtin_bit_cast(h8, tt == 2 ? alo[cbuf][e] : ahi[cbuf][e]),
+                                            tt == 0 ? blo[nb] : bhi[nb], acc[e][nb]);
+                        asm volatile("" : "+a"(acc[e][nb]));
+                        // conversion pair p of the NEXT step's operands: first part after MFMA 3p, second after
+                        // 3p + 1; in step 1 (raw H1 of the next chunk issued at the end of step 0) one MFMA later
+                        {
+                            const int q = m == 0 ? i : i - 1;
+                            if (q >= 0 && q % 3 == 0 && q / 3 < 8)
+                                conv_a(d[(q / 3) >> 2][8 * (m ^ 1) + 2 * ((q / 3) & 3)],
+                                       d[(q / 3) >> 2][8 * (m ^ 1) + 2 * ((q / 3) & 3) + 1], cph, ct0, ct1);
+                            if (q >= 0 && q % 3 == 1 && q / 3 < 8) {
+                                unsigned pl;
+                                conv_b(cph, ct0, ct1, pl);
+                                ahi[cbuf ^ 1][(q / 3) >> 2][(q / 3) & 3] = cph;
+                                alo[cbuf ^ 1][(q / 3) >> 2][(q / 3) & 3] = pl;
+                                asm volatile("" ::"v"(ahi[cbuf ^ 1][(q / 3) >> 2]), "v"(alo[cbuf ^ 1][(q / 3) >> 2]));
+                            }
+                        }
+                        if (j == 1) blo[nb] = *(const h8*)(rn + nb * 4096 + (bo ^ 64));
+                        if (j == 5) bhi[nb] = *(const h8*)(rn + nb * 4096 + bo);
+                        if (m == 0) {
+                            if (i == 2) GPDE_GLDS(gsrc, ldst, 0);
+                            if (i == 8) GPDE_GLDS(gsrc, ldst, 1024);
+                            if (i == 14) GPDE_GLDS(gsrc, ldst, 2048);
+                            if (i == 20) GPDE_GLDS(gsrc, ldst, 3072);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (m == 0) {
+                    // raw H1 of chunk c + 1 (single-buffered: its last reader ran two MFMAs ago); at the last
+                    // chunk this is chunk 0 with THIS tile's attributes - unused, the next tile starts afresh
+                    h1gen(d[0], A1, A2, B1[0], B2[0]);
+                    h1gen(d[1], A1, A2, B1[1], B2[1]);
+                    A1 = *(const h8*)w1n;
+                    A2 = *(const h8*)(w1n + 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if constexpr (PH == 0) {
+                load_perm(e0n);
+                src_l = a.src[min(e0 + lane, e_clamp)];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int s0 = e0 + 32 * b, s1 = min(s0 + 32, eb);
+                    nf_v[b] = a.dst[min(s0, e_clamp)];
+                    nl_v[b] = a.dst[min(max(s1 - 1, s0), e_clamp)];
+                }
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else if constexpr (PH == 2) {
+                load_attr();
+                x_issue(0);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            } else if constexpr (PH >= 3 && PH <= 5) {
+                x_issue(4 * (PH - 2));
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            slot = slot1;
+        };
+        chunk(std::integral_constant<int, 0>{}, 0);
+        chunk(std::integral_constant<int, 1>{}, 1);
+        chunk(std::integral_constant<int, 2>{}, 2);
+        chunk(std::integral_constant<int, 3>{}, 3);
+        chunk(std::integral_constant<int, 4>{}, 4);
+        chunk(std::integral_constant<int, 5>{}, 5);
+        for (int c = 6; c < NKC; ++c) chunk(std::integral_constant<int, 6>{}, c);
+
+
+        TM_MARK(tm_loop);
+        // ---- per 32-edge half: un-scale + bias, split (ReLU inside), aggregation by destination segment ----
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            u4 g2hi[4][2], g2lo[4][2];
+            float ie[16];           // per-edge un-scale of this half's 16 accumulator rows: four 16-byte LDS reads
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 t4 = *(const f32x4*)&Es[32 * b + 8 * q4 + 4 * h];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ie[4 * q4 + j] = t4[j];
+            }
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                float y[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    y[r] = fmaf(acc[b][nb][r], ie[r] * ucv[nb], b2v[nb]);
+                    acc[b][nb][r] = 0.f;
+                }
+#pragma unroll
+                for (int p_ = 0; p_ < 8; ++p_) {
+                    unsigned ph, pl;
+                    conv_pair(y[2 * p_], y[2 * p_ + 1], ph, pl);
+                    g2hi[nb][p_ >> 2][p_ & 3] = ph;
+                    g2lo[nb][p_ >> 2][p_ & 3] = pl;
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one column block at a time: 16 live values, not 64
+            }
+            const int s0 = e0 + 32 * b;
+            const int s_end = min(s0 + 32, e_end);
+            int e_seg = s0;
+            const int n_last_b = __builtin_amdgcn_readfirstlane(nl_v[b]);
+            int node = __builtin_amdgcn_readfirstlane(nf_v[b]);
+            while (e_seg < s_end) {
+                const int seg_end = (node == n_last_b) ? s_end : min(a.rowptr[node + 1], s_end);
+                if (node != cur) {
+                    if (cur >= 0) flush(cur);
+                    cur = node;
+                }
+                const int lo = e_seg - s0 - 4 * h, hi = seg_end - s0 - 4 * h;
+                const bool full = (e_seg == s0) && (seg_end == s0 + 32);       // the whole half is one segment (scalar)
+                const unsigned* xu = Xs + 32 * b * GP_W;
+                // four operand groups g = (cb, m): 8 x_j words each (k slot tq <-> edge er(8m + tq) + 4h), read one
+                // group ahead of the 12 MFMAs that use them.  The loads are unconditional and materialised by an asm
+                // before the masks: hipcc otherwise sinks each load into its mask's branch and waits per word.
+                unsigned wq[2][8];
+                auto ldx = [&](int g, unsigned (&w)[8]) {
+                    const int cb = g >> 1, m = g & 1;
+#pragma unroll
+                    for (int tq = 0; tq < 8; ++tq) {
+                        const int er = ((8 * m + tq) & 3) + 8 * ((8 * m + tq) >> 2);
+                        w[tq] = xu[(er + 4 * h) * GP_W + cb * 32 + l31];
+                    }
+                };
+                ldx(0, wq[0]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cb = g >> 1, m = g & 1;
+                    unsigned (&w)[8] = wq[g & 1];
+                    if (g + 1 < 4) ldx(g + 1, wq[(g + 1) & 1]);
+                    asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
+                    if (!full) {
+#pragma unroll
+                        for (int tq = 0; tq < 8; ++tq) {
+                            const int er = ((8 * m + tq) & 3) + 8 * ((8 * m + tq) >> 2);
+                            const unsigned keep = (er >= lo && er < hi) ? 0xffffffffu : 0u;
+                            w[tq] &= keep;
+                        }
+                    }
+                    u4 ah, al;
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) {
+                        ah[jp] = __builtin_amdgcn_perm(w[2 * jp + 1], w[2 * jp], 0x05040100u);
+                        al[jp] = __builtin_amdgcn_perm(w[2 * jp + 1], w[2 * jp], 0x07060302u);
+                    }
+                    const h8 xhi = __builtin_bit_cast(h8, ah), xlo = __builtin_bit_cast(h8, al);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) {
+                        const h8 gh = __builtin_bit_cast(h8, g2hi[nb][m]), gl = __builtin_bit_cast(h8, g2lo[nb][m]);
+                        Z[cb][nb] = mfma16(xhi, gh, Z[cb][nb]);
+                        Z[cb][nb] = mfma16(xhi, gl, Z[cb][nb]);
+                        Z[cb][nb] = mfma16(xlo, gh, Z[cb][nb]);
+                        asm volatile("" : "+a"(Z[cb][nb]));      // Z stays in AGPRs (else: 128 copies per segment)
+                    }
+                }
+                e_seg = seg_end;
+                if (e_seg < s_end) node = a.dst[e_seg];
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) asm volatile("" : "+a"(Z[cb][nb]));
+        TM_MARK(tm_post);
+    }
+    if (cur >= 0) flush(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef GPDE_V6_TIMING
+    if (lane == 0) {
+        atomicAdd(&gpde_v6_tm[0], (unsigned long long)tm_pro);
+        atomicAdd(&gpde_v6_tm[1], (unsigned long long)tm_loop);
+        atomicAdd(&gpde_v6_tm[2], (unsigned long long)tm_post);
+        atomicAdd(&gpde_v6_tm[3], (unsigned long long)maxtiles);
+    }
+#endif
+}
+
+size_t v6_lds_bytes(int K1P) {
+    return (size_t)NS * TILE_B + (size_t)K1P * 32 + (size_t)NW * TE * GP_W * 4 + (size_t)NW * TE * 4 + 64;
+}
+
+}  // namespace
+
+#ifdef GPDE_V6_TIMING
+extern "C" int gpde_debug_v6_timing(unsigned long long* out4, int reset) {
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(gpde_v6_tm), 32) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gpde_v6_tm), z, 32) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+// 3-Linear kernels with at least 8 k1 chunks (the side loads of a tile are spread over its first seven), attributes +
+// bias slot within one K = 8 group, split-x input (a.xs) present
+bool gpde_fused_f16v6_supported(const GpdeFusedArgs& a) {
+    return a.K1P / GP_BK >= 8 && a.k0 + 1 <= 8 && v6_lds_bytes(a.K1P) <= 160 * 1024 && a.xs != nullptr &&
+           a.kt == 0 && a.hout == nullptr;
+}
+
+int gpde_launch_fused_f16v6(const GpdeFusedArgs& a, hipStream_t stream) {
+    const int ns = a.K2P / GP_TN;
+    const dim3 grid(a.n_groups * ns), block(256);
+    const size_t lds = v6_lds_bytes(a.K1P);
+    // per call: the attribute is per device and cheap to set (no process-wide "done" flag)
+    GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gpde_fused_f16v6_kernel, grid, block, lds, stream, a);
+    GP_LAUNCH_CHECK("gpde_fused_f16v6_kernel");
+    return GPDE_OK;
+}

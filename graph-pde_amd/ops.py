@@ -200,9 +200,7 @@ _AGGR = {"add": _lib.GPDE_AGGR_ADD, "mean": _lib.GPDE_AGGR_MEAN}
 # arithmetic of the hidden k1 x k2 layer: "f32" = fp32 MFMA (exact fmaf chains); "f16split" = f16
 # MFMA on two-term split operands with fp32 accumulation (include/gpde.h GPDE_FWD_F16SPLIT)
 _PRECISION = {"f32": _lib.GPDE_FWD_DEFAULT, "f16split": _lib.GPDE_FWD_F16SPLIT,
-              "f16split2wg": _lib.GPDE_FWD_F16SPLIT | 4,   # 2wg: two 4-wave workgroups per CU (A/B)
-              "f16splitq": _lib.GPDE_FWD_F16SPLIT | 8,     # q: 8 tiles x 64 columns, barrier per 4 chunks (A/B)
-              "f16split4w": _lib.GPDE_FWD_F16SPLIT | 2,     # 4w: one-wave-per-SIMD kernel (A/B)
+              "f16split_8wave": _lib.GPDE_FWD_F16SPLIT | 2,   # force the 8-wave kernel (small-graph path) everywhere
               "f16split_agg16": _lib.GPDE_FWD_F16SPLIT | 16,  # aggregation on split f16 regardless of size
               "f16split_agg32": _lib.GPDE_FWD_F16SPLIT | 32}  # aggregation on fp32 MFMA regardless of size
 DEFAULT_PRECISION = os.environ.get("GPDE_PRECISION", "f16split")
@@ -337,6 +335,13 @@ def launch_plan(n_nodes: int, n_edges: int, pm: PackedMlp, ws_bytes: int):
     _lib.check(rc, "gpde_nnconv_fwd_plan")
     return {"n_chunks": nch.value, "nodes_per_chunk": npc.value, "fused_workgroups": wgs.value,
             "mode": mode.value}
+
+
+def fused_kernel_name(n_nodes: int, n_edges: int, pm: PackedMlp, precision: Optional[str] = None) -> str:
+    """Symbol of the fused edge kernel a forward call of this size / arithmetic launches
+    (gpde_nnconv_fwd_kernel).  `n_nodes` is accepted for symmetry with launch_plan and unused."""
+    precision = DEFAULT_PRECISION if precision is None else precision
+    return _lib.lib().gpde_nnconv_fwd_kernel(n_edges, len(pm.dims) - 1, pm.dims_c, _PRECISION[precision]).decode()
 
 
 # ----------------------------------------------------------------------------------------------

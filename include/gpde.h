@@ -45,9 +45,9 @@ enum {
     GPDE_FWD_F16SPLIT = 1, /* hidden k1 x k2 layer on f16 MFMA with two-term operand splitting
                               (x = hi + lo, 3 MFMAs, fp32 accumulate; per-product error < 2^-21,
                               DESIGN.md §3b); ignored for kernels without a hidden GEMM */
-    GPDE_FWD_F16SPLIT_4WAVE = 2, /* with F16SPLIT: use the one-wave-per-SIMD kernel (A/B, debugging) */
-    GPDE_FWD_F16SPLIT_2WG = 4,   /* with F16SPLIT: two independent 4-wave workgroups per CU (A/B) */
-    GPDE_FWD_F16SPLIT_QUAD = 8,  /* with F16SPLIT: 8 edge tiles x 64 columns, one barrier per 4 chunks (A/B) */
+    GPDE_FWD_F16SPLIT_8WAVE = 2, /* with F16SPLIT: force the 8-wave kernel (gpde_fused_f16v3_kernel: the path of small
+                                    graphs, node-table attributes and gpde_hidden_fwd) where the default would be the
+                                    one-wave-per-SIMD kernel gpde_fused_f16v6_kernel (A/B, parity tests) */
     GPDE_FWD_AGG_F16 = 16,       /* with F16SPLIT: aggregation x_j (x) h_e on split-f16 MFMA too, also for small
                                     graphs (default: from 32768 edges on; three tiny pre-pass launches) */
     GPDE_FWD_AGG_F32 = 32        /* with F16SPLIT: keep the aggregation on fp32 MFMA (A/B) */
@@ -124,6 +124,13 @@ int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edge_attr, int
 int gpde_nnconv_fwd_plan(int64_t n_nodes, int64_t n_edges, int n_layers, const int32_t* dims,
                          size_t ws_bytes, int32_t* n_chunks, int64_t* nodes_per_chunk,
                          int32_t* fused_workgroups, int32_t* mode);
+
+/* Symbol (without template arguments) of the fused edge kernel gpde_nnconv_fwd launches for a graph of
+ * `n_edges` edges, this kernel MLP and these flags: "gpde_fused_f16v6_kernel" (one wave per SIMD, 64 x 128
+ * wave tile; GPDE_FWD_F16SPLIT from 32768 edges on), "gpde_fused_f16v3_kernel" (8 waves; smaller graphs,
+ * GPDE_FWD_F16SPLIT_8WAVE) or "gpde_fused_kernel" (fp32 MFMA; 2-Linear and >= 4-Linear kernels).  Host-side
+ * query, no device work; static storage.  bench.py keys its rocprofv3 / PMC records on this name. */
+const char* gpde_nnconv_fwd_kernel(int64_t n_edges, int n_layers, const int32_t* dims, uint32_t flags);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward of the fused NNConv (what autograd computes through nn_conv.py:267-282,

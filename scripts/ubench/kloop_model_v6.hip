@@ -1,0 +1,269 @@
+// Model of the v6 K loop: FOUR waves per workgroup (one per SIMD, up to 512 registers each), wave tile
+// 64 edges x 128 hidden columns.  Per 32-wide k chunk and wave: 48 f16 MFMAs (2 edge blocks x 4 column
+// blocks x 2 k16 steps x 3 split products) + 4 H1 MFMAs, 16 ds_read_b128 of W2 fragments, 2 of (W1|b1),
+// 16 conversion pairs (5 VALU each), 4 LDS-DMA pieces of the next W2 chunk image, one s_barrier.
+// Flags ablate the parts; the result is cycles per chunk (ideal 52 x 32 = 1664) and chip TFLOP/s.
+//   hipcc --offload-arch=gfx950 -O3 -o kloop_model_v6 kloop_model_v6.hip && ./kloop_model_v6
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float relu1(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+
+constexpr int TILE_B = 16384;
+// FLAGS: 1 conversions, 2 barrier, 4 W2 DMA ring + counted wait, 8 H1 MFMAs, 16 W2 fragment reads,
+//        32 keep 128 extra accumulator registers (Z) live across the loop, 64 H1 MFMAs by asm into VGPRs
+// NS: ring slots (3: DMA one chunk ahead, vmcnt(0) per chunk; 4: two chunks ahead, vmcnt(4))
+template <int FLAGS, int NS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void kern(long* out, const char* gsrc, float seed, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    char* w1s = smem + NS * TILE_B;           // 32 KiB
+    for (int i = threadIdx.x; i < (NS * TILE_B + 32768) / 4; i += 256) ((float*)smem)[i] = (float)((i * 2654435761u) >> 20) * 1e-3f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sw = (l31 >> 1) & 7;
+    const int rowb = l31 * 128;
+    const int boff[2] = {rowb + (((0 + h) ^ sw) << 4), rowb + (((2 + h) ^ sw) << 4)};
+
+    u4 ahi[2][2], alo[2][2];
+    h8 bhi[4], blo[4], B1[2], B2[2];
+    f32x16 d[2], acc[2][4], Z[2][4];
+    for (int b = 0; b < 2; ++b)
+        for (int e = 0; e < 2; ++e)
+            for (int j = 0; j < 4; ++j) { ahi[b][e][j] = 0x3c003c00u + j * 17 + lane; alo[b][e][j] = 0x14001400u + j; }
+    for (int e = 0; e < 2; ++e)
+        for (int j = 0; j < 8; ++j) { B1[e][j] = (_Float16)(seed + j * 0.1f + e); B2[e][j] = (_Float16)(seed - j * 0.1f); }
+    for (int e = 0; e < 2; ++e)
+        for (int nb = 0; nb < 4; ++nb)
+            for (int r = 0; r < 16; ++r) { acc[e][nb][r] = 0.f; Z[e][nb][r] = seed * r; }
+    for (int e = 0; e < 2; ++e)
+        for (int r = 0; r < 16; ++r) d[e][r] = seed * (r + 1) * 0.01f;
+    for (int nb = 0; nb < 4; ++nb) { bhi[nb] = *(const h8*)(ring + nb * 4096 + boff[0]); blo[nb] = *(const h8*)(ring + nb * 4096 + (boff[0] ^ 64)); }
+
+    const unsigned long long gbase = (unsigned long long)gsrc + (size_t)(blockIdx.x % 8) * 32 * TILE_B + wave * 4096;
+    const unsigned lane16 = lane * 16;
+    // the 4 pieces of a wave are 1 KiB apart in the global image AND in the LDS slot: one address, the
+    // instruction's immediate offset advances both sides
+    auto issue_w2 = [&](int chunk, int slot, int piece) {
+        unsigned long long gb = gbase + (size_t)chunk * TILE_B;
+        asm volatile("" : "+s"(gb));
+        const char* g = (const char*)(gb + lane16);
+        char* l = ring + slot * TILE_B + wave * 4096;
+        if (piece == 0) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        if (piece == 1) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 1024, 0);
+        if (piece == 2) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 2048, 0);
+        if (piece == 3) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 3072, 0);
+    };
+    // one asm statement per conversion pair (relu, hi = rtz16, lo = rn16(y - hi)): a single compiler
+    // boundary pad instead of one per instruction.  The inputs are MFMA results: the H1 MFMAs are placed
+    // >= 3 MFMAs before the first conversion that reads them (hipcc pads nothing for asm operands).
+    auto conv_a = [&](const f32x16& v, int m, int jp, unsigned& ph, unsigned& t0_, unsigned& t1_) {
+        asm("v_max_i32 %1, 0, %3\n\t"
+            "v_max_i32 %2, 0, %4\n\t"
+            "v_cvt_pkrtz_f16_f32 %0, %1, %2"
+            : "=&v"(ph), "=&v"(t0_), "=&v"(t1_) : "v"(v[8 * m + 2 * jp]), "v"(v[8 * m + 2 * jp + 1]));
+    };
+    auto conv_b = [&](int jp, unsigned ph, unsigned t0_, unsigned t1_, u4& hi, u4& lo) {
+        unsigned pl;
+        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(pl) : "v"(t0_), "v"(t1_), "v"(ph));
+        hi[jp] = ph;
+        lo[jp] = pl;
+    };
+    // H1 MFMA with a VGPR destination (the builtin lands in AGPRs in a 512-register kernel and every value
+    // then costs a v_accvgpr_read before the conversion)
+    auto h1gen = [&](f32x16& dd, h8 a1, h8 a2, h8 b1, h8 b2) {
+        if (FLAGS & 64) {
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(dd) : "v"(a1), "v"(b1));
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(dd) : "v"(a2), "v"(b2));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dd[r] = 0.f;
+            dd = mfma16(a1, b1, dd);
+            dd = mfma16(a2, b2, dd);
+        }
+    };
+
+    if (FLAGS & 4) {
+        for (int p = 0; p < 4; ++p) issue_w2(1, 1, p);
+        if (NS == 4) for (int p = 0; p < 4; ++p) issue_w2(2, 2, p);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (FLAGS & 32) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) asm volatile("" : "+a"(Z[e][nb]));
+    }
+    int slot = 0;
+    unsigned cph = 0, ct0 = 0, ct1 = 0;
+    h8 A1 = *(const h8*)(w1s + l31 * 32), A2 = *(const h8*)(w1s + l31 * 32 + 16);
+    long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        int slot1 = slot + 1 == NS ? 0 : slot + 1;            // next chunk's slot
+        int slot2 = slot1 + 1 == NS ? 0 : slot1 + 1;
+        int slot3 = slot2 + 1 == NS ? 0 : slot2 + 1;
+        const int dslot = NS == 3 ? slot2 : slot3;            // DMA target: chunk it+2 (3 slots) / it+3 (4 slots)
+        const int dchunk = (it + (NS == 3 ? 2 : 3)) & 31;
+        const char* rb0 = ring + slot * TILE_B;
+        const char* rb1 = ring + slot1 * TILE_B;
+        const char* w1n = w1s + (size_t)((((it + 1) & 31) * 32) + l31) * 32;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int cb = m;              // operand buffer of this step; the next step's is cb ^ 1
+            // where the NEXT step's B fragments live
+            const char* rn = (m == 0) ? rb0 : rb1;
+            const int bo = boff[m ^ 1];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int t = j >> 1, e = j & 1;
+                    const int i = nb * 6 + j;
+                    acc[e][nb] = mfma16(__builtin_bit_cast(h8, t == 2 ? alo[cb][e] : ahi[cb][e]), t == 0 ? blo[nb] : bhi[nb], acc[e][nb]);
+                    asm volatile("" : "+a"(acc[e][nb]));
+                    // conversion pair p of the next step's operands: first part (relu, relu, hi) after MFMA 3p,
+                    // second part (lo) after MFMA 3p + 1.  In step 1 the raw H1 of the next chunk was issued at
+                    // the end of step 0: everything one MFMA later (pair 7 after MFMAs 22 / 23).
+                    {
+                        const int q = m == 0 ? i : i - 1;
+                        if ((FLAGS & 1) && q >= 0 && q % 3 == 0 && q / 3 < 8) conv_a(d[(q / 3) >> 2], m ^ 1, (q / 3) & 3, cph, ct0, ct1);
+                        if ((FLAGS & 1) && q >= 0 && q % 3 == 1 && q / 3 < 8) {
+                            conv_b((q / 3) & 3, cph, ct0, ct1, ahi[cb ^ 1][(q / 3) >> 2], alo[cb ^ 1][(q / 3) >> 2]);
+                            asm volatile("" ::"v"(ahi[cb ^ 1][(q / 3) >> 2]), "v"(alo[cb ^ 1][(q / 3) >> 2]));
+                        }
+                    }
+                    if (FLAGS & 16) {
+                        if (j == 1) blo[nb] = *(const h8*)(rn + nb * 4096 + (bo ^ 64));
+                        if (j == 5) bhi[nb] = *(const h8*)(rn + nb * 4096 + bo);
+                    }
+                    if ((FLAGS & 4) && m == 0 && (i == 2 || i == 8 || i == 14 || i == 20)) issue_w2(dchunk, dslot, (i - 2) / 6);
+                    if ((FLAGS & 8) && m == 0 && i == 4) A1 = *(const h8*)w1n;
+                    if ((FLAGS & 8) && m == 0 && i == 10) A2 = *(const h8*)(w1n + 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (m == 0 && (FLAGS & 8)) {
+                // H1 of the next chunk (single-buffered raw H1: its last reader ran just above)
+                h1gen(d[0], A1, A2, B1[0], B2[0]);
+                h1gen(d[1], A1, A2, B1[1], B2[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (FLAGS & 4) {
+            if (NS == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // this chunk's 4 pieces stay in flight
+        }
+        if (FLAGS & 2) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot1;
+    }
+    long t1 = clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (FLAGS & 32) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) asm volatile("" : "+a"(Z[e][nb]));
+    }
+    float s = 0;
+    for (int e = 0; e < 2; ++e)
+        for (int nb = 0; nb < 4; ++nb)
+            for (int r = 0; r < 16; ++r) s += acc[e][nb][r] + ((FLAGS & 32) ? Z[e][nb][r] : 0.f);
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
+    if (s == 1234.5f) out[1] = 1;
+}
+
+// Does the immediate offset of global_load_lds advance BOTH the global address and the LDS address?
+__global__ void dma_offset_test(const unsigned* g, unsigned* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int i = threadIdx.x; i < 2048; i += 64) ((unsigned*)smem)[i] = 0xdeadbeefu;
+    __syncthreads();
+    const char* gp = (const char*)g + threadIdx.x * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (__attribute__((address_space(3))) void*)smem, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (__attribute__((address_space(3))) void*)smem, 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (__attribute__((address_space(3))) void*)smem, 16, 3072, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += 64) out[i] = ((unsigned*)smem)[i];
+}
+
+template <int FLAGS, int NS>
+void run(long* d, const char* src, const char* what) {
+    const int lds = NS * TILE_B + 32768;
+    const int iters = 2048;
+    hipFuncSetAttribute((const void*)kern<FLAGS, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((kern<FLAGS, NS>), dim3(256), dim3(256), lds, 0, d, src, 1.0f, 64);
+    hipDeviceSynchronize();
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a, 0);
+    hipLaunchKernelGGL((kern<FLAGS, NS>), dim3(256), dim3(256), lds, 0, d, src, 1.0f, iters);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    long hcyc;
+    hipMemcpy(&hcyc, d, 8, hipMemcpyDeviceToHost);
+    const int nm = 48 + ((FLAGS & 8) ? 4 : 0);
+    (void)0;
+    const double tf = 256.0 * 4 * iters * nm * 32768.0 / (ms * 1e-3) / 1e12;
+    printf("NS %d flags %2d %-46s: %6.0f cycles/chunk (ideal %d)  %7.1f TFLOP/s  %.2f ms  err=%s\n", NS, FLAGS, what,
+           (double)hcyc / iters, nm * 32, tf, ms, hipGetErrorString(hipGetLastError()));
+}
+
+int main() {
+    long* d; char* src;
+    hipMalloc(&d, 64);
+    const size_t nsrc = (size_t)8 * 32 * TILE_B;
+    hipMalloc(&src, nsrc);
+    {   // random f16 bit patterns in a sane range (power draw depends on the data)
+        unsigned short* hsrc = (unsigned short*)malloc(nsrc);
+        unsigned s = 12345u;
+        for (size_t i = 0; i < nsrc / 2; ++i) { s = s * 1664525u + 1013904223u; hsrc[i] = (unsigned short)(0x3000u + ((s >> 16) & 0x0fffu) + ((s >> 3) & 0x8000u)); }
+        hipMemcpy(src, hsrc, nsrc, hipMemcpyHostToDevice);
+        free(hsrc);
+    }
+    {
+        unsigned *g, *o, hg[2048], ho[2048];
+        for (int i = 0; i < 2048; ++i) hg[i] = i;
+        hipMalloc(&g, 8192); hipMalloc(&o, 8192);
+        hipMemcpy(g, hg, 8192, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(dma_offset_test, dim3(1), dim3(64), 8192, 0, g, o);
+        hipMemcpy(ho, o, 8192, hipMemcpyDeviceToHost);
+        int ok = 1;
+        for (int i = 0; i < 2048; ++i) {
+            const int piece = i / 256;
+            const unsigned want = (piece == 0 || piece == 1 || piece == 3) ? (unsigned)i : 0xdeadbeefu;
+            if (ho[i] != want) { if (ok) printf("dma offset test: word %d = %u, expected %u\n", i, ho[i], want); ok = 0; }
+        }
+        printf("dma immediate offset advances global AND lds address: %s\n", ok ? "YES" : "NO");
+    }
+    run<0, 3>(d, src, "48 MFMA only");
+    run<16, 3>(d, src, "+ 16 W2 fragment reads");
+    run<16 | 8, 3>(d, src, "+ H1 (4 MFMA, 2 LDS reads)");
+    run<16 | 8 | 1, 3>(d, src, "+ conversions");
+    run<16 | 8 | 1 | 32, 3>(d, src, "+ 128 live Z registers");
+    run<16 | 8 | 1 | 32 | 2, 3>(d, src, "+ s_barrier per chunk");
+    run<16 | 8 | 1 | 32 | 2 | 4, 3>(d, src, "+ DMA ring, wait per chunk (FULL, 3 slots)");
+    run<16 | 8 | 1 | 32 | 4, 3>(d, src, "DMA, no barrier (racy, timing only)");
+    run<16 | 8 | 1 | 32 | 2 | 4, 4>(d, src, "FULL, 4 slots (DMA two chunks ahead)");
+    run<64 | 16 | 8 | 1 | 32 | 2 | 4, 3>(d, src, "FULL, 3 slots, H1 MFMA into VGPRs (asm)");
+    run<64 | 16 | 8 | 1 | 32 | 2 | 4, 4>(d, src, "FULL, 4 slots, H1 MFMA into VGPRs (asm)");
+    return 0;
+}

@@ -167,7 +167,7 @@ def test_module_forward_drop_in():
             g["x"].to(d), g["edge_index"].to(d), g["edge_attr"].to(d))
 
 
-F16_VARIANTS = ["f16split", "f16split_agg16", "f16split_agg32", "f16split4w", "f16split2wg", "f16splitq"]   # default + A/B kernels
+F16_VARIANTS = ["f16split", "f16split_agg16", "f16split_agg32", "f16split_8wave"]   # default + forced aggregation arithmetic / kernel
 
 
 @pytest.mark.parametrize("variant", F16_VARIANTS)
