@@ -10,6 +10,7 @@ one H node: autograd sums their dL/dH and `HiddenFunction.backward` runs the MLP
 from __future__ import annotations
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import ops
 
@@ -30,6 +31,7 @@ class NNConvFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable        # the native backward is not itself differentiable: create_graph=True raises
     def backward(ctx, grad_out):
         if ctx.attr_needs_grad:
             raise NotImplementedError(
@@ -68,6 +70,7 @@ class HiddenFunction(torch.autograd.Function):
         return h
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_h):
         if ctx.attr_needs_grad:
             raise NotImplementedError(
@@ -92,6 +95,7 @@ class NNConvHiddenFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable        # the native backward is not itself differentiable: create_graph=True raises
     def backward(ctx, grad_out):
         x, hidden, w_last, b_last, root = ctx.saved_tensors
         gx, gh, gw, gb, groot, gbias = ops.nnconv_backward_hidden_raw(

@@ -664,12 +664,8 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 EdgeBwdArgs ea{x, rowptr, src, dst, dZ, dS, Hlast, dUc, dx, e0, e1, na, K2P};
                 const size_t lds = (size_t)4 * (32 * EB_XS + 32 * EB_HS) * 4;
                 const size_t lds2 = (size_t)(2 * EB2_DZ + 4 * 2 * EB2_H) * 4 + 4 * 64 * 4;
-                static bool set = false;
-                if (!set) {
-                    GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_edge_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_edge_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-                    set = true;
-                }
+                static GpdeLdsOnce once;
+                if (int rc_ = once.ensure(gpde_edge_bwd_kernel, gpde_edge_bwd2_kernel)) return rc_;
                 if (!dx) { gpde_set_error("gpde_nnconv_bwd: grad_x must be provided"); return GPDE_EINVAL; }
                 // staged kernel where a 128-slot group rarely spans more than two destinations
                 const char* fe = getenv("GPDE_EDGE_BWD");          // "1" / "2": force a variant (tests, A/B)

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "gpde.h"
+#include <atomic>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -70,6 +71,29 @@ void gpde_set_error(const char* fmt, ...);
             return GPDE_EHIP;                                                           \
         }                                                                               \
     } while (0)
+
+// Raise a kernel's dynamic-LDS limit once per DEVICE (the attribute is per device; a process-wide "done" flag
+// breaks a second GPU in the same process).  Thread-safe: the worst case is two threads setting
+// the same value.  The limit is set to the whole 160 KiB so that later, larger requests need no second call.
+struct GpdeLdsOnce {
+    std::atomic<unsigned> done{0};       // bit d: device d has the attribute
+    template <typename... Fn>
+    int ensure(Fn... fns) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) dev = 0;
+        if (done.load(std::memory_order_acquire) & (1u << dev)) return GPDE_OK;
+        const void* fl[] = {(const void*)fns...};
+        for (const void* f : fl) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) {
+                gpde_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e));
+                return GPDE_EHIP;
+            }
+        }
+        done.fetch_or(1u << dev, std::memory_order_release);
+        return GPDE_OK;
+    }
+};
 
 // ---- kernel launchers (one translation unit each) ---------------------------------------------
 struct GpdeFusedArgs {

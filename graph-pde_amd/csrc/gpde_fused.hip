@@ -455,14 +455,9 @@ int gpde_launch_fused(int mode, bool f16split, const GpdeFusedArgs& a, hipStream
     const int ns = a.K2P / GP_TN;
     const dim3 grid(a.n_groups * ns), block(256);
     const size_t lds = (size_t)(2 * BS_TILE + GP_WAVES * XS_WAVE + GP_WAVES * GP_TE) * sizeof(float) + 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void* fns[4] = {(const void*)gpde_fused_kernel<0, false>, (const void*)gpde_fused_kernel<1, false>,
-                              (const void*)gpde_fused_kernel<1, true>, (const void*)gpde_fused_kernel<2, false>};
-        for (const void* f : fns)
-            GP_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static GpdeLdsOnce once;
+    if (int rc = once.ensure(gpde_fused_kernel<0, false>, gpde_fused_kernel<1, false>, gpde_fused_kernel<1, true>,
+                             gpde_fused_kernel<2, false>)) return rc;
     switch (mode) {
         case 0: hipLaunchKernelGGL((gpde_fused_kernel<0, false>), grid, block, lds, stream, a); break;
         case 1:

@@ -522,12 +522,10 @@ int gpde_launch_fused_f16v3(const GpdeFusedArgs& a, hipStream_t stream) {
     const int ns = a.K2P / GP_TN;
     const dim3 grid(a.n_groups * ns), block(512);
     const size_t lds = v3_lds_bytes(a.K1P);
-    // set per launch: the attribute is per device, a process-wide "done" flag would be wrong for a second GPU
-    // and racy between threads (include/gpde.h promises re-entrancy)
-    const void* fn = a.hout ? (const void*)gpde_fused_f16v3_kernel<true, false, false>
-                   : a.kt ? (a.xs ? (const void*)gpde_fused_f16v3_kernel<false, true, true> : (const void*)gpde_fused_f16v3_kernel<false, false, true>)
-                   : (a.xs ? (const void*)gpde_fused_f16v3_kernel<false, true, false> : (const void*)gpde_fused_f16v3_kernel<false, false, false>);
-    GP_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static GpdeLdsOnce once;
+    if (int rc = once.ensure(gpde_fused_f16v3_kernel<false, false, false>, gpde_fused_f16v3_kernel<false, true, false>,
+                             gpde_fused_f16v3_kernel<true, false, false>, gpde_fused_f16v3_kernel<false, false, true>,
+                             gpde_fused_f16v3_kernel<false, true, true>)) return rc;
     if (a.hout) {
         if (a.kt) { gpde_set_error("hidden-activation output from node-table attributes is not built"); return GPDE_EUNSUPPORTED; }
         hipLaunchKernelGGL((gpde_fused_f16v3_kernel<true, false, false>), grid, block, lds, stream, a);

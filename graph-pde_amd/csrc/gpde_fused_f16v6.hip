@@ -563,8 +563,8 @@ int gpde_launch_fused_f16v6(const GpdeFusedArgs& a, hipStream_t stream) {
     const int ns = a.K2P / GP_TN;
     const dim3 grid(a.n_groups * ns), block(256);
     const size_t lds = v6_lds_bytes(a.K1P);
-    // per call: the attribute is per device and cheap to set (no process-wide "done" flag)
-    GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_fused_f16v6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static GpdeLdsOnce once;
+    if (int rc = once.ensure(gpde_fused_f16v6_kernel)) return rc;
     hipLaunchKernelGGL(gpde_fused_f16v6_kernel, grid, block, lds, stream, a);
     GP_LAUNCH_CHECK("gpde_fused_f16v6_kernel");
     return GPDE_OK;

@@ -238,12 +238,8 @@ int gpde_launch_zagg(const GpdeFusedArgs& a, hipStream_t stream) {
     const int ns = a.K2P / GP_TN;
     const dim3 grid(a.n_groups * ns), block(256);
     const size_t lds = (size_t)GP_WAVES * 2 * XS_TILE * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_zagg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gpde_zagg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static GpdeLdsOnce once;
+    if (int rc = once.ensure(gpde_zagg_kernel<false>, gpde_zagg_kernel<true>)) return rc;
     if (a.xs && a.hmax) hipLaunchKernelGGL(gpde_zagg_kernel<true>, grid, block, lds, stream, a);
     else hipLaunchKernelGGL(gpde_zagg_kernel<false>, grid, block, lds, stream, a);
     GP_LAUNCH_CHECK("gpde_zagg_kernel");

@@ -68,8 +68,8 @@ def _key(edge_attr: torch.Tensor, csr, hidden_params: List[Optional[torch.Tensor
     st = edge_attr.untyped_storage()
     grad = torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in hidden_params)
     return (str(edge_attr.device), st.data_ptr(), edge_attr.storage_offset(), tuple(edge_attr.shape),
-            tuple(edge_attr.stride()), edge_attr._version, id(csr),
-            tuple((0, 0) if p is None else (p.data_ptr(), p._version) for p in hidden_params),
+            tuple(edge_attr.stride()), ops._ver(edge_attr), id(csr),
+            tuple((0, 0) if p is None else (p.data_ptr(), ops._ver(p)) for p in hidden_params),
             precision, grad)
 
 

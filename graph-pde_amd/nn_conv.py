@@ -7,9 +7,11 @@
 
 Same constructor, attributes (`in_channels, out_channels, nn, aggr, root, bias`), parameter
 names / shapes (`root [in,out]`, `bias [out]`), `reset_parameters`, `forward(x, edge_index,
-edge_attr)`, `__repr__`; instances pickle with `torch.save(model)` (no native handles on the
-module).  `forward` runs the fused HIP operator of libgpde.so; there is no other execution path
-(CPU tensors raise).
+edge_attr)`, `message(x_j, pseudo)`, `update(aggr_out, x)`, `__repr__`; instances pickle with
+`torch.save(model)` (no native handles on the module).  `forward` runs the fused HIP operator of
+libgpde.so; there is no other execution path: CPU tensors (a model moved back with `model.cpu()`,
+UAI1_full_resolution.py:287-303) are staged to the current HIP device, run through the same kernels and
+the result is copied back - without a HIP device the call raises.
 """
 from __future__ import annotations
 
@@ -39,10 +41,13 @@ def _reset(nn):
 
 
 def _uniform(size, tensor):
-    """`torch_geometric.nn.inits.uniform`: U(-1/sqrt(size), 1/sqrt(size))."""
+    """`torch_geometric.nn.inits.uniform`: U(-1/sqrt(size), 1/sqrt(size)).  Written under no_grad on the
+    parameter itself (not through `.data`): the in-place version counter moves, so packed-weight caches
+    keyed on it cannot serve the old values."""
     if tensor is not None:
         bound = 1.0 / math.sqrt(size)
-        tensor.data.uniform_(-bound, bound)
+        with torch.no_grad():
+            tensor.uniform_(-bound, bound)
 
 
 class NNConv_old(torch.nn.Module):
@@ -80,6 +85,8 @@ class NNConv_old(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_attr):      # nn_conv.py:267-271
         x = x.unsqueeze(-1) if x.dim() == 1 else x
+        if not x.is_cuda:
+            return self._forward_staged(x, edge_index, edge_attr)
         if isinstance(edge_attr, ops.NodeAttr):
             # opt-in: attributes read from node data inside the kernel.  Inference on
             # the default f16-split kernel; anything else takes the tensor the reference would build.
@@ -92,16 +99,24 @@ class NNConv_old(torch.nn.Module):
                 return ops.nnconv_forward_nodeattr_raw(x, csr, edge_attr, pm, self.root, self.bias, self.aggr)
             edge_attr = edge_attr.materialize(edge_index)
         pseudo = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
+        lin = ops.mlp_linears(self.nn)
+        weights = [l.weight for l in lin]
+        biases = [l.bias for l in lin]
+        return self._propagate(x, edge_index, pseudo, weights, biases, self.root, self.bias, use_hidden_cache=True)
+
+    def _check_width(self):
         if self.in_channels != ops.WIDTH or self.out_channels != ops.WIDTH:
             raise NotImplementedError(
                 f"the MI355X operator is built for in_channels = out_channels = {ops.WIDTH} (the "
                 f"width of every reference configuration), got {self.in_channels}->{self.out_channels}")
-        lin = ops.mlp_linears(self.nn)
-        weights = [l.weight for l in lin]
-        biases = [l.bias for l in lin]
+
+    def _propagate(self, x, edge_index, pseudo, weights, biases, root, bias, use_hidden_cache):
+        """propagate() of the reference (gather, message, aggregate, update) as ONE native operator on device
+        tensors; `weights / biases / root / bias` are the tensors to use (the module's own, or staged copies)."""
+        self._check_width()
         # cross-depth reuse (hidden_cache.py): this module applied again with the same edge_attr and
         # weights shares one hidden-activation tensor with the earlier applications
-        if hidden_cache.MODE != "off" and x.is_cuda and self.aggr in ("add", "mean") and \
+        if use_hidden_cache and hidden_cache.MODE != "off" and self.aggr in ("add", "mean") and \
                 pseudo.dtype == torch.float32 and x.dtype == torch.float32:
             csr = ops.csr_for(edge_index, x.size(0))
             pm = ops.pack_mlp(weights, biases)
@@ -111,12 +126,66 @@ class NNConv_old(torch.nn.Module):
             if hit is not None:
                 hidden, hmax, hn = hit
                 if hn < csr.n_nodes:        # H of the leading nodes only: mixed forward (inference)
-                    return ops.nnconv_forward_mixed_raw(x, csr, pseudo, hidden, hmax, hn, pm, self.root,
-                                                        self.bias, self.aggr)
+                    return ops.nnconv_forward_mixed_raw(x, csr, pseudo, hidden, hmax, hn, pm, root,
+                                                        bias, self.aggr)
                 return NNConvHiddenFunction.apply(x, hidden, csr, pm, weights[-1], biases[-1],
-                                                  self.root, self.bias, self.aggr, hmax)
-        return NNConvFunction.apply(x, edge_index, pseudo, self.root, self.bias, self.aggr,
+                                                  root, bias, self.aggr, hmax)
+        return NNConvFunction.apply(x, edge_index, pseudo, root, bias, self.aggr,
                                     len(weights), *weights, *biases)
+
+    def _forward_staged(self, x, edge_index, edge_attr):
+        """CPU tensors (`model.cpu()` + evaluation, UAI1_full_resolution.py:287-303): inputs and
+        parameters are copied to the current HIP device (`.to()` is differentiable, so gradients flow back to
+        the CPU parameters), the SAME kernels run, the output returns to the caller's device."""
+        dev = ops.staging_device()
+        if isinstance(edge_attr, ops.NodeAttr):
+            edge_attr = edge_attr.materialize(edge_index)
+        pseudo = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
+        ei_d = ops.stage_const(edge_index, dev)
+        ea_d = pseudo.to(dev) if pseudo.requires_grad else ops.stage_const(pseudo, dev)
+        lin = ops.mlp_linears(self.nn)
+        weights = [l.weight.to(dev) for l in lin]
+        biases = [None if l.bias is None else l.bias.to(dev) for l in lin]
+        root = None if self.root is None else self.root.to(dev)
+        bias = None if self.bias is None else self.bias.to(dev)
+        out = self._propagate(x.to(dev), ei_d, ea_d, weights, biases, root, bias, use_hidden_cache=False)
+        return out.to(x.device)
+
+    def message(self, x_j, pseudo):                    # nn_conv.py:273-275
+        """m_e = x_j[e] . W(pseudo_e)  ([E, in] x [E, in, out] -> [E, out]).  Computed by the same native
+        operator on the graph in which every edge has its own target (E nodes, edge e: e -> e, aggr='add', no
+        root / bias): out[e] = x_j[e] . h_Theta(pseudo_e), exactly the reference's message."""
+        x_j = x_j.unsqueeze(-1) if x_j.dim() == 1 else x_j
+        pseudo = pseudo.unsqueeze(-1) if pseudo.dim() == 1 else pseudo
+        e = x_j.size(0)
+        dev = x_j.device if x_j.is_cuda else ops.staging_device()
+        ar = torch.arange(e, device=dev, dtype=torch.int64)
+        ident = torch.stack([ar, ar])
+        lin = ops.mlp_linears(self.nn)
+        weights = [l.weight.to(dev) for l in lin]
+        biases = [None if l.bias is None else l.bias.to(dev) for l in lin]
+        self._check_width()
+        out = NNConvFunction.apply(x_j.to(dev), ident, pseudo.to(dev), None, None, "add", len(weights), *weights, *biases)
+        return out.to(x_j.device)
+
+    def update(self, aggr_out, x):                     # nn_conv.py:277-282
+        """aggr_out + x . root + bias.  The `x . root + bias` term is the native operator on the graph without
+        edges (its epilogue kernel); the sum with aggr_out is one elementwise add."""
+        if self.root is None and self.bias is None:
+            return aggr_out
+        self._check_width()
+        dev = x.device if x.is_cuda else ops.staging_device()
+        n = x.size(0)
+        empty = torch.empty(2, 0, dtype=torch.int64, device=dev)
+        lin = ops.mlp_linears(self.nn)
+        weights = [l.weight.detach().to(dev) for l in lin]
+        biases = [None if l.bias is None else l.bias.detach().to(dev) for l in lin]
+        k0 = weights[0].size(1)
+        term = NNConvFunction.apply(x.to(dev), empty, torch.empty(0, k0, device=dev),
+                                    None if self.root is None else self.root.to(dev),
+                                    None if self.bias is None else self.bias.to(dev), "add", len(weights),
+                                    *weights, *biases)
+        return aggr_out + term.to(aggr_out.device)
 
     def __repr__(self):                               # nn_conv.py:284-286
         return "{}({}, {})".format(self.__class__.__name__, self.in_channels, self.out_channels)

@@ -45,6 +45,42 @@ def _stream_ptr(device) -> int:
     return int(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _ver(t: torch.Tensor) -> int:
+    """In-place version counter for cache keys; inference tensors do not track one (reading `_version`
+    raises) and cannot be modified in place outside inference mode, so 0 is a valid stand-in."""
+    return 0 if t.is_inference() else t._version
+
+
+def staging_device() -> torch.device:
+    """Where CPU tensors are staged: the current HIP device.  There is ONE execution path - the HIP kernels
+    of libgpde.so; a model moved back with `model.cpu()` (UAI1_full_resolution.py:287-303) has its inputs and
+    parameters copied to the GPU for the call and the result copied back.  Without a GPU this raises."""
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "the NNConv hot path runs only on an MI355X through libgpde.so: CPU tensors are staged to the "
+            "current HIP device, and no HIP device is visible (no CPU / composite fallback exists by design)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+_stage_cache: "dict[tuple, tuple]" = {}        # constant inputs (edge_index, edge_attr) staged once per tensor
+
+
+def stage_const(t: torch.Tensor, dev: torch.device) -> torch.Tensor:
+    """Device copy of a CPU tensor that is not differentiated (edge_index, edge_attr), cached on the tensor's
+    storage + version so that the `depth` applications of one forward share the copy (and its CSR)."""
+    if t.is_cuda:
+        return t
+    st = t.untyped_storage()
+    key = (st.data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype, _ver(t), str(dev))
+    hit = _stage_cache.pop(key, None)
+    if hit is None:
+        hit = (st, t.detach().to(dev))
+    _stage_cache[key] = hit                     # MRU
+    while len(_stage_cache) > 16:
+        _stage_cache.pop(next(iter(_stage_cache)))
+    return hit[1]
+
+
 def _require_cuda(t: torch.Tensor, name: str):
     if not t.is_cuda:
         raise RuntimeError(
@@ -60,6 +96,9 @@ def build_csr(edge_index: torch.Tensor, n_nodes: int) -> Csr:
     lib = _lib.lib()
     dev = edge_index.device
     e = int(edge_index.size(1))
+    if e == 0:                     # a graph without edges (update() of the module surface): nothing to sort
+        z = torch.zeros(0, dtype=torch.int32, device=dev)
+        return Csr(n_nodes, 0, torch.zeros(n_nodes + 1, dtype=torch.int32, device=dev), z, z.clone(), z.clone())
     rowptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
     src = torch.empty(e, dtype=torch.int32, device=dev)
     dst = torch.empty(e, dtype=torch.int32, device=dev)
@@ -92,7 +131,7 @@ def csr_for(edge_index: torch.Tensor, n_nodes: int) -> Csr:
     cannot be recycled for a different graph while cached; the cache is a byte-bounded LRU."""
     storage = edge_index.untyped_storage()
     key = (str(edge_index.device), storage.data_ptr(), edge_index.storage_offset(),
-           tuple(edge_index.shape), tuple(edge_index.stride()), edge_index._version, n_nodes)
+           tuple(edge_index.shape), tuple(edge_index.stride()), _ver(edge_index), n_nodes)
     hit = _csr_cache.pop(key, None)
     if hit is not None:
         _csr_cache[key] = hit            # move to the MRU end
@@ -106,8 +145,13 @@ def csr_for(edge_index: torch.Tensor, n_nodes: int) -> Csr:
 
 
 def clear_caches():
+    """Drop the CSR / packed-weight / staging caches.  REQUIRED after writing a parameter or an index tensor
+    through `.data` (`p.data.add_(..)`, `p.data.clamp_()`, `dist.broadcast(p.data)`): such writes do not bump
+    the version counter the cache keys are built on (tests/test_host_logic.py pins this contract)."""
     _csr_cache.clear()
     _pack_cache.clear()
+    _pack_by_ptr.clear()
+    _stage_cache.clear()
 
 
 # ----------------------------------------------------------------------------------------------
@@ -153,10 +197,15 @@ class PackedMlp:
     dims_c: object                  # ctypes int32 array (kept alive)
 
 
-_pack_cache: "dict[tuple, tuple]" = {}       # key -> (weakrefs of the parameters, PackedMlp)
+_pack_cache: "dict[tuple, tuple]" = {}       # key -> (weakrefs of the parameters, PackedMlp); LRU order
+_pack_by_ptr: "dict[tuple, tuple]" = {}      # parameter addresses -> current key (older versions are evicted)
+_PACK_CACHE_MAX_BYTES = 1 << 30
 
 
 def pack_mlp(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]) -> PackedMlp:
+    """gpde_mlp_pack, cached per parameter set and version.  An optimizer step bumps the versions: the new
+    pack REPLACES the entry of the same parameter addresses (no dead packs pile up: one [6,1024,1024,4096]
+    pack is 24 MB), and the cache is a byte-bounded LRU."""
     lib = _lib.lib()
     n = len(weights)
     for w in weights:
@@ -164,13 +213,15 @@ def pack_mlp(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Te
         if w.dtype != torch.float32:
             raise NotImplementedError(f"kernel-network weights must be float32, got {w.dtype}")
     dims = tuple([int(weights[0].size(1))] + [int(w.size(0)) for w in weights])
-    key = tuple((w.data_ptr(), w._version) for w in weights) + \
-        tuple((0, 0) if b is None else (b.data_ptr(), b._version) for b in biases) + (dims,)
-    hit = _pack_cache.get(key)
+    ptrs = tuple(w.data_ptr() for w in weights) + tuple(0 if b is None else b.data_ptr() for b in biases) + (dims,)
+    key = tuple((w.data_ptr(), _ver(w)) for w in weights) + \
+        tuple((0, 0) if b is None else (b.data_ptr(), _ver(b)) for b in biases) + (dims,)
+    hit = _pack_cache.pop(key, None)
     if hit is not None:
         refs, pm = hit
         # same parameter objects still alive => the addresses were not recycled
         if all(r() is t for r, t in zip(refs, list(weights) + [b for b in biases if b is not None])):
+            _pack_cache[key] = hit           # MRU
             return pm
     dims_c = _lib.dims_array(dims)
     nbytes = int(lib.gpde_mlp_pack_bytes(n, dims_c))
@@ -186,10 +237,19 @@ def pack_mlp(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Te
         rc = lib.gpde_mlp_pack(n, dims_c, wp, bp, packed.data_ptr(), nbytes, _stream_ptr(dev))
     _lib.check(rc, "gpde_mlp_pack")
     pm = PackedMlp(dims, packed, dims_c)
-    if len(_pack_cache) >= 256:
-        _pack_cache.pop(next(iter(_pack_cache)))
+    old_key = _pack_by_ptr.get(ptrs)
+    if old_key is not None:
+        _pack_cache.pop(old_key, None)       # the same parameters at an older version
     refs = [weakref.ref(t) for t in list(weights) + [b for b in biases if b is not None]]
     _pack_cache[key] = (refs, pm)
+    _pack_by_ptr[ptrs] = key
+    while len(_pack_cache) > 1 and sum(v[1].packed.numel() * 4 for v in _pack_cache.values()) > _PACK_CACHE_MAX_BYTES:
+        k0 = next(iter(_pack_cache))
+        _pack_cache.pop(k0)
+    if len(_pack_by_ptr) > 4096:
+        live = set(_pack_cache)
+        for k in [k for k, v in _pack_by_ptr.items() if v not in live]:
+            _pack_by_ptr.pop(k)
     return pm
 
 

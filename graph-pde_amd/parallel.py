@@ -47,38 +47,48 @@ def shard(items: Sequence, rank: int, world: int) -> List:
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], world: int | None = None,
                         group=None, average: bool = True) -> int:
     """Sum (or average) `p.grad` of every parameter across ranks with ONE flat all-reduce.
-    Parameters without a gradient contribute zeros so all ranks agree on the layout.  Returns the
-    number of elements reduced."""
+    Parameters without a gradient on this rank contribute zeros so all ranks agree on the layout; one
+    extra element per parameter carries "some rank had a gradient", and a parameter that had none on
+    EVERY rank keeps `grad = None` - with the reference optimizer (Adam, weight_decay=5e-4,
+    UAI1_full_resolution.py:242) a zero gradient would still decay the weight and create Adam state, and
+    the training result would depend on the world size.  Returns the number of gradient elements reduced."""
     params = [p for p in params if p.requires_grad]
     if not params:
         return 0
     if world is None:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
+    n_grad = sum(p.numel() for p in params)
     if world == 1:
-        return sum(p.numel() for p in params)
+        return n_grad
     dev, dt = params[0].device, params[0].dtype
-    flat = torch.zeros(sum(p.numel() for p in params), device=dev, dtype=dt)
+    flat = torch.zeros(n_grad + len(params), device=dev, dtype=dt)
     off = 0
-    for p in params:
+    for i, p in enumerate(params):
         if p.grad is not None:
             flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            flat[n_grad + i] = 1.0
         off += p.numel()
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    has = flat[n_grad:].cpu()                 # one small device->host copy per step
     if average:
-        flat /= world
+        flat[:n_grad] /= world
     off = 0
-    for p in params:
-        g = flat[off:off + p.numel()].view_as(p)
-        if p.grad is None:
-            p.grad = g.clone()
-        else:
-            p.grad.copy_(g)
+    for i, p in enumerate(params):
+        if float(has[i]) > 0.0:
+            g = flat[off:off + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
         off += p.numel()
-    return flat.numel()
+    return n_grad
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
-    """Replicate rank `src`'s weights (start of a data-parallel run)."""
+    """Replicate rank `src`'s weights (start of a data-parallel run).  The broadcast writes into
+    `t.detach()` under no_grad - it shares the parameter's version counter, so the packed-weight / hidden
+    caches of graph_pde_amd.ops see the new values (a write through `.data` would not bump it)."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src, group=group)
+        with torch.no_grad():
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.detach(), src=src, group=group)

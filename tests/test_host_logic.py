@@ -53,13 +53,40 @@ def test_module_pickles_like_torch_save_model():
     pickle.dumps(conv)
 
 
-def test_cpu_tensors_are_refused_not_silently_computed():
+@pytest.mark.skipif(torch.cuda.is_available(), reason="with a HIP device CPU tensors are staged to it (GPU tier)")
+def test_cpu_tensors_without_a_gpu_raise_not_silently_compute():
+    """CPU tensors are STAGED to the HIP device (one execution path); on a box without one the call must fail
+    loudly - there is no composite / oracle fallback to fall into."""
     conv = gp.NNConv_old(64, 64, DenseNet([6, 8, 4096], torch.nn.ReLU), aggr="mean")
     x = torch.randn(5, 64)
     ei = torch.tensor([[0, 1, 2], [1, 2, 3]])
     ea = torch.randn(3, 6)
     with pytest.raises(RuntimeError, match="no CPU"):
         conv(x, ei, ea)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        conv.message(x[:3], ea)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        conv.update(x, x)
+
+
+def test_module_surface_has_the_reference_methods():
+    """nn_conv.py:234-286: __init__, reset_parameters, forward, message, update, __repr__."""
+    import inspect
+    for name, params in (("forward", ["self", "x", "edge_index", "edge_attr"]), ("message", ["self", "x_j", "pseudo"]),
+                         ("update", ["self", "aggr_out", "x"]), ("reset_parameters", ["self"])):
+        assert list(inspect.signature(getattr(gp.NNConv_old, name)).parameters) == params, name
+
+
+def test_version_helper_accepts_inference_tensors():
+    with torch.inference_mode():
+        t = torch.arange(4)
+    assert ops._ver(t) == 0                      # reading t._version would raise
+    u = torch.zeros(3)
+    v0 = ops._ver(u)
+    u.add_(1)
+    assert ops._ver(u) == v0 + 1
+    u.data.add_(1)                               # the documented hole: .data writes do not move the counter
+    assert ops._ver(u) == v0 + 1
 
 
 def test_unsupported_configurations_fail_loudly():
