@@ -1,39 +1,50 @@
 #!/usr/bin/env python3
 """Benchmark of the fused NNConv forward on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config g241|g61|g16] [--kernel-width 1024]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config g241|g121|g61|g16] [--kernel-width 1024]
+    python bench.py --train [--gpus N] ...          # training-step mode (BASELINE config 5 shape, see below)
 
-One "step" = one `conv(x, edge_index, edge_attr)` forward of the headline operator on one PDE
-sample: the Darcy-241^2 r=0.10 lattice radius graph (N = 58,081 nodes, E = 95,539,625 edges,
-BASELINE.json configs[1]) with the kernel MLP DenseNet([6,1024,1024,4096]), width 64, aggr='mean',
-root + bias (UAI1_full_resolution.py:21,56-59).  Inputs are synthetic of that shape (SURVEY.md
-§8d), resident in HBM and with the destination CSR already built (its build time is printed to
-stderr) when the timed region starts.  N > 1: one process per GPU (torch.distributed / RCCL for
-the barrier only), each rank runs its own independent sample: weak scaling, no data-path
-collective.  Rank 0 prints ONE JSON line.
+One "step" = one `conv(x, edge_index, edge_attr)` forward of the headline operator on one PDE sample: the
+Darcy-241^2 r=0.10 lattice radius graph (N = 58,081 nodes, E = 95,539,625 edges, BASELINE.json configs[1])
+with the kernel MLP DenseNet([6,1024,1024,4096]), width 64, aggr='mean', root + bias
+(UAI1_full_resolution.py:21,56-59).  Inputs are synthetic of that shape, resident in HBM and
+with the destination CSR already built (its build time goes to stderr) when the timed region starts.
+N > 1: one process per GPU (torch.distributed / RCCL for the barrier only), each rank runs its own
+independent sample: weak scaling, no data-path collective.  Rank 0 prints ONE JSON line.
 
-Extra objects on the line:
-  precision     "f16split" (default): the k1 x k2 hidden layer runs on f16 MFMA with two-term
-                operand splitting and fp32 accumulation (error class of fp32);
-                "f32": every contraction on fp32 MFMA (exact fmaf chains).  `alt_precision`
-                carries the other mode's throughput and the distance between the two outputs.
-  roofline      dominant kernel = gpde_fused_*kernel (edge MLP + outer-product aggregation).
-                bound 'mfma' (fp32 MFMA, 157.3 TFLOP/s): the path is compute-bound.
-                achieved = ALGORITHMIC FLOPs of the reference formulation (10,506,304 FLOP/edge at
-                1024^2) x edges per launch / average launch duration (HIP events recorded inside
-                libgpde.so on the kernel's own stream).  The kernel re-associates the last layer
-                 and executes ~4.4x fewer FLOPs, so `frac` can exceed 1;
-                `frac_executed` is executed FLOPs / peak.  The HBM view BASELINE.json asks for is
-                in `hbm_*` (40.5 algorithmic B/edge vs 8 TB/s).
-  cpu_baseline  the CPU oracle (plain-PyTorch restatement of the reference path, kind "port")
-                timed on this host's cores on a bounded sample: all in-edges of a stratified
-                subset of destination rows of the same graph; the same rows give `rel_l2_sample`.
+`value` = whole-job M-edges/s over the K timed steps bracketed by barrier + synchronize (max over ranks);
+`median_step_ms` / `value_at_median` come from per-step HIP events on the kernels' stream (SURVEY.md §8d asks
+for the median).  Objects on the line:
+  roofline      of the dominant kernel (its symbol from gpde_nnconv_fwd_kernel).  The path is compute bound
+                (SURVEY.md §8d), so `bound` = "mfma".  `achieved` = MFMA FLOPs the kernel EXECUTES per launch /
+                average launch duration (HIP events inside libgpde.so on the kernel's own stream), `peak` = the
+                dense peak of the pipe it runs on (f16 2.5 PFLOP/s, fp32 157.3 TFLOP/s), `frac` = achieved/peak.
+                `algorithmic_ratio` = the reference formulation's FLOPs (10,506,304 per edge at 1024^2) at the
+                same duration / the fp32 MFMA peak - above 1 because the kernel re-associates the last layer
+                 and runs the hidden layer on the f16 pipe; NOT a roofline fraction.  `traffic` =
+                HBM-side bytes per launch from the PMC record of THIS kernel symbol in profiles/traffic_r02.json
+                (null when the record is of another kernel), next to the algorithmic bytes per launch.
+  alt_precision the exact-fp32 arithmetic (every contraction on fp32 MFMA) on the same inputs: median of >= 5
+                steps, and the distance between the two outputs.
+  cpu_baseline  the CPU oracle (plain-PyTorch restatement of the reference path, kind "port") timed on this
+                host's cores on a bounded sample: all in-edges (>= 1 M) of a stratified subset of destination
+                rows of the same graph; the same rows give `rel_l2_sample`.
+  mgkn          BASELINE configs 3 and 4 (MGKN-orthogonal Burgers-1D s=8192, MGKN-general Darcy-2D L=5):
+                ms per model forward, NNConv calls, M-edge-applications/s, max rel-L2 of the distinct NNConv
+                applications vs the fp64 oracle on the same tensors, time share per kernel kind.
+  depth_reuse   cross-depth reuse probe (s=61, depth 6).
+
+--train: one training step per rank and step = forward + native backward (gpde_nnconv_bwd) of a depth-`--depth`
+KernelNN-shaped stack on the rank's own sample + ONE flat RCCL gradient all-reduce (parallel.allreduce_gradients)
++ Adam; reports samples/s, ms/step and the all-reduce share.  Default graph g61 (the reference's own training
+resolution, UAI1_full_resolution.py:39-46).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -44,7 +55,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 CONFIGS = {
-    # name: (s, r)   BASELINE.json configs[1] is g241; g61/g16 are quick-look sizes
+    # name: (s, r)   BASELINE.json configs[1] is g241; the others are quick-look sizes
     "g241": (241, 0.10),
     "g121": (121, 0.10),
     "g61": (61, 0.10),
@@ -53,6 +64,7 @@ CONFIGS = {
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+TRAFFIC_FILE = os.path.join(REPO, "profiles", "traffic_r02.json")
 
 
 def log(*a):
@@ -67,42 +79,199 @@ def algorithmic_flops_per_edge(dims, w=64):
     return f + 2 * w * w + w
 
 
-def executed_flops_per_edge(dims, w=64, precision="f32"):
-    """MFMA FLOPs the fused kernel issues per edge for a 3-Linear MLP, as
-    (fp32-MFMA FLOPs, f16-MFMA FLOPs): H1 generation (K padded to 8, repeated per 128-column
-    slice) and the 64 x k2 outer product are always fp32 MFMA; the k1 x k2 layer is fp32 MFMA
-    ("f32") or 3 f16 MFMAs per product ("f16split")."""
+def executed_flops_per_edge(dims, kernel, agg_f16, w=64):
+    """MFMA FLOPs the fused kernel issues per edge for a 3-Linear MLP, as (fp32-MFMA, f16-MFMA):
+      gpde_fused_kernel        everything on fp32 MFMA; H1 with K padded to 8, regenerated per 128-column slice
+      gpde_fused_f16v3_kernel  hidden layer = 3 f16 MFMAs per product; H1 = 2 f16 MFMAs (K = 16) per 32 k1 rows
+                               and 64-column wave tile
+      gpde_fused_f16v6_kernel  the same with a 128-column wave tile (half the H1 regeneration)
+    the 64 x k2 outer product (aggregation) is 3 f16 MFMAs per product when `agg_f16`, else fp32 MFMA."""
     k1p = (dims[1] + 31) // 32 * 32
     k2p = (dims[2] + 127) // 128 * 128
     agg = 2 * w * k2p
     hidden = 2 * k1p * k2p
-    if precision == "f32":
+    if kernel == "gpde_fused_kernel":
         return (2 * 8 * k1p * (k2p // 128) + agg + hidden, 0)
-    if precision == "f16split4w":            # 4-wave kernel: H1 on fp32 MFMA per 128-column slice
-        return (2 * 8 * k1p * (k2p // 128) + agg, 3 * hidden)
-    # default 8-wave kernel: H1 as 2 f16 MFMAs (K = 16) per 32-row chunk and 64-column wave tile
-    h1 = 2 * 2 * 16 * k1p * (k2p // 64)
-    if precision == "f16split_agg32":        # aggregation kept on fp32 MFMA
-        return (agg, 3 * hidden + h1)
-    # aggregation on split f16 as well (DESIGN.md §3c; default from 32768 edges on)
-    return (0, 3 * hidden + h1 + 3 * agg)
+    tile = 64 if kernel == "gpde_fused_f16v3_kernel" else 128
+    h1 = 2 * 2 * 16 * k1p * (k2p // tile)
+    if agg_f16:
+        return (0, 3 * hidden + h1 + 3 * agg)
+    return (agg, 3 * hidden + h1)
+
+
+def traffic_record(config, kw, kernel):
+    """HBM-side traffic of `kernel` from the committed PMC record, or (None, reason)."""
+    if not os.path.exists(TRAFFIC_FILE):
+        return None, "no profiles/traffic_r02.json"
+    try:
+        tj = json.load(open(TRAFFIC_FILE))
+    except Exception as ex:       # noqa: BLE001
+        return None, f"unreadable traffic file: {ex}"
+    if tj.get("config") != config or tj.get("kernel_width") != kw:
+        return None, f"PMC record is for {tj.get('config')} / width {tj.get('kernel_width')}"
+    rec = tj.get("kernels", {}).get(kernel)
+    if rec is None:
+        return None, f"PMC record holds {sorted(tj.get('kernels', {}))}, not {kernel}: re-run scripts/gpu/profile.sh"
+    return rec, tj.get("source", "")
+
+
+def make_conv(kw, dev, k0=6, seed=0):
+    import graph_pde_amd as gp
+    torch.manual_seed(seed)
+    mlp = torch.nn.Sequential(torch.nn.Linear(k0, kw), torch.nn.ReLU(), torch.nn.Linear(kw, kw),
+                              torch.nn.ReLU(), torch.nn.Linear(kw, 4096))
+    return gp.NNConv_old(64, 64, mlp, aggr="mean").to(dev)          # weights: seed 0, replicated
+
+
+def median_ms(fn, steps, warmup=1):
+    """Median of per-call HIP-event times (events on torch's current stream = the kernels' stream)."""
+    for _ in range(warmup):
+        fn()
+    evs = []
+    for _ in range(steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    return statistics.median(a.elapsed_time(b) for a, b in evs)
+
+
+# ------------------------------------------------------------------------------------------------------
+# MGKN configurations (BASELINE configs 3 and 4)
+# ------------------------------------------------------------------------------------------------------
+def mgkn_probe(dev, steps=10):
+    from graph_pde_amd import _lib, mgkn_workloads, ops
+    from oracle.nnconv_oracle import nnconv_forward, rel_l2
+    out = {}
+    for name, build in mgkn_workloads.WORKLOADS.items():
+        wl = build(dev)
+        wl.forward()                                              # CSR / pack caches warm
+        ms = median_ms(wl.forward, steps, warmup=2)
+        _lib.profile_begin()
+        wl.forward()
+        kinds = _lib.profile_end()
+        tot = sum(v[0] for v in kinds.values()) or 1.0
+        # parity of every distinct NNConv application of the forward against the fp64 oracle, same tensors
+        worst = 0.0
+        for conv, x, ei, ea in wl.pairs:
+            with torch.no_grad():
+                y = conv(x, ei, ea)
+            lin = ops.mlp_linears(conv.nn)
+            ref = nnconv_forward(x.cpu(), ei.cpu(), ea.cpu(), [l.weight.detach().cpu() for l in lin],
+                                 [l.bias.detach().cpu() for l in lin],
+                                 None if conv.root is None else conv.root.detach().cpu(),
+                                 None if conv.bias is None else conv.bias.detach().cpu(), aggr=conv.aggr,
+                                 dtype=torch.float64, chunk_edges=8192)
+            worst = max(worst, rel_l2(y.cpu(), ref))
+        top = max(kinds, key=lambda k: kinds[k][0])
+        out[name] = {
+            "workload": wl.description, "nnconv_calls": wl.calls, "edge_applications": wl.edge_applications,
+            "ms_per_forward": round(ms, 3),
+            "M_edge_applications_per_s": round(wl.edge_applications / ms / 1e3, 2),
+            "max_rel_l2_vs_oracle": worst,
+            "kernel_time_share": {k: round(v[0] / tot, 3) for k, v in kinds.items() if v[1]},
+            "kernel_launches": {k: v[1] for k, v in kinds.items() if v[1]},
+            "gpu_kernel_ms_per_forward": round(tot, 3),
+            "top_kernel_kind": top,
+            "bound": "launch / latency (<= 131 k edges per call, SURVEY.md §8d)",
+        }
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# training-step mode
+# ------------------------------------------------------------------------------------------------------
+def train_mode(args, rank, world, dev, use_dist, barrier):
+    import torch.distributed as dist
+    from graph_pde_amd import hidden_cache, parallel, synth
+    s, r = CONFIGS[args.config]
+    conv = make_conv(args.kernel_width, dev)
+    fc1 = torch.nn.Linear(6, 64).to(dev)
+    fc2 = torch.nn.Linear(64, 1).to(dev)
+    torch.manual_seed(1)
+    for m in (fc1, fc2):
+        m.reset_parameters()
+    params = list(fc1.parameters()) + list(conv.parameters()) + list(fc2.parameters())
+    if use_dist:
+        for m in (fc1, conv, fc2):
+            parallel.broadcast_parameters(m)
+    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=5e-4)          # UAI1_full_resolution.py:242
+    ei, ea, n = synth.darcy_graph(s, r, device=dev, seed=rank)           # this rank's sample
+    e = int(ei.shape[1])
+    g = torch.Generator(device=dev).manual_seed(10 + rank)
+    feat = torch.randn(n, 6, device=dev, generator=g)
+    y = torch.randn(n, device=dev, generator=g)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        h = fc1(feat)
+        for _ in range(args.depth):                                       # KernelNN.forward, UAI1:26-33
+            h = torch.relu(conv(h, ei, ea))
+        out = fc2(h).view(-1)
+        loss = torch.norm(out - y, 1)                                      # UAI1:265
+        loss.backward()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        n_red = parallel.allreduce_gradients(params, world=world if use_dist else 1)
+        b.record()
+        opt.step()
+        return a, b, n_red
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    evs = [step() for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ar_ms = sum(a.elapsed_time(b) for a, b, _ in evs) / max(args.steps, 1)
+    if use_dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        return None
+    ms = 1e3 * elapsed / args.steps
+    return {
+        "metric": "training samples/s, GKN Darcy-2D (fwd + native bwd + RCCL grad all-reduce + Adam)",
+        "value": round(world * 1e3 / ms, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 (hidden layer + aggregation: 2-term f16-split MFMA, f32 accumulate)",
+        "data": "synthetic",
+        "config": {"workload": f"one training step per GPU and step: KernelNN stack (fc1, {args.depth} x relu(NNConv_old), fc2) on "
+                               f"the {s}x{s} r={r} radius graph (N={n}, E={e}), kernel MLP [6,{args.kernel_width},"
+                               f"{args.kernel_width},4096], L1 loss, Adam(1e-4, wd 5e-4); one sample per GPU per step",
+                   "graph": args.config, "depth": args.depth, "hidden_cache": hidden_cache.MODE,
+                   "parallelism": f"dp{world} (independent samples, one flat gradient all-reduce)"},
+        "M_edge_applications_per_s": round(world * args.depth * e / (ms * 1e-3) / 1e6, 2),
+        "allreduce": {"elements": evs[-1][2], "ms_per_step": round(ar_ms, 3), "share_of_step": round(ar_ms / ms, 5),
+                      "backend": "nccl (RCCL)" if use_dist else "none (single process)"},
+    }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="g241", choices=sorted(CONFIGS))
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS))
     ap.add_argument("--kernel-width", type=int, default=1024)
-    ap.add_argument("--cpu-rows", type=int, default=512, help="destination rows of the CPU sample")
+    ap.add_argument("--cpu-rows", type=int, default=640, help="destination rows of the CPU sample (>= 1 M edges on g241)")
     ap.add_argument("--cpu-threads", type=int, default=64, help="threads of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reuse-probe", action="store_true",
                     help="skip the depth x module probe of the cross-depth hidden-activation reuse")
+    ap.add_argument("--no-mgkn", action="store_true", help="skip the MGKN configurations (BASELINE configs 3, 4)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the exact-fp32 leg")
     ap.add_argument("--precision", default=None, choices=["f32", "f16split", "f16split_8wave", "f16split_agg16", "f16split_agg32"],
                     help="arithmetic of the hidden layer (default: graph_pde_amd.ops.DEFAULT_PRECISION)")
+    ap.add_argument("--train", action="store_true", help="training-step mode (see the module docstring)")
+    ap.add_argument("--depth", type=int, default=6, help="--train: NNConv applications per forward")
     args = ap.parse_args()
+    if args.config is None:
+        args.config = "g61" if args.train else "g241"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -122,16 +291,26 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    import graph_pde_amd as gp
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.train:
+        line = train_mode(args, rank, world, dev, use_dist, barrier)
+        if line is not None:
+            print(json.dumps(line), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return
+
     from graph_pde_amd import _lib, ops, synth
 
     s, r = CONFIGS[args.config]
     kw = args.kernel_width
     dims = [6, kw, kw, 4096]
-    torch.manual_seed(0)
-    mlp = torch.nn.Sequential(torch.nn.Linear(6, kw), torch.nn.ReLU(), torch.nn.Linear(kw, kw),
-                              torch.nn.ReLU(), torch.nn.Linear(kw, 4096))
-    conv = gp.NNConv_old(64, 64, mlp, aggr="mean").to(dev)          # weights: seed 0, replicated
+    conv = make_conv(kw, dev)
 
     t0 = time.time()
     ei, ea, n = synth.darcy_graph(s, r, device=dev, seed=rank)       # independent sample per rank
@@ -152,32 +331,28 @@ def main():
     ws = torch.empty(ops.workspace_bytes(n, e, pm), dtype=torch.uint8, device=dev)
     out = torch.empty(n, 64, dtype=torch.float32, device=dev)
     plan = ops.launch_plan(n, e, pm, ws.numel())
-
     precision = args.precision or ops.DEFAULT_PRECISION
+    kernel = ops.fused_kernel_name(n, e, pm, precision)
 
-    def step():
-        ops.nnconv_forward_raw(x, csr, ea, pm, conv.root, conv.bias, "mean", out=out, ws=ws,
-                               precision=precision)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step(prec=precision):
+        ops.nnconv_forward_raw(x, csr, ea, pm, conv.root, conv.bias, "mean", out=out, ws=ws, precision=prec)
 
     for _ in range(args.warmup):
         step()
     barrier()
-    lib = _lib.lib()
-    lib.gpde_profile_begin()
+    _lib.profile_begin()
+    evs = []
     t_start = time.perf_counter()
     for _ in range(args.steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
         step()
+        b.record()
+        evs.append((a, b))
     barrier()
     elapsed = time.perf_counter() - t_start
-    import ctypes
-    fused_ms, launches, other_ms = ctypes.c_double(), ctypes.c_int32(), ctypes.c_double()
-    lib.gpde_profile_end(ctypes.byref(fused_ms), ctypes.byref(launches), ctypes.byref(other_ms))
+    kinds = _lib.profile_end()
+    step_ms = [a.elapsed_time(b) for a, b in evs]
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -189,61 +364,63 @@ def main():
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * e / (elapsed / args.steps) / 1e6                  # M-edges/s, whole job
+    med = statistics.median(step_ms)
 
     # ---- roofline of the dominant kernel (rank 0's launches) --------------------------------------
-    f_alg = algorithmic_flops_per_edge(dims)
-    f_exe32, f_exe16 = executed_flops_per_edge(dims, precision=precision)
-    n_launch = max(int(launches.value), 1)
-    avg_launch_ms = fused_ms.value / n_launch
+    fused_ms, launches = kinds["fused"]
+    n_launch = max(int(launches), 1)
+    avg_launch_ms = fused_ms / n_launch
     edges_per_launch = e * args.steps / n_launch
-    achieved_tf = f_alg * edges_per_launch / (avg_launch_ms * 1e-3) / 1e12
-    executed_tf = f_exe32 * edges_per_launch / (avg_launch_ms * 1e-3) / 1e12
-    executed_tf16 = f_exe16 * edges_per_launch / (avg_launch_ms * 1e-3) / 1e12
-    bytes_per_edge = (40.0 * e + 512.0 * n + 4.0 * sum(p.numel() for p in conv.parameters())) / e
+    agg_f16 = kernel != "gpde_fused_kernel" and precision != "f16split_agg32" and (e >= 32768 or precision == "f16split_agg16")
+    f_alg = algorithmic_flops_per_edge(dims)
+    f_exe32, f_exe16 = executed_flops_per_edge(dims, kernel, agg_f16)
+    rate = edges_per_launch / (avg_launch_ms * 1e-3) / 1e12           # 1e12 edges/s through the kernel
+    on_f16 = f_exe16 > 0
+    achieved = (f_exe16 if on_f16 else f_exe32) * rate
+    peak = PEAK_F16_MFMA_TFLOPS if on_f16 else PEAK_FP32_MFMA_TFLOPS
+    n_param = sum(p.numel() for p in conv.parameters())
+    alg_bytes_per_launch = (40.0 * e + 512.0 * n + 4.0 * n_param) * edges_per_launch / e   # SURVEY §8(d) x units per launch
+    rec, src = traffic_record(args.config, kw, kernel)
+    traffic = None if rec is None else rec.get("hbm_bytes_per_launch")
+    other_ms = sum(v[0] for k, v in kinds.items() if k != "fused")
     edges_per_s_rank = e / (elapsed / args.steps)
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "traffic_r01.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("config") == args.config and tj.get("kernel_width") == kw:
-                traffic = tj.get("fused_hbm_bytes_per_launch", {}).get(precision)
-        except Exception:
-            traffic = None
+    bytes_per_edge = (40.0 * e + 512.0 * n + 4.0 * n_param) / e
     roofline = {
-        "kernel": {"f16split": "gpde_fused_f16v3_kernel", "f16split4w": "gpde_fused_f16_kernel"}.get(
-            precision, "gpde_fused_kernel<1>"),
-        "bound": "mfma",
-        "achieved": round(achieved_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved_tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+        "kernel": kernel, "bound": "mfma", "pipe": "f16 MFMA (2-term split operands, fp32 accumulate)" if on_f16 else "fp32 MFMA",
+        "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+        "traffic": traffic, "traffic_source": src if rec is not None else None,
+        "traffic_note": None if rec is not None else src,
+        "traffic_detail": rec,
+        "algorithmic_bytes_per_launch": round(alg_bytes_per_launch),
+        "traffic_over_algorithmic": None if traffic is None else round(traffic / alg_bytes_per_launch, 2),
         "avg_launch_ms": round(avg_launch_ms, 3), "launches_per_step": n_launch // args.steps,
+        "executed_flop_per_edge": {"fp32_mfma": f_exe32, "f16_mfma": f_exe16},
+        "executed_fp32_mfma_tflops": round(f_exe32 * rate, 2),
         "algorithmic_flop_per_edge": f_alg,
-        "executed_f32_mfma_flop_per_edge": f_exe32, "executed_f16_mfma_flop_per_edge": f_exe16,
-        "executed_f32_mfma_tflops": round(executed_tf, 2),
-        "executed_f16_mfma_tflops": round(executed_tf16, 2),
-        # share of the matrix pipe's time the executed MFMAs need at peak rate
-        "frac_executed": round(executed_tf / PEAK_FP32_MFMA_TFLOPS + executed_tf16 / PEAK_F16_MFMA_TFLOPS, 4),
-        "fused_share_of_step": round(fused_ms.value / (1e3 * elapsed), 4),
-        "node_kernels_ms_per_step": round(other_ms.value / args.steps, 3),
+        "algorithmic_tflops": round(f_alg * rate, 2),
+        "algorithmic_ratio": round(f_alg * rate / PEAK_FP32_MFMA_TFLOPS, 4),
+        "algorithmic_ratio_note": "reference-formulation FLOPs / fp32 MFMA peak; > 1 because the last layer is re-associated "
+                                  "(DESIGN.md §2) and the hidden layer runs on the f16 pipe - not a roofline fraction",
+        "fused_share_of_step": round(fused_ms / (1e3 * elapsed), 4),
+        "node_kernels_ms_per_step": round(other_ms / args.steps, 3),
+        "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in kinds.items() if v[1]},
         "hbm_algorithmic_bytes_per_edge": round(bytes_per_edge, 2),
         "hbm_achieved_GBs": round(edges_per_s_rank * bytes_per_edge / 1e9, 2),
         "hbm_frac": round(edges_per_s_rank * bytes_per_edge / 1e9 / PEAK_HBM_GBS, 6),
+        "hbm_note": "BASELINE.json's HBM target is not the binding bound: >= 205 FLOP/B against a machine balance of 19.7",
     }
 
-    # ---- the other arithmetic on the same inputs, one step, for reference ---------------------------
+    # ---- the exact-fp32 arithmetic on the same inputs: median of >= 5 steps -------------------------
     alt = None
-    if world == 1:
-        other = "f32" if precision == "f16split" else "f16split"
+    if world == 1 and not args.no_alt:
+        other = "f32" if precision != "f32" else "f16split"
         out_main = out.clone()
-        ops.nnconv_forward_raw(x, csr, ea, pm, conv.root, conv.bias, "mean", out=out, ws=ws, precision=other)
-        torch.cuda.synchronize()
-        ta = time.perf_counter()
-        ops.nnconv_forward_raw(x, csr, ea, pm, conv.root, conv.bias, "mean", out=out, ws=ws, precision=other)
-        torch.cuda.synchronize()
-        tb = time.perf_counter() - ta
+        alt_steps = max(5, min(args.steps, 10))
+        alt_ms = median_ms(lambda: step(other), alt_steps, warmup=1)
         d = (out.double() - out_main.double()).norm() / out.double().norm()
-        alt = {"precision": other, "value": round(e / tb / 1e6, 3), "unit": "M-edges/s",
-               "rel_l2_between_precisions": float(d)}
+        alt = {"precision": other, "kernel": ops.fused_kernel_name(n, e, pm, other),
+               "value": round(e / alt_ms / 1e3, 3), "unit": "M-edges/s", "median_step_ms": round(alt_ms, 3),
+               "steps": alt_steps, "rel_l2_between_precisions": float(d)}
         out.copy_(out_main)
 
     # ---- CPU baseline + parity on a bounded sample --------------------------------------------------
@@ -265,13 +442,12 @@ def main():
         ws_c = [l.weight.detach().cpu() for l in lin]
         bs_c = [l.bias.detach().cpu() for l in lin]
         root_c, bias_c = conv.root.detach().cpu(), conv.bias.detach().cpu()
-        run = lambda: nnconv_forward(x_c, ei_s, ea_s, ws_c, bs_c, root_c, bias_c, aggr="mean",
-                                     dtype=torch.float32, chunk_edges=65536)
         # warm-up on a slice, then one timed pass over the whole sample
         nnconv_forward(x_c, ei_s[:, :65536], ea_s[:65536], ws_c, bs_c, root_c, bias_c, aggr="mean",
                        chunk_edges=65536)
         tc = time.perf_counter()
-        y_cpu = run()
+        y_cpu = nnconv_forward(x_c, ei_s, ea_s, ws_c, bs_c, root_c, bias_c, aggr="mean",
+                               dtype=torch.float32, chunk_edges=65536)
         tcpu = time.perf_counter() - tc
         es = int(ei_s.shape[1])
         cpu = {"value": round(es / tcpu / 1e6, 5), "unit": "M-edges/s", "cores": ncores,
@@ -281,14 +457,20 @@ def main():
         rel = rel_l2(out[rows.to(dev)].cpu(), y_cpu[rows])
         log(f"[bench] CPU oracle sample: {es} edges in {tcpu:.2f}s; rel-L2 GPU vs CPU rows = {rel:.3e}")
 
+    del ws
+    torch.cuda.empty_cache()
+
+    # ---- MGKN configurations -----------------------------------------------------------------------------
+    mgkn = None
+    if not args.no_mgkn and world == 1:
+        mgkn = mgkn_probe(dev)
+
     # ---- cross-depth reuse: depth applications of ONE module, as KernelNN.forward does
     #      (UAI1_full_resolution.py:29-30), on the reference's own training resolution s=61 r=0.10 -- the
     #      headline graph's hidden activations (E x 4 KiB = 391 GB) do not fit one GPU.  Not part of `value`.
     reuse = None
     if not args.no_reuse_probe and world == 1:
         from graph_pde_amd import hidden_cache
-        del ws
-        torch.cuda.empty_cache()
         ei6, ea6, n6 = synth.darcy_graph(61, 0.1, device=dev, seed=0)
         x6 = torch.randn(n6, 64, device=dev)
         depth = 6
@@ -314,8 +496,9 @@ def main():
 
         def fwd_bwd():
             conv.zero_grad(set_to_none=True)
-            for p_ in conv.parameters():
-                p_.data.mul_(1.0)                       # new weight version: as after an optimiser step
+            with torch.no_grad():
+                for p_ in conv.parameters():
+                    p_.mul_(1.0)                        # new weight version: as after an optimiser step
             model_fwd(x6).square().mean().backward()
         res = {}
         mode0 = hidden_cache.MODE
@@ -343,6 +526,7 @@ def main():
         "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if precision == "f32" else "f32 (hidden layer + aggregation: 2-term f16-split MFMA, f32 accumulate)",
         "precision": precision, "data": "synthetic",
+        "median_step_ms": round(med, 3), "value_at_median": round(world * e / med / 1e3, 3),
         "config": {"workload": f"GKN Darcy-2D {s}x{s} lattice radius graph r={r} "
                                f"(N={n}, E={e} per sample), NNConv_old fwd width=64, kernel MLP "
                                f"[6,{kw},{kw},4096], aggr=mean, root+bias; one sample per GPU",
@@ -350,9 +534,10 @@ def main():
                    "plan": plan},
         "rel_l2_sample": rel,
         "alt_precision": alt,
-        "depth_reuse": reuse,
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "mgkn": mgkn,
+        "depth_reuse": reuse,
     }
     print(json.dumps(line), flush=True)
     if use_dist:

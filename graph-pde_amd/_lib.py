@@ -102,7 +102,21 @@ SIGNATURES = {
     "gpde_profile_begin": (ctypes.c_int, []),
     "gpde_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), c_i32p,
                                         ctypes.POINTER(ctypes.c_double)]),
+    "gpde_profile_end_kinds": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), c_i32p]),
 }
+PROF_KINDS = ("fused", "gemm3", "epilogue", "prep", "other")        # GPDE_PROF_* of include/gpde.h
+
+
+def profile_begin():
+    lib().gpde_profile_begin()
+
+
+def profile_end():
+    """{kind: (ms, launches)} of the kernels gpde_nnconv_fwd launched on this thread since profile_begin()."""
+    ms = (ctypes.c_double * len(PROF_KINDS))()
+    n = (ctypes.c_int32 * len(PROF_KINDS))()
+    check(lib().gpde_profile_end_kinds(ms, n), "gpde_profile_end_kinds")
+    return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(PROF_KINDS)}
 
 _lib = None
 _lock = threading.Lock()

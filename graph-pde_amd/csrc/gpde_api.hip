@@ -21,7 +21,7 @@ extern "C" const char* gpde_last_error(void) { return g_err; }
 namespace {
 
 // ---- optional HIP-event timing of the kernels of gpde_nnconv_fwd (bench.py roofline leg) -------
-struct EvPair { hipEvent_t a, b; int kind; };   // kind 0 = fused kernel, 1 = gemm3 + epilogue
+struct EvPair { hipEvent_t a, b; int kind; };   // kind: GPDE_PROF_* (include/gpde.h)
 thread_local bool g_prof_on = false;
 thread_local std::vector<EvPair> g_prof;
 
@@ -262,6 +262,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
         return GPDE_EUNSUPPORTED;
     }
     if ((!hidden || mixed) && fc.g2f16) {
+        ProfScope psp(GPDE_PROF_PREP, stream);
         rc = gpde_launch_g2_prep(x, n_nodes, edge_attr, n_edges, L.k0, pk + L.off_w1 + (size_t)L.K1P * 8,
                                  (unsigned*)(w + P.off_scal), (unsigned*)(w + P.off_xs), stream, kt, sel, src, dst);
         if (rc != GPDE_OK) return rc;
@@ -297,14 +298,14 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
             f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
             f.nc0 = (int)nc0; f.nc1 = (int)nc1; f.e_chunk0 = 0; f.n_groups = P.n_groups;
             {
-                ProfScope ps(0, stream);
+                ProfScope ps(GPDE_PROF_FUSED, stream);
                 if (from_h) rc = gpde_launch_zagg(f, stream);
                 else if (fc.kind == FK_V6) rc = gpde_launch_fused_f16v6(f, stream);
                 else if (fc.kind == FK_V3) rc = gpde_launch_fused_f16v3(f, stream);
                 else rc = gpde_launch_fused(mode, (flags & GPDE_FWD_F16SPLIT) != 0 && mode == 1, f, stream);
             }
             if (rc != GPDE_OK) return rc;
-            ProfScope ps1(1, stream);
+            ProfScope ps1(GPDE_PROF_GEMM3, stream);
             GpdeGemm3Args g;
             g.zbuf = zbuf; g.w3q = pk + L.off_w3q; g.part = part; g.nn = nn; g.K2P = L.K2P;
             g.splits = splits;
@@ -315,7 +316,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
         e.part = part; e.x = x; e.rowptr = rowptr; e.src = src;
         e.b3 = pk + L.off_b3; e.root = root; e.bias = bias; e.out = out;
         e.nc0 = (int)nc0; e.nn = nn; e.splits = splits; e.aggr = aggr;
-        ProfScope ps2(1, stream);
+        ProfScope ps2(GPDE_PROF_EPILOGUE, stream);
         rc = gpde_launch_epilogue(e, stream);
         if (rc != GPDE_OK) return rc;
     }
@@ -404,21 +405,35 @@ extern "C" int gpde_profile_begin(void) {
     return GPDE_OK;
 }
 
-extern "C" int gpde_profile_end(double* fused_ms, int32_t* fused_launches, double* other_ms) {
+extern "C" int gpde_profile_end_kinds(double* ms_by_kind, int32_t* launches_by_kind) {
     g_prof_on = false;
-    double f = 0.0, o = 0.0;
-    int nf = 0;
+    for (int k = 0; k < GPDE_PROF_KINDS; ++k) {
+        if (ms_by_kind) ms_by_kind[k] = 0.0;
+        if (launches_by_kind) launches_by_kind[k] = 0;
+    }
     for (auto& p : g_prof) {
         float ms = 0.f;
         GP_HIP_CHECK(hipEventSynchronize(p.b));
         GP_HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
-        if (p.kind == 0) { f += ms; ++nf; } else { o += ms; }
+        const int k = (p.kind >= 0 && p.kind < GPDE_PROF_KINDS) ? p.kind : GPDE_PROF_KINDS - 1;
+        if (ms_by_kind) ms_by_kind[k] += ms;
+        if (launches_by_kind) launches_by_kind[k] += 1;
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
     }
     g_prof.clear();
-    if (fused_ms) *fused_ms = f;
-    if (fused_launches) *fused_launches = nf;
+    return GPDE_OK;
+}
+
+extern "C" int gpde_profile_end(double* fused_ms, int32_t* fused_launches, double* other_ms) {
+    double ms[GPDE_PROF_KINDS];
+    int32_t n[GPDE_PROF_KINDS];
+    int rc = gpde_profile_end_kinds(ms, n);
+    if (rc != GPDE_OK) return rc;
+    double o = 0.0;
+    for (int k = 0; k < GPDE_PROF_KINDS; ++k) if (k != GPDE_PROF_FUSED) o += ms[k];
+    if (fused_ms) *fused_ms = ms[GPDE_PROF_FUSED];
+    if (fused_launches) *fused_launches = n[GPDE_PROF_FUSED];
     if (other_ms) *other_ms = o;
     return GPDE_OK;
 }

@@ -255,6 +255,16 @@ int gpde_radius_graph_fill(const double* pos, int64_t n, int dim, double r, cons
  * summed duration of the node-side kernels (gemm3 + epilogue).  Not for production calls. */
 int gpde_profile_begin(void);
 int gpde_profile_end(double* fused_ms, int32_t* fused_launches, double* other_ms);
+/* The same, split by kernel kind: ms_by_kind / launches_by_kind are arrays of GPDE_PROF_KINDS entries. */
+enum {
+    GPDE_PROF_FUSED = 0,     /* fused edge kernel (gpde_nnconv_fwd_kernel names it) or gpde_zagg_kernel */
+    GPDE_PROF_GEMM3 = 1,     /* per-node last Linear Z . W3 */
+    GPDE_PROF_EPILOGUE = 2,  /* split-K sum, b3, mean, x . root + bias */
+    GPDE_PROF_PREP = 3,      /* pre-passes of the split-f16 aggregation (3 tiny kernels + memset) */
+    GPDE_PROF_OTHER = 4,
+    GPDE_PROF_KINDS = 5
+};
+int gpde_profile_end_kinds(double* ms_by_kind, int32_t* launches_by_kind);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,109 @@
+"""GPU tier: parity AT THE HEADLINE SCALE (BASELINE.json configs[1]: Darcy 241^2, r = 0.10, N = 58,081,
+E = 95,539,625, kernel MLP [6,1024,1024,4096]) on the kernels bench.py times.
+
+* 2,048+ stratified destination rows (corner, edge and interior nodes; >= 3 M in-edges) of the full-graph
+  output against the float64 CPU oracle evaluated on exactly those rows' in-edges, for the default
+  arithmetic (gpde_fused_f16v6_kernel: hidden layer + aggregation on 2-term split f16 MFMA), the 8-wave
+  kernel, the fp32-aggregation variant and the exact-fp32 path: <= 1e-5 relative L2 and within 4x of the
+  exact-fp32 path's own distance.
+* a >= 32,768-edge graph with the 1024^2 MLP whose typical hidden activations sit >= 2^12 BELOW the a-priori
+  bound the f16 aggregation scales them by (one outlier edge inflates the global bound): the crude bound of
+  DESIGN.md §3c must not cost accuracy.
+"""
+import pytest
+import torch
+
+from graph_pde_amd import _lib, ops, synth
+from oracle.nnconv_oracle import nnconv_forward, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _mlp(kw, seed):
+    torch.manual_seed(seed)
+    mlp = torch.nn.Sequential(torch.nn.Linear(6, kw), torch.nn.ReLU(), torch.nn.Linear(kw, kw),
+                              torch.nn.ReLU(), torch.nn.Linear(kw, 4096))
+    lin = [l for l in mlp if isinstance(l, torch.nn.Linear)]
+    return [l.weight.detach() for l in lin], [l.bias.detach() for l in lin]
+
+
+def _stratified_rows(s, count):
+    n = s * s
+    special = [0, s - 1, n - s, n - 1, s // 2, n - 1 - s // 2, (s // 2) * s, (s // 2) * s + s - 1,
+               (s // 2) * s + s // 2, s + 1, 2 * s - 2, n - 2 * s + 1]          # corners, edge midpoints, centre, near-corner
+    rows = torch.linspace(0, n - 1, count).round().long()
+    return torch.cat([rows, torch.tensor(special)]).unique()
+
+
+def test_headline_graph_rows_match_the_fp64_oracle():
+    d = torch.device("cuda:0")
+    s, r, kw = 241, 0.10, 1024
+    ws_, bs_ = _mlp(kw, 0)
+    torch.manual_seed(1)
+    root, bias = (torch.rand(64, 64) - 0.5) / 4, (torch.rand(64) - 0.5) / 4
+    ei, ea, n = synth.darcy_graph(s, r, device=d, seed=0)
+    e = int(ei.shape[1])
+    assert (n, e) == (58081, 95539625)
+    x = torch.randn(n, 64, device=d, generator=torch.Generator(device=d).manual_seed(2))
+    csr = ops.csr_for(ei, n)
+    pm = ops.pack_mlp([w.to(d) for w in ws_], [b.to(d) for b in bs_])
+    assert ops.fused_kernel_name(n, e, pm, "f16split") == "gpde_fused_f16v6_kernel"
+    ws = torch.empty(ops.workspace_bytes(n, e, pm), dtype=torch.uint8, device=d)
+    rows = _stratified_rows(s, 2048)
+    outs = {}
+    for prec in ("f16split", "f16split_8wave", "f16split_agg32", "f32"):
+        calls = _lib.n_native_calls
+        y = ops.nnconv_forward_raw(x, csr, ea, pm, root.to(d), bias.to(d), "mean", ws=ws, precision=prec)
+        torch.cuda.synchronize()
+        assert _lib.n_native_calls == calls + 1
+        assert torch.isfinite(y).all()
+        outs[prec] = y[rows.to(d)].cpu()
+    # the oracle on all in-edges of the chosen rows, in the reference's (input) edge order
+    rowptr = csr.rowptr.cpu().long()
+    slots = torch.cat([torch.arange(int(rowptr[i]), int(rowptr[i + 1])) for i in rows.tolist()])
+    eid, _ = torch.sort(csr.perm.cpu().long()[slots])
+    assert eid.numel() >= 3_000_000
+    ei_s, ea_s = ei[:, eid.to(d)].cpu(), ea[eid.to(d)].cpu()
+    del ws
+    torch.set_num_threads(min(64, torch.get_num_threads() if torch.get_num_threads() > 8 else 64))
+    y64 = nnconv_forward(x.cpu(), ei_s, ea_s, ws_, bs_, root, bias, aggr="mean", dtype=torch.float64,
+                         chunk_edges=65536)[rows]
+    err = {p: rel_l2(o, y64) for p, o in outs.items()}
+    print("headline rows rel-L2 vs fp64 oracle:", {k: f"{v:.2e}" for k, v in err.items()}, "edges", int(eid.numel()))
+    for p in ("f16split", "f16split_8wave", "f16split_agg32"):
+        assert err[p] <= TOL and err[p] <= 4 * err["f32"] + 2e-7, err
+    assert err["f32"] <= TOL, err
+
+
+def test_hidden_activations_far_below_the_apriori_bound():
+    """h <= max|b2| + max_k ||W2_k||_1 * max_e B_e is what the f16 aggregation scales the hidden activations by
+    (B_e = per-edge bound of the first layer, its MAXIMUM over edges enters).  A single edge whose attributes are
+    2^6 larger than everybody else's raises the global bound 2^6-fold: the typical activation then sits >= 2^12
+    below the bound and uses only the bottom of the f16 range the scale reserves.  The split must still deliver
+    fp32-class accuracy (values above 2^-18 of the bound keep both terms normal).  No cancellation
+    is constructed: the exact-fp32 path stays at its usual 1e-7."""
+    kw = 1024
+    ws_, bs_ = _mlp(kw, 3)
+    g = torch.Generator().manual_seed(4)
+    ei, ea, n = synth.darcy_graph(41, 0.10, seed=5)
+    e = int(ei.shape[1])
+    assert e >= 32768
+    ea = ea.clone()
+    ea[e // 2] *= 64.0                                                     # the outlier edge
+    x = torch.randn(n, 64, generator=g)
+    h1 = torch.relu(torch.nn.functional.linear(ea.double(), ws_[0].double(), bs_[0].double()))
+    h = torch.relu(torch.nn.functional.linear(h1, ws_[1].double(), bs_[1].double()))
+    b_e = (ea.double().abs() @ ws_[0].double().abs().max(0).values) + bs_[0].double().abs().max()
+    bound = bs_[1].abs().max().double() + ws_[1].double().abs().sum(1).max() * b_e.max()
+    typical = h[h > 0].median()
+    assert float(bound / typical) >= 2.0 ** 12, float(torch.log2(bound / typical))
+    y64 = nnconv_forward(x, ei, ea, ws_, bs_, None, None, aggr="mean", dtype=torch.float64)
+    from tests.test_gpu_parity import run_native
+    err = {}
+    for prec in ("f16split", "f16split_8wave", "f16split_agg32", "f32"):
+        err[prec] = rel_l2(run_native(x, ei, ea, ws_, bs_, None, None, "mean", precision=prec), y64)
+    print("far-below-bound rel-L2:", {k: f"{v:.2e}" for k, v in err.items()},
+          "bound / typical h = 2^%.1f" % float(torch.log2(bound / typical)))
+    for p in ("f16split", "f16split_8wave", "f16split_agg32"):
+        assert err[p] <= TOL and err[p] <= 4 * err["f32"] + 2e-7, err

@@ -1,0 +1,37 @@
+"""GPU tier: BASELINE configs 3 and 4 (MGKN-orthogonal Burgers-1D s=8192; MGKN-general Darcy-2D, L = 5) -
+every distinct NNConv application of one model forward against the float64 CPU oracle on the same tensors,
+and the forward runs the native path for every call (graph_pde_amd/mgkn_workloads.py)."""
+import pytest
+import torch
+
+from graph_pde_amd import _lib, mgkn_workloads, ops
+from oracle.nnconv_oracle import nnconv_forward, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.mark.parametrize("name", sorted(mgkn_workloads.WORKLOADS))
+def test_mgkn_forward_calls_match_oracle(name):
+    d = torch.device("cuda:0")
+    wl = mgkn_workloads.WORKLOADS[name](d)
+    calls = _lib.n_native_calls
+    outs = wl.forward()
+    torch.cuda.synchronize()
+    assert _lib.n_native_calls - calls >= wl.calls            # one native call per NNConv application
+    assert all(torch.isfinite(o).all() for o in outs)
+    assert wl.calls == {"mgkn_orthogonal_burgers1d": 52, "mgkn_general_darcy2d": 65}[name]
+    worst = 0.0
+    for conv, x, ei, ea in wl.pairs:
+        with torch.no_grad():
+            y = conv(x, ei, ea)
+        lin = ops.mlp_linears(conv.nn)
+        ref = nnconv_forward(x.cpu(), ei.cpu(), ea.cpu(), [l.weight.detach().cpu() for l in lin],
+                             [l.bias.detach().cpu() for l in lin],
+                             None if conv.root is None else conv.root.detach().cpu(),
+                             None if conv.bias is None else conv.bias.detach().cpu(), aggr=conv.aggr,
+                             dtype=torch.float64, chunk_edges=8192)
+        err = rel_l2(y.cpu(), ref)
+        worst = max(worst, err)
+        assert err <= TOL, (name, tuple(ei.shape), err)
+    print(name, "max rel-L2 over", len(wl.pairs), "NNConv applications:", f"{worst:.2e}")

@@ -227,9 +227,32 @@ def test_bench_flop_accounting_matches_survey():
     spec.loader.exec_module(bench)
     assert bench.algorithmic_flops_per_edge([6, 1024, 1024, 4096]) == 10506304
     assert bench.algorithmic_flops_per_edge([6, 256, 256, 4096]) == 2239552
-    f32, f16 = bench.executed_flops_per_edge([6, 1024, 1024, 4096], precision="f32")
+    dims = [6, 1024, 1024, 4096]
+    f32, f16 = bench.executed_flops_per_edge(dims, "gpde_fused_kernel", False)
     assert (f32, f16) == (2 * 8 * 1024 * 8 + 2 * 64 * 1024 + 2 * 1024 * 1024, 0)
-    f32, f16 = bench.executed_flops_per_edge([6, 1024, 1024, 4096], precision="f16split")
+    f32, f16 = bench.executed_flops_per_edge(dims, "gpde_fused_f16v3_kernel", True)
     assert f32 == 0 and f16 == 3 * 2 * 1024 * 1024 + 2 * 2 * 16 * 1024 * 16 + 3 * 2 * 64 * 1024 == 7733248
-    f32, f16 = bench.executed_flops_per_edge([6, 1024, 1024, 4096], precision="f16split_agg32")
+    f32, f16 = bench.executed_flops_per_edge(dims, "gpde_fused_f16v3_kernel", False)
     assert f32 == 131072 and f16 == 7340032
+    # the one-wave-per-SIMD kernel regenerates H1 per 128-column tile: half of the 8-wave kernel's
+    f32, f16 = bench.executed_flops_per_edge(dims, "gpde_fused_f16v6_kernel", True)
+    assert f32 == 0 and f16 == 3 * 2 * 1024 * 1024 + 2 * 2 * 16 * 1024 * 8 + 3 * 2 * 64 * 1024 == 7208960
+
+
+def test_bench_refuses_a_traffic_record_of_another_kernel(tmp_path, monkeypatch):
+    """roofline.traffic must describe the kernel that was timed: the PMC record is keyed by kernel symbol."""
+    import importlib.util, json, os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    f = tmp_path / "traffic.json"
+    f.write_text(json.dumps({"config": "g241", "kernel_width": 1024, "source": "test",
+                             "kernels": {"gpde_fused_f16v3_kernel": {"hbm_bytes_per_launch": 1.0e11}}}))
+    monkeypatch.setattr(bench, "TRAFFIC_FILE", str(f))
+    rec, why = bench.traffic_record("g241", 1024, "gpde_fused_f16v6_kernel")
+    assert rec is None and "gpde_fused_f16v6_kernel" in why
+    rec, why = bench.traffic_record("g241", 1024, "gpde_fused_f16v3_kernel")
+    assert rec["hbm_bytes_per_launch"] == 1.0e11
+    rec, why = bench.traffic_record("g121", 1024, "gpde_fused_f16v3_kernel")
+    assert rec is None
