@@ -166,9 +166,15 @@ def mgkn_probe(dev, steps=10):
                                  dtype=torch.float64, chunk_edges=8192)
             worst = max(worst, rel_l2(y.cpu(), ref))
         top = max(kinds, key=lambda k: kinds[k][0])
+        wl_f = build(dev, fused_glue=True)                        # opt-in: relu(x + conv) inside the last kernel
+        y_plain, y_fused = wl.forward(), wl_f.forward()
+        ms_fused = median_ms(wl_f.forward, steps, warmup=2)
         out[name] = {
             "workload": wl.description, "nnconv_calls": wl.calls, "edge_applications": wl.edge_applications,
             "ms_per_forward": round(ms, 3),
+            "ms_per_forward_fused_glue": round(ms_fused, 3),
+            "fused_glue_rel_l2_vs_unfused": max(float((a_.double() - b_.double()).norm() / a_.double().norm().clamp_min(1e-30))
+                                                for a_, b_ in zip(y_plain, y_fused)),
             "M_edge_applications_per_s": round(wl.edge_applications / ms / 1e3, 2),
             "max_rel_l2_vs_oracle": worst,
             "kernel_time_share": {k: round(v[0] / tot, 3) for k, v in kinds.items() if v[1]},

@@ -43,6 +43,18 @@ SIGNATURES = {
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "gpde_nnconv_fwd_act": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                           ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "gpde_nnconv_fwd_hidden_act": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                                  ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                                  ctypes.c_void_p]),
     "gpde_nnconv_fwd_plan": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, c_i32p,
                                             ctypes.c_size_t, c_i32p, c_i64p, c_i32p, c_i32p]),
     "gpde_nnconv_fwd_kernel": (ctypes.c_char_p, [ctypes.c_int64, ctypes.c_int, c_i32p, ctypes.c_uint32]),

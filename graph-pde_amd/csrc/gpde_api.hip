@@ -66,9 +66,11 @@ struct Plan {
 };
 
 int pick_splits(int64_t nn) {
+    // gemm3 streams Z from HBM with one 16 KiB chunk in flight per workgroup: ~1000 resident workgroups
+    // (4 per CU) keep ~16 MB in flight, enough for the HBM latency-bandwidth product
     const int64_t tiles = (nn + 63) / 64;
     int s = 1;
-    while (s < 64 && tiles * s < 512) s *= 2;
+    while (s < 64 && tiles * s < 1024) s *= 2;
     return s;
 }
 
@@ -134,7 +136,12 @@ int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws
     int groups = num_cus_impl() / ns;
     if (groups < 1) groups = 1;
     const int64_t tiles_chunk = ((E + GP_TE - 1) / GP_TE + P->n_chunks - 1) / P->n_chunks;
-    const int64_t gcap = (tiles_chunk + GP_WAVES - 1) / GP_WAVES;
+    int64_t gcap = (tiles_chunk + GP_WAVES - 1) / GP_WAVES;
+    // small graphs (MGKN levels): let a wave own as little as ONE destination node.  Its in-edges are a partial
+    // tile (the matrix pipe idles anyway), but the per-node flush of Z - 32 KiB per node and slice - is what such a
+    // launch spends its time on, and it is spread over the chip instead of a handful of waves
+    const int64_t gcap_nodes = (npc + GP_WAVES - 1) / GP_WAVES;
+    if (gcap < gcap_nodes) gcap = gcap_nodes;
     if (groups > gcap) groups = (int)(gcap < 1 ? 1 : gcap);
     P->n_groups = groups;
     return GPDE_OK;
@@ -208,7 +215,8 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
              int n_layers, const int32_t* dims, const void* packed, const float* root,
              const float* bias, int aggr, uint32_t flags, const float* hidden, float* out, void* ws,
              size_t ws_bytes, hipStream_t stream, int kt = 0, const int* sel = nullptr,
-             const float* hidden_absmax = nullptr, int64_t hidden_nodes = -1) {
+             const float* hidden_absmax = nullptr, int64_t hidden_nodes = -1, const float* residual = nullptr,
+             int relu_out = 0) {
     // hidden_nodes in [0, n_nodes): MIXED call (gpde_nnconv_fwd_mixed) -- `hidden` covers the in-edges of
     // nodes [0, hidden_nodes) only (a graph whose H does not fit memory, e.g. 391 GB at the 241^2 graph);
     // those nodes aggregate from it, the others run the fused kernel on edge_attr
@@ -308,7 +316,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
             ProfScope ps1(GPDE_PROF_GEMM3, stream);
             GpdeGemm3Args g;
             g.zbuf = zbuf; g.w3q = pk + L.off_w3q; g.part = part; g.nn = nn; g.K2P = L.K2P;
-            g.splits = splits;
+            g.splits = splits; g.rowptr = rowptr; g.nc0 = (int)nc0;
             rc = gpde_launch_gemm3(g, stream);
             if (rc != GPDE_OK) return rc;
         }
@@ -316,6 +324,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
         e.part = part; e.x = x; e.rowptr = rowptr; e.src = src;
         e.b3 = pk + L.off_b3; e.root = root; e.bias = bias; e.out = out;
         e.nc0 = (int)nc0; e.nn = nn; e.splits = splits; e.aggr = aggr;
+        e.residual = residual; e.relu_out = relu_out;
         ProfScope ps2(GPDE_PROF_EPILOGUE, stream);
         rc = gpde_launch_epilogue(e, stream);
         if (rc != GPDE_OK) return rc;
@@ -396,6 +405,36 @@ extern "C" int gpde_nnconv_fwd_hidden(const float* x, int64_t n_nodes, const flo
     }
     return fwd_impl(x, n_nodes, nullptr, n_edges, rowptr, src, dst, nullptr, n_layers, dims, packed, root, bias,
                     aggr, 0, hidden, out, ws, ws_bytes, (hipStream_t)stream_, 0, nullptr, hidden_absmax);
+}
+
+extern "C" int gpde_nnconv_fwd_act(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
+                                   const int32_t* rowptr, const int32_t* src, const int32_t* dst, const int32_t* perm,
+                                   int n_layers, const int32_t* dims, const void* packed, const float* root,
+                                   const float* bias, int aggr, uint32_t flags, const float* residual, int relu_out,
+                                   float* out, void* ws, size_t ws_bytes, void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || !dims || !packed || !rowptr || (n_nodes > 0 && (!x || !out)) ||
+        (n_edges > 0 && (!edge_attr || !src || !dst || !perm)) || (residual && residual == out)) {
+        gpde_set_error("gpde_nnconv_fwd_act: null/negative argument (or residual aliases out)");
+        return GPDE_EINVAL;
+    }
+    return fwd_impl(x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, n_layers, dims, packed, root, bias,
+                    aggr, flags, nullptr, out, ws, ws_bytes, (hipStream_t)stream_, 0, nullptr, nullptr, -1, residual,
+                    relu_out);
+}
+
+extern "C" int gpde_nnconv_fwd_hidden_act(const float* x, int64_t n_nodes, const float* hidden, const float* hidden_absmax,
+                                          int64_t n_edges, const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                                          int n_layers, const int32_t* dims, const void* packed, const float* root,
+                                          const float* bias, int aggr, const float* residual, int relu_out, float* out,
+                                          void* ws, size_t ws_bytes, void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || !dims || !packed || !rowptr || (n_nodes > 0 && (!x || !out)) ||
+        (n_edges > 0 && (!hidden || !src || !dst)) || (residual && residual == out)) {
+        gpde_set_error("gpde_nnconv_fwd_hidden_act: null/negative argument (or residual aliases out)");
+        return GPDE_EINVAL;
+    }
+    return fwd_impl(x, n_nodes, nullptr, n_edges, rowptr, src, dst, nullptr, n_layers, dims, packed, root, bias,
+                    aggr, 0, hidden, out, ws, ws_bytes, (hipStream_t)stream_, 0, nullptr, hidden_absmax, -1, residual,
+                    relu_out);
 }
 
 extern "C" int gpde_profile_begin(void) {

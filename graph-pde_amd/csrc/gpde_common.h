@@ -154,6 +154,8 @@ struct GpdeGemm3Args {
     const float* w3q;      // [64*K2P/4][64][4]
     float* part;           // [splits][nn][64]
     int nn, K2P, splits;
+    const int32_t* rowptr; // optional: tiles of 64 nodes without in-edges are skipped (nodes nc0 .. nc0 + nn)
+    int nc0;
 };
 int gpde_launch_gemm3(const GpdeGemm3Args& a, hipStream_t stream);
 
@@ -167,6 +169,8 @@ struct GpdeEpilogueArgs {
     const float* bias;     // [64] or nullptr
     float* out;            // [N][64]
     int nc0, nn, splits, aggr;
+    const float* residual; // optional [N][64] added to the result (may alias x, never out)
+    int relu_out;          // clamp the result at 0
 };
 int gpde_launch_epilogue(const GpdeEpilogueArgs& a, hipStream_t stream);
 

@@ -18,49 +18,66 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 constexpr int G3_TM = 64;     // nodes per workgroup
-constexpr int G3_AS = 36;     // LDS row stride of the A tile
+constexpr int G3_BK = 64;     // contraction elements per chunk
+constexpr int G3_AS = 68;     // LDS row stride of the A tile (floats): 272-byte rows, conflict-free b128 reads
 
-// grid = (node tiles, splits); block = 256 (4 waves: 2 node blocks x 2 out blocks of 32)
+// grid = (node tiles, splits); block = 256 (4 waves: 2 node blocks x 2 out blocks of 32).
+// The kernel streams Z once (256 KiB per node at k2 = 1024: HBM bound) against W3q from L2.  Chunks of 64
+// contraction elements are double-buffered in LDS with ONE barrier per chunk; the next chunk's global loads are
+// issued right behind the barrier, before the 32 MFMAs of the current one, so that a chunk's HBM latency sits
+// under the previous chunk's arithmetic.  A 64-node tile without any in-edge (the destination sub-ranges of the
+// MGKN inter-level graphs cover 0.5 - 35 % of the nodes, MGKN_general_darcy2d.py:76-90) returns at once: its Z
+// rows were never written and the epilogue does not read its partial sums (deg = 0).
 __global__ __launch_bounds__(256) void gpde_gemm3_kernel(GpdeGemm3Args a) {
-    __shared__ __attribute__((aligned(16))) float As[G3_TM * G3_AS];
-    __shared__ __attribute__((aligned(16))) float Bs[8 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float As[2][G3_TM * G3_AS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][G3_BK / 4 * 64 * 4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int mi = wave >> 1, ni = wave & 1;
     const int node0 = blockIdx.x * G3_TM;
+    if (a.rowptr) {
+        const int n1 = min(node0 + G3_TM, a.nn);
+        if (a.rowptr[a.nc0 + n1] == a.rowptr[a.nc0 + node0]) return;
+    }
     const int split = blockIdx.y;
     const size_t KK = (size_t)GP_W * a.K2P;
     const size_t klen = KK / a.splits;
     const size_t kk_lo = klen * split;
+    const int nchunks = (int)(klen / G3_BK);
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    for (size_t kk0 = kk_lo; kk0 < kk_lo + klen; kk0 += 32) {
-        f32x4 av[2], bv[2];
+    // this thread's 4 A pieces (row f >> 4, 16-byte unit f & 15) and 4 B pieces of a chunk
+    f32x4 av[4], bv[4];
+    auto gload = [&](size_t kk0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i;
-            const int row = f >> 3, kq = f & 7;
+            const int row = f >> 4, kq = f & 15;
             av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (node0 + row < a.nn)
                 av[i] = *(const f32x4*)&a.zbuf[(size_t)(node0 + row) * KK + kk0 + kq * 4];
             bv[i] = *(const f32x4*)&a.w3q[kk0 * 64 + (size_t)f * 4];
         }
-        __syncthreads();   // previous chunk's reads done
+    };
+    gload(kk_lo);
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i;
-            *(f32x4*)&As[(f >> 3) * G3_AS + (f & 7) * 4] = av[i];
-            *(f32x4*)&Bs[f * 4] = bv[i];
+            *(f32x4*)&As[buf][(f >> 4) * G3_AS + (f & 15) * 4] = av[i];
+            *(f32x4*)&Bs[buf][f * 4] = bv[i];
         }
-        __syncthreads();
+        __syncthreads();          // chunk c visible; everybody is done with chunk c - 1 (the other buffer)
+        if (c + 1 < nchunks) gload(kk_lo + (size_t)(c + 1) * G3_BK);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 af = *(const f32x4*)&As[(mi * 32 + l31) * G3_AS + q * 8 + h * 4];
-            const f32x4 bf = *(const f32x4*)&Bs[((q * 2 + h) * 64 + ni * 32 + l31) * 4];
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 af = *(const f32x4*)&As[buf][(mi * 32 + l31) * G3_AS + q * 8 + h * 4];
+            const f32x4 bf = *(const f32x4*)&Bs[buf][((q * 2 + h) * 64 + ni * 32 + l31) * 4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc = mfma32(af[t], bf[t], acc);
         }
@@ -102,6 +119,10 @@ __global__ __launch_bounds__(256) void gpde_epilogue_kernel(GpdeEpilogueArgs a) 
         t += tr;
     }
     if (a.bias) t += a.bias[lane];
+    // opt-in caller glue: x' = relu(residual + conv(x)) of the MGKN V-cycles
+    // (MGKN_general_darcy2d.py:79-80,89-90; MGKN_orthogonal_burgers1d.py:74-82) without two more elementwise launches
+    if (a.residual) t += a.residual[(size_t)i * GP_W + lane];
+    if (a.relu_out) t = fmaxf(t, 0.f);
     a.out[(size_t)i * GP_W + lane] = t;
 }
 

@@ -47,7 +47,8 @@ class Workload:
         self.description = description
 
 
-def orthogonal_burgers(device, s: int = 8192, depth: int = 4, ker_width: int = 1024, seed: int = 0) -> Workload:
+def orthogonal_burgers(device, s: int = 8192, depth: int = 4, ker_width: int = 1024, seed: int = 0,
+                       fused_glue: bool = False) -> Workload:
     torch.manual_seed(seed)
     graphs = [(ei.to(device), ea.to(device), n) for ei, ea, n in synth.burgers_multipole_graphs(s, seed=seed)]
     nlev = len(graphs)                              # level + 1 graphs: nearest neighbours + one per level
@@ -61,7 +62,10 @@ def orthogonal_burgers(device, s: int = 8192, depth: int = 4, ker_width: int = 1
             xs = [p.clone() for p in phis]
             for _ in range(depth):                  # MGKN_orthogonal_burgers1d.py:65-82
                 for l in reversed(range(nlev)):
-                    xs[l] = F.relu(xs[l] + convs[l](phis[l], graphs[l][0], graphs[l][1]))
+                    if fused_glue:      # opt-in: the relu(x + conv) glue inside the operator's last kernel
+                        xs[l] = convs[l](phis[l], graphs[l][0], graphs[l][1], residual=xs[l], activation="relu")
+                    else:
+                        xs[l] = F.relu(xs[l] + convs[l](phis[l], graphs[l][0], graphs[l][1]))
             return xs
 
     pairs = [(convs[l], phis[l], graphs[l][0], graphs[l][1]) for l in range(nlev)]
@@ -70,7 +74,8 @@ def orthogonal_burgers(device, s: int = 8192, depth: int = 4, ker_width: int = 1
                     f"max({ker_width}//2^l,16), {edges} edges per sweep")
 
 
-def general_darcy(device, s: int = 421, depth: int = 5, ker_width: int = 256, seed: int = 0) -> Workload:
+def general_darcy(device, s: int = 421, depth: int = 5, ker_width: int = 256, seed: int = 0,
+                  fused_glue: bool = False) -> Workload:
     torch.manual_seed(seed)
     m = [2400, 1600, 400, 100, 25]
     r_inner = [0.5 / 8 * 1.41, 0.5 / 8, 0.5 / 4, 0.5 / 2, 0.5]
@@ -100,13 +105,19 @@ def general_darcy(device, s: int = 421, depth: int = 5, ker_width: int = 256, se
             xx = x0
             for _ in range(depth):                  # MGKN_general_darcy2d.py:76-90
                 for l in range(L - 1):
-                    xx = F.relu(xx + down[l](xx, gd[l][0], gd[l][1]))
+                    if fused_glue:
+                        xx = down[l](xx, gd[l][0], gd[l][1], residual=xx, activation="relu")
+                    else:
+                        xx = F.relu(xx + down[l](xx, gd[l][0], gd[l][1]))
                 for l in reversed(range(L)):
                     a, b = offs[l], offs[l + 1]
                     xx = xx.clone()
                     xx[a:b] = inner[l](xx[a:b].clone(), g["inner"][l][0], g["inner"][l][1])
                     if l > 0:
-                        xx = F.relu(xx + up[l - 1](xx, gu[l - 1][0], gu[l - 1][1]))
+                        if fused_glue:
+                            xx = up[l - 1](xx, gu[l - 1][0], gu[l - 1][1], residual=xx, activation="relu")
+                        else:
+                            xx = F.relu(xx + up[l - 1](xx, gu[l - 1][0], gu[l - 1][1]))
             return [xx]
 
     pairs = [(inner[l], x0[offs[l]:offs[l + 1]].contiguous(), g["inner"][l][0], g["inner"][l][1]) for l in range(L)]

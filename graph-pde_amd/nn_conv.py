@@ -83,7 +83,16 @@ class NNConv_old(torch.nn.Module):
         _uniform(size, self.root)
         _uniform(size, self.bias)
 
-    def forward(self, x, edge_index, edge_attr):      # nn_conv.py:267-271
+    def forward(self, x, edge_index, edge_attr, *, residual=None, activation=None):      # nn_conv.py:267-271
+        """The reference signature `forward(x, edge_index, edge_attr)`.  Two keyword-only, opt-in extras fuse the
+        callers' elementwise glue into the operator's last kernel: `residual` (a [N, 64] tensor
+        added to the result) and `activation="relu"` - `conv(x, ei, ea, residual=x, activation="relu")` equals
+        `F.relu(x + conv(x, ei, ea))` (MGKN_general_darcy2d.py:79-80).  Fused for inference on device tensors;
+        when a gradient is needed the same value is composed from the unfused operator and torch ops."""
+        if activation not in (None, "relu"):
+            raise ValueError(f"activation must be None or 'relu', got {activation!r}")
+        if residual is not None or activation is not None:
+            return self._forward_act(x, edge_index, edge_attr, residual, activation == "relu")
         x = x.unsqueeze(-1) if x.dim() == 1 else x
         if not x.is_cuda:
             return self._forward_staged(x, edge_index, edge_attr)
@@ -103,6 +112,30 @@ class NNConv_old(torch.nn.Module):
         weights = [l.weight for l in lin]
         biases = [l.bias for l in lin]
         return self._propagate(x, edge_index, pseudo, weights, biases, self.root, self.bias, use_hidden_cache=True)
+
+    def _forward_act(self, x, edge_index, edge_attr, residual, relu):
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad) or
+                                                  any(p.requires_grad for p in self.parameters()))
+        fusable = x.is_cuda and x.dim() == 2 and not isinstance(edge_attr, ops.NodeAttr) and not needs_grad and \
+            x.dtype == torch.float32
+        if not fusable:
+            y = self.forward(x, edge_index, edge_attr)
+            if residual is not None:
+                y = residual + y
+            return torch.relu(y) if relu else y
+        self._check_width()
+        pseudo = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
+        lin = ops.mlp_linears(self.nn)
+        weights = [l.weight for l in lin]
+        biases = [l.bias for l in lin]
+        csr = ops.csr_for(edge_index, x.size(0))
+        pm = ops.pack_mlp(weights, biases)
+        if hidden_cache.MODE != "off" and self.aggr in ("add", "mean") and pseudo.dtype == torch.float32:
+            hit = hidden_cache.lookup(self, pseudo, csr, pm, weights, biases, allow_partial=False)
+            if hit is not None and hit[2] == csr.n_nodes:
+                return ops.nnconv_forward_hidden_raw(x, csr, hit[0].detach(), pm, self.root, self.bias, self.aggr,
+                                                     hmax=hit[1], residual=residual, relu=relu)
+        return ops.nnconv_forward_raw(x, csr, pseudo, pm, self.root, self.bias, self.aggr, residual=residual, relu=relu)
 
     def _check_width(self):
         if self.in_channels != ops.WIDTH or self.out_channels != ops.WIDTH:

@@ -270,11 +270,23 @@ def workspace_bytes(n_nodes: int, n_edges: int, pm: PackedMlp) -> int:
     return int(_lib.lib().gpde_nnconv_fwd_workspace_bytes(n_nodes, n_edges, len(pm.dims) - 1, pm.dims_c))
 
 
+def _check_residual(residual, x, n):
+    if residual is None:
+        return None
+    _require_cuda(residual, "residual")
+    if residual.dtype != torch.float32 or tuple(residual.shape) != (n, WIDTH):
+        raise ValueError(f"residual must be float32 [{n},{WIDTH}], got {residual.dtype} {tuple(residual.shape)}")
+    return residual.contiguous()
+
+
 def nnconv_forward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor, pm: PackedMlp,
                        root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,
                        out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
-                       precision: Optional[str] = None) -> torch.Tensor:
-    """One gpde_nnconv_fwd call on the current stream. x [N,64] f32, edge_attr [E,k0] f32."""
+                       precision: Optional[str] = None, residual: Optional[torch.Tensor] = None,
+                       relu: bool = False) -> torch.Tensor:
+    """One gpde_nnconv_fwd call on the current stream. x [N,64] f32, edge_attr [E,k0] f32.
+    `residual` / `relu` (opt-in): out = act(residual + NNConv(x)) in the last kernel
+    (gpde_nnconv_fwd_act)."""
     lib = _lib.lib()
     _require_cuda(x, "x")
     _require_cuda(edge_attr, "edge_attr")
@@ -303,13 +315,23 @@ def nnconv_forward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor, pm: P
         out = torch.empty(n, WIDTH, dtype=torch.float32, device=x.device)
     if ws is None:
         ws = torch.empty(max(workspace_bytes(n, e, pm), 1), dtype=torch.uint8, device=x.device)
+    residual = _check_residual(residual, x, n)
     with torch.cuda.device(x.device):
-        rc = lib.gpde_nnconv_fwd(x.data_ptr(), n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(),
-                                 csr.src.data_ptr(), csr.dst.data_ptr(), csr.perm.data_ptr(),
-                                 len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(),
-                                 None if root_c is None else root_c.data_ptr(),
-                                 None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
-                                 _PRECISION[precision], out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
+        if residual is None and not relu:
+            rc = lib.gpde_nnconv_fwd(x.data_ptr(), n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(),
+                                     csr.src.data_ptr(), csr.dst.data_ptr(), csr.perm.data_ptr(),
+                                     len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(),
+                                     None if root_c is None else root_c.data_ptr(),
+                                     None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
+                                     _PRECISION[precision], out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
+        else:
+            rc = lib.gpde_nnconv_fwd_act(x.data_ptr(), n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(),
+                                         csr.src.data_ptr(), csr.dst.data_ptr(), csr.perm.data_ptr(),
+                                         len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(),
+                                         None if root_c is None else root_c.data_ptr(),
+                                         None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
+                                         _PRECISION[precision], None if residual is None else residual.data_ptr(),
+                                         1 if relu else 0, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
     _lib.check(rc, "gpde_nnconv_fwd")
     _lib.n_native_calls += 1
     return out
@@ -517,7 +539,8 @@ def hidden_forward_raw(csr: Csr, edge_attr: torch.Tensor, pm: PackedMlp,
 def nnconv_forward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, pm: PackedMlp,
                               root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,
                               out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
-                              hmax: Optional[torch.Tensor] = None) -> torch.Tensor:
+                              hmax: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                              relu: bool = False) -> torch.Tensor:
     """gpde_nnconv_fwd_hidden: aggregation + last Linear + update() from given hidden activations
     (`hmax`: the max |H| scalar hidden_forward_raw returned; enables the split-f16 aggregation)."""
     lib = _lib.lib()
@@ -538,14 +561,16 @@ def nnconv_forward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, p
         out = torch.empty(n, WIDTH, dtype=torch.float32, device=x.device)
     if ws is None:
         ws = torch.empty(max(workspace_bytes(n, e, pm), 1), dtype=torch.uint8, device=x.device)
+    residual = _check_residual(residual, x, n)
     with torch.cuda.device(x.device):
-        rc = lib.gpde_nnconv_fwd_hidden(x.data_ptr(), n, hidden.data_ptr(),
-                                        None if hmax is None else hmax.data_ptr(), e, csr.rowptr.data_ptr(),
-                                        csr.src.data_ptr(), csr.dst.data_ptr(), len(pm.dims) - 1,
-                                        pm.dims_c, pm.packed.data_ptr(),
-                                        None if root_c is None else root_c.data_ptr(),
-                                        None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
-                                        out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
+        rc = lib.gpde_nnconv_fwd_hidden_act(x.data_ptr(), n, hidden.data_ptr(),
+                                            None if hmax is None else hmax.data_ptr(), e, csr.rowptr.data_ptr(),
+                                            csr.src.data_ptr(), csr.dst.data_ptr(), len(pm.dims) - 1,
+                                            pm.dims_c, pm.packed.data_ptr(),
+                                            None if root_c is None else root_c.data_ptr(),
+                                            None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
+                                            None if residual is None else residual.data_ptr(), 1 if relu else 0,
+                                            out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
     _lib.check(rc, "gpde_nnconv_fwd_hidden")
     _lib.n_native_calls += 1
     return out

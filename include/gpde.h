@@ -117,6 +117,23 @@ int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edge_attr, int
                     const float* root, const float* bias, int aggr, uint32_t flags, float* out,
                     void* ws, size_t ws_bytes, void* stream);
 
+/* gpde_nnconv_fwd / gpde_nnconv_fwd_hidden with the callers' elementwise glue fused into the last kernel
+ * (opt-in, the module surface does not change):
+ *     out = act(residual + NNConv(x))        residual [N][64] or NULL (may alias x, must not alias out),
+ *                                            relu_out != 0: act = max(., 0), else identity
+ * - `F.relu(x + conv(x, ...))` of the MGKN V-cycles (MGKN_general_darcy2d.py:79-80,89-90;
+ * MGKN_orthogonal_burgers1d.py:74-82) and `F.relu(conv(...))` of KernelNN.forward (UAI1_full_resolution.py:30). */
+int gpde_nnconv_fwd_act(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
+                        const int32_t* rowptr, const int32_t* src, const int32_t* dst, const int32_t* perm,
+                        int n_layers, const int32_t* dims, const void* packed, const float* root,
+                        const float* bias, int aggr, uint32_t flags, const float* residual, int relu_out,
+                        float* out, void* ws, size_t ws_bytes, void* stream);
+int gpde_nnconv_fwd_hidden_act(const float* x, int64_t n_nodes, const float* hidden, const float* hidden_absmax,
+                               int64_t n_edges, const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                               int n_layers, const int32_t* dims, const void* packed, const float* root,
+                               const float* bias, int aggr, const float* residual, int relu_out, float* out,
+                               void* ws, size_t ws_bytes, void* stream);
+
 /* Launch plan gpde_nnconv_fwd will follow for these sizes and this workspace (host-side query, no
  * device work): number of destination-node chunks, nodes per chunk, workgroups of the fused
  * kernel per chunk, and which fused variant runs (0: one hidden layer, 1: two hidden layers with

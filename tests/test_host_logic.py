@@ -74,7 +74,11 @@ def test_module_surface_has_the_reference_methods():
     import inspect
     for name, params in (("forward", ["self", "x", "edge_index", "edge_attr"]), ("message", ["self", "x_j", "pseudo"]),
                          ("update", ["self", "aggr_out", "x"]), ("reset_parameters", ["self"])):
-        assert list(inspect.signature(getattr(gp.NNConv_old, name)).parameters) == params, name
+        sig = inspect.signature(getattr(gp.NNConv_old, name)).parameters
+        positional = [k for k, v in sig.items() if v.kind is not inspect.Parameter.KEYWORD_ONLY]
+        assert positional == params, name
+        # extras (the opt-in fused glue of forward) are keyword-only and default to "off"
+        assert all(v.default is None for v in sig.values() if v.kind is inspect.Parameter.KEYWORD_ONLY), name
 
 
 def test_version_helper_accepts_inference_tensors():
