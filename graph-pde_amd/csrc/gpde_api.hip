@@ -61,7 +61,8 @@ struct Plan {
     int64_t nodes_per_chunk;
     int n_chunks;
     int n_groups;        // fused-kernel edge groups (workgroups per hidden slice)
-    size_t off_part, off_z, off_ha, off_hb, off_xs, off_scal;
+    size_t off_part, off_z, off_ha, off_hb, off_xs, off_scal, off_blk;
+    int nblk_max;        // f16v6 work queue: block-bound slots (0: no queue)
     size_t h_floats;     // mode 2: floats per ping-pong activation buffer
 };
 
@@ -93,6 +94,10 @@ int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws
         fixed = 2 * align_up(P->h_floats * sizeof(float));
     }
     fixed += xs_bytes;
+    // f16v6 work queue: block bounds [nblk_max + 1] + block count + one counter per column slice
+    P->nblk_max = (L.mode == 1 && E < ((int64_t)1 << 31) - GP_QBLOCK) ? (int)(E / GP_QBLOCK + E / 8 / (GP_QBLOCK / 8)) + 10 : 0;
+    const size_t blk_bytes = P->nblk_max ? align_up(((size_t)P->nblk_max + 2 + 64) * 4) : 0;
+    fixed += blk_bytes;
     int64_t npc;
     if (sizing) {
         // recommended: all nodes if Z fits 4 GiB, else 4 GiB worth of nodes (at least one tile)
@@ -130,6 +135,7 @@ int make_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws
     P->off_hb = off;   off += (L.mode == 2 && !hidden_given) ? align_up(P->h_floats * sizeof(float)) : 0;
     P->off_xs = off;   off += xs_bytes ? xs_bytes - kAlign : 0;
     P->off_scal = off; off += xs_bytes ? kAlign : 0;
+    P->off_blk = off;  off += blk_bytes;
     if (needed) *needed = off;
     // fused-kernel grid: ~one workgroup per CU, never more edge groups than 4-wave tile sets
     const int ns = L.K2P / GP_TN;
@@ -307,6 +313,13 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
             f.nc0 = (int)nc0; f.nc1 = (int)nc1; f.e_chunk0 = 0; f.n_groups = P.n_groups;
             {
                 ProfScope ps(GPDE_PROF_FUSED, stream);
+                if (!from_h && fc.kind == FK_V6 && P.nblk_max && L.K2P / GP_TN <= 64 && !(flags & GPDE_FWD_STATIC_RANGES)) {
+                    int32_t* blk = (int32_t*)(w + P.off_blk);
+                    f.blk = blk; f.qn = blk + P.nblk_max + 1; f.qctr = (unsigned*)(blk + P.nblk_max + 2);
+                    rc = gpde_launch_block_bounds(rowptr, (int)nc0, (int)nc1, P.nblk_max, blk, blk + P.nblk_max + 1,
+                                                  (unsigned*)(blk + P.nblk_max + 2), L.K2P / GP_TN, stream);
+                    if (rc != GPDE_OK) return rc;
+                }
                 if (from_h) rc = gpde_launch_zagg(f, stream);
                 else if (fc.kind == FK_V6) rc = gpde_launch_fused_f16v6(f, stream);
                 else if (fc.kind == FK_V3) rc = gpde_launch_fused_f16v3(f, stream);

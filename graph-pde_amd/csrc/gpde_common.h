@@ -118,6 +118,9 @@ struct GpdeFusedArgs {
     const unsigned* scal;  // [0] bits of max |x|, [1] bits of max_e B_e   (gpde_prep.hip)
     const unsigned* hmax;  // zagg f16: bits of max |H| (recorded by gpde_hidden_fwd)
     unsigned* hmax_out;    // f16v3 WRITE_H: atomicMax target for the bits of max |H| (nullable)
+    const int32_t* blk;    // f16v6 work queue: node-aligned block bounds (edge offsets) [*qn + 1], or nullptr = static ranges
+    const int32_t* qn;     //   number of blocks of this launch (device scalar, written by the block-bounds pre-pass)
+    unsigned* qctr;        //   one draw counter per column slice, zeroed by the pre-pass
     int kt;                // f16v3, attributes from a node table (row f3): table row stride, 0 = edge_attr tensor
     int sel[8];            // slot d of an edge's attribute = attr[(sel[d] >> 8 ? dst : src) * kt + (sel[d] & 255)]
     int k0, K1P, K2P;
@@ -131,6 +134,11 @@ int gpde_launch_g2_prep(const float* x, int64_t n_nodes, const float* attr, int6
                         const float* wmax8, unsigned* scal, unsigned* xs, hipStream_t stream,
                         int kt = 0, const int* sel = nullptr, const int32_t* src = nullptr,
                         const int32_t* dst = nullptr);
+// block bounds + queue counters of the f16v6 work queue (gpde_prep.hip): blk [nblk_max + 1], qn [1], qctr [n_slices]
+constexpr int GP_QBLOCK = 4096;    // edges per big block (node-aligned: a block holds whole destination nodes); the
+                                   // last 1/8 of the edges is cut into blocks of GP_QBLOCK / 8
+int gpde_launch_block_bounds(const int32_t* rowptr, int nc0, int nc1, int nblk_max, int32_t* blk, int32_t* qn,
+                             unsigned* qctr, int n_slices, hipStream_t stream);
 // 2^(13 - floor(log2 v)) for v in the normal range, else 1: puts a maximum v into [2^13, 2^14)
 __host__ __device__ static inline float gpde_pow2_to_2p13(float v) {
     union { float f; unsigned u; } a; a.f = v;

@@ -66,7 +66,7 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
     char* w1s = smem + NS * TILE_B;                                  // [K1P][hi 16 B | lo 16 B]
     unsigned* Xs_all = (unsigned*)(w1s + (size_t)a.K1P * 32);        // [4 waves][64 rows][64 words]
     float* Es_all = (float*)(Xs_all + NW * TE * GP_W);               // [4][64]
-    int* red = (int*)(Es_all + NW * TE);                             // [4]
+    int* red = (int*)(Es_all + NW * TE);                             // [2][4]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -83,20 +83,49 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
 
     for (int i = tid; i < a.K1P * 2; i += 256) ((f32x4*)w1s)[i] = ((const f32x4*)a.w1h)[i];
 
-    // ---- node-aligned edge range of this wave --------------------------------------------------------
+    // ---- work assignment ---------------------------------------------------------------------------------
+    // Queue mode (a.blk != nullptr, the default): the chunk's edges are cut into node-aligned BLOCKS of ~4096 edges
+    // (a.blk[b] .. a.blk[b+1], gpde_prep.hip) and every wave draws its next block from ONE counter per column slice
+    // (a.qctr[slice]; the workgroups of a slice share an XCD).  The 128 waves of a slice therefore work on
+    // CONSECUTIVE blocks at any time - a window of a few hundred destination nodes whose sources (x_j rows) are the
+    // same lattice band for all of them, so the gather hits in the XCD's L2 (4 MiB) instead of missing it on every
+    // edge (measured: HBM-side fetch per launch 56 GB with contiguous per-wave ranges).  A node's in-edges lie in one
+    // block and one wave walks them in CSR order: the sum order does not depend on which wave drew the block -
+    // results stay bit-reproducible.  The queue also levels the load (the tail is one block, not one range).
+    // Static mode (a.blk == nullptr): one contiguous node-aligned range per wave.
     const int e_lo = a.rowptr[a.nc0], e_hi = a.rowptr[a.nc1];
-    const long tot = (long)e_hi - e_lo;
-    const int nranges = a.n_groups * NW;
-    const int wg = group * NW + wave;
-    const int na = lower_bound_node(a.rowptr, a.nc0, a.nc1, e_lo + tot * wg / nranges);
-    const int nb_ = (wg == nranges - 1) ? a.nc1
-                                        : lower_bound_node(a.rowptr, a.nc0, a.nc1, e_lo + tot * (wg + 1) / nranges);
-    const int ea = a.rowptr[na], eb = a.rowptr[nb_];
-    const int ntiles = (eb - ea + TE - 1) / TE;
-    if (lane == 0) red[wave] = ntiles;
+    const bool queue = a.blk != nullptr;
+    int blk_a = 0, blk_b = 0;           // current block / range [blk_a, blk_b)
+    const int nblk = queue ? *a.qn : 0;
+    bool have;
+    auto draw_block = [&](int& ba, int& bb) {        // wave-uniform; false when the queue is empty
+        for (;;) {
+            int b = 0;
+            if (lane == 0) b = (int)atomicAdd(a.qctr + slice, 1u);
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (b >= nblk) return false;
+            ba = a.blk[b];
+            bb = a.blk[b + 1];
+            if (bb > ba) return true;
+        }
+    };
+    if (queue) {
+        have = draw_block(blk_a, blk_b);
+    } else {
+        const long tot = (long)e_hi - e_lo;
+        const int nranges = a.n_groups * NW;
+        const int wg = group * NW + wave;
+        const int na = lower_bound_node(a.rowptr, a.nc0, a.nc1, e_lo + tot * wg / nranges);
+        const int nb_ = (wg == nranges - 1) ? a.nc1
+                                            : lower_bound_node(a.rowptr, a.nc0, a.nc1, e_lo + tot * (wg + 1) / nranges);
+        blk_a = a.rowptr[na];
+        blk_b = a.rowptr[nb_];
+        have = blk_b > blk_a;
+    }
+    // red[parity][wave]: "this wave has no tile" flags of the current tile round (double-buffered by parity)
+    if (lane == 0) { red[wave] = have ? 0 : 1; red[4 + wave] = 0; }
     __syncthreads();
-    const int maxtiles = max(max(red[0], red[1]), max(red[2], red[3]));
-    if (maxtiles == 0) return;
+    if (red[0] + red[1] + red[2] + red[3] == 4) return;
 
     // ---- W2 chunk DMA: 4 x 1 KiB per wave per chunk, one address, immediate offsets on both sides -----
     const unsigned long long w2base = (unsigned long long)a.w2h + (size_t)slice * NKC * TILE_B + wave * 4096;
@@ -189,7 +218,7 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
         char* l1 = ring + TILE_B + wave * 4096;
         GPDE_GLDS(g1, l1, 0); GPDE_GLDS(g1, l1, 1024); GPDE_GLDS(g1, l1, 2048); GPDE_GLDS(g1, l1, 3072);
     }
-    load_perm(ea);
+    load_perm(have ? blk_a : e_hi);
     load_attr();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -236,9 +265,26 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
 #ifdef GPDE_V6_TIMING
     long long tm_pro = 0, tm_loop = 0, tm_post = 0, tm0_ = clock64();
 #endif
-    for (int t = 0; t < maxtiles; ++t) {
-        const int e0 = ea + t * TE;
+    int e0 = have ? blk_a : e_hi;
+    int n_rounds = 0;
+    for (int t = 0;; ++t) {
+        // ---- this tile, and where the NEXT one starts (its edge ids / attributes are prefetched during this one) ----
+        const int eb = have ? blk_b : e0;                        // no tile: everything below is masked out
         const int e_end = min(e0 + TE, eb);
+        const bool last_in_blk = have && (e0 + TE >= blk_b);
+        int na_ = 0, nb_ = 0;
+        bool have_n = have && !last_in_blk;
+        if (last_in_blk && queue) have_n = draw_block(na_, nb_);      // drawn ONE tile ahead: no block is held in reserve
+        const int e0n = !have ? e_hi : (last_in_blk ? (have_n ? na_ : e_hi) : e0 + TE);
+        if (t > 0) {
+            // all four waves out of tiles -> done.  Flags of this round were written before the barrier; the other
+            // parity is rewritten two rounds later, behind at least one K loop of barriers
+            if (lane == 0) red[(t & 1) * 4 + wave] = have ? 0 : 1;
+            __syncthreads();
+            const int* rf = red + (t & 1) * 4;
+            if (rf[0] + rf[1] + rf[2] + rf[3] == 4) break;
+        }
+        ++n_rounds;
 
         // ---- attributes of this lane's two edges: validity, bias slot, per-edge scale, f16 split ------------
         h8 B1[2], B2[2];        // H1 MFMA operands: B1 = h ? attr_lo : attr_hi ; B2 = h ? 0 : attr_hi
@@ -307,7 +353,6 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
         // destination of the first / last edge of the two 32-edge halves: loaded with the other side loads at the
         // end of chunk 0 (all lanes the same address), made scalar after the K loop
         int nf_v[2] = {0, 0}, nl_v[2] = {0, 0};
-        const int e0n = e0 + TE;
         unsigned cph = 0, ct0 = 0, ct1 = 0;
         h8 A1, A2;
         {
@@ -522,6 +567,15 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) asm volatile("" : "+a"(Z[cb][nb]));
         TM_MARK(tm_post);
+        // ---- advance ---------------------------------------------------------------------------------------
+        if (last_in_blk) {
+            have = have_n;
+            blk_a = na_;
+            blk_b = nb_;
+            e0 = have ? blk_a : e_hi;
+        } else if (have) {
+            e0 += TE;
+        }
     }
     if (cur >= 0) flush(cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -530,7 +584,7 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
         atomicAdd(&gpde_v6_tm[0], (unsigned long long)tm_pro);
         atomicAdd(&gpde_v6_tm[1], (unsigned long long)tm_loop);
         atomicAdd(&gpde_v6_tm[2], (unsigned long long)tm_post);
-        atomicAdd(&gpde_v6_tm[3], (unsigned long long)maxtiles);
+        atomicAdd(&gpde_v6_tm[3], (unsigned long long)n_rounds);
     }
 #endif
 }

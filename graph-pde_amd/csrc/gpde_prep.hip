@@ -68,7 +68,42 @@ __global__ void k_split_x(const float* __restrict__ x, size_t n, const unsigned*
     }
 }
 
+// Work queue of gpde_fused_f16v6_kernel: the edges of destination nodes [nc0, nc1) cut into node-aligned blocks -
+// GP_QBLOCK edges each over the first 7/8 of the edges, GP_QBLOCK / 8 over the rest (guided self-scheduling: big
+// blocks keep the per-block partial tile rare, small blocks at the end keep the tail short).
+// blk[b] = first CSR slot of the first node whose in-edges start at or after the b-th target offset.
+__global__ void k_block_bounds(const int32_t* __restrict__ rowptr, int nc0, int nc1, int nblk_max, int32_t* __restrict__ blk,
+                               int32_t* __restrict__ qn, unsigned* __restrict__ qctr, int n_slices) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e_lo = rowptr[nc0], e_hi = rowptr[nc1];
+    const long tot = (long)e_hi - e_lo;
+    const int nbig = (int)(tot / 8 * 7 / GP_QBLOCK);
+    const long rest = tot - (long)nbig * GP_QBLOCK;
+    constexpr int SMALL = GP_QBLOCK / 8;
+    const int nblk = min(nbig + (int)((rest + SMALL - 1) / SMALL), nblk_max);
+    if (b == 0) *qn = nblk;
+    if (b < n_slices) qctr[b] = 0u;
+    if (b > nblk) return;
+    if (b == nblk) { blk[b] = e_hi; return; }
+    const long target = (long)e_lo + (b <= nbig ? (long)b * GP_QBLOCK : (long)nbig * GP_QBLOCK + (long)(b - nbig) * SMALL);
+    int lo = nc0, hi = nc1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((long)rowptr[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    blk[b] = rowptr[lo];
+}
+
 }  // namespace
+
+int gpde_launch_block_bounds(const int32_t* rowptr, int nc0, int nc1, int nblk_max, int32_t* blk, int32_t* qn,
+                             unsigned* qctr, int n_slices, hipStream_t stream) {
+    const int threads = nblk_max + 1 > n_slices ? nblk_max + 1 : n_slices;
+    hipLaunchKernelGGL(k_block_bounds, dim3((threads + 255) / 256), dim3(256), 0, stream, rowptr, nc0, nc1, nblk_max, blk, qn,
+                       qctr, n_slices);
+    GP_LAUNCH_CHECK("k_block_bounds");
+    return GPDE_OK;
+}
 
 int gpde_launch_g2_prep(const float* x, int64_t n_nodes, const float* attr, int64_t n_edges, int k0,
                         const float* wmax8, unsigned* scal, unsigned* xs, hipStream_t stream, int kt,

@@ -48,6 +48,8 @@ enum {
     GPDE_FWD_F16SPLIT_8WAVE = 2, /* with F16SPLIT: force the 8-wave kernel (gpde_fused_f16v3_kernel: the path of small
                                     graphs, node-table attributes and gpde_hidden_fwd) where the default would be the
                                     one-wave-per-SIMD kernel gpde_fused_f16v6_kernel (A/B, parity tests) */
+    GPDE_FWD_STATIC_RANGES = 4,  /* gpde_fused_f16v6_kernel: one contiguous edge range per wave instead of the block work queue
+                                    (A/B of the x_j gather locality, parity tests) */
     GPDE_FWD_AGG_F16 = 16,       /* with F16SPLIT: aggregation x_j (x) h_e on split-f16 MFMA too, also for small
                                     graphs (default: from 32768 edges on; three tiny pre-pass launches) */
     GPDE_FWD_AGG_F32 = 32        /* with F16SPLIT: keep the aggregation on fp32 MFMA (A/B) */
