@@ -111,6 +111,11 @@ SIGNATURES = {
     "gpde_radius_graph_fill": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
                                               ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
                                               ctypes.c_int64, ctypes.c_void_p]),
+    "gpde_radius_graph2_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                                ctypes.c_double, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]),
+    "gpde_radius_graph2_fill": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                               ctypes.c_double, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_int64, ctypes.c_void_p]),
     "gpde_profile_begin": (ctypes.c_int, []),
     "gpde_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), c_i32p,
                                         ctypes.POINTER(ctypes.c_double)]),

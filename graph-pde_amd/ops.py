@@ -681,26 +681,56 @@ def hidden_backward_raw(csr: Csr, edge_attr: torch.Tensor, dims: Sequence[int],
 # ----------------------------------------------------------------------------------------------
 # radius graph
 # ----------------------------------------------------------------------------------------------
-def radius_graph(pos: torch.Tensor, r: float) -> torch.Tensor:
+def radius_graph(pos: torch.Tensor, r: float, reference_ties: bool = False,
+                 pos_dst: Optional[torch.Tensor] = None) -> torch.Tensor:
     """edge_index int64 [2,E] of the radius graph of `pos` [n,dim] (dim 1..3), in the reference's
-    order (sorted by source, then target; self-loops included) — the GPU replacement of
-    `ball_connectivity` (utilities.py:250-255).  One sync (the edge count) per graph."""
+    order (sorted by source, then target; self-loops included) - the GPU replacement of
+    `ball_connectivity` (utilities.py:250-255).  One sync (the edge count) per graph.
+
+    `pos_dst`: a second point set - edges (j in pos -> i in pos_dst), the inter-level graphs of
+    RandomMultiMeshGenerator (multipole-graph-neural-operator/utilities.py:617-632).
+    `reference_ties=True`: scikit-learn's dot-product-expansion arithmetic, so that pairs at exactly distance r
+    are kept / dropped exactly as by the reference (gpde_radius_graph2_*, GPDE_RADIUS_REFERENCE_TIES); the default
+    tests the exact float64 sum of squares (symmetric graph)."""
     lib = _lib.lib()
     _require_cuda(pos, "pos")
     if pos.dim() == 1:
         pos = pos.unsqueeze(1)
     pos = pos.detach().to(torch.float64).contiguous()
-    n, dim = int(pos.size(0)), int(pos.size(1))
+    if pos_dst is None:
+        pd = pos
+    else:
+        _require_cuda(pos_dst, "pos_dst")
+        pd = (pos_dst.unsqueeze(1) if pos_dst.dim() == 1 else pos_dst).detach().to(torch.float64).contiguous()
+        if pd.size(1) != pos.size(1):
+            raise ValueError("pos and pos_dst must have the same dimension")
+    n, nd, dim = int(pos.size(0)), int(pd.size(0)), int(pos.size(1))
+    flags = 1 if reference_ties else 0
     dev = pos.device
     deg = torch.empty(n, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.gpde_radius_graph_count(pos.data_ptr(), n, dim, float(r), deg.data_ptr(),
-                                               _stream_ptr(dev)), "gpde_radius_graph_count")
+        _lib.check(lib.gpde_radius_graph2_count(pos.data_ptr(), n, pd.data_ptr(), nd, dim, float(r), flags,
+                                                deg.data_ptr(), _stream_ptr(dev)), "gpde_radius_graph2_count")
     offs = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     torch.cumsum(deg, 0, out=offs[1:])
     e = int(offs[-1].item())
     ei = torch.empty(2, e, dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.gpde_radius_graph_fill(pos.data_ptr(), n, dim, float(r), offs.data_ptr(),
-                                              ei.data_ptr(), e, _stream_ptr(dev)), "gpde_radius_graph_fill")
+        _lib.check(lib.gpde_radius_graph2_fill(pos.data_ptr(), n, pd.data_ptr(), nd, dim, float(r), flags,
+                                               offs.data_ptr(), ei.data_ptr(), e, _stream_ptr(dev)),
+                   "gpde_radius_graph2_fill")
     return ei
+
+
+def multilevel_radius_graphs(pos_levels: Sequence[torch.Tensor], radii_inner: Sequence[float],
+                             radii_inter: Sequence[float], reference_ties: bool = True):
+    """The inner / down / up graphs of RandomMultiMeshGenerator.ball_connectivity
+    (multipole-graph-neural-operator/utilities.py:602-640) built on the GPU from the per-level point sets:
+    inner[l] = radius graph of level l (local node ids), down[l] = edges (level l -> level l + 1) within
+    radii_inter[l], up[l] = down[l] with the rows swapped (utilities.py:631: the SAME edge order).  Returns
+    {"inner": [...], "down": [...], "up": [...]} of int64 [2, E] tensors with level-local node ids."""
+    inner = [radius_graph(p, r, reference_ties=reference_ties) for p, r in zip(pos_levels, radii_inner)]
+    down = [radius_graph(pos_levels[l], radii_inter[l], reference_ties=reference_ties, pos_dst=pos_levels[l + 1])
+            for l in range(len(pos_levels) - 1)]
+    up = [d.flip(0) for d in down]
+    return {"inner": inner, "down": down, "up": up}

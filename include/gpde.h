@@ -267,6 +267,20 @@ int gpde_radius_graph_count(const double* pos, int64_t n, int dim, double r, int
 int gpde_radius_graph_fill(const double* pos, int64_t n, int dim, double r, const int64_t* offsets,
                            int64_t* edge_index, int64_t n_edges, void* stream);
 
+/* The same between TWO point sets - edges (j in pos_src -> i in pos_dst), row-major np.where order - which is what
+ * the inner (pos_dst == pos_src) and inter-level graphs of RandomMultiMeshGenerator.ball_connectivity are
+ * (multipole-graph-neural-operator/utilities.py:602-640: pairwise_distances(X, Y) <= r), and with the choice of
+ * arithmetic: flags = 0 tests sum_k (dx_k)^2 <= r^2 exactly in float64 (symmetric graphs);
+ * GPDE_RADIUS_REFERENCE_TIES evaluates scikit-learn's dot-product expansion operation by operation, so that pairs at
+ * exactly distance r are kept or dropped as in the reference (its default s = 61, r = 0.10 graph: 376,471 edges).
+ * pos_dst == pos_src with n_dst == n_src means ONE point set: self-loops, diagonal forced to distance 0. */
+enum { GPDE_RADIUS_REFERENCE_TIES = 1 };
+int gpde_radius_graph2_count(const double* pos_src, int64_t n_src, const double* pos_dst, int64_t n_dst, int dim,
+                             double r, uint32_t flags, int32_t* deg, void* stream);
+int gpde_radius_graph2_fill(const double* pos_src, int64_t n_src, const double* pos_dst, int64_t n_dst, int dim,
+                            double r, uint32_t flags, const int64_t* offsets, int64_t* edge_index, int64_t n_edges,
+                            void* stream);
+
 /* HIP-event timing of the kernels launched by gpde_nnconv_fwd on the calling thread (used by
  * bench.py for the roofline figure; events are recorded on the same stream as the kernels).
  * gpde_profile_begin() arms it; gpde_profile_end() disarms it, SYNCHRONISES on the recorded

@@ -176,9 +176,37 @@ def _save(name, conv, x, ei, ea, y32, y64):
           f"{float((y32.double() - y64).norm() / y64.norm()):.2e} -> {os.path.getsize(path)} B")
 
 
+def case_mesh_ties(ref_util):
+    # 9. radius graphs AT TIE RADII by the reference's own SquareMeshGenerator: r = 0.10 on the 31^2 and 61^2
+    #    lattices has thousands of pairs at exactly distance r, and sklearn's dot-product expansion keeps only some of
+    #    them (22,951 of 25,673 at s = 31; 376,471 of 386,221 at s = 61 - the reference's training
+    #    graph, UAI1_full_resolution.py:39-46,141-142).  Pins oracle/radius_oracle.c and the native
+    #    reference_ties mode.  s = 31: the full edge list; s = 61: edge count, out- / in-degrees and the SHA-256 of
+    #    the int64 edge_index bytes (the list itself would be 6 MB).
+    import hashlib
+    out = {}
+    for s9 in (31, 61):
+        mesh9 = ref_util.SquareMeshGenerator([[0, 1], [0, 1]], [s9, s9])
+        ei9 = mesh9.ball_connectivity(0.10).numpy().astype(np.int64)
+        out[f"n_edges_s{s9}"] = np.int64(ei9.shape[1])
+        out[f"outdeg_s{s9}"] = np.bincount(ei9[0], minlength=s9 * s9).astype(np.int16)
+        out[f"indeg_s{s9}"] = np.bincount(ei9[1], minlength=s9 * s9).astype(np.int16)
+        out[f"sha256_s{s9}"] = np.array(hashlib.sha256(np.ascontiguousarray(ei9).tobytes()).hexdigest())
+        if s9 == 31:
+            out["edge_index_s31"] = ei9.astype(np.int32)
+    out["r"] = np.float64(0.10)
+    path = os.path.join(HERE, "mesh_ties.npz")
+    np.savez_compressed(path, **out)
+    print(f"mesh_ties: s=31 E={int(out['n_edges_s31'])}, s=61 E={int(out['n_edges_s61'])} -> {os.path.getsize(path)} B")
+
+
+
 def main():
     _install_stubs()
     ref_util = _load("utilities", os.path.join(REF, "utilities.py"))
+    if len(sys.argv) > 1 and sys.argv[1] == "ties":      # only the tie-radius mesh fixture
+        case_mesh_ties(ref_util)
+        return
     ref_nn_conv = _load("nn_conv", os.path.join(REF, "nn_conv.py"))
     sys.path.insert(0, os.path.join(REPO, "graph-pde_amd"))
     import synth
@@ -307,6 +335,8 @@ def main():
     path = os.path.join(HERE, "mgkn_graphs_s20.npz")
     np.savez_compressed(path, **out)
     print(f"mgkn_graphs_s20: inner {e_in.shape[1]} / down {e_dn.shape[1]} edges -> {os.path.getsize(path)} B")
+
+    case_mesh_ties(ref_util)
 
 
 if __name__ == "__main__":

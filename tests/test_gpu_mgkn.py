@@ -37,15 +37,27 @@ def test_mgkn_forward_calls_match_oracle(name):
     print(name, "max rel-L2 over", len(wl.pairs), "NNConv applications:", f"{worst:.2e}")
 
 
+@pytest.mark.parametrize("mode", ["off", "auto"])
 @pytest.mark.parametrize("name", sorted(mgkn_workloads.WORKLOADS))
-def test_fused_glue_is_bit_identical_to_the_unfused_composition(name):
+def test_fused_glue_is_bit_identical_to_the_unfused_composition(name, mode):
     """forward(..., residual=x, activation="relu") == F.relu(x + conv(...)): the same fp32 add and max, done in
-    the epilogue kernel (opt-in)."""
+    the epilogue kernel (opt-in).  Compared on the same execution path: with the cross-depth cache
+    off, and with it on once both models are past their first forward (the very first application of a module runs
+    the direct kernel, later ones the cached-H kernels - same value to the last bit or two, not the same bits)."""
+    from graph_pde_amd import hidden_cache
     d = torch.device("cuda:0")
-    a = mgkn_workloads.WORKLOADS[name](d)
-    b = mgkn_workloads.WORKLOADS[name](d, fused_glue=True)
-    for ya, yb in zip(a.forward(), b.forward()):
-        assert torch.equal(ya, yb)
+    mode0 = hidden_cache.MODE
+    hidden_cache.MODE = mode
+    hidden_cache.clear()
+    try:
+        a = mgkn_workloads.WORKLOADS[name](d)
+        b = mgkn_workloads.WORKLOADS[name](d, fused_glue=True)
+        a.forward(), b.forward()
+        for ya, yb in zip(a.forward(), b.forward()):
+            assert torch.equal(ya, yb)
+    finally:
+        hidden_cache.MODE = mode0
+        hidden_cache.clear()
 
 
 def test_fused_glue_with_gradients_composes_the_unfused_operator():

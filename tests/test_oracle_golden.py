@@ -156,3 +156,58 @@ def test_oracle_gradients_match_autograd_through_the_reference_module(name):
         assert rel_l2(groot, r["groot"]) <= tol
     if gbias is not None:
         assert rel_l2(gbias, r["gbias"]) <= tol
+
+
+def _lattice(s):
+    import numpy as np
+    g = np.linspace(0.0, 1.0, s)
+    return np.vstack([xx.ravel() for xx in np.meshgrid(g, g)]).T          # utilities.py:247 ('xy' meshgrid)
+
+
+def test_radius_oracle_reproduces_the_reference_at_tie_radii():
+    """tests/golden/mesh_ties.npz comes from the reference's own SquareMeshGenerator.ball_connectivity(0.10) on the
+    31^2 and 61^2 lattices, where thousands of pairs sit at exactly distance r and scikit-learn's rounding keeps only
+    some of them.  oracle/radius_oracle.c (the C restatement of that arithmetic) must return the same edge list."""
+    import hashlib
+    import os
+    import numpy as np
+    from oracle import radius_oracle
+    from tests.conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "mesh_ties.npz"))
+    r = float(g["r"])
+    ei31 = radius_oracle.radius_edges(_lattice(31), r)
+    assert np.array_equal(ei31, g["edge_index_s31"].astype(np.int64))
+    for s in (31, 61):
+        ei = radius_oracle.radius_edges(_lattice(s), r)
+        assert ei.shape[1] == int(g[f"n_edges_s{s}"]) == {31: 22951, 61: 376471}[s]
+        assert np.array_equal(np.bincount(ei[0], minlength=s * s), g[f"outdeg_s{s}"])
+        assert np.array_equal(np.bincount(ei[1], minlength=s * s), g[f"indeg_s{s}"])
+        assert hashlib.sha256(np.ascontiguousarray(ei).tobytes()).hexdigest() == str(g[f"sha256_s{s}"])
+        # the reference graph is NOT symmetric at a tie radius; the exact float64 test is, and keeps more pairs
+        ex = radius_oracle.radius_edges(_lattice(s), r, reference_ties=False)
+        assert ex.shape[1] > ei.shape[1]
+        pairs = set(map(tuple, ex.T.tolist()))
+        assert all((b, a) in pairs for a, b in list(pairs)[:2000])
+    assert not np.array_equal(np.bincount(ei31[0], minlength=961), np.bincount(ei31[1], minlength=961))
+
+
+def test_radius_oracle_two_point_sets_match_the_multilevel_fixture():
+    """Inter-level graphs are pairwise_distances(X, Y) <= r between two sampled point sets
+    (multipole-graph-neural-operator/utilities.py:617-632); the fixture is the reference generator's output."""
+    import os
+    import numpy as np
+    from graph_pde_amd import synth
+    from oracle import radius_oracle
+    from tests.conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "mgkn_graphs_s20.npz"))
+    m = [int(v) for v in g["m"]]
+    pos = synth.lattice_positions(int(g["s"])).double().numpy()
+    pts = [pos[g[f"idx{l}"]] for l in range(len(m))]
+    offs = np.concatenate([[0], np.cumsum(m)])
+    for l in range(len(m)):
+        lo, hi = g["range"][l]
+        assert np.array_equal(radius_oracle.radius_edges(pts[l], float(g["radii_inner"][l])) + offs[l], g["edge_index"][:, lo:hi])
+    for l in range(len(m) - 1):
+        lo, hi = g["range_down"][l]
+        ei = radius_oracle.radius_edges(pts[l], float(g["radii_inter"][l]), y=pts[l + 1])
+        assert np.array_equal(ei + np.array([[offs[l]], [offs[l + 1]]]), g["edge_index_down"][:, lo:hi])
