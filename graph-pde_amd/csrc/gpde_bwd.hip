@@ -42,6 +42,13 @@ __global__ void k_pad_mat(const float* __restrict__ W, int rows, int cols, int l
     const int c = i % colsP, r = i / colsP;
     out[i] = (r < rows && c < cols) ? W[(size_t)r * ld + c] : 0.f;
 }
+__global__ void k_transpose(const float* __restrict__ W, int rows, int cols, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    out[(size_t)c * rows + r] = W[i];
+}
+
 __global__ void k_unpad_mat(const float* __restrict__ P, int rows, int cols, int ldp, float* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)rows * cols) return;
@@ -74,20 +81,33 @@ __global__ void k_nbr_sum(const float* __restrict__ x, const int32_t* __restrict
     for (int e = rowptr[n0 + i]; e < rowptr[n0 + i + 1]; ++e) s += x[(size_t)src[e] * GP_W + lane];
     S[(size_t)i * GP_W + lane] = s;
 }
-// partial column sums: P[split][col] = sum over the split's rows of M[row][col]
-__global__ void k_colsum(const float* __restrict__ M, int rows, int cols, int ld, int splits,
-                         float* __restrict__ P) {
-    __shared__ float red[4][64];
+// partial column sums: P[split][col] = sum over the split's rows of M[row][col].  A lane owns four consecutive
+// columns (16-byte loads, a wave reads 1 KiB of a row), the four waves interleave rows, four rows in flight per wave:
+// the bias gradients read every dU once (8 KiB per edge at two 1024-wide layers) and are pure HBM streaming.
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ M, int rows, int cols, int ld, int splits,
+                                                float* __restrict__ P) {
+    __shared__ f32x4 red[4][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + lane, split = blockIdx.y;
+    const int col = blockIdx.x * 256 + lane * 4, split = blockIdx.y;
     const int rps = (rows + splits - 1) / splits;
     const int r_lo = split * rps, r_hi = min(rows, r_lo + rps);
-    float s = 0.f;
-    if (col < cols)
-        for (int r = r_lo + rg; r < r_hi; r += 4) s += M[(size_t)r * ld + col];
-    red[rg][lane] = s;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (col < cols) {
+        const float* p = M + col;
+        int r = r_lo + rg;
+        for (; r + 12 < r_hi; r += 16) {
+            const f32x4 a = *(const f32x4*)(p + (size_t)r * ld), b = *(const f32x4*)(p + (size_t)(r + 4) * ld);
+            const f32x4 c = *(const f32x4*)(p + (size_t)(r + 8) * ld), d = *(const f32x4*)(p + (size_t)(r + 12) * ld);
+            s0 += a; s1 += b; s2 += c; s3 += d;
+        }
+        for (; r < r_hi; r += 4) s0 += *(const f32x4*)(p + (size_t)r * ld);
+    }
+    red[rg][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (rg == 0 && col < cols) P[(size_t)split * cols + col] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (rg == 0 && col < cols) {
+        const f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        *(f32x4*)(P + (size_t)split * cols + col) = t;
+    }
 }
 
 // ---- per-edge backward through the aggregation -----------------------------------------------------
@@ -368,6 +388,8 @@ struct BwdPlan {
     size_t off_wp[GPDE_MAX_LAYERS], off_bp[GPDE_MAX_LAYERS], off_dwp[GPDE_MAX_LAYERS], off_dbp[GPDE_MAX_LAYERS];
     size_t off_w3p, off_dw3p, off_b3, off_db3, off_part, part_floats, off_pack, pack_bytes;
     size_t off_H[GPDE_MAX_LAYERS + 1], off_dU[2], off_Z, off_dZ, off_gT, off_S, off_dS;
+    size_t off_w2t, off_w2ts, off_ucol2, off_rowsc;   // dU_1 on split f16: W2^T fp32, its split tile image, 2^-t per k1, row scales
+    bool f16s_du1;
     size_t total;
 };
 
@@ -399,9 +421,17 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     // packed MLP image for the fused f16-split recompute of the last hidden layer (3-Linear kernels)
     P->pack_bytes = (n_layers == 3 && dims[0] + 1 <= 8) ? gpde_mlp_pack_bytes(n_layers, dims) : 0;
     P->off_pack = take(P->pack_bytes / 4);
+    // dU_1 = (dU_2 . W_2) (.) [H_1 > 0] on split-f16 MFMA (gpde_gemm_f16s.hip): 3-Linear kernels, k2 padded >= 256
+    P->f16s_du1 = n_layers == 3 && gpde_gemm_f16s_supported(1, P->KP[1], P->KP[2], P->KP[2]);
+    P->off_w2t = P->off_w2ts = P->off_ucol2 = 0;
+    if (P->f16s_du1) {
+        P->off_w2t = take((size_t)P->KP[1] * P->KP[2]);
+        P->off_w2ts = take((size_t)P->KP[1] * P->KP[2]);
+        P->off_ucol2 = take(P->KP[1]);
+    }
     const size_t fixed = off;
     // per-chunk buffers: per edge (hsum + 2*kmax) floats, per node (2*64*K2P + 3*64) floats
-    const size_t per_edge = (hsum + 2 * (size_t)kmax) * 4, per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4;
+    const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0)) * 4, per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4;
     int64_t Ec, Nc;
     const size_t slack = 64 * 256;       // alignment of the per-chunk buffers below
     if (sizing) {
@@ -423,6 +453,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     P->off_dU[0] = take((size_t)Ec * kmax); P->off_dU[1] = take((size_t)Ec * kmax);
     P->off_Z = take((size_t)Nc * GP_W * P->K2P); P->off_dZ = take((size_t)Nc * GP_W * P->K2P);
     P->off_gT = take((size_t)Nc * GP_W); P->off_S = take((size_t)Nc * GP_W); P->off_dS = take((size_t)Nc * GP_W);
+    P->off_rowsc = take(P->f16s_du1 ? (size_t)2 * Ec : 1);
     P->total = off + 256 + (sizing ? slack : 0);
     if (!sizing && P->total > ws_bytes) { gpde_set_error("gpde_nnconv_bwd: internal plan %zu > workspace %zu", P->total, ws_bytes); return GPDE_EWORKSPACE; }
     return GPDE_OK;
@@ -499,6 +530,13 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         GP_HIP_CHECK(hipMemsetAsync(F(P.off_dwp[l]), 0, wn * 4, st));
         GP_HIP_CHECK(hipMemsetAsync(F(P.off_dbp[l]), 0, (size_t)P.KP[l] * 4, st));
     }
+    const bool f16s_du1 = do_mlp && P.f16s_du1 && !getenv("GPDE_BWD_GEMM_F32");
+    if (f16s_du1) {
+        // B operand of dU_1 = dU_2 . W_2: rows = k1 (output), contraction = k2  ->  W_2^T, split + swizzled like the forward's W2
+        const size_t wn = (size_t)P.KP[2] * P.KP[1];
+        hipLaunchKernelGGL(k_transpose, dim3(nblk(wn)), dim3(T), 0, st, F(P.off_wp[2]), P.KP[2], P.KP[1], F(P.off_w2t));
+        if ((rc = gpde_pack_split_nk(F(P.off_w2t), P.KP[1], P.KP[2], P.KP[1], P.KP[2], F(P.off_w2ts), F(P.off_ucol2), st)) != GPDE_OK) return rc;
+    }
     const size_t w3n = (size_t)GP_W * GP_W * K2P;
     if (do_conv) {
         hipLaunchKernelGGL(k_pad_mat, dim3(nblk(w3n)), dim3(T), 0, st, W[n - 1], GP_W * GP_W, dims[n - 1], dims[n - 1],
@@ -568,12 +606,20 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             if ((rc2 = gemm_tn_acc(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, F(P.off_dwp[l]), Kin,
                                    F(P.off_part), P.part_floats, 1, st)) != GPDE_OK) return rc2;
             {
-                int splits = 1; while (splits < 64 && (Kl / 64) * splits < 512 && rows / (splits * 2) >= 64) splits *= 2;
-                if ((size_t)splits * Kl > P.part_floats) splits = 1;
-                hipLaunchKernelGGL(k_colsum, dim3((Kl + 63) / 64, splits), dim3(T), 0, st, dUc, rows, Kl, Kl, splits, F(P.off_part));
+                const int cb = (Kl + 255) / 256;
+                int splits = 1; while (splits < 512 && cb * splits < 2048 && rows / (splits * 2) >= 64) splits *= 2;
+                while (splits > 1 && (size_t)splits * Kl > P.part_floats) splits /= 2;
+                hipLaunchKernelGGL(k_colsum, dim3(cb, splits), dim3(T), 0, st, dUc, rows, Kl, Kl, splits, F(P.off_part));
                 if ((rc2 = gpde_launch_reduce_splits(F(P.off_part), Kl, splits, Kl, F(P.off_dbp[l]), 1, st)) != GPDE_OK) return rc2;
             }
-            if (l > 1) {
+            if (l > 1 && l == 2 && f16s_du1 && rows >= 64) {
+                float* dUo = bufs[nb_]; nb_ ^= 1;
+                GpdeGemmF16sArgs g{};
+                g.A = dUc; g.lda = Kl; g.M = rows; g.bsplit = F(P.off_w2ts); g.ucol = F(P.off_ucol2);
+                g.mask = F(P.off_H[l - 1]); g.ldmask = Kin; g.C = dUo; g.ldc = Kin; g.K = Kl; g.N = Kin;
+                if ((rc2 = gpde_launch_gemm_f16s_nt(g, F(P.off_rowsc), st)) != GPDE_OK) return rc2;
+                dUc = dUo;
+            } else if (l > 1) {
                 float* dUo = bufs[nb_]; nb_ ^= 1;
                 GpdeGemmArgs g = gemm0();
                 g.A = dUc; g.lda = Kl; g.B = F(P.off_wp[l]); g.ldb = Kin; g.b_kcontig = 0;

@@ -211,4 +211,19 @@ struct GpdeGemmArgs {
 int gpde_launch_gemm(const GpdeGemmArgs& g, hipStream_t stream);
 int gpde_launch_reduce_splits(const float* P, size_t n, int splits, size_t stride, float* C,
                               int accumulate, hipStream_t stream);
+// C = (A . B^T) (.) [mask > 0] on split-f16 MFMA (gpde_gemm_f16s.hip): A [M][K] fp32 rows, B given as the split tile
+// image of gpde_pack_split_nk ([N/128][K/32][128 rows][hi 64 B | lo 64 B], rows scaled by 2^t_n; ucol = 2^-t_n)
+struct GpdeGemmF16sArgs {
+    const float* A; int lda; int M;
+    const void* bsplit; const float* ucol;
+    const float* mask; int ldmask;      // optional [M][ldmask]
+    float* C; int ldc;
+    int K, N;                           // padded sizes: K % 128 == 0, N % 128 == 0
+    const float* sc; const float* isc;  // per-row scales (filled by the launcher's pre-pass)
+    int n_groups;
+};
+bool gpde_gemm_f16s_supported(int M, int N, int K, int lda);
+int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a, float* row_scale_ws /* 2 * M floats */, hipStream_t stream);
+// split tile image of a row-major [n][k] matrix (ld = k): the W2 layout of gpde_mlp_pack for any operand
+int gpde_pack_split_nk(const float* Wnk, int n, int k, int NP, int KP, void* out, float* ucol, hipStream_t stream);
 int gpde_num_cus();

@@ -1,0 +1,364 @@
+// C[M][N] = (A[M][K] . B[N][K]^T) (.) [mask > 0]   on 2-term split f16 MFMA, fp32 accumulate - the backward's
+// dU_1 = (dU_2 . W_2) (.) [H_1 > 0]  (what autograd computes through the ReLU + Linear of DenseNet.forward,
+// /root/reference/graph-neural-operator/utilities.py:223-227, on `loss.backward()`, UAI1_full_resolution.py:266).
+//
+// Same arithmetic and the same K loop as the forward kernel gpde_fused_f16v6_kernel (gpde_fused_f16v6.hip): one wave
+// per SIMD, 512 registers, wave tile 64 rows x 128 columns, 3 MFMAs per product (hi.lo, hi.hi, lo.hi), B = the
+// pre-split, pre-swizzled 16 KiB chunk images of gpde_mlp_pack's W2 layout streamed through a 3-slot LDS ring by
+// LDS-DMA.  What differs is where the A operand comes from: fp32 rows in memory instead of the H1 MFMA.
+//   * every wave stages the 32-k chunks of ITS 64 rows through a private 3-slot LDS ring by LDS-DMA in FULL 128-byte
+//     lines (8 rows per 1 KiB piece, 8 pieces per chunk).  The first version loaded the MFMA fragments straight from
+//     memory (32 bytes of 32 different lines per instruction): the texture-address path, not HBM, bound it at 12.6 ns
+//     per row (cdna guide: "fragment-shaped loads", +18..45 %).  Units are XOR-swizzled through the source address so
+//     that the fragment reads - lane (row l31, k-group h) wants k = 16 m + 8 half + 4 h + {0..3}, the order the packed
+//     B image pairs with its operand slots (gpde_pack.hip) - are conflict-free ds_read_b128;
+//   * the pieces of chunk c + 3 are issued during chunk c BEHIND its four B pieces and the chunk ends with
+//     s_waitcnt vmcnt(8): B(c + 2) and A(c + 2) are retired, A(c + 3) stays in flight across the barrier; chunk c + 1
+//     is read and converted (16 pairs) during chunk c into the other operand buffer (the loop is unrolled by two);
+//   * rows carry per-row power-of-two scales 2^(13 - E(max_k |A[row][k]|)) from a pre-pass (k_row_scale_kernel: one
+//     read of A), B rows their pack-time scales: both exact, undone once after the K loop.  Error per product
+//     < 2^-20 as in the forward.
+// Rows are independent: tiles of 64 rows are dealt round-robin to the waves, no node alignment, no aggregation.
+#include "gpde_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+#define GPDE_GLDS(g, l, off)                                                                       \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),         \
+                                     (__attribute__((address_space(3))) void*)(l), 16, off, 0)
+
+constexpr int NS = 3;                      // ring slots
+constexpr int TILE_B = GP_TN * 128;        // 16 KiB per B chunk image
+constexpr int TE = 64;                     // rows per wave tile
+constexpr int NW = 4;
+
+// per-row scale: sc[row] = 2^(13 - E(max_k |A[row][k]|)) (1 for an all-zero / non-finite-range row), isc = 1 / sc
+__global__ void k_row_scale_kernel(const float* __restrict__ A, int M, int K, int lda, float* __restrict__ sc,
+                                   float* __restrict__ isc) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    unsigned m = 0;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 v = *(const f32x4*)&A[(size_t)row * lda + k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = max(m, __float_as_uint(v[j]) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if (lane == 0) {
+        const int eb = (int)((m >> 23) & 0xff);
+        const bool ok = eb >= 20 && eb <= 230;
+        sc[row] = ok ? __int_as_float((267 - eb) << 23) : 1.f;
+        isc[row] = ok ? __int_as_float((eb - 13) << 23) : 1.f;
+    }
+}
+
+constexpr int A_SLOT = NW * TE * 128;      // 32 KiB: one 32-k chunk of the workgroup's 256 rows (fp32)
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                               // [3][16 KiB]  B chunk images
+    char* aring = smem + NS * TILE_B;                                // [3][4 waves][64 rows][128 B]  A chunks (fp32)
+    float* Es_all = (float*)(aring + NS * A_SLOT);                   // [4][64] per-row un-scales
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+    float* Es = Es_all + wave * TE;
+    char* awave = aring + wave * (TE * 128);
+
+    const int ns = a.N / GP_TN;
+    // Workgroup b runs on XCD b % 8.  The ns column slices of one row group read the SAME A rows (4 KiB per row at
+    // K = 1024): they share an XCD, so that seven of eight reads of a row hit that XCD's L2 (with slice = b % ns the
+    // eight L2s each fetched every row: 8x the fabric traffic and 2.8 us per chunk instead of 1.3).
+    int slice, group;
+    if (a.n_groups % 8 == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        slice = j % ns;
+        group = xcd + 8 * (j / ns);
+    } else {
+        slice = blockIdx.x % ns;
+        group = blockIdx.x / ns;
+    }
+    const int NKC = a.K / GP_BK;
+    const int ntile = (a.M + TE - 1) / TE;
+    const int stride = a.n_groups * NW;
+    const int rounds = (ntile + stride - 1) / stride;
+    if (rounds == 0) return;
+
+    // K-loop rotation: row group g walks the chunks starting at rot(g).  All workgroups move through K at the same
+    // rate; without the skew they ask for the same 128-byte column of 4 KiB-strided rows at the same time.
+    const int rot = (group * 11) % NKC;
+    auto kc = [&](int c) { const int v = c + rot; return v >= NKC ? v - NKC : v; };
+    const unsigned long long bbase = (unsigned long long)a.bsplit + (size_t)slice * NKC * TILE_B + wave * 4096;
+    const unsigned lane16 = lane * 16;
+    auto b_src = [&](int chunk) {
+        unsigned long long gb = bbase + (size_t)chunk * TILE_B;
+        asm volatile("" : "+s"(gb));
+        return (const char*)(gb + lane16);
+    };
+    float ucv[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) ucv[nb] = a.ucol[slice * GP_TN + nb * 32 + l31];
+    const int sw = (l31 >> 1) & 7;
+    const int boff[2] = {l31 * 128 + (((0 + h) ^ sw) << 4), l31 * 128 + (((2 + h) ^ sw) << 4)};
+
+    // conversion of a pair of raw values: y = v * row scale, hi = rtz16(y), lo = rn16(y - hi)
+    auto conv_a = [&](float v0, float v1, float sc, unsigned& ph, unsigned& t0_, unsigned& t1_) {
+        asm("v_mul_f32 %1, %5, %3\n\t"
+            "v_mul_f32 %2, %5, %4\n\t"
+            "v_cvt_pkrtz_f16_f32 %0, %1, %2"
+            : "=&v"(ph), "=&v"(t0_), "=&v"(t1_) : "v"(v0), "v"(v1), "v"(sc));
+    };
+    auto conv_b = [&](unsigned ph, unsigned t0_, unsigned t1_, unsigned& pl) {
+        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(pl) : "v"(t0_), "v"(t1_), "v"(ph));
+    };
+
+    {   // chunks 0 and 1 of this slice's B
+        const char* g0 = b_src(kc(0));
+        char* l0 = ring + wave * 4096;
+        GPDE_GLDS(g0, l0, 0); GPDE_GLDS(g0, l0, 1024); GPDE_GLDS(g0, l0, 2048); GPDE_GLDS(g0, l0, 3072);
+        const char* g1 = b_src(kc(1));
+        char* l1 = ring + TILE_B + wave * 4096;
+        GPDE_GLDS(g1, l1, 0); GPDE_GLDS(g1, l1, 1024); GPDE_GLDS(g1, l1, 2048); GPDE_GLDS(g1, l1, 3072);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][nb][r] = 0.f;
+    int slot = 0;           // B ring slot of the current chunk
+    int aslot = 0;          // A ring slot of the current chunk
+
+    for (int t = 0; t < rounds; ++t) {
+        const int tile = (t * a.n_groups + group) * NW + wave;
+        const int r0 = tile * TE;                                  // may lie beyond M: loads clamp, stores are masked
+        float sc[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int row = min(r0 + 32 * e + l31, a.M - 1);
+            sc[e] = a.sc[row];
+            if (h == 0) Es[32 * e + l31] = a.isc[row];
+        }
+        // A chunk DMA: piece j = rows 8j .. 8j+7 of the wave's tile in FULL 128-byte lines (8 lanes per row), the
+        // 16-byte units of a row XOR-swizzled through the SOURCE address (unit u of row r is stored at u ^ ((r>>1)&7):
+        // conflict-free ds_read_b128 of the fragments below, as for the B image)
+        const float* apiece[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 8 * j + (lane >> 3);
+            const int row = min(r0 + r, a.M - 1);
+            apiece[j] = a.A + (size_t)row * a.lda + 4 * ((lane & 7) ^ ((r >> 1) & 7));
+        }
+        auto issue_a = [&](int as, int chunk) {
+            char* l = awave + as * A_SLOT;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) GPDE_GLDS(apiece[j] + chunk * GP_BK, l + j * 1024, 0);
+        };
+        // fragment reads: piece q = 2 m + half of edge block e holds k = 16 m + 8 half + 4 h + {0..3} = unit 2 q + h
+        auto read_a = [&](int as, f32x4 (&raw)[2][4]) {
+            const char* l = awave + as * A_SLOT;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    raw[e][q] = *(const f32x4*)(l + (32 * e + l31) * 128 + (((2 * q + h) ^ sw) << 4));
+        };
+        const int as1 = aslot + 1 == NS ? 0 : aslot + 1, as2 = as1 + 1 == NS ? 0 : as1 + 1;
+        issue_a(aslot, kc(0));
+        issue_a(as1, kc(1));
+        issue_a(as2, kc(2));
+        h8 bhi[4], blo[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            bhi[nb] = *(const h8*)(ring + slot * TILE_B + nb * 4096 + boff[0]);
+            blo[nb] = *(const h8*)(ring + slot * TILE_B + nb * 4096 + (boff[0] ^ 64));
+        }
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // chunk 0 of A landed (1 and 2 may still fly)
+        __builtin_amdgcn_sched_barrier(0);
+        u4 ahi[2][2][2], alo[2][2][2];                            // [chunk parity][edge block][k16 step]
+        f32x4 raw[2][4];
+        read_a(aslot, raw);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {                         // p = 4 m + jp
+                unsigned ph, pl, t0_, t1_;
+                conv_a(raw[e][p >> 1][2 * (p & 1)], raw[e][p >> 1][2 * (p & 1) + 1], sc[e], ph, t0_, t1_);
+                conv_b(ph, t0_, t1_, pl);
+                ahi[0][e][p >> 2][p & 3] = ph;
+                alo[0][e][p >> 2][p & 3] = pl;
+            }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // chunk 1 of A landed (converted during chunk 0)
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned cph = 0, ct0 = 0, ct1 = 0;
+
+        // one chunk; PAR = c & 1 selects the operand buffers (static: the loop is unrolled by two)
+        auto chunk = [&](auto par_tag, int c) {
+            constexpr int PAR = decltype(par_tag)::value;
+            const int slot1 = slot + 1 == NS ? 0 : slot + 1;
+            const int slot2 = slot1 + 1 == NS ? 0 : slot1 + 1;
+            const int an1 = aslot + 1 == NS ? 0 : aslot + 1;      // A(c + 1): converted during this chunk
+            int c2 = c + 2;
+            if (c2 >= NKC) c2 -= NKC;
+            const char* gsrc = b_src(kc(c2));
+            char* ldst = ring + slot2 * TILE_B + wave * 4096;
+            const char* rb0 = ring + slot * TILE_B;
+            const char* rb1 = ring + slot1 * TILE_B;
+            const int c3 = kc(min(c + 3, NKC - 1));                   // A(c + 3) (clamped at the tile's end: unused) -> A(c)'s slot
+            char* adst = awave + aslot * A_SLOT;
+            read_a(an1, raw);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const char* rn = (m == 0) ? rb0 : rb1;
+                const int bo = boff[m ^ 1];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const int tt = j >> 1, e = j & 1;
+                        const int i = nb * 6 + j;
+                        acc[e][nb] = mfma16(__builtin_bit_cast(h8, tt == 2 ? alo[PAR][e][m] : ahi[PAR][e][m]),
+                                            tt == 0 ? blo[nb] : bhi[nb], acc[e][nb]);
+                        asm volatile("" : "+a"(acc[e][nb]));
+                        // the 16 conversion pairs of chunk c + 1, eight per step: pair p = 8 m + i / 3 <-> edge block
+                        // p >> 3 ... laid out as (e, p8 = 4 m' + jp)
+                        {
+                            const int pp = 8 * m + i / 3;                 // 0..15
+                            const int ce = pp >> 3, p8 = pp & 7;
+                            if (i % 3 == 0 && i / 3 < 8)
+                                conv_a(raw[ce][p8 >> 1][2 * (p8 & 1)], raw[ce][p8 >> 1][2 * (p8 & 1) + 1], sc[ce], cph, ct0, ct1);
+                            if (i % 3 == 1 && i / 3 < 8) {
+                                unsigned pl;
+                                conv_b(cph, ct0, ct1, pl);
+                                ahi[PAR ^ 1][ce][p8 >> 2][p8 & 3] = cph;
+                                alo[PAR ^ 1][ce][p8 >> 2][p8 & 3] = pl;
+                                asm volatile("" ::"v"(ahi[PAR ^ 1][ce][p8 >> 2]), "v"(alo[PAR ^ 1][ce][p8 >> 2]));
+                            }
+                        }
+                        if (j == 1) blo[nb] = *(const h8*)(rn + nb * 4096 + (bo ^ 64));
+                        if (j == 5) bhi[nb] = *(const h8*)(rn + nb * 4096 + bo);
+                        if (m == 0) {
+                            if (i == 2) GPDE_GLDS(gsrc, ldst, 0);
+                            if (i == 8) GPDE_GLDS(gsrc, ldst, 1024);
+                            if (i == 14) GPDE_GLDS(gsrc, ldst, 2048);
+                            if (i == 20) GPDE_GLDS(gsrc, ldst, 3072);
+                        }
+                        // the eight A pieces of chunk c + 3, behind the four B pieces, two per MFMA gap
+                        if (m == 1 && (i == 2 || i == 8 || i == 14 || i == 20)) {
+                            const int k = (i - 2) / 6;
+                            GPDE_GLDS(apiece[2 * k] + c3 * GP_BK, adst + (2 * k) * 1024, 0);
+                            GPDE_GLDS(apiece[2 * k + 1] + c3 * GP_BK, adst + (2 * k + 1) * 1024, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // B(c + 2) and A(c + 2) landed; A(c + 3) flies
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            slot = slot1;
+            aslot = an1;
+        };
+        for (int c = 0; c < NKC; c += 2) {
+            chunk(std::integral_constant<int, 0>{}, c);
+            chunk(std::integral_constant<int, 1>{}, c + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the clamped tail pieces: nothing may land in the ring later
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- un-scale, mask, store --------------------------------------------------------------------------
+        // The 64 mask words of an edge block are loaded as ONE batch (rows clamped, no branches) before the first
+        // store: a load -> wait -> select -> store chain per element cost 60 us of a 90 us tile.
+        const bool has_mask = a.mask != nullptr;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float mk[16][4];
+            if (has_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(r0 + 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h, a.M - 1);
+                    const float* mp = a.mask + (size_t)row * a.ldmask + slice * GP_TN + l31;
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) mk[r][nb] = mp[nb * 32];
+                }
+            }
+            // full tiles (all but the last) store without per-row branches: a branch per row makes hipcc wait for
+            // the previous row's stores (vmcnt(0)) before the next
+            auto store_rows = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int row = r0 + rr;
+                    const float ie = Es[rr];
+                    float* cp = a.C + (size_t)row * a.ldc + slice * GP_TN + l31;
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) {
+                        float v = acc[e][nb][r] * (ie * ucv[nb]);
+                        acc[e][nb][r] = 0.f;
+                        if (has_mask) v = mk[r][nb] > 0.f ? v : 0.f;
+                        if (FULL || row < a.M) cp[nb * 32] = v;
+                    }
+                }
+            };
+            if (r0 + TE <= a.M) store_rows(std::true_type{});
+            else store_rows(std::false_type{});
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace
+
+size_t gpde_gemm_f16s_workspace_floats(int M) { return (size_t)2 * (M > 0 ? M : 1); }
+
+// K a multiple of 128 and >= 256 (the chunk loop is unrolled by four, three chunks of rows are in flight),
+// N a multiple of 128, rows 16-byte aligned
+bool gpde_gemm_f16s_supported(int M, int N, int K, int lda) {
+    return M > 0 && N % GP_TN == 0 && K % 128 == 0 && K >= 256 && lda % 4 == 0;
+}
+
+int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a_in, float* row_scale_ws, hipStream_t stream) {
+    GpdeGemmF16sArgs a = a_in;
+    if (!gpde_gemm_f16s_supported(a.M, a.N, a.K, a.lda)) {
+        gpde_set_error("gpde_gemm_f16s_nt: unsupported shape M=%d N=%d K=%d", a.M, a.N, a.K);
+        return GPDE_EUNSUPPORTED;
+    }
+    float* sc = row_scale_ws;
+    float* isc = row_scale_ws + a.M;
+    hipLaunchKernelGGL(k_row_scale_kernel, dim3((a.M + 3) / 4), dim3(256), 0, stream, a.A, a.M, a.K, a.lda, sc, isc);
+    a.sc = sc;
+    a.isc = isc;
+    const int ns = a.N / GP_TN;
+    int groups = gpde_num_cus() / ns;
+    if (groups < 1) groups = 1;
+    const int ntile = (a.M + TE - 1) / TE;
+    const int gcap = (ntile + NW - 1) / NW;
+    if (groups > gcap) groups = gcap;
+    a.n_groups = groups;
+    const size_t lds = (size_t)NS * TILE_B + (size_t)NS * A_SLOT + NW * TE * 4 + 64;
+    static GpdeLdsOnce once;
+    if (int rc = once.ensure(gpde_gemm_f16s_nt_kernel)) return rc;
+    hipLaunchKernelGGL(gpde_gemm_f16s_nt_kernel, dim3(groups * ns), dim3(256), lds, stream, a);
+    GP_LAUNCH_CHECK("gpde_gemm_f16s_nt_kernel");
+    return GPDE_OK;
+}

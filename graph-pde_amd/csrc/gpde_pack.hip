@@ -220,6 +220,12 @@ __global__ void pack_g2_consts_kernel(const float* __restrict__ W2, const float*
 
 }  // namespace
 
+int gpde_pack_split_nk(const float* Wnk, int n, int k, int NP, int KP, void* out, float* ucol, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_w2_f16split_kernel, dim3(NP), dim3(256), 0, stream, Wnk, n, k, NP, KP, (_Float16*)out, ucol);
+    GP_LAUNCH_CHECK("pack_w2_f16split_kernel");
+    return GPDE_OK;
+}
+
 extern "C" size_t gpde_mlp_pack_bytes(int n_layers, const int32_t* dims) {
     GpdePackLayout L;
     if (!dims || gpde_pack_layout(n_layers, dims, &L) != GPDE_OK) return 0;

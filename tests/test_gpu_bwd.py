@@ -1,0 +1,64 @@
+"""GPU tier: the backward's dU_1 = (dU_2 . W_2) (.) [H_1 > 0] on split-f16 MFMA (gpde_gemm_f16s_nt_kernel,
+csrc/gpde_gemm_f16s.hip; 3-Linear kernels with k2 >= 256) - gradients against float64 autograd through the oracle
+(the reference's loss.backward()), against the exact-fp32 GEMM path, and bit-reproducibility of the weight
+gradients."""
+import pytest
+import torch
+
+from graph_pde_amd import ops
+from oracle.nnconv_oracle import rel_l2
+from tests.test_gpu_parity import _oracle_grads, dev
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _case(dims, n, e, seed):
+    torch.manual_seed(seed)
+    ei = torch.stack([torch.randint(0, n, (e,)), torch.randint(0, n - 5, (e,))])
+    ei[1, : e // 10] = 3                                   # one destination spanning many tiles
+    ea, x = torch.randn(e, dims[0]), torch.randn(n, 64)
+    mlp = torch.nn.Sequential(*sum([[torch.nn.Linear(dims[i], dims[i + 1]), torch.nn.ReLU()]
+                                    for i in range(len(dims) - 1)], [])[:-1])
+    ws_ = [l.weight.detach() for l in mlp if isinstance(l, torch.nn.Linear)]
+    bs_ = [l.bias.detach() for l in mlp if isinstance(l, torch.nn.Linear)]
+    root = torch.empty(64, 64).uniform_(-0.125, 0.125)
+    bias = torch.empty(64).uniform_(-0.125, 0.125)
+    return x, ei, ea, ws_, bs_, root, bias, torch.randn(n, 64)
+
+
+def _native(x, ei, ea, ws_, bs_, root, gout, aggr="mean"):
+    d = dev()
+    csr = ops.build_csr(ei.to(d), x.shape[0])
+    out = ops.nnconv_backward_raw(x.to(d), csr, ea.to(d), [w.to(d) for w in ws_], [b.to(d) for b in bs_], root.to(d), aggr,
+                                  gout.to(d))
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("dims,n,e", [([6, 256, 256, 4096], 200, 3000), ([6, 200, 300, 4096], 150, 2500),
+                                      ([6, 1024, 1024, 4096], 60, 900), ([4, 512, 256, 4096], 120, 1100)])
+def test_backward_with_split_f16_du1_matches_reference_autograd(dims, n, e, monkeypatch):
+    x, ei, ea, ws_, bs_, root, bias, gout = _case(dims, n, e, sum(dims))
+    rx, rW, rb, rroot, rbias = _oracle_grads(x, ei, ea, ws_, bs_, root, bias, "mean", gout)
+    monkeypatch.delenv("GPDE_BWD_GEMM_F32", raising=False)
+    gx, gW, gb, groot, gbias = _native(x, ei, ea, ws_, bs_, root, gout)
+    monkeypatch.setenv("GPDE_BWD_GEMM_F32", "1")
+    fx, fW, fb, froot, fbias = _native(x, ei, ea, ws_, bs_, root, gout)
+    assert rel_l2(gx.cpu(), rx) <= TOL
+    for l in range(3):
+        e16, e32 = rel_l2(gW[l].cpu(), rW[l]), rel_l2(fW[l].cpu(), rW[l])
+        assert e16 <= TOL and e16 <= 4 * e32 + 2e-7, (f"dW{l}", e16, e32)
+        assert rel_l2(gb[l].cpu(), rb[l]) <= TOL, (f"db{l}", rel_l2(gb[l].cpu(), rb[l]))
+    # layer 1 is where the two arithmetics differ (dW_1, db_1 come from dU_1); they must agree closely
+    assert rel_l2(gW[0].cpu(), fW[0].cpu()) <= 2e-6, rel_l2(gW[0].cpu(), fW[0].cpu())
+    assert torch.equal(gW[2], fW[2]) and torch.equal(gW[1], fW[1])          # untouched by the change
+
+
+def test_weight_gradients_are_bit_reproducible():
+    x, ei, ea, ws_, bs_, root, bias, gout = _case([6, 256, 256, 4096], 200, 3000, 5)
+    a = _native(x, ei, ea, ws_, bs_, root, gout)
+    b = _native(x, ei, ea, ws_, bs_, root, gout)
+    for l in range(3):
+        assert torch.equal(a[1][l], b[1][l]) and torch.equal(a[2][l], b[2][l])
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
