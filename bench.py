@@ -269,6 +269,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reuse-probe", action="store_true",
                     help="skip the depth x module probe of the cross-depth hidden-activation reuse")
+    ap.add_argument("--no-backward-probe", action="store_true", help="skip the single-call backward timing (g121)")
     ap.add_argument("--no-mgkn", action="store_true", help="skip the MGKN configurations (BASELINE configs 3, 4)")
     ap.add_argument("--no-alt", action="store_true", help="skip the exact-fp32 leg")
     ap.add_argument("--precision", default=None, choices=["f32", "f16split", "f16split_8wave", "f16split_static", "f16split_agg16", "f16split_agg32"],
@@ -525,6 +526,46 @@ def main():
                  "note": "forward: fixed weights, H built once and reused by all later calls; "
                          "forward_backward: new weight version every step, H rebuilt once per step"}
 
+    # ---- backward of ONE NNConv call on the s=121 graph: what `loss.backward()` costs per
+    #      edge through the same operator (dx, dW_1..3, db_1..3, droot, dbias), hidden-activation cache off so that the
+    #      recompute is inside the time.  Not part of `value`.
+    backward = None
+    if not args.no_backward_probe and world == 1:
+        from graph_pde_amd import hidden_cache
+        mode0 = hidden_cache.MODE
+        hidden_cache.MODE = "off"
+        hidden_cache.clear()
+        try:
+            eib, eab, nb_ = synth.darcy_graph(121, 0.1, device=dev, seed=0)
+            xb = torch.randn(nb_, 64, device=dev, requires_grad=True)
+            tb = []
+            for it in range(4):
+                conv.zero_grad(set_to_none=True)
+                xb.grad = None
+                yb = conv(xb, eib, eab)
+                lossb = yb.square().mean()
+                torch.cuda.synchronize()
+                tq = time.perf_counter()
+                lossb.backward()
+                torch.cuda.synchronize()
+                tb.append(time.perf_counter() - tq)
+            tb_med = sorted(tb[1:])[1]
+            eb_ = int(eib.shape[1])
+            backward = {"graph": "g121 (N=%d, E=%d)" % (nb_, eb_), "ms": round(1e3 * tb_med, 2),
+                        "M_edges_per_s": round(eb_ / tb_med / 1e6, 2),
+                        "grads_finite": bool(torch.isfinite(xb.grad).all()) and
+                        all(bool(torch.isfinite(p_.grad).all()) for p_ in conv.parameters()),
+                        "arithmetic": "dU_1 and dW_2 GEMMs on the 2-term f16 split (gpde_gemm_f16s_nt_kernel), "
+                                      "recompute of H_2 on the forward's kernel, remaining products fp32 MFMA",
+                        "note": "median of 3 timed backward passes after one warm-up; parity of every gradient "
+                                "against float64 autograd: tests/test_gpu_bwd.py, tests/test_gpu_parity.py"}
+            log(f"[bench] backward g121: {backward['ms']} ms, {backward['M_edges_per_s']} M-edges/s")
+            del eib, eab, xb, yb, lossb
+        finally:
+            hidden_cache.MODE = mode0
+            hidden_cache.clear()
+        torch.cuda.empty_cache()
+
     line = {
         "metric": "M-edges/s through fused NNConv fwd (width=64)",
         "value": round(value, 3), "unit": "M-edges/s", "n_gpus": world, "steps": args.steps,
@@ -544,6 +585,7 @@ def main():
         "cpu_baseline": cpu,
         "mgkn": mgkn,
         "depth_reuse": reuse,
+        "backward": backward,
     }
     print(json.dumps(line), flush=True)
     if use_dist:

@@ -380,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd2_kernel(EdgeBwdArgs a) {
 size_t al(size_t v) { return (v + 255) / 256 * 256; }
 unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
+constexpr int BWD_TN_KSPLITS = 8;      // K splits of the dW_2 GEMM: 4 row quads x 8 splits x 8 slices = 256 workgroups
 struct BwdPlan {
     int n_layers, nh;                 // nh = hidden layers = n_layers - 1
     int KP[GPDE_MAX_LAYERS + 1];      // padded widths: KP[0] = pad32(k0), KP[l] = pad128(k_l), l < n_layers
@@ -390,6 +391,7 @@ struct BwdPlan {
     size_t off_H[GPDE_MAX_LAYERS + 1], off_dU[2], off_Z, off_dZ, off_gT, off_S, off_dS;
     size_t off_w2t, off_w2ts, off_ucol2, off_rowsc;   // dU_1 on split f16: W2^T fp32, its split tile image, 2^-t per k1, row scales
     bool f16s_du1;
+    bool f16s_dw2; size_t off_tnws;   // dW_2 on the split-f16 GEMM: transposed dU_2 + split image of H_1^T per edge chunk
     size_t total;
 };
 
@@ -429,13 +431,17 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
         P->off_w2ts = take((size_t)P->KP[1] * P->KP[2]);
         P->off_ucol2 = take(P->KP[1]);
     }
+    P->f16s_dw2 = P->f16s_du1 && P->KP[2] % 64 == 0 && P->KP[1] % GP_TN == 0;
     const size_t fixed = off;
-    // per-chunk buffers: per edge (hsum + 2*kmax) floats, per node (2*64*K2P + 3*64) floats
-    const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0)) * 4, per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4;
+    // per-chunk buffers: per edge (hsum + 2*kmax) floats (+ KP1 + KP2 for the transposed operands of dW_2), per node
+    // (2*64*K2P + 3*64) floats
+    const size_t tn_edge = P->f16s_dw2 ? (size_t)P->KP[1] + P->KP[2] : 0;
+    const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0) + tn_edge) * 4, per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4;
     int64_t Ec, Nc;
-    const size_t slack = 64 * 256;       // alignment of the per-chunk buffers below
+    // alignment of the per-chunk buffers below + the K padding of the transposed operands
+    const size_t slack = 64 * 256 + (P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats(0, P->KP[2], P->KP[1], BWD_TN_KSPLITS) * 4 : 0);
     if (sizing) {
-        Ec = (int64_t)(((size_t)12 << 30) / per_edge); Nc = (int64_t)(((size_t)8 << 30) / per_node);
+        Ec = (int64_t)(((size_t)(P->f16s_dw2 ? 18 : 12) << 30) / per_edge); Nc = (int64_t)(((size_t)8 << 30) / per_node);
     } else if (ws_bytes >= fixed + (size_t)(E > 0 ? E : 1) * per_edge + (size_t)(N > 0 ? N : 1) * per_node + slack) {
         Ec = E; Nc = N;                  // everything in one chunk
     } else {
@@ -454,6 +460,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     P->off_Z = take((size_t)Nc * GP_W * P->K2P); P->off_dZ = take((size_t)Nc * GP_W * P->K2P);
     P->off_gT = take((size_t)Nc * GP_W); P->off_S = take((size_t)Nc * GP_W); P->off_dS = take((size_t)Nc * GP_W);
     P->off_rowsc = take(P->f16s_du1 ? (size_t)2 * Ec : 1);
+    P->off_tnws = take(P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats((int)Ec, P->KP[2], P->KP[1], BWD_TN_KSPLITS) : 1);
     P->total = off + 256 + (sizing ? slack : 0);
     if (!sizing && P->total > ws_bytes) { gpde_set_error("gpde_nnconv_bwd: internal plan %zu > workspace %zu", P->total, ws_bytes); return GPDE_EWORKSPACE; }
     return GPDE_OK;
@@ -470,7 +477,9 @@ int gemm_tn_acc(const float* A, int lda, int M, const float* B, int ldb, int Nco
                 int ldc_dense, float* part, size_t part_floats, int accumulate, hipStream_t st) {
     const int tiles = ((M + 127) / 128) * ((Ncols + 127) / 128);
     int splits = 1;
-    while (splits < 16 && tiles * splits < 512 && rows / (splits * 2) >= 256) splits *= 2;
+    // skinny outputs (dW_1: 1024 x 8) are pure streaming of the tall operand: enough splits to put ~1024 workgroups
+    // on it (16 splits = 128 workgroups read dU_1 at 0.8 TB/s)
+    while (splits < 256 && tiles * splits < 1024 && rows / (splits * 2) >= 256) splits *= 2;
     const size_t cn = (size_t)M * Ncols;
     if ((size_t)splits * cn > part_floats) splits = (int)(part_floats / cn) ? (int)(part_floats / cn) : 1;
     GpdeGemmArgs g = gemm0();
@@ -531,6 +540,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         GP_HIP_CHECK(hipMemsetAsync(F(P.off_dbp[l]), 0, (size_t)P.KP[l] * 4, st));
     }
     const bool f16s_du1 = do_mlp && P.f16s_du1 && !getenv("GPDE_BWD_GEMM_F32");
+    const bool f16s_dw2 = f16s_du1 && P.f16s_dw2 && !getenv("GPDE_BWD_DW2_F32");
     if (f16s_du1) {
         // B operand of dU_1 = dU_2 . W_2: rows = k1 (output), contraction = k2  ->  W_2^T, split + swizzled like the forward's W2
         const size_t wn = (size_t)P.KP[2] * P.KP[1];
@@ -603,8 +613,14 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         for (int l = n - 1; l >= 1; --l) {
             const int Kl = P.KP[l], Kin = P.KP[l - 1];
             int rc2;
-            if ((rc2 = gemm_tn_acc(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, F(P.off_dwp[l]), Kin,
-                                   F(P.off_part), P.part_floats, 1, st)) != GPDE_OK) return rc2;
+            if (l == 2 && f16s_dw2 && rows >= 8192) {
+                // dW_2 += dU_2^T . H_1 on the split-f16 GEMM (contraction over the edges: both operands transposed)
+                if ((rc2 = gpde_launch_gemm_f16s_tn(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, BWD_TN_KSPLITS,
+                                                    F(P.off_tnws), F(P.off_part), st)) != GPDE_OK) return rc2;
+                if ((rc2 = gpde_launch_reduce_splits(F(P.off_part), (size_t)Kl * Kin, BWD_TN_KSPLITS, (size_t)Kl * Kin,
+                                                     F(P.off_dwp[l]), 1, st)) != GPDE_OK) return rc2;
+            } else if ((rc2 = gemm_tn_acc(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, F(P.off_dwp[l]), Kin,
+                                          F(P.off_part), P.part_floats, 1, st)) != GPDE_OK) return rc2;
             {
                 const int cb = (Kl + 255) / 256;
                 int splits = 1; while (splits < 512 && cb * splits < 2048 && rows / (splits * 2) >= 64) splits *= 2;

@@ -221,9 +221,15 @@ struct GpdeGemmF16sArgs {
     int K, N;                           // padded sizes: K % 128 == 0, N % 128 == 0
     const float* sc; const float* isc;  // per-row scales (filled by the launcher's pre-pass)
     int n_groups;
+    int ksplits; size_t cstride;        // split-K (> 1): partial s at C + s * cstride; M <= 4 * 64 * n per launch group
 };
 bool gpde_gemm_f16s_supported(int M, int N, int K, int lda);
 int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a, float* row_scale_ws /* 2 * M floats */, hipStream_t stream);
+// weight-gradient form: part[s] = partial sums over K split s of dU^T . H (dU [rows][n_out], H [rows][n_in], fp32,
+// contraction over the rows); ws = gpde_gemm_f16s_tn_ws_floats(...) floats, part = ksplits * n_out * n_in floats
+size_t gpde_gemm_f16s_tn_ws_floats(int rows_max, int n_out, int n_in, int ksplits);
+int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H, int ldh, int n_in, int rows,
+                             int ksplits, float* ws, float* part, hipStream_t stream);
 // split tile image of a row-major [n][k] matrix (ld = k): the W2 layout of gpde_mlp_pack for any operand
 int gpde_pack_split_nk(const float* Wnk, int n, int k, int NP, int KP, void* out, float* ucol, hipStream_t stream);
 int gpde_num_cus();

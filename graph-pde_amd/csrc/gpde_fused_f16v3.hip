@@ -256,6 +256,10 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
     for (int t = 0; t < maxtiles; ++t) {
         const int e0 = ea + t * GP_TE;
         const int e_end = min(e0 + GP_TE, eb);
+        // One chunk pair per tile (K1P = 64): the x_j rows of this tile are issued in pair 0, with no barrier since
+        // the previous tile's aggregation - the partner wave of the pair (same edges, other column half) may still be
+        // reading the shared x stage.  (With two or more pairs the rows are issued behind pair 0's closing barrier.)
+        if (!WRITE_H && NP == 1 && t > 0) __builtin_amdgcn_s_barrier();
 
         // ---- attributes of this lane's edge: validity, bias slot, per-edge scale, f16 split --------
         h8 B1, B2;          // H1 MFMA operands: B1 = h ? attr_lo : attr_hi ; B2 = h ? 0 : attr_hi
@@ -325,6 +329,12 @@ __global__ __launch_bounds__(512, 2) void gpde_fused_f16v3_kernel(GpdeFusedArgs 
             if (cB >= NKC) cB -= NKC;
             issue_w2(cA, sb ^ 2);
             issue_w2(cB, (sb ^ 2) + 1);
+            // The counted waits below assume that the four DMA are OLDER than the side loads.  Nothing else orders a
+            // plain global load against an LDS-DMA: hipcc hoisted the next tile's edge-id load above the fourth DMA,
+            // vmcnt(1) then let that DMA (the second piece of chunk cB) fly past the barrier, and after a cold-cache
+            // stall its lo units were read stale (1e-4 errors in one tile, one in ~10 runs under memory pressure).
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
             if (kp == 0) {
                 load_perm(e0n);
                 if constexpr (!WRITE_H) load_sidx(e0);

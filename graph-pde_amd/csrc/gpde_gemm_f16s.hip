@@ -80,8 +80,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
 
     const int ns = a.N / GP_TN;
     // Workgroup b runs on XCD b % 8.  The ns column slices of one row group read the SAME A rows (4 KiB per row at
-    // K = 1024): they share an XCD, so that seven of eight reads of a row hit that XCD's L2 (with slice = b % ns the
-    // eight L2s each fetched every row: 8x the fabric traffic and 2.8 us per chunk instead of 1.3).
+    // K = 1024): they share an XCD, so that seven of eight reads of a row can hit that XCD's L2.
     int slice, group;
     if (a.n_groups % 8 == 0) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -91,17 +90,29 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
         slice = blockIdx.x % ns;
         group = blockIdx.x / ns;
     }
-    const int NKC = a.K / GP_BK;
+    const int NKCT = a.K / GP_BK;                   // chunks of the whole K (the B image's row of tiles)
     const int ntile = (a.M + TE - 1) / TE;
-    const int stride = a.n_groups * NW;
-    const int rounds = (ntile + stride - 1) / stride;
-    if (rounds == 0) return;
-
-    // K-loop rotation: row group g walks the chunks starting at rot(g).  All workgroups move through K at the same
-    // rate; without the skew they ask for the same 128-byte column of 4 KiB-strided rows at the same time.
-    const int rot = (group * 11) % NKC;
-    auto kc = [&](int c) { const int v = c + rot; return v >= NKC ? v - NKC : v; };
-    const unsigned long long bbase = (unsigned long long)a.bsplit + (size_t)slice * NKC * TILE_B + wave * 4096;
+    // split-K (ksplits > 1: the weight-gradient use, few rows and a very long K): group = (K split, row quad), one
+    // tile per wave, partial products of split s at C + s * cstride
+    int NKC = NKCT, kc0 = 0, rounds, tgroup = group, tstride = a.n_groups;
+    float* Cout = a.C;
+    if (a.ksplits > 1) {
+        const int nq = (ntile + NW - 1) / NW;
+        const int ks = group / nq;
+        if (ks >= a.ksplits) return;
+        NKC = NKCT / a.ksplits;
+        kc0 = ks * NKC;
+        tgroup = group % nq;
+        tstride = nq;
+        rounds = 1;
+        Cout += (size_t)ks * a.cstride;
+    } else {
+        const int stride = a.n_groups * NW;
+        rounds = (ntile + stride - 1) / stride;
+        if (rounds == 0) return;
+    }
+    auto kc = [&](int c) { return kc0 + c; };
+    const unsigned long long bbase = (unsigned long long)a.bsplit + (size_t)slice * NKCT * TILE_B + wave * 4096;
     const unsigned lane16 = lane * 16;
     auto b_src = [&](int chunk) {
         unsigned long long gb = bbase + (size_t)chunk * TILE_B;
@@ -149,7 +160,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
     int aslot = 0;          // A ring slot of the current chunk
 
     for (int t = 0; t < rounds; ++t) {
-        const int tile = (t * a.n_groups + group) * NW + wave;
+        const int tile = (t * tstride + tgroup) * NW + wave;
         const int r0 = tile * TE;                                  // may lie beyond M: loads clamp, stores are masked
         float sc[2];
 #pragma unroll
@@ -310,7 +321,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                     const int rr = 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const int row = r0 + rr;
                     const float ie = Es[rr];
-                    float* cp = a.C + (size_t)row * a.ldc + slice * GP_TN + l31;
+                    float* cp = Cout + (size_t)row * a.ldc + slice * GP_TN + l31;
 #pragma unroll
                     for (int nb = 0; nb < 4; ++nb) {
                         float v = acc[e][nb][r] * (ie * ucv[nb]);
@@ -339,21 +350,29 @@ bool gpde_gemm_f16s_supported(int M, int N, int K, int lda) {
 
 int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a_in, float* row_scale_ws, hipStream_t stream) {
     GpdeGemmF16sArgs a = a_in;
-    if (!gpde_gemm_f16s_supported(a.M, a.N, a.K, a.lda)) {
-        gpde_set_error("gpde_gemm_f16s_nt: unsupported shape M=%d N=%d K=%d", a.M, a.N, a.K);
+    if (a.ksplits < 1) a.ksplits = 1;
+    if (!gpde_gemm_f16s_supported(a.M, a.N, a.K, a.lda) || a.K % (64 * a.ksplits) != 0 || a.K / a.ksplits < 256) {
+        gpde_set_error("gpde_gemm_f16s_nt: unsupported shape M=%d N=%d K=%d ksplits=%d", a.M, a.N, a.K, a.ksplits);
         return GPDE_EUNSUPPORTED;
     }
-    float* sc = row_scale_ws;
-    float* isc = row_scale_ws + a.M;
-    hipLaunchKernelGGL(k_row_scale_kernel, dim3((a.M + 3) / 4), dim3(256), 0, stream, a.A, a.M, a.K, a.lda, sc, isc);
-    a.sc = sc;
-    a.isc = isc;
+    if (row_scale_ws) {                      // per-row scales from one read of A; otherwise the caller filled sc / isc
+        float* sc = row_scale_ws;
+        float* isc = row_scale_ws + a.M;
+        hipLaunchKernelGGL(k_row_scale_kernel, dim3((a.M + 3) / 4), dim3(256), 0, stream, a.A, a.M, a.K, a.lda, sc, isc);
+        a.sc = sc;
+        a.isc = isc;
+    }
     const int ns = a.N / GP_TN;
-    int groups = gpde_num_cus() / ns;
-    if (groups < 1) groups = 1;
     const int ntile = (a.M + TE - 1) / TE;
-    const int gcap = (ntile + NW - 1) / NW;
-    if (groups > gcap) groups = gcap;
+    int groups;
+    if (a.ksplits > 1) {
+        groups = (ntile + NW - 1) / NW * a.ksplits;
+    } else {
+        groups = gpde_num_cus() / ns;
+        if (groups < 1) groups = 1;
+        const int gcap = (ntile + NW - 1) / NW;
+        if (groups > gcap) groups = gcap;
+    }
     a.n_groups = groups;
     const size_t lds = (size_t)NS * TILE_B + (size_t)NS * A_SLOT + NW * TE * 4 + 64;
     static GpdeLdsOnce once;
@@ -361,4 +380,120 @@ int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a_in, float* row_scale_ws, 
     hipLaunchKernelGGL(gpde_gemm_f16s_nt_kernel, dim3(groups * ns), dim3(256), lds, stream, a);
     GP_LAUNCH_CHECK("gpde_gemm_f16s_nt_kernel");
     return GPDE_OK;
+}
+
+// ---- operands of the weight-gradient GEMM  dW[n_out][n_in] = sum_e dU[e][n_out] . H[e][n_in] -----------------------
+// (the contraction runs over the edges: both operands are transposed into K-contiguous form, one pass each)
+namespace {
+// bits[col] = max over rows of |M[row][col]| as fp32 bit pattern (bits zeroed by the caller)
+__global__ __launch_bounds__(256) void k_colabsmax(const float* __restrict__ M, int rows, int cols, int ld, int splits,
+                                                   unsigned* __restrict__ bits) {
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 256 + lane * 4, split = blockIdx.y;
+    if (col >= cols) return;
+    const int rps = (rows + splits - 1) / splits;
+    const int r_lo = split * rps, r_hi = min(rows, r_lo + rps);
+    unsigned m[4] = {0u, 0u, 0u, 0u};
+    const float* p = M + col;
+    for (int r = r_lo + rg; r < r_hi; r += 4) {
+        const f32x4 v = *(const f32x4*)(p + (size_t)r * ld);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = max(m[j], __float_as_uint(v[j]) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (m[j]) atomicMax(bits + col + j, m[j]);
+}
+// the scales of k_row_scale_kernel / pack_w2_f16split_kernel from the maxima
+__global__ void k_scales_from_max(const unsigned* __restrict__ bits, int n, float* __restrict__ sc, float* __restrict__ isc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int eb = (int)((bits[i] >> 23) & 0xff);
+    const bool ok = eb >= 20 && eb <= 230;
+    sc[i] = ok ? __int_as_float((267 - eb) << 23) : 1.f;
+    isc[i] = ok ? __int_as_float((eb - 13) << 23) : 1.f;
+}
+// dst[c][e] = src[e][c] for e < rows, 0 for rows <= e < ldd   (64 x 64 tiles through LDS)
+__global__ __launch_bounds__(256) void k_transpose_pad(const float* __restrict__ src, int rows, int ld,
+                                                       float* __restrict__ dst, int ldd) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = e0 + ty + 4 * i;
+        tile[ty + 4 * i][tx] = e < rows ? src[(size_t)e * ld + c0 + tx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i;
+        dst[(size_t)c * ldd + e0 + tx] = tile[tx][ty + 4 * i];
+    }
+}
+// The split tile image of gpde_pack.hip's pack_w2_f16split_kernel for B[n][k] = H[k][n] * sc[n] (H row-major [rows][ld],
+// k = the edge): workgroup = one 16 KiB tile (slice of 128 n, chunk of 32 k), thread = (n, k16 step m).
+__global__ __launch_bounds__(256) void k_pack_split_kn(const float* __restrict__ H, int rows, int ld,
+                                                       const float* __restrict__ sc, int nkct,
+                                                       _Float16* __restrict__ out) {
+    const int n = threadIdx.x & 127, m = threadIdx.x >> 7;
+    const int kcn = blockIdx.x, slice = blockIdx.y;
+    const int e0 = kcn * 32 + 16 * m;
+    const float s = sc[slice * 128 + n];
+    float w[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = (e0 + k < rows) ? H[(size_t)(e0 + k) * ld + slice * 128 + n] * s : 0.f;
+    const int sw = (n >> 1) & 7;
+    _Float16* row = out + ((size_t)(slice * (size_t)nkct + kcn) * 128 + n) * 64;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        h8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = w[8 * (j >> 2) + 4 * hh + (j & 3)];
+            hi[j] = (_Float16)v;
+            lo[j] = (_Float16)(v - (float)hi[j]);
+        }
+        *(h8*)(row + (((m * 2 + hh) ^ sw) << 3)) = hi;
+        *(h8*)(row + (((4 + m * 2 + hh) ^ sw) << 3)) = lo;
+    }
+}
+}  // namespace
+
+size_t gpde_gemm_f16s_tn_ws_floats(int rows_max, int n_out, int n_in, int ksplits) {
+    const size_t epad = (size_t)rows_max + 64 * (size_t)ksplits;
+    return epad * n_out + epad * n_in + 3 * (size_t)(n_out + n_in) + 64;
+}
+
+// part[s][n_out][n_in] (s < ksplits, stride n_out * n_in) = partial sums of dU^T . H over the K splits
+int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H, int ldh, int n_in, int rows,
+                             int ksplits, float* ws, float* part, hipStream_t stream) {
+    if (rows < 1 || n_out % 64 != 0 || n_in % GP_TN != 0 || ldu % 4 != 0 || ldh % 4 != 0 || ksplits < 1) {
+        gpde_set_error("gpde_gemm_f16s_tn: unsupported shape rows=%d n_out=%d n_in=%d", rows, n_out, n_in);
+        return GPDE_EUNSUPPORTED;
+    }
+    int ksp = ((rows + 64 * ksplits - 1) / (64 * ksplits)) * 64;       // K per split (a multiple of 64: even chunk count)
+    if (ksp < 256) ksp = 256;
+    const int epad = ksp * ksplits;
+    float* At = ws;                                            // [n_out][epad]
+    _Float16* Bimg = (_Float16*)(At + (size_t)n_out * epad);   // [n_in / 128][epad / 32][128][64]
+    float* sca = (float*)(Bimg + (size_t)n_in * epad * 2);
+    float* isca = sca + n_out;
+    float* scb = isca + n_out;
+    float* ucolb = scb + n_in;
+    unsigned* bits = (unsigned*)(ucolb + n_in);                // [n_out + n_in]
+    GP_HIP_CHECK(hipMemsetAsync(bits, 0, (size_t)(n_out + n_in) * 4, stream));
+    int splits = 1;
+    while (splits < 256 && rows / (splits * 2) >= 64) splits *= 2;
+    hipLaunchKernelGGL(k_colabsmax, dim3((n_out + 255) / 256, splits), dim3(256), 0, stream, dU, rows, n_out, ldu, splits, bits);
+    hipLaunchKernelGGL(k_colabsmax, dim3((n_in + 255) / 256, splits), dim3(256), 0, stream, H, rows, n_in, ldh, splits, bits + n_out);
+    hipLaunchKernelGGL(k_scales_from_max, dim3((n_out + 255) / 256), dim3(256), 0, stream, bits, n_out, sca, isca);
+    hipLaunchKernelGGL(k_scales_from_max, dim3((n_in + 255) / 256), dim3(256), 0, stream, bits + n_out, n_in, scb, ucolb);
+    hipLaunchKernelGGL(k_transpose_pad, dim3(epad / 64, n_out / 64), dim3(256), 0, stream, dU, rows, ldu, At, epad);
+    hipLaunchKernelGGL(k_pack_split_kn, dim3(epad / 32, n_in / 128), dim3(256), 0, stream, H, rows, ldh, scb, epad / 32, Bimg);
+    GP_LAUNCH_CHECK("gpde_gemm_f16s_tn operand kernels");
+    GpdeGemmF16sArgs g{};
+    g.A = At; g.lda = epad; g.M = n_out; g.bsplit = Bimg; g.ucol = ucolb; g.mask = nullptr; g.ldmask = 0;
+    g.C = part; g.ldc = n_in; g.K = epad; g.N = n_in; g.sc = sca; g.isc = isca;
+    g.ksplits = ksplits; g.cstride = (size_t)n_out * n_in;
+    return gpde_launch_gemm_f16s_nt(g, nullptr, stream);
 }

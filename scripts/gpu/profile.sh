@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r02}
-B="python $R/bench.py --no-cpu-baseline --no-reuse-probe --no-mgkn --no-alt"
+B="python $R/bench.py --no-cpu-baseline --no-reuse-probe --no-mgkn --no-alt --no-backward-probe"
 mkdir -p $R/gpurun_out/prof_$TAG
 cd $R
 timeout 300 rocprofv3 --output-format csv --kernel-trace --stats -d gpurun_out/prof_$TAG/stats -o run -- $B --steps 3 --warmup 1 > gpurun_out/prof_$TAG/stats.log 2>&1; echo "stats rc=$?"

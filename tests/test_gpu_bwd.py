@@ -62,3 +62,44 @@ def test_weight_gradients_are_bit_reproducible():
     for l in range(3):
         assert torch.equal(a[1][l], b[1][l]) and torch.equal(a[2][l], b[2][l])
     assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+
+
+def test_dw2_on_the_split_f16_gemm_matches_reference_autograd(monkeypatch):
+    """From 8192 edges per chunk on, dW_2 = dU_2^T . H_1 runs on the same split-f16 GEMM (operands transposed into
+    K-contiguous form, 8 K splits): against float64 autograd and against the fp32 GEMM it replaces."""
+    dims, n, e = [6, 256, 256, 4096], 300, 20000
+    x, ei, ea, ws_, bs_, root, bias, gout = _case(dims, n, e, 77)
+    rx, rW, rb, rroot, rbias = _oracle_grads(x, ei, ea, ws_, bs_, root, bias, "mean", gout)
+    monkeypatch.delenv("GPDE_BWD_GEMM_F32", raising=False)
+    monkeypatch.delenv("GPDE_BWD_DW2_F32", raising=False)
+    gx, gW, gb, groot, gbias = _native(x, ei, ea, ws_, bs_, root, gout)
+    g2 = _native(x, ei, ea, ws_, bs_, root, gout)
+    monkeypatch.setenv("GPDE_BWD_DW2_F32", "1")
+    fx, fW, fb, froot, fbias = _native(x, ei, ea, ws_, bs_, root, gout)
+    # Against float64 row by row: with 5 M hidden activations one or two lie within rounding of the ReLU kink, where the
+    # fp32-level forward and the float64 oracle pick different masks (a single flipped entry moves ITS row of dW_2 by
+    # ~1/sqrt(E) - 7e-4 of the whole matrix at this size, in the fp32 path exactly as in the split path).  All other
+    # rows must match to the gradient tolerance.
+    rows16 = ((gW[1].cpu().double() - rW[1].double()).norm(dim=1) / rW[1].double().norm(dim=1))
+    rows32 = ((fW[1].cpu().double() - rW[1].double()).norm(dim=1) / rW[1].double().norm(dim=1))
+    assert int((rows16 > TOL).sum()) <= 4 and int((rows16 > TOL).sum()) <= int((rows32 > TOL).sum()) + 1, \
+        (rows16.max(), rows32.max())
+    assert float(rows16.median()) <= 2e-6
+    assert not torch.equal(gW[1], fW[1])                    # the split path did run
+    assert rel_l2(gW[1].cpu(), fW[1].cpu()) <= 2e-6
+    assert torch.equal(gW[1], g2[1][1])                     # and is bit-reproducible
+    for l in (0, 2):
+        assert torch.equal(gW[l], fW[l])
+
+
+def test_dw2_split_gemm_at_headline_widths_agrees_with_fp32(monkeypatch):
+    dims, n, e = [6, 1024, 1024, 4096], 500, 30011           # a ragged K: 30011 rows pad to 8 splits of 3776
+    x, ei, ea, ws_, bs_, root, bias, gout = _case(dims, n, e, 78)
+    monkeypatch.delenv("GPDE_BWD_GEMM_F32", raising=False)
+    monkeypatch.delenv("GPDE_BWD_DW2_F32", raising=False)
+    gx, gW, gb, groot, gbias = _native(x, ei, ea, ws_, bs_, root, gout)
+    monkeypatch.setenv("GPDE_BWD_DW2_F32", "1")
+    fx, fW, fb, froot, fbias = _native(x, ei, ea, ws_, bs_, root, gout)
+    assert not torch.equal(gW[1], fW[1])
+    assert rel_l2(gW[1].cpu(), fW[1].cpu()) <= 2e-6, rel_l2(gW[1].cpu(), fW[1].cpu())
+    assert torch.isfinite(gW[1]).all()
