@@ -22,8 +22,9 @@
 // (Z of the chunk from the recomputed or given H) and the two edge kernels below -- except the recompute
 // of the last hidden layer of 3-Linear kernels, which reuses the forward's fused f16-split kernel with
 // its store epilogue (gpde_fused_f16v3_kernel<true, ...>).
-// Weight-gradient reductions use ordered split partials (deterministic); dx_j uses fp32 atomics
-// (as the reference's scatter backward does on a GPU).
+// Weight-gradient reductions use ordered split partials (deterministic).  dx_j: with the source-ordered slot list
+// (gpde_nnconv_bwd_ordered) per-edge contributions are written out and summed per source node in slot order by
+// k_dx_reduce (bit-reproducible); without it, fp32 atomics (as the reference's scatter backward does on a GPU).
 #include "gpde_common.h"
 #include <cstdlib>
 #include <vector>
@@ -121,6 +122,7 @@ struct EdgeBwdArgs {
     const float* x; const int32_t* rowptr; const int32_t* src; const int32_t* dst;
     const float* dZ; const float* dS; const float* H; float* dU; float* dx;
     int e0, e1, n0, K2P;
+    float* dxe;       // ordered mode: per-edge contributions [e1 - e0][64] instead of atomics on dx
 };
 __global__ __launch_bounds__(256, 2) void gpde_edge_bwd_kernel(EdgeBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -215,7 +217,8 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd_kernel(EdgeBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                atomicAdd(&a.dx[(size_t)j * GP_W + c], dxa[cb][r] + ds[c]);
+                if (a.dxe) a.dxe[(size_t)(e - a.e0) * GP_W + c] = dxa[cb][r] + ds[c];
+                else atomicAdd(&a.dx[(size_t)j * GP_W + c], dxa[cb][r] + ds[c]);
             }
     }
 }
@@ -371,10 +374,48 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd2_kernel(EdgeBwdArgs a) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
                 const int c = cb * 32 + l31;
-                atomicAdd(&a.dx[(size_t)j * GP_W + c], dxa[cb][r] + ds[c]);
+                if (a.dxe) a.dxe[(size_t)(e - a.e0) * GP_W + c] = dxa[cb][r] + ds[c];
+                else atomicAdd(&a.dx[(size_t)j * GP_W + c], dxa[cb][r] + ds[c]);
             }
         }
     }
+}
+
+// Ordered mode: dx[j] += sum of the per-edge contributions of the out-edges of j that lie in this chunk's slot range
+// [e0, e1), in ascending slot order (src_slots is ascending inside a source: the chunk's part is one sub-range).
+// One wave per source node, lane = channel: a single owner per dx element, no atomics -> bit-reproducible.
+__global__ __launch_bounds__(256) void k_dx_reduce(const float* __restrict__ dxe, const int32_t* __restrict__ srp,
+                                                   const int32_t* __restrict__ ssl, int n_nodes, int e0, int e1,
+                                                   float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n_nodes) return;
+    int lo = srp[j], hi = srp[j + 1];
+    const int end = hi;
+    while (lo < hi) {                                   // first position with slot >= e0
+        const int mid = (lo + hi) >> 1;
+        if (ssl[mid] < e0) lo = mid + 1; else hi = mid;
+    }
+    int p = lo;
+    if (p >= end || ssl[p] >= e1) return;
+    float acc = dx[(size_t)j * GP_W + lane];            // continue the running sum: the result does not depend on the chunking
+    for (; p + 8 <= end; p += 8) {
+        int sl[8];
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sl[q] = ssl[p + q];
+        if (sl[7] >= e1) break;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = dxe[(size_t)(sl[q] - e0) * GP_W + lane];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += v[q];
+    }
+    for (; p < end; ++p) {
+        const int sl = ssl[p];
+        if (sl >= e1) break;
+        acc += dxe[(size_t)(sl - e0) * GP_W + lane];
+    }
+    dx[(size_t)j * GP_W + lane] = acc;
 }
 
 size_t al(size_t v) { return (v + 255) / 256 * 256; }
@@ -391,6 +432,7 @@ struct BwdPlan {
     size_t off_H[GPDE_MAX_LAYERS + 1], off_dU[2], off_Z, off_dZ, off_gT, off_S, off_dS;
     size_t off_w2t, off_w2ts, off_ucol2, off_rowsc;   // dU_1 on split f16: W2^T fp32, its split tile image, 2^-t per k1, row scales
     bool f16s_du1;
+    size_t off_dxe;                   // per-edge dx contributions of a chunk (ordered mode)
     bool f16s_dw2; size_t off_tnws;   // dW_2 on the split-f16 GEMM: transposed dU_2 + split image of H_1^T per edge chunk
     size_t total;
 };
@@ -436,7 +478,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     // per-chunk buffers: per edge (hsum + 2*kmax) floats (+ KP1 + KP2 for the transposed operands of dW_2), per node
     // (2*64*K2P + 3*64) floats
     const size_t tn_edge = P->f16s_dw2 ? (size_t)P->KP[1] + P->KP[2] : 0;
-    const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0) + tn_edge) * 4, per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4;
+    const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0) + tn_edge + GP_W) * 4, per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4;
     int64_t Ec, Nc;
     // alignment of the per-chunk buffers below + the K padding of the transposed operands
     const size_t slack = 64 * 256 + (P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats(0, P->KP[2], P->KP[1], BWD_TN_KSPLITS) * 4 : 0);
@@ -460,6 +502,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     P->off_Z = take((size_t)Nc * GP_W * P->K2P); P->off_dZ = take((size_t)Nc * GP_W * P->K2P);
     P->off_gT = take((size_t)Nc * GP_W); P->off_S = take((size_t)Nc * GP_W); P->off_dS = take((size_t)Nc * GP_W);
     P->off_rowsc = take(P->f16s_du1 ? (size_t)2 * Ec : 1);
+    P->off_dxe = take((size_t)Ec * GP_W);
     P->off_tnws = take(P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats((int)Ec, P->KP[2], P->KP[1], BWD_TN_KSPLITS) : 1);
     P->total = off + 256 + (sizing ? slack : 0);
     if (!sizing && P->total > ws_bytes) { gpde_set_error("gpde_nnconv_bwd: internal plan %zu > workspace %zu", P->total, ws_bytes); return GPDE_EWORKSPACE; }
@@ -518,7 +561,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
              const float* const* b, const float* root, int aggr, const float* grad_out, float* grad_x,
              float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias,
              const float* hidden, float* grad_hidden_out, const float* grad_hidden_in, void* ws,
-             size_t ws_bytes, hipStream_t st) {
+             size_t ws_bytes, hipStream_t st, const int32_t* src_rowptr = nullptr, const int32_t* src_slots = nullptr) {
     const bool do_conv = phase != BWD_MLP, do_mlp = phase != BWD_CONV;
     BwdPlan P;
     int rc = make_bwd_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P);
@@ -723,7 +766,8 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             // per-edge backward through the aggregation -> dU_{n-1}, dx_j
             float* dUc = phase == BWD_FULL ? F(P.off_dU[0]) : grad_hidden_out + (size_t)e0 * K2P;
             {
-                EdgeBwdArgs ea{x, rowptr, src, dst, dZ, dS, Hlast, dUc, dx, e0, e1, na, K2P};
+                const bool ordered = src_rowptr && src_slots;
+                EdgeBwdArgs ea{x, rowptr, src, dst, dZ, dS, Hlast, dUc, dx, e0, e1, na, K2P, ordered ? F(P.off_dxe) : nullptr};
                 const size_t lds = (size_t)4 * (32 * EB_XS + 32 * EB_HS) * 4;
                 const size_t lds2 = (size_t)(2 * EB2_DZ + 4 * 2 * EB2_H) * 4 + 4 * 64 * 4;
                 static GpdeLdsOnce once;
@@ -735,6 +779,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 const bool staged = force ? force == 2 : (int64_t)rows >= (int64_t)32 * nn;
                 if (staged) hipLaunchKernelGGL(gpde_edge_bwd2_kernel, dim3((rows + 127) / 128), dim3(T), lds2, st, ea);
                 else hipLaunchKernelGGL(gpde_edge_bwd_kernel, dim3((rows + 127) / 128), dim3(T), lds, st, ea);
+                if (ordered) hipLaunchKernelGGL(k_dx_reduce, dim3((N + 3) / 4), dim3(T), 0, st, F(P.off_dxe), src_rowptr, src_slots, N, e0, e1, dx);
             }
             // MLP backward over the chunk's edges
             if (phase == BWD_FULL) { if ((rc = mlp_backward(dUc, rows)) != GPDE_OK) return rc; }
@@ -776,13 +821,14 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
 
 }  // namespace
 
-extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
-                               const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                               const int32_t* perm, const int32_t* rowptr_host, int n_layers,
-                               const int32_t* dims, const float* const* W, const float* const* b,
-                               const float* root, int aggr, const float* grad_out, float* grad_x,
-                               float* const* grad_W, float* const* grad_b, float* grad_root,
-                               float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
+extern "C" int gpde_nnconv_bwd_ordered(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
+                                       const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                                       const int32_t* perm, const int32_t* rowptr_host, const int32_t* src_rowptr,
+                                       const int32_t* src_slots, int n_layers,
+                                       const int32_t* dims, const float* const* W, const float* const* b,
+                                       const float* root, int aggr, const float* grad_out, float* grad_x,
+                                       float* const* grad_W, float* const* grad_b, float* grad_root,
+                                       float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
     if (n_nodes < 0 || n_edges < 0 || !dims || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws ||
         (n_nodes > 0 && !x) || (n_edges > 0 && (!edge_attr || !src || !dst || !perm))) {
         gpde_set_error("gpde_nnconv_bwd: null/negative argument");
@@ -791,12 +837,25 @@ extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edg
     if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
     return bwd_impl(BWD_FULL, x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims,
                     W, b, root, aggr, grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, nullptr, nullptr,
-                    nullptr, ws, ws_bytes, (hipStream_t)stream_);
+                    nullptr, ws, ws_bytes, (hipStream_t)stream_, src_rowptr, src_slots);
 }
 
-extern "C" int gpde_nnconv_bwd_hidden(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
+extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
+                               const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                               const int32_t* perm, const int32_t* rowptr_host, int n_layers,
+                               const int32_t* dims, const float* const* W, const float* const* b,
+                               const float* root, int aggr, const float* grad_out, float* grad_x,
+                               float* const* grad_W, float* const* grad_b, float* grad_root,
+                               float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
+    return gpde_nnconv_bwd_ordered(x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, nullptr, nullptr,
+                                   n_layers, dims, W, b, root, aggr, grad_out, grad_x, grad_W, grad_b, grad_root,
+                                   grad_bias, ws, ws_bytes, stream_);
+}
+
+extern "C" int gpde_nnconv_bwd_hidden_ordered(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
                                       const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                                      const int32_t* rowptr_host, int n_layers, const int32_t* dims,
+                                      const int32_t* rowptr_host, const int32_t* src_rowptr,
+                                      const int32_t* src_slots, int n_layers, const int32_t* dims,
                                       const float* w_last, const float* b_last, const float* root, int aggr,
                                       const float* grad_out, float* grad_x, float* grad_hidden,
                                       float* grad_w_last, float* grad_b_last, float* grad_root,
@@ -816,7 +875,19 @@ extern "C" int gpde_nnconv_bwd_hidden(const float* x, int64_t n_nodes, const flo
     gW[n_layers - 1] = grad_w_last; gb[n_layers - 1] = grad_b_last;
     return bwd_impl(BWD_CONV, x, n_nodes, nullptr, n_edges, rowptr, src, dst, nullptr, rowptr_host, n_layers, dims,
                     W, b, root, aggr, grad_out, grad_x, gW, gb, grad_root, grad_bias, hidden, grad_hidden, nullptr,
-                    ws, ws_bytes, (hipStream_t)stream_);
+                    ws, ws_bytes, (hipStream_t)stream_, src_rowptr, src_slots);
+}
+
+extern "C" int gpde_nnconv_bwd_hidden(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
+                                      const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                                      const int32_t* rowptr_host, int n_layers, const int32_t* dims,
+                                      const float* w_last, const float* b_last, const float* root, int aggr,
+                                      const float* grad_out, float* grad_x, float* grad_hidden,
+                                      float* grad_w_last, float* grad_b_last, float* grad_root,
+                                      float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
+    return gpde_nnconv_bwd_hidden_ordered(x, n_nodes, hidden, n_edges, rowptr, src, dst, rowptr_host, nullptr, nullptr,
+                                          n_layers, dims, w_last, b_last, root, aggr, grad_out, grad_x, grad_hidden,
+                                          grad_w_last, grad_b_last, grad_root, grad_bias, ws, ws_bytes, stream_);
 }
 
 extern "C" int gpde_hidden_bwd(const float* edge_attr, int64_t n_edges, const int32_t* perm, int n_layers,

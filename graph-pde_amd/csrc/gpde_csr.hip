@@ -60,6 +60,11 @@ size_t sort_temp_bytes(int64_t n_edges, int64_t n_nodes) {
 
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
+__global__ void csr_iota_kernel(uint32_t* __restrict__ v, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) v[e] = (uint32_t)e;
+}
+
 }  // namespace
 
 extern "C" size_t gpde_csr_workspace_bytes(int64_t n_edges, int64_t n_nodes) {
@@ -105,5 +110,41 @@ extern "C" int gpde_csr_from_coo(const int64_t* edge_index, int64_t stride_row, 
     hipLaunchKernelGGL(csr_rowptr_kernel, dim3((N + 1 + T - 1) / T), dim3(T), 0, stream, dst, E, N,
                        rowptr);
     GP_LAUNCH_CHECK("gpde_csr kernels");
+    return GPDE_OK;
+}
+
+// CSR slots regrouped by SOURCE node: src_slots = the slots 0..E-1 stably sorted by src[slot] (ascending slot inside a
+// source), src_rowptr[j] = first position of source j.  The backward reduces dx_j = sum over the out-edges of j in
+// THIS order instead of by atomics (what autograd's index_select backward does in the reference:
+// /root/reference/graph-neural-operator/nn_conv.py:271 -> PyG propagate; result order there is unspecified).
+extern "C" int gpde_csr_source_order(const int32_t* src, int64_t n_edges, int64_t n_nodes, int32_t* src_rowptr,
+                                     int32_t* src_slots, void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_edges < 0 || n_nodes < 0 || !src_rowptr || (n_edges > 0 && (!src || !src_slots))) {
+        gpde_set_error("gpde_csr_source_order: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (n_edges >= ((int64_t)1 << 31) - 64 || n_nodes >= ((int64_t)1 << 31) - 64) {
+        gpde_set_error("gpde_csr_source_order: sizes exceed the int32 CSR");
+        return GPDE_EUNSUPPORTED;
+    }
+    if (ws_bytes < gpde_csr_workspace_bytes(n_edges, n_nodes) || (!ws && n_edges > 0)) {
+        gpde_set_error("gpde_csr_source_order: workspace %zu < %zu bytes", ws_bytes, gpde_csr_workspace_bytes(n_edges, n_nodes));
+        return GPDE_EWORKSPACE;
+    }
+    const int T = 256;
+    const int E = (int)n_edges, N = (int)n_nodes;
+    uint32_t* keys_out = (uint32_t*)ws;
+    if (E > 0) {
+        char* w = (char*)ws + align256((size_t)E * 4);
+        uint32_t* vals = (uint32_t*)w;  w += align256((size_t)E * 4);
+        size_t temp_bytes = sort_temp_bytes(n_edges, n_nodes);
+        hipLaunchKernelGGL(csr_iota_kernel, dim3((E + T - 1) / T), dim3(T), 0, stream, vals, E);
+        GP_HIP_CHECK(rocprim::radix_sort_pairs((void*)w, temp_bytes, (const uint32_t*)src, keys_out, vals,
+                                               (uint32_t*)src_slots, (size_t)E, 0, sort_bits(n_nodes), stream));
+    }
+    hipLaunchKernelGGL(csr_rowptr_kernel, dim3((N + 1 + T - 1) / T), dim3(T), 0, stream, (const int32_t*)keys_out, E, N,
+                       src_rowptr);
+    GP_LAUNCH_CHECK("gpde_csr_source_order kernels");
     return GPDE_OK;
 }

@@ -31,6 +31,28 @@ class Csr:
     dst: torch.Tensor      # int32 [E]  target node of each CSR slot (sorted ascending)
     perm: torch.Tensor     # int32 [E]  CSR slot -> original edge id (stable within a target)
     _rowptr_host: Optional[torch.Tensor] = None
+    _src_order: Optional[tuple] = None
+
+    @property
+    def src_order(self):
+        """(src_rowptr int32 [N+1], src_slots int32 [E]): the CSR slots regrouped by SOURCE node
+        (gpde_csr_source_order), built on first use and kept with the CSR.  The backward sums dx_j over the out-edges
+        of j in this order instead of by atomics: gradients are bit-reproducible.  GPDE_BWD_DX=atomic skips it."""
+        if DX_MODE == "atomic":
+            return None, None
+        if self._src_order is None:
+            lib = _lib.lib()
+            dev = self.rowptr.device
+            srp = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
+            ssl = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
+            nbytes = int(lib.gpde_csr_workspace_bytes(self.n_edges, self.n_nodes))
+            ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.gpde_csr_source_order(self.src.data_ptr(), self.n_edges, self.n_nodes, srp.data_ptr(),
+                                               ssl.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+            _lib.check(rc, "gpde_csr_source_order")
+            self._src_order = (srp, ssl)
+        return self._src_order
 
     @property
     def rowptr_host(self) -> torch.Tensor:
@@ -39,6 +61,9 @@ class Csr:
         if self._rowptr_host is None:
             self._rowptr_host = self.rowptr.cpu().contiguous()
         return self._rowptr_host
+
+
+DX_MODE = os.environ.get("GPDE_BWD_DX", "ordered")     # "ordered" (bit-reproducible grad_x) | "atomic"
 
 
 def _stream_ptr(device) -> int:
@@ -465,10 +490,12 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
             _lib.check(-2, "gpde_nnconv_bwd_workspace_bytes")
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     rph = csr.rowptr_host
+    srp, ssl = csr.src_order
     with torch.cuda.device(dev):
-        rc = lib.gpde_nnconv_bwd(x.data_ptr(), n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(),
+        rc = lib.gpde_nnconv_bwd_ordered(x.data_ptr(), n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(),
                                  csr.src.data_ptr(), csr.dst.data_ptr(), csr.perm.data_ptr(),
-                                 rph.data_ptr(), nl, dims_c, arr(ws_), arr(bs_),
+                                 rph.data_ptr(), None if srp is None else srp.data_ptr(),
+                                 None if ssl is None else ssl.data_ptr(), nl, dims_c, arr(ws_), arr(bs_),
                                  None if root_c is None else root_c.data_ptr(), _AGGR[aggr],
                                  grad_out.data_ptr(), gx.data_ptr(), arr(gW), arr(gb),
                                  None if groot is None else groot.data_ptr(),
@@ -636,10 +663,11 @@ def nnconv_backward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, 
         _lib.check(-2, "gpde_nnconv_bwd_workspace_bytes")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     p = lambda t: None if t is None else t.data_ptr()
+    srp, ssl = csr.src_order
     with torch.cuda.device(dev):
-        rc = lib.gpde_nnconv_bwd_hidden(x.data_ptr(), n, hidden.data_ptr(), e, csr.rowptr.data_ptr(),
+        rc = lib.gpde_nnconv_bwd_hidden_ordered(x.data_ptr(), n, hidden.data_ptr(), e, csr.rowptr.data_ptr(),
                                         csr.src.data_ptr(), csr.dst.data_ptr(), csr.rowptr_host.data_ptr(),
-                                        nl, dims_c, w_last.data_ptr(), p(b_c), p(root_c), _AGGR[aggr],
+                                        p(srp), p(ssl), nl, dims_c, w_last.data_ptr(), p(b_c), p(root_c), _AGGR[aggr],
                                         grad_out.data_ptr(), gx.data_ptr(), gh.data_ptr(), gw.data_ptr(),
                                         p(gb), p(groot), p(gbias), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
     _lib.check(rc, "gpde_nnconv_bwd_hidden")

@@ -170,6 +170,23 @@ int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int
                     const float* root, int aggr, const float* grad_out, float* grad_x,
                     float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias,
                     void* ws, size_t ws_bytes, void* stream);
+/* The same with a bit-reproducible grad_x.  gpde_nnconv_bwd accumulates dx_j over the out-edges of j by fp32
+ * atomics (run-to-run differences at the 1e-7 level, like the reference's index_select backward on a GPU);
+ * given the CSR slots regrouped by source node (gpde_csr_source_order below: src_rowptr [N+1], src_slots [E]) the
+ * per-edge contributions are written out and summed per source in ascending slot order by one owner per element.
+ * src_rowptr == NULL or src_slots == NULL selects the atomic path.  Weight gradients are ordered either way. */
+int gpde_nnconv_bwd_ordered(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
+                            const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                            const int32_t* perm, const int32_t* rowptr_host, const int32_t* src_rowptr,
+                            const int32_t* src_slots, int n_layers,
+                            const int32_t* dims, const float* const* W, const float* const* b,
+                            const float* root, int aggr, const float* grad_out, float* grad_x,
+                            float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias,
+                            void* ws, size_t ws_bytes, void* stream);
+/* src_slots = CSR slots 0..E-1 stably sorted by their source node, src_rowptr[j] = first position of source j;
+ * `src` is the array gpde_csr_from_coo wrote; workspace: gpde_csr_workspace_bytes(n_edges, n_nodes). */
+int gpde_csr_source_order(const int32_t* src, int64_t n_edges, int64_t n_nodes, int32_t* src_rowptr,
+                          int32_t* src_slots, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Cross-depth reuse of the kernel MLP.  The reference applies ONE NNConv
@@ -231,6 +248,15 @@ int gpde_nnconv_bwd_hidden(const float* x, int64_t n_nodes, const float* hidden,
                            const float* grad_out, float* grad_x, float* grad_hidden,
                            float* grad_w_last, float* grad_b_last, float* grad_root, float* grad_bias,
                            void* ws, size_t ws_bytes, void* stream);
+/* bit-reproducible grad_x, as gpde_nnconv_bwd_ordered */
+int gpde_nnconv_bwd_hidden_ordered(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
+                                   const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                                   const int32_t* rowptr_host, const int32_t* src_rowptr,
+                                   const int32_t* src_slots, int n_layers, const int32_t* dims,
+                                   const float* w_last, const float* b_last, const float* root, int aggr,
+                                   const float* grad_out, float* grad_x, float* grad_hidden,
+                                   float* grad_w_last, float* grad_b_last, float* grad_root, float* grad_bias,
+                                   void* ws, size_t ws_bytes, void* stream);
 int gpde_hidden_bwd(const float* edge_attr, int64_t n_edges, const int32_t* perm, int n_layers,
                     const int32_t* dims, const float* const* W, const float* const* b,
                     const float* grad_hidden, float* const* grad_W, float* const* grad_b, void* ws,

@@ -55,13 +55,39 @@ def test_backward_with_split_f16_du1_matches_reference_autograd(dims, n, e, monk
     assert torch.equal(gW[2], fW[2]) and torch.equal(gW[1], fW[1])          # untouched by the change
 
 
-def test_weight_gradients_are_bit_reproducible():
-    x, ei, ea, ws_, bs_, root, bias, gout = _case([6, 256, 256, 4096], 200, 3000, 5)
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_all_gradients_are_bit_reproducible(variant, monkeypatch):
+    """Weight gradients: ordered split partials.  grad_x: per-edge contributions summed per source node in slot order
+    (gpde_nnconv_bwd_ordered + gpde_csr_source_order) instead of atomics - for both per-edge kernels, and identical
+    whether the edges are processed in one chunk or in several (a smaller workspace)."""
+    monkeypatch.setenv("GPDE_EDGE_BWD", variant)
+    x, ei, ea, ws_, bs_, root, bias, gout = _case([6, 256, 256, 4096], 200, 9000, 5)
     a = _native(x, ei, ea, ws_, bs_, root, gout)
     b = _native(x, ei, ea, ws_, bs_, root, gout)
+    assert torch.equal(a[0], b[0])
     for l in range(3):
         assert torch.equal(a[1][l], b[1][l]) and torch.equal(a[2][l], b[2][l])
     assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    # several node / edge chunks: same grad_x bits (chunks are applied in order, one owner per element)
+    d = dev()
+    csr = ops.build_csr(ei.to(d), x.shape[0])
+    from graph_pde_amd import _lib
+    dims_c = _lib.dims_array([6, 256, 256, 4096])
+    full = int(_lib.lib().gpde_nnconv_bwd_workspace_bytes(x.shape[0], ei.shape[1], 3, dims_c))
+    small = torch.empty(full // 3, dtype=torch.uint8, device=d)
+    c = ops.nnconv_backward_raw(x.to(d), csr, ea.to(d), [w.to(d) for w in ws_], [b_.to(d) for b_ in bs_], root.to(d), "mean",
+                                gout.to(d), ws=small)
+    assert torch.equal(c[0], a[0])
+
+
+def test_ordered_grad_x_matches_the_atomic_path(monkeypatch):
+    x, ei, ea, ws_, bs_, root, bias, gout = _case([6, 256, 256, 4096], 200, 9000, 6)
+    a = _native(x, ei, ea, ws_, bs_, root, gout)
+    monkeypatch.setattr(ops, "DX_MODE", "atomic")
+    b = _native(x, ei, ea, ws_, bs_, root, gout)
+    assert rel_l2(a[0].cpu(), b[0].cpu()) <= 1e-6
+    rx = _oracle_grads(x, ei, ea, ws_, bs_, root, bias, "mean", gout)[0]
+    assert rel_l2(a[0].cpu(), rx) <= TOL
 
 
 def test_dw2_on_the_split_f16_gemm_matches_reference_autograd(monkeypatch):

@@ -78,7 +78,6 @@ def test_fused_glue_with_gradients_composes_the_unfused_operator():
         g = torch.randn_like(y1)
         (g1,) = torch.autograd.grad((y1 * g).sum(), x)
         (g2,) = torch.autograd.grad((y2 * g).sum(), x)
-        # dx accumulates by fp32 atomics: the two backward passes agree to summation order, not to the bit
-        assert float((g1 - g2).norm() / g2.norm()) < 1e-6
+        assert torch.equal(g1, g2)       # grad_x is summed per source node in slot order: reproducible to the bit
     finally:
         hidden_cache.MODE = mode0
