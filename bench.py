@@ -272,7 +272,7 @@ def main():
     ap.add_argument("--no-backward-probe", action="store_true", help="skip the single-call backward timing (g121)")
     ap.add_argument("--no-mgkn", action="store_true", help="skip the MGKN configurations (BASELINE configs 3, 4)")
     ap.add_argument("--no-alt", action="store_true", help="skip the exact-fp32 leg")
-    ap.add_argument("--precision", default=None, choices=["f32", "f16split", "f16split_8wave", "f16split_static", "f16split_agg16", "f16split_agg32"],
+    ap.add_argument("--precision", default=None, choices=["f32", "f16split", "f16split_8wave", "f16split_static", "f16split_agg16", "f16split_agg32", "f16split_noedge"],
                     help="arithmetic of the hidden layer (default: graph_pde_amd.ops.DEFAULT_PRECISION)")
     ap.add_argument("--train", action="store_true", help="training-step mode (see the module docstring)")
     ap.add_argument("--depth", type=int, default=6, help="--train: NNConv applications per forward")

@@ -268,6 +268,53 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
         hfinal = in;
     }
 
+    // ---- low in-degree graphs: the last Linear per EDGE (the reference's own association) --------------------------
+    // The re-association of DESIGN.md §2 trades 8.4 MFLOP per edge for 8.4 MFLOP per NODE plus a 256 KiB Z round
+    // trip per node - a loss when a node has two or three in-edges (MGKN-orthogonal Burgers: 8192 nodes, 16 k edges,
+    // 2 x 2.1 GB of Z per call).  There W_e = W3 . h_e is formed tile by tile on the split-f16 GEMM and contracted
+    // with x_j in its epilogue ([E][4096] never exists), messages are summed per destination in CSR order.
+    const bool edge_path = ((flags & GPDE_FWD_F16SPLIT) || (hidden && hidden_absmax)) && !mixed && !kt && L.has_w3s && P.n_chunks == 1 &&
+                           n_edges >= 4096 && n_edges <= 4 * n_nodes && n_edges < ((int64_t)1 << 24) &&
+                           !(flags & GPDE_FWD_NO_EDGE_PATH) &&
+                           (hidden || (L.mode == 1 && (L.K1P / GP_BK) % 2 == 0 && L.k0 + 1 <= 8)) &&   // H by the fused store kernel
+                           (size_t)(n_edges) * L.K2P + gpde_edge_messages_ws_floats(n_edges, GP_W * GP_W) <=
+                               (size_t)n_nodes * GP_W * L.K2P;
+    if (edge_path) {
+        float* Hbuf = zbuf;                                  // the Z region is free on this path
+        float* ews = zbuf + (hidden ? 0 : (size_t)n_edges * L.K2P);
+        const float* Hrows = hidden;
+        if (!hidden) {
+            ProfScope ps(GPDE_PROF_FUSED, stream);
+            GpdeFusedArgs f{};
+            f.attr = edge_attr; f.rowptr = rowptr; f.perm = perm;
+            f.w1 = pk + L.off_w1; f.w2t = pk + L.off_w2t; f.b2 = pk + L.off_b2;
+            f.w2h = pk + L.off_w2h; f.ucol = pk + L.off_ucol; f.w1h = pk + L.off_w1h; f.fcol = pk + L.off_fcol;
+            f.hout = Hbuf; f.hmax_out = nullptr; f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
+            f.nc0 = 0; f.nc1 = (int)n_nodes; f.e_chunk0 = 0;
+            const int ns = L.K2P / GP_TN;
+            int groups = gpde_num_cus() / ns; if (groups < 1) groups = 1;
+            const int64_t gcap = ((n_edges + GP_TE - 1) / GP_TE + GP_WAVES - 1) / GP_WAVES;
+            if (groups > gcap) groups = (int)gcap;
+            f.n_groups = groups;
+            if (!gpde_fused_f16v3_supported(f)) { gpde_set_error("gpde_nnconv_fwd: per-edge path on an unsupported kernel MLP"); return GPDE_EUNSUPPORTED; }
+            if ((rc = gpde_launch_fused_f16v3(f, stream)) != GPDE_OK) return rc;
+            Hrows = Hbuf;
+        }
+        {
+            ProfScope ps(GPDE_PROF_GEMM3, stream);
+            rc = gpde_launch_edge_messages(Hrows, L.K2P, n_edges, pk + L.off_w3s, pk + L.off_ucol3, x, src, rowptr, n_nodes,
+                                           ews, part, stream);
+            if (rc != GPDE_OK) return rc;
+        }
+        GpdeEpilogueArgs e;
+        e.part = part; e.x = x; e.rowptr = rowptr; e.src = src;
+        e.b3 = pk + L.off_b3; e.root = root; e.bias = bias; e.out = out;
+        e.nc0 = 0; e.nn = (int)n_nodes; e.splits = 1; e.aggr = aggr;
+        e.residual = residual; e.relu_out = relu_out;
+        ProfScope ps2(GPDE_PROF_EPILOGUE, stream);
+        return gpde_launch_epilogue(e, stream);
+    }
+
     const unsigned* xs = nullptr;
     const unsigned* scal = nullptr;
     const FusedChoice fc = choose_fused(L, mode, flags, n_edges, kt);

@@ -45,6 +45,9 @@ struct GpdePackLayout {
     int frontKP[GPDE_MAX_LAYERS + 1];
     size_t off_front_w[GPDE_MAX_LAYERS];
     size_t off_front_b[GPDE_MAX_LAYERS];
+    size_t off_w3s;  // split tile image of W3 [4096][K2P] (rows n = c*64+o, gpde_pack.hip W2 layout) for the per-edge last
+    size_t off_ucol3;// layer of low in-degree graphs (gpde_launch_edge_messages) + its [4096] row un-scales; K2P >= 256 only
+    int has_w3s;
     size_t total_floats;
     int has_b3;
 };
@@ -222,9 +225,15 @@ struct GpdeGemmF16sArgs {
     const float* sc; const float* isc;  // per-row scales (filled by the launcher's pre-pass)
     int n_groups;
     int ksplits; size_t cstride;        // split-K (> 1): partial s at C + s * cstride; M <= 4 * 64 * n per launch group
+    const float* xc_x; const int32_t* xc_src;   // contract epilogue (per-edge last layer): C = P[N/128][M][64], see the kernel
 };
 bool gpde_gemm_f16s_supported(int M, int N, int K, int lda);
 int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a, float* row_scale_ws /* 2 * M floats */, hipStream_t stream);
+// per-edge last layer of the forward for low in-degree graphs (the reference's own association, never forming [E][4096])
+size_t gpde_edge_messages_ws_floats(int64_t n_edges, int n_out);
+int gpde_launch_edge_messages(const float* H, int K2P, int64_t n_edges, const void* w3s, const float* ucol3,
+                              const float* x, const int32_t* src, const int32_t* rowptr, int64_t n_nodes, float* ws,
+                              float* part, hipStream_t stream);
 // weight-gradient form: part[s] = partial sums over K split s of dU^T . H (dU [rows][n_out], H [rows][n_in], fp32,
 // contraction over the rows); ws = gpde_gemm_f16s_tn_ws_floats(...) floats, part = ksplits * n_out * n_in floats
 size_t gpde_gemm_f16s_tn_ws_floats(int rows_max, int n_out, int n_in, int ksplits);

@@ -299,6 +299,41 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
         // ---- un-scale, mask, store --------------------------------------------------------------------------
         // The 64 mask words of an edge block are loaded as ONE batch (rows clamped, no branches) before the first
         // store: a load -> wait -> select -> store chain per element cost 60 us of a 90 us tile.
+        if (a.xc_x) {
+            // Contract epilogue (per-edge last layer of the NNConv forward, gpde_api.hip): row = CSR slot e, column
+            // n = c * 64 + o of W_e = W3 . h_e (nn_conv.py:273-274: `weight = self.nn(pseudo).view(-1, 64, 64)`); this
+            // slice holds c = 2 * slice + {0, 1}.  m_e[o] += x_j[c] * W_e[c][o] (nn_conv.py:275) is formed here, so the
+            // [E][4096] tensor is never written: P[slice][e][o] = partial message over the slice's two input channels.
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float xv0[16], xv1[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(r0 + 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h, a.M - 1);
+                    const float* xp = a.xc_x + (size_t)a.xc_src[row] * GP_W + 2 * slice;
+                    xv0[r] = xp[0];
+                    xv1[r] = xp[1];
+                }
+                auto store_rows = [&](auto full_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const int row = r0 + rr;
+                        const float ie = Es[rr];
+                        const float m0 = ie * (acc[e][0][r] * ucv[0] * xv0[r] + acc[e][2][r] * ucv[2] * xv1[r]);
+                        const float m1 = ie * (acc[e][1][r] * ucv[1] * xv0[r] + acc[e][3][r] * ucv[3] * xv1[r]);
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) acc[e][nb][r] = 0.f;
+                        float* pp = Cout + ((size_t)slice * a.M + row) * GP_W + l31;
+                        if (FULL || row < a.M) { pp[0] = m0; pp[32] = m1; }
+                    }
+                };
+                if (r0 + TE <= a.M) store_rows(std::true_type{});
+                else store_rows(std::false_type{});
+            }
+            continue;
+        }
         const bool has_mask = a.mask != nullptr;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -379,6 +414,58 @@ int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a_in, float* row_scale_ws, 
     if (int rc = once.ensure(gpde_gemm_f16s_nt_kernel)) return rc;
     hipLaunchKernelGGL(gpde_gemm_f16s_nt_kernel, dim3(groups * ns), dim3(256), lds, stream, a);
     GP_LAUNCH_CHECK("gpde_gemm_f16s_nt_kernel");
+    return GPDE_OK;
+}
+
+// ---- per-edge last layer of the forward: messages of the low in-degree graphs ------------------------------------
+namespace {
+// part[node][o] = sum over the in-edges e of the node (CSR order) of sum over the slices s (ascending) of P[s][e][o]:
+// the scatter-add of PyG's propagate (call site nn_conv.py:271) over the partial messages of the contract epilogue.
+// One wave per destination node, lane = output channel; loads in batches of eight, sums in order.
+__global__ __launch_bounds__(256) void k_edge_slices_reduce(const float* __restrict__ P, int ns, int M,
+                                                            const int32_t* __restrict__ rowptr, int n_nodes,
+                                                            float* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_nodes) return;
+    const int r0 = rowptr[i], r1 = rowptr[i + 1];
+    float t = 0.f;
+    for (int e = r0; e < r1; ++e) {
+        const float* pe = P + (size_t)e * GP_W + lane;
+        int s = 0;
+        for (; s + 8 <= ns; s += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = pe[(size_t)(s + q) * M * GP_W];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += v[q];
+        }
+        for (; s < ns; ++s) t += pe[(size_t)s * M * GP_W];
+    }
+    part[(size_t)i * GP_W + lane] = t;
+}
+}  // namespace
+
+size_t gpde_edge_messages_ws_floats(int64_t n_edges, int n_out) {
+    return (size_t)(n_out / GP_TN) * (size_t)n_edges * GP_W + 2 * (size_t)n_edges + 64;
+}
+
+// part[node][64] = sum_{e -> node} x_src(e) . view(W3 . H[e], 64, 64)   (H [E][K2P] fp32 rows in CSR order, w3s / ucol3 =
+// split image of W3 [4096][K2P] from gpde_mlp_pack); ws: gpde_edge_messages_ws_floats(E, 4096) floats
+int gpde_launch_edge_messages(const float* H, int K2P, int64_t n_edges, const void* w3s, const float* ucol3,
+                              const float* x, const int32_t* src, const int32_t* rowptr, int64_t n_nodes, float* ws,
+                              float* part, hipStream_t stream) {
+    const int n_out = GP_W * GP_W, ns = n_out / GP_TN;
+    float* Pm = ws;
+    float* rsc = ws + (size_t)ns * n_edges * GP_W;
+    GpdeGemmF16sArgs g{};
+    g.A = H; g.lda = K2P; g.M = (int)n_edges; g.bsplit = w3s; g.ucol = ucol3; g.mask = nullptr; g.ldmask = 0;
+    g.C = Pm; g.ldc = GP_W; g.K = K2P; g.N = n_out; g.ksplits = 1; g.cstride = 0;
+    g.xc_x = x; g.xc_src = src;
+    if (int rc = gpde_launch_gemm_f16s_nt(g, rsc, stream)) return rc;
+    hipLaunchKernelGGL(k_edge_slices_reduce, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, stream, Pm, ns, (int)n_edges,
+                       rowptr, (int)n_nodes, part);
+    GP_LAUNCH_CHECK("k_edge_slices_reduce");
     return GPDE_OK;
 }
 

@@ -50,6 +50,11 @@ int gpde_pack_layout(int n_layers, const int32_t* dims, GpdePackLayout* L) {
     }
     L->off_w3q = take((size_t)GP_W * L->K2P * GP_W);
     L->off_b3 = take((size_t)GP_W * GP_W);
+    L->has_w3s = L->K2P >= 256;
+    if (L->has_w3s) {
+        L->off_w3s = take((size_t)GP_W * GP_W * L->K2P);
+        L->off_ucol3 = take((size_t)GP_W * GP_W);
+    }
     L->total_floats = off;
     return GPDE_OK;
 }
@@ -282,6 +287,10 @@ extern "C" int gpde_mlp_pack(int n_layers, const int32_t* dims, const float* con
                        W[n_layers - 1], L.k2, L.K2P, P + L.off_w3q);
     hipLaunchKernelGGL(pack_pad_vec_kernel, dim3(blocks(GP_W * GP_W)), dim3(T), 0, stream,
                        b[n_layers - 1], GP_W * GP_W, GP_W * GP_W, P + L.off_b3);
+    if (L.has_w3s) {
+        rc = gpde_pack_split_nk(W[n_layers - 1], GP_W * GP_W, L.k2, GP_W * GP_W, L.K2P, P + L.off_w3s, P + L.off_ucol3, stream);
+        if (rc != GPDE_OK) return rc;
+    }
     GP_LAUNCH_CHECK("gpde_mlp_pack kernels");
     return GPDE_OK;
 }

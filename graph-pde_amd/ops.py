@@ -288,7 +288,8 @@ _PRECISION = {"f32": _lib.GPDE_FWD_DEFAULT, "f16split": _lib.GPDE_FWD_F16SPLIT,
               "f16split_8wave": _lib.GPDE_FWD_F16SPLIT | 2,   # force the 8-wave kernel (small-graph path) everywhere
               "f16split_static": _lib.GPDE_FWD_F16SPLIT | 4,  # v6 with static per-wave ranges instead of the block queue
               "f16split_agg16": _lib.GPDE_FWD_F16SPLIT | 16,  # aggregation on split f16 regardless of size
-              "f16split_agg32": _lib.GPDE_FWD_F16SPLIT | 32}  # aggregation on fp32 MFMA regardless of size
+              "f16split_agg32": _lib.GPDE_FWD_F16SPLIT | 32,  # aggregation on fp32 MFMA regardless of size
+              "f16split_noedge": _lib.GPDE_FWD_F16SPLIT | 64}  # never the per-edge last layer of low in-degree graphs
 DEFAULT_PRECISION = os.environ.get("GPDE_PRECISION", "f16split")
 
 

@@ -52,7 +52,10 @@ enum {
                                     (A/B of the x_j gather locality, parity tests) */
     GPDE_FWD_AGG_F16 = 16,       /* with F16SPLIT: aggregation x_j (x) h_e on split-f16 MFMA too, also for small
                                     graphs (default: from 32768 edges on; three tiny pre-pass launches) */
-    GPDE_FWD_AGG_F32 = 32        /* with F16SPLIT: keep the aggregation on fp32 MFMA (A/B) */
+    GPDE_FWD_AGG_F32 = 32,       /* with F16SPLIT: keep the aggregation on fp32 MFMA (A/B) */
+    GPDE_FWD_NO_EDGE_PATH = 64   /* never take the per-edge last layer of low in-degree graphs (mean in-degree <= 4,
+                                  * >= 4096 edges, k2 >= 256: W_e = W3 . h_e on the split-f16 GEMM, contracted with x_j
+                                  * in its epilogue) - A/B against the re-associated path */
 };
 
 #define GPDE_MAX_LAYERS 8
