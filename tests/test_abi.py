@@ -36,10 +36,12 @@ def test_version_and_pack_queries():
     d = _lib.dims_array([6, 1024, 1024, 4096])
     nbytes = l.gpde_mlp_pack_bytes(3, d)
     # W1|b1 [1024+1][8] + W2 tiles (fp32 and f16-split) 2*1024*1024 + b2, ucol 2*1024 + W3 + B3
-    assert nbytes == 4 * (1025 * 8 + 2 * (1024 * 1024 + 1024) + 1024 * 8 + 16 + 64 * 1024 * 64 + 4096)
+    # + the split image of W3 [4096][1024] and its 4096 row un-scales (per-edge last layer, k2 >= 256)
+    assert nbytes == 4 * (1025 * 8 + 2 * (1024 * 1024 + 1024) + 1024 * 8 + 16 + 64 * 1024 * 64 + 4096 + 4096 * 1024 + 4096)
     # widths that are not tile multiples are padded (1000 -> K1P 1024 / K2P 1024, 500 -> 512)
     d = _lib.dims_array([6, 500, 1000, 4096])
-    assert l.gpde_mlp_pack_bytes(3, d) == 4 * (513 * 8 + 2 * (1024 * 512 + 1024) + 512 * 8 + 16 + 64 * 1024 * 64 + 4096)
+    assert l.gpde_mlp_pack_bytes(3, d) == 4 * (513 * 8 + 2 * (1024 * 512 + 1024) + 512 * 8 + 16 + 64 * 1024 * 64 + 4096
+                                                  + 4096 * 1024 + 4096)
     # last layer must emit width^2 values
     d = _lib.dims_array([6, 32, 100])
     assert l.gpde_mlp_pack_bytes(2, d) == 0
