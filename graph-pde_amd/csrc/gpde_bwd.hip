@@ -86,13 +86,18 @@ __global__ void k_nbr_sum(const float* __restrict__ x, const int32_t* __restrict
 // columns (16-byte loads, a wave reads 1 KiB of a row), the four waves interleave rows, four rows in flight per wave:
 // the bias gradients read every dU once (8 KiB per edge at two 1024-wide layers) and are pure HBM streaming.
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ M, int rows, int cols, int ld, int splits,
-                                                float* __restrict__ P) {
+                                                float* __restrict__ P, unsigned* __restrict__ absmax_bits) {
     __shared__ f32x4 red[4][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int col = blockIdx.x * 256 + lane * 4, split = blockIdx.y;
     const int rps = (rows + splits - 1) / splits;
     const int r_lo = split * rps, r_hi = min(rows, r_lo + rps);
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    unsigned mx[4] = {0u, 0u, 0u, 0u};       // optional: column maxima of |M| (bit patterns) from the same pass
+    auto upd = [&](const f32x4& v) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mx[j] = max(mx[j], __float_as_uint(v[j]) & 0x7fffffffu);
+    };
     if (col < cols) {
         const float* p = M + col;
         int r = r_lo + rg;
@@ -100,8 +105,16 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ M, int
             const f32x4 a = *(const f32x4*)(p + (size_t)r * ld), b = *(const f32x4*)(p + (size_t)(r + 4) * ld);
             const f32x4 c = *(const f32x4*)(p + (size_t)(r + 8) * ld), d = *(const f32x4*)(p + (size_t)(r + 12) * ld);
             s0 += a; s1 += b; s2 += c; s3 += d;
+            if (absmax_bits) { upd(a); upd(b); upd(c); upd(d); }
         }
-        for (; r < r_hi; r += 4) s0 += *(const f32x4*)(p + (size_t)r * ld);
+        for (; r < r_hi; r += 4) {
+            const f32x4 a = *(const f32x4*)(p + (size_t)r * ld);
+            s0 += a;
+            if (absmax_bits) upd(a);
+        }
+        if (absmax_bits)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (mx[j]) atomicMax(absmax_bits + col + j, mx[j]);
     }
     red[rg][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -109,6 +122,85 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ M, int
         const f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
         *(f32x4*)(P + (size_t)split * cols + col) = t;
     }
+}
+
+// First-layer gradients in ONE pass over dU_1:  P[split][k][d] = sum_rows dU[row][k] * H0[row][d]  (d < 8: the gathered
+// edge attributes, zero padded) and P[split][K*8 + k] = sum_rows dU[row][k]  (the bias gradient).  The product is
+// 1024 x 8 wide and E deep: pure streaming of dU (4 KiB per edge); the fp32 GEMM read it at 1.5 TB/s with 8-column
+// tiles and k_colsum read it a second time.  A lane owns four consecutive columns, the four waves interleave rows and
+// are summed in wave order; splits are reduced in order by gpde_reduce_splits_kernel (deterministic).
+__global__ __launch_bounds__(256) void k_dw_first(const float* __restrict__ dU, const float* __restrict__ H0, int ldh, int rows, int K,
+                                                  int splits, float* __restrict__ P) {
+    __shared__ float red[4][64][37];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 256 + lane * 4, split = blockIdx.y;
+    const int rps = (rows + splits - 1) / splits;
+    const int r_lo = split * rps, r_hi = min(rows, r_lo + rps);
+    float acc[4][8], sb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        sb[c] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) acc[c][d] = 0.f;
+    }
+    if (col < K) {
+        const float* p = dU + col;
+        auto step = [&](const f32x4& v, const f32x4& ha, const f32x4& hb) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                sb[c] += v[c];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    acc[c][d] = fmaf(v[c], ha[d], acc[c][d]);
+                    acc[c][4 + d] = fmaf(v[c], hb[d], acc[c][4 + d]);
+                }
+            }
+        };
+        int r = r_lo + rg;
+        for (; r + 12 < r_hi; r += 16) {
+            f32x4 v[4], ha[4], hb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q] = *(const f32x4*)(p + (size_t)(r + 4 * q) * K);
+                ha[q] = *(const f32x4*)(H0 + (size_t)(r + 4 * q) * ldh);
+                hb[q] = *(const f32x4*)(H0 + (size_t)(r + 4 * q) * ldh + 4);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) step(v[q], ha[q], hb[q]);
+        }
+        for (; r < r_hi; r += 4)
+            step(*(const f32x4*)(p + (size_t)r * K), *(const f32x4*)(H0 + (size_t)r * ldh), *(const f32x4*)(H0 + (size_t)r * ldh + 4));
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) red[rg][lane][c * 9 + d] = acc[c][d];
+        red[rg][lane][c * 9 + 8] = sb[c];
+    }
+    __syncthreads();
+    if (rg == 0 && col < K) {
+        float* Pw = P + (size_t)split * K * 9;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int d = 0; d < 9; ++d) {
+                const float t = ((red[0][lane][c * 9 + d] + red[1][lane][c * 9 + d]) + red[2][lane][c * 9 + d]) + red[3][lane][c * 9 + d];
+                if (d < 8) Pw[(size_t)(col + c) * 8 + d] = t;
+                else Pw[(size_t)K * 8 + col + c] = t;
+            }
+        }
+    }
+}
+
+// ordered reduction of k_dw_first's partials into the padded gradient buffers: dW[k][ldw] (first 8 columns), db[k]
+__global__ void k_dw_first_reduce(const float* __restrict__ P, int splits, int K, int ldw, float* __restrict__ dW,
+                                  float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * 9) return;
+    float t = 0.f;
+    for (int s = 0; s < splits; ++s) t += P[(size_t)s * K * 9 + i];
+    if (i < K * 8) dW[(size_t)(i >> 3) * ldw + (i & 7)] += t;
+    else db[i - K * 8] += t;
 }
 
 // ---- per-edge backward through the aggregation -----------------------------------------------------
@@ -656,21 +748,36 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         for (int l = n - 1; l >= 1; --l) {
             const int Kl = P.KP[l], Kin = P.KP[l - 1];
             int rc2;
-            if (l == 2 && f16s_dw2 && rows >= 8192) {
+            if (l == 1 && dims[0] <= 8 && Kin >= 8 && Kin % 4 == 0 && Kl % 4 == 0 && rows >= 1024 && !getenv("GPDE_BWD_DW1_GEMM")) {
+                // dW_1 and db_1 from one pass over dU_1 (k_dw_first; attribute slots beyond k0 are zero columns of H_0)
+                const int cb = (Kl + 255) / 256;
+                int splits = 1; while (splits < 512 && cb * splits < 2048 && rows / (splits * 2) >= 64) splits *= 2;
+                while (splits > 1 && (size_t)splits * Kl * 9 > P.part_floats) splits /= 2;
+                if ((size_t)splits * Kl * 9 <= P.part_floats) {
+                    hipLaunchKernelGGL(k_dw_first, dim3(cb, splits), dim3(T), 0, st, dUc, F(P.off_H[0]), Kin, rows, Kl, splits, F(P.off_part));
+                    hipLaunchKernelGGL(k_dw_first_reduce, dim3(nblk((size_t)Kl * 9)), dim3(T), 0, st, F(P.off_part), splits, Kl, Kin,
+                                       F(P.off_dwp[l]), F(P.off_dbp[l]));
+                    continue;      // l == 1 is the last layer of the loop: nothing below it to back-propagate into
+                }
+            }
+            const bool tn_split = l == 2 && f16s_dw2 && rows >= 8192;
+            unsigned* du_bits = tn_split ? (unsigned*)F(P.off_rowsc) : nullptr;   // free until the dU_1 GEMM below
+            {   // db_l = column sums of dU_l; the same pass collects the column maxima the split dW_2 GEMM scales with
+                const int cb = (Kl + 255) / 256;
+                int splits = 1; while (splits < 512 && cb * splits < 2048 && rows / (splits * 2) >= 64) splits *= 2;
+                while (splits > 1 && (size_t)splits * Kl > P.part_floats) splits /= 2;
+                if (du_bits) GP_HIP_CHECK(hipMemsetAsync(du_bits, 0, (size_t)Kl * 4, st));
+                hipLaunchKernelGGL(k_colsum, dim3(cb, splits), dim3(T), 0, st, dUc, rows, Kl, Kl, splits, F(P.off_part), du_bits);
+                if ((rc2 = gpde_launch_reduce_splits(F(P.off_part), Kl, splits, Kl, F(P.off_dbp[l]), 1, st)) != GPDE_OK) return rc2;
+            }
+            if (tn_split) {
                 // dW_2 += dU_2^T . H_1 on the split-f16 GEMM (contraction over the edges: both operands transposed)
                 if ((rc2 = gpde_launch_gemm_f16s_tn(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, BWD_TN_KSPLITS,
-                                                    F(P.off_tnws), F(P.off_part), st)) != GPDE_OK) return rc2;
+                                                    F(P.off_tnws), F(P.off_part), st, du_bits)) != GPDE_OK) return rc2;
                 if ((rc2 = gpde_launch_reduce_splits(F(P.off_part), (size_t)Kl * Kin, BWD_TN_KSPLITS, (size_t)Kl * Kin,
                                                      F(P.off_dwp[l]), 1, st)) != GPDE_OK) return rc2;
             } else if ((rc2 = gemm_tn_acc(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, F(P.off_dwp[l]), Kin,
                                           F(P.off_part), P.part_floats, 1, st)) != GPDE_OK) return rc2;
-            {
-                const int cb = (Kl + 255) / 256;
-                int splits = 1; while (splits < 512 && cb * splits < 2048 && rows / (splits * 2) >= 64) splits *= 2;
-                while (splits > 1 && (size_t)splits * Kl > P.part_floats) splits /= 2;
-                hipLaunchKernelGGL(k_colsum, dim3(cb, splits), dim3(T), 0, st, dUc, rows, Kl, Kl, splits, F(P.off_part));
-                if ((rc2 = gpde_launch_reduce_splits(F(P.off_part), Kl, splits, Kl, F(P.off_dbp[l]), 1, st)) != GPDE_OK) return rc2;
-            }
             if (l > 1 && l == 2 && f16s_du1 && rows >= 64) {
                 float* dUo = bufs[nb_]; nb_ ^= 1;
                 GpdeGemmF16sArgs g{};
@@ -799,7 +906,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         if ((rc = gemm_tn_acc(x, GP_W, GP_W, grad_out, GP_W, GP_W, N, grad_root, GP_W, F(P.off_part), P.part_floats, 0, st)) != GPDE_OK) return rc;
     if (do_conv && grad_bias) {
         int splits = 1; while (splits < 64 && N / (splits * 2) >= 64) splits *= 2;
-        hipLaunchKernelGGL(k_colsum, dim3(1, splits), dim3(T), 0, st, grad_out, N, GP_W, GP_W, splits, F(P.off_part));
+        hipLaunchKernelGGL(k_colsum, dim3(1, splits), dim3(T), 0, st, grad_out, N, GP_W, GP_W, splits, F(P.off_part), (unsigned*)nullptr);
         if ((rc = gpde_launch_reduce_splits(F(P.off_part), GP_W, splits, GP_W, grad_bias, 0, st)) != GPDE_OK) return rc;
     }
     // ---- un-pad the weight gradients into torch layout -------------------------------------------------------

@@ -238,7 +238,8 @@ int gpde_launch_edge_messages(const float* H, int K2P, int64_t n_edges, const vo
 // contraction over the rows); ws = gpde_gemm_f16s_tn_ws_floats(...) floats, part = ksplits * n_out * n_in floats
 size_t gpde_gemm_f16s_tn_ws_floats(int rows_max, int n_out, int n_in, int ksplits);
 int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H, int ldh, int n_in, int rows,
-                             int ksplits, float* ws, float* part, hipStream_t stream);
+                             int ksplits, float* ws, float* part, hipStream_t stream,
+                             const unsigned* du_absmax_bits = nullptr /* [n_out] column maxima of |dU| as bit patterns */);
 // split tile image of a row-major [n][k] matrix (ld = k): the W2 layout of gpde_mlp_pack for any operand
 int gpde_pack_split_nk(const float* Wnk, int n, int k, int NP, int KP, void* out, float* ucol, hipStream_t stream);
 int gpde_num_cus();

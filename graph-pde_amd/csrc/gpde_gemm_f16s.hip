@@ -522,6 +522,7 @@ __global__ __launch_bounds__(256) void k_transpose_pad(const float* __restrict__
 __global__ __launch_bounds__(256) void k_pack_split_kn(const float* __restrict__ H, int rows, int ld,
                                                        const float* __restrict__ sc, int nkct,
                                                        _Float16* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) _Float16 img[128 * 64];      // the 16 KiB tile, final layout
     const int n = threadIdx.x & 127, m = threadIdx.x >> 7;
     const int kcn = blockIdx.x, slice = blockIdx.y;
     const int e0 = kcn * 32 + 16 * m;
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(256) void k_pack_split_kn(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < 16; ++k) w[k] = (e0 + k < rows) ? H[(size_t)(e0 + k) * ld + slice * 128 + n] * s : 0.f;
     const int sw = (n >> 1) & 7;
-    _Float16* row = out + ((size_t)(slice * (size_t)nkct + kcn) * 128 + n) * 64;
+    _Float16* row = img + n * 64;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
         h8 hi, lo;
@@ -543,6 +544,13 @@ __global__ __launch_bounds__(256) void k_pack_split_kn(const float* __restrict__
         *(h8*)(row + (((m * 2 + hh) ^ sw) << 3)) = hi;
         *(h8*)(row + (((4 + m * 2 + hh) ^ sw) << 3)) = lo;
     }
+    __syncthreads();
+    // the image leaves in full lines: a row's units written straight from the registers were 16-byte pieces 128 bytes
+    // apart (2.5 TB/s for read + write); 256 threads x 4 x 16 bytes, consecutive lanes consecutive units
+    h8* dst = (h8*)(out + ((size_t)slice * (size_t)nkct + kcn) * (128 * 64));
+    const h8* srcl = (const h8*)img;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q * 256 + threadIdx.x] = srcl[q * 256 + threadIdx.x];
 }
 }  // namespace
 
@@ -553,7 +561,7 @@ size_t gpde_gemm_f16s_tn_ws_floats(int rows_max, int n_out, int n_in, int ksplit
 
 // part[s][n_out][n_in] (s < ksplits, stride n_out * n_in) = partial sums of dU^T . H over the K splits
 int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H, int ldh, int n_in, int rows,
-                             int ksplits, float* ws, float* part, hipStream_t stream) {
+                             int ksplits, float* ws, float* part, hipStream_t stream, const unsigned* du_absmax_bits) {
     if (rows < 1 || n_out % 64 != 0 || n_in % GP_TN != 0 || ldu % 4 != 0 || ldh % 4 != 0 || ksplits < 1) {
         gpde_set_error("gpde_gemm_f16s_tn: unsupported shape rows=%d n_out=%d n_in=%d", rows, n_out, n_in);
         return GPDE_EUNSUPPORTED;
@@ -571,7 +579,9 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
     GP_HIP_CHECK(hipMemsetAsync(bits, 0, (size_t)(n_out + n_in) * 4, stream));
     int splits = 1;
     while (splits < 256 && rows / (splits * 2) >= 64) splits *= 2;
-    hipLaunchKernelGGL(k_colabsmax, dim3((n_out + 255) / 256, splits), dim3(256), 0, stream, dU, rows, n_out, ldu, splits, bits);
+    // column maxima of dU: given by the caller when another pass over dU has already collected them (k_colsum)
+    if (du_absmax_bits) GP_HIP_CHECK(hipMemcpyAsync(bits, du_absmax_bits, (size_t)n_out * 4, hipMemcpyDeviceToDevice, stream));
+    else hipLaunchKernelGGL(k_colabsmax, dim3((n_out + 255) / 256, splits), dim3(256), 0, stream, dU, rows, n_out, ldu, splits, bits);
     hipLaunchKernelGGL(k_colabsmax, dim3((n_in + 255) / 256, splits), dim3(256), 0, stream, H, rows, n_in, ldh, splits, bits + n_out);
     hipLaunchKernelGGL(k_scales_from_max, dim3((n_out + 255) / 256), dim3(256), 0, stream, bits, n_out, sca, isca);
     hipLaunchKernelGGL(k_scales_from_max, dim3((n_in + 255) / 256), dim3(256), 0, stream, bits + n_out, n_in, scb, ucolb);
