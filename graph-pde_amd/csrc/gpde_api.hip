@@ -276,7 +276,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
     const bool edge_path = ((flags & GPDE_FWD_F16SPLIT) || (hidden && hidden_absmax)) && !mixed && !kt && L.has_w3s && P.n_chunks == 1 &&
                            n_edges >= 4096 && n_edges <= 4 * n_nodes && n_edges < ((int64_t)1 << 24) &&
                            !(flags & GPDE_FWD_NO_EDGE_PATH) &&
-                           (hidden || (L.mode == 1 && (L.K1P / GP_BK) % 2 == 0 && L.k0 + 1 <= 8)) &&   // H by the fused store kernel
+                           (hidden || (L.mode == 1 && L.k0 + 1 <= 8 && ((L.K1P / GP_BK) % 2 == 0 || L.K1P / GP_BK >= 8))) &&   // H by a fused store kernel
                            (size_t)(n_edges) * L.K2P + gpde_edge_messages_ws_floats(n_edges, GP_W * GP_W) <=
                                (size_t)n_nodes * GP_W * L.K2P;
     if (edge_path) {
@@ -296,8 +296,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
             const int64_t gcap = ((n_edges + GP_TE - 1) / GP_TE + GP_WAVES - 1) / GP_WAVES;
             if (groups > gcap) groups = (int)gcap;
             f.n_groups = groups;
-            if (!gpde_fused_f16v3_supported(f)) { gpde_set_error("gpde_nnconv_fwd: per-edge path on an unsupported kernel MLP"); return GPDE_EUNSUPPORTED; }
-            if ((rc = gpde_launch_fused_f16v3(f, stream)) != GPDE_OK) return rc;
+            if ((rc = gpde_launch_fused_store(f, stream)) != GPDE_OK) return rc;
             Hrows = Hbuf;
         }
         {

@@ -703,7 +703,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         gpde_pack_layout(n, dims, &PL) == GPDE_OK && PL.mode == 1) {
         GpdeFusedArgs probe{};
         probe.k0 = PL.k0; probe.K1P = PL.K1P; probe.K2P = PL.K2P;
-        if (gpde_fused_f16v3_supported(probe)) {
+        if (gpde_fused_store_supported(probe)) {
             if ((rc = gpde_mlp_pack(n, dims, W, b, F(P.off_pack), P.pack_bytes, st)) != GPDE_OK) return rc;
             fast_last = true;
         }
@@ -725,7 +725,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             int groups = gpde_num_cus() / ns; if (groups < 1) groups = 1;
             const int gcap = (rows / GP_TE + GP_WAVES) / GP_WAVES; if (groups > gcap) groups = gcap;
             f.n_groups = groups;
-            int rc2 = gpde_launch_fused_f16v3(f, st);
+            int rc2 = gpde_launch_fused_store(f, st);
             if (rc2 != GPDE_OK) return rc2;
             last = n - 2;
         }
@@ -1055,7 +1055,7 @@ extern "C" int gpde_hidden_fwd(const float* edge_attr, int64_t n_edges, const in
         const int64_t gcap = ((n_edges + GP_TE - 1) / GP_TE + GP_WAVES - 1) / GP_WAVES;
         if (groups > gcap) groups = (int)gcap;
         f.n_groups = groups;
-        if (gpde_fused_f16v3_supported(f)) return gpde_launch_fused_f16v3(f, st);
+        if (gpde_fused_store_supported(f)) return gpde_launch_fused_store(f, st);
     }
     // general path (any layer count, exact fp32): chunks of edges through the dense GEMM
     if (!W || !b || !ws) { gpde_set_error("gpde_hidden_fwd: weights / workspace needed for the general path"); return GPDE_EINVAL; }

@@ -156,6 +156,9 @@ int gpde_launch_zagg(const GpdeFusedArgs& a, hipStream_t stream);
 // 8-wave (two per SIMD) variant with f16 H1 generation (gpde_fused_f16v3.hip)
 bool gpde_fused_f16v3_supported(const GpdeFusedArgs& a);
 int gpde_launch_fused_f16v3(const GpdeFusedArgs& a, hipStream_t stream);
+// store variant (a.hout): gpde_fused_f16v6_kernel<true> where covered, else gpde_fused_f16v3_kernel<true>
+bool gpde_fused_store_supported(GpdeFusedArgs probe);
+int gpde_launch_fused_store(const GpdeFusedArgs& a, hipStream_t stream);
 // one wave per SIMD, 64 x 128 wave tile, 512 registers (gpde_fused_f16v6.hip): the default from 32768 edges on
 bool gpde_fused_f16v6_supported(const GpdeFusedArgs& a);
 int gpde_launch_fused_f16v6(const GpdeFusedArgs& a, hipStream_t stream);

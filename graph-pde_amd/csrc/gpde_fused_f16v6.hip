@@ -25,6 +25,7 @@
 //     issued during chunk c (4 pieces per wave, one address + immediate offsets), retired by the
 //     s_waitcnt vmcnt(0) + s_barrier that ends chunk c; fragments are read half a chunk ahead, in place.
 #include "gpde_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -59,6 +60,10 @@ constexpr int TILE_B = GP_TN * 128;        // 16 KiB per W2 chunk image: [128 co
 constexpr int TE = 64;                     // edges per wave tile (two MFMA row blocks)
 constexpr int NW = 4;                      // waves per workgroup
 
+// WRITE_H: the store variant (gpde_hidden_fwd, the backward's recompute of H_2, the per-edge path of gpde_api.hip): the
+// hidden activations of the tile go to a.hout ([CSR slot][K2P] fp32) instead of into the aggregation; no x_j, no Z, static
+// edge ranges (rows are independent).
+template <bool WRITE_H>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // ONE LDS object (cdna guide, glds trap a)
@@ -138,8 +143,14 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
 
     // constants of the un-scaling: h <= max|b2| + max_k ||W2_k||_1 * max_e B_e (pack-time constants in fcol[8..9])
     float b2v[4], ucv[4];
-    float z_unscale;
-    {
+    float z_unscale = 1.f;
+    if constexpr (WRITE_H) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            b2v[nb] = a.b2[slice * GP_TN + nb * 32 + l31];
+            ucv[nb] = a.ucol[slice * GP_TN + nb * 32 + l31];
+        }
+    } else {
         const float sx = gpde_pow2_to_2p13(__uint_as_float(a.scal[0]));
         const float hb = a.fcol[8] + a.fcol[9] * __uint_as_float(a.scal[1]);
         const float sh = gpde_pow2_to_2p13(hb);
@@ -231,6 +242,7 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[e][nb][r] = 0.f; Z[e][nb][r] = 0.f; }
     int cur = -1;
+    [[maybe_unused]] float hmax_run = 0.f;      // WRITE_H: running maximum of the stored activations (>= 0)
 
     // one plain-store flush per (node, slice): the row base is wave-uniform (scalar address arithmetic), the lane
     // part of the address is ONE tile-invariant offset - 32 per-row vector addresses would be hoisted out of the
@@ -388,7 +400,7 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
             int c1 = c + 2;                                               // (W1|b1) rows read in this chunk: chunk c + 2
             if (c1 >= NKC) c1 -= NKC;
             const char* w1n = w1s + (size_t)(c1 * GP_BK + l31) * 32;
-            if constexpr (PH >= 2 && PH <= 5) x_addr(4 * (PH - 2));      // consumes src_l (loaded two chunks ago)
+            if constexpr (!WRITE_H && PH >= 2 && PH <= 5) x_addr(4 * (PH - 2));      // consumes src_l (loaded two chunks ago)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int cbuf = m;                                       // operand buffer of this step
@@ -439,7 +451,15 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if constexpr (PH == 0) {
+            if constexpr (WRITE_H && PH == 0) {
+                load_perm(e0n);
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            } else if constexpr (WRITE_H && PH == 2) {
+                load_attr();
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else if constexpr (WRITE_H) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if constexpr (PH == 0) {
                 load_perm(e0n);
                 src_l = a.src[min(e0 + lane, e_clamp)];
 #pragma unroll
@@ -473,7 +493,35 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
 
 
         TM_MARK(tm_loop);
-        // ---- per 32-edge half: un-scale + bias, split (ReLU inside), aggregation by destination segment ----
+        if constexpr (WRITE_H) {
+            // ---- un-scale + bias + ReLU, store the tile's hidden activations (128-byte runs along the columns) ----
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float ie[16];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 t4 = *(const f32x4*)&Es[32 * b + 8 * q4 + 4 * h];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ie[4 * q4 + j] = t4[j];
+                }
+                auto store_rows = [&](auto full_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int e = e0 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        float* hp = a.hout + (size_t)(e - a.e_chunk0) * a.K2P + slice * GP_TN + l31;
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) {
+                            const float y = fmaxf(fmaf(acc[b][nb][r], ie[r] * ucv[nb], b2v[nb]), 0.f);
+                            acc[b][nb][r] = 0.f;
+                            if (FULL || e < eb) { hp[nb * 32] = y; hmax_run = fmaxf(hmax_run, y); }
+                        }
+                    }
+                };
+                if (e0 + TE <= eb) store_rows(std::true_type{});
+                else store_rows(std::false_type{});
+            }
+        } else
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             u4 g2hi[4][2], g2lo[4][2];
@@ -562,6 +610,7 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                 if (e_seg < s_end) node = a.dst[e_seg];
             }
         }
+        if constexpr (!WRITE_H)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -577,7 +626,13 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
             e0 += TE;
         }
     }
-    if (cur >= 0) flush(cur);
+    if constexpr (WRITE_H) {
+        if (a.hmax_out) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) hmax_run = fmaxf(hmax_run, __shfl_xor(hmax_run, o));
+            if (lane == 0 && hmax_run > 0.f) atomicMax(a.hmax_out, __float_as_uint(hmax_run));
+        }
+    } else if (cur >= 0) flush(cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef GPDE_V6_TIMING
     if (lane == 0) {
@@ -609,8 +664,8 @@ extern "C" int gpde_debug_v6_timing(unsigned long long* out4, int reset) {
 // 3-Linear kernels with at least 8 k1 chunks (the side loads of a tile are spread over its first seven), attributes +
 // bias slot within one K = 8 group, split-x input (a.xs) present
 bool gpde_fused_f16v6_supported(const GpdeFusedArgs& a) {
-    return a.K1P / GP_BK >= 8 && a.k0 + 1 <= 8 && v6_lds_bytes(a.K1P) <= 160 * 1024 && a.xs != nullptr &&
-           a.kt == 0 && a.hout == nullptr;
+    return a.K1P / GP_BK >= 8 && a.k0 + 1 <= 8 && v6_lds_bytes(a.K1P) <= 160 * 1024 && a.kt == 0 &&
+           (a.hout != nullptr || a.xs != nullptr);
 }
 
 int gpde_launch_fused_f16v6(const GpdeFusedArgs& a, hipStream_t stream) {
@@ -618,8 +673,28 @@ int gpde_launch_fused_f16v6(const GpdeFusedArgs& a, hipStream_t stream) {
     const dim3 grid(a.n_groups * ns), block(256);
     const size_t lds = v6_lds_bytes(a.K1P);
     static GpdeLdsOnce once;
-    if (int rc = once.ensure(gpde_fused_f16v6_kernel)) return rc;
-    hipLaunchKernelGGL(gpde_fused_f16v6_kernel, grid, block, lds, stream, a);
+    if (int rc = once.ensure(gpde_fused_f16v6_kernel<false>, gpde_fused_f16v6_kernel<true>)) return rc;
+    if (a.hout) {
+        GpdeFusedArgs b = a;
+        b.blk = nullptr; b.qn = nullptr; b.qctr = nullptr;             // rows are independent: static ranges
+        hipLaunchKernelGGL(gpde_fused_f16v6_kernel<true>, grid, block, lds, stream, b);
+    } else hipLaunchKernelGGL(gpde_fused_f16v6_kernel<false>, grid, block, lds, stream, a);
     GP_LAUNCH_CHECK("gpde_fused_f16v6_kernel");
     return GPDE_OK;
+}
+
+// The store variant of the fused kernel (H rows instead of the aggregation): the one-wave-per-SIMD kernel where its
+// shape is covered (>= 8 k1 chunks), else the 8-wave kernel.  GPDE_STORE_V3=1 forces the latter (A/B).
+bool gpde_fused_store_supported(GpdeFusedArgs probe) {
+    if (!probe.hout) probe.hout = (float*)(uintptr_t)8;      // "will be present"
+    return gpde_fused_f16v6_supported(probe) || gpde_fused_f16v3_supported(probe);
+}
+
+int gpde_launch_fused_store(const GpdeFusedArgs& f, hipStream_t stream) {
+    if (!f.hout) { gpde_set_error("gpde_launch_fused_store: hout is null"); return GPDE_EINVAL; }
+    static const bool force_v3 = getenv("GPDE_STORE_V3") != nullptr;
+    if (!force_v3 && gpde_fused_f16v6_supported(f)) return gpde_launch_fused_f16v6(f, stream);
+    if (gpde_fused_f16v3_supported(f)) return gpde_launch_fused_f16v3(f, stream);
+    gpde_set_error("fused store kernel: unsupported kernel MLP (K1P = %d, k0 = %d)", f.K1P, f.k0);
+    return GPDE_EUNSUPPORTED;
 }
