@@ -64,10 +64,18 @@ def test_all_gradients_are_bit_reproducible(variant, monkeypatch):
     x, ei, ea, ws_, bs_, root, bias, gout = _case([6, 256, 256, 4096], 200, 9000, 5)
     a = _native(x, ei, ea, ws_, bs_, root, gout)
     b = _native(x, ei, ea, ws_, bs_, root, gout)
-    assert torch.equal(a[0], b[0])
+
+    def same(u, v, name):       # on failure: which gradient, how many entries, where, how far
+        if not torch.equal(u, v):
+            dif = (u != v).nonzero()
+            raise AssertionError(f"{name}: {dif.shape[0]} of {u.numel()} entries differ between two identical calls, first "
+                                 f"{dif[:6].tolist()}, rel-L2 {float((u - v).norm() / u.norm()):.2e}")
+    same(a[0], b[0], "grad_x")
     for l in range(3):
-        assert torch.equal(a[1][l], b[1][l]) and torch.equal(a[2][l], b[2][l])
-    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+        same(a[1][l], b[1][l], f"grad_W{l + 1}")
+        same(a[2][l], b[2][l], f"grad_b{l + 1}")
+    same(a[3], b[3], "grad_root")
+    same(a[4], b[4], "grad_bias")
     # several node / edge chunks: same grad_x bits (chunks are applied in order, one owner per element)
     d = dev()
     csr = ops.build_csr(ei.to(d), x.shape[0])
