@@ -14,7 +14,7 @@ What this does, and nothing else:
     value after the script's own assignment has run (ntrain / ntest / epochs, so that a plumbing run
     takes a minute instead of days).
 The script is looked up under /root/reference (build container) or oracle/_ref (staged there by
-__graft_entry__.build(); git-ignored, travels with the gpurun snapshot).
+scripts/stage_reference.py for a GPU-box run and removed afterwards; git-ignored, travels with the gpurun snapshot).
 """
 from __future__ import annotations
 
@@ -41,7 +41,7 @@ def find_script(name: str) -> str:
             p = os.path.join(root, proj, name)
             if os.path.exists(p):
                 return p
-    raise FileNotFoundError(f"{name}: not under {ROOTS} (run __graft_entry__.build() where /root/reference exists)")
+    raise FileNotFoundError(f"{name}: not under {ROOTS} (run scripts/stage_reference.py where /root/reference exists)")
 
 
 def smooth_field(rng, n, s, sigma):
