@@ -203,6 +203,41 @@ __global__ void k_dw_first_reduce(const float* __restrict__ P, int splits, int K
     else db[i - K * 8] += t;
 }
 
+// First hidden layer as a streaming kernel: H1[row][k] = relu(b[k] + sum_{d < 8} W[k][d] * H0[row][d]) (DenseNet.forward's
+// first Linear + ReLU, utilities.py:223-227, on the gathered attributes; slots >= k0 are zero columns of both operands).
+// 8 FLOP per 4 bytes written: a GEMM shape only in name - the fp32 MFMA GEMM wrote it at 1.8 TB/s.  A lane owns four
+// consecutive columns (weights in registers, 16-byte stores: a wave writes 1 KiB of a row), the waves interleave rows.
+__global__ __launch_bounds__(256) void k_first_layer(const float* __restrict__ H0, int ld0, const float* __restrict__ Wp, int ldw,
+                                                     const float* __restrict__ bp, int rows, int K, float* __restrict__ H1) {
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 256 + lane * 4;
+    if (col >= K) return;
+    float w[4][8], b[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        b[c] = bp[col + c];
+        const f32x4 w0 = *(const f32x4*)(Wp + (size_t)(col + c) * ldw), w1 = *(const f32x4*)(Wp + (size_t)(col + c) * ldw + 4);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { w[c][d] = w0[d]; w[c][4 + d] = w1[d]; }
+    }
+    const int rps = (rows + gridDim.y - 1) / gridDim.y;
+    const int r_lo = blockIdx.y * rps, r_hi = min(rows, r_lo + rps);
+    for (int r = r_lo + rg; r < r_hi; r += 4) {
+        const f32x4 a0 = *(const f32x4*)(H0 + (size_t)r * ld0), a1 = *(const f32x4*)(H0 + (size_t)r * ld0 + 4);
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float t = b[c];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) t = fmaf(w[c][d], a0[d], t);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) t = fmaf(w[c][4 + d], a1[d], t);
+            o[c] = fmaxf(t, 0.f);
+        }
+        *(f32x4*)(H1 + (size_t)r * K + col) = o;
+    }
+}
+
 // ---- per-edge backward through the aggregation -----------------------------------------------------
 //   dU[e][n]  = (sum_c x_j[c] dZ_i[c][n]) * (H[e][n] > 0)
 //   dx[j][c] += sum_n dZ_i[c][n] H[e][n] + dS_i[c]                       (fp32 atomics)
@@ -730,6 +765,13 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             last = n - 2;
         }
         for (int l = 1; l <= last; ++l) {
+            if (l == 1 && dims[0] <= 8 && P.KP[0] >= 8 && P.KP[1] % 4 == 0 && rows >= 1024 && !getenv("GPDE_BWD_H1_GEMM")) {
+                const int cb = (P.KP[1] + 255) / 256;
+                int rb = rows / 64; if (rb > 4096 / cb) rb = 4096 / cb; if (rb < 1) rb = 1;
+                hipLaunchKernelGGL(k_first_layer, dim3(cb, rb), dim3(T), 0, st, F(P.off_H[0]), P.KP[0], F(P.off_wp[1]), P.KP[0],
+                                   F(P.off_bp[1]), rows, P.KP[1], F(P.off_H[1]));
+                continue;
+            }
             GpdeGemmArgs g = gemm0();
             g.A = F(P.off_H[l - 1]); g.lda = P.KP[l - 1]; g.B = F(P.off_wp[l]); g.ldb = P.KP[l - 1];
             g.C = F(P.off_H[l]); g.ldc = P.KP[l]; g.M = rows; g.N = P.KP[l]; g.K = P.KP[l - 1];
@@ -751,7 +793,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             if (l == 1 && dims[0] <= 8 && Kin >= 8 && Kin % 4 == 0 && Kl % 4 == 0 && rows >= 1024 && !getenv("GPDE_BWD_DW1_GEMM")) {
                 // dW_1 and db_1 from one pass over dU_1 (k_dw_first; attribute slots beyond k0 are zero columns of H_0)
                 const int cb = (Kl + 255) / 256;
-                int splits = 1; while (splits < 512 && cb * splits < 2048 && rows / (splits * 2) >= 64) splits *= 2;
+                int splits = 1; while (splits < 256 && cb * splits < 1024 && rows / (splits * 2) >= 64) splits *= 2;
                 while (splits > 1 && (size_t)splits * Kl * 9 > P.part_floats) splits /= 2;
                 if ((size_t)splits * Kl * 9 <= P.part_floats) {
                     hipLaunchKernelGGL(k_dw_first, dim3(cb, splits), dim3(T), 0, st, dUc, F(P.off_H[0]), Kin, rows, Kl, splits, F(P.off_part));
