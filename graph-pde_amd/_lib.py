@@ -16,6 +16,8 @@ LIB_PATH = os.environ.get("GPDE_LIB", os.path.join(_PKG, "libgpde.so"))   # GPDE
 GPDE_OK = 0
 GPDE_AGGR_ADD, GPDE_AGGR_MEAN = 0, 1
 GPDE_FWD_DEFAULT, GPDE_FWD_F16SPLIT = 0, 1
+# the other forward flags of include/gpde.h (A/B switches; tests/test_abi.py checks these values against the header)
+GPDE_FWD_F16SPLIT_8WAVE, GPDE_FWD_STATIC_RANGES, GPDE_FWD_AGG_F16, GPDE_FWD_AGG_F32, GPDE_FWD_NO_EDGE_PATH = 2, 4, 16, 32, 64
 GPDE_WIDTH = 64
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)

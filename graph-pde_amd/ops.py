@@ -285,11 +285,11 @@ _AGGR = {"add": _lib.GPDE_AGGR_ADD, "mean": _lib.GPDE_AGGR_MEAN}
 # arithmetic of the hidden k1 x k2 layer: "f32" = fp32 MFMA (exact fmaf chains); "f16split" = f16
 # MFMA on two-term split operands with fp32 accumulation (include/gpde.h GPDE_FWD_F16SPLIT)
 _PRECISION = {"f32": _lib.GPDE_FWD_DEFAULT, "f16split": _lib.GPDE_FWD_F16SPLIT,
-              "f16split_8wave": _lib.GPDE_FWD_F16SPLIT | 2,   # force the 8-wave kernel (small-graph path) everywhere
-              "f16split_static": _lib.GPDE_FWD_F16SPLIT | 4,  # v6 with static per-wave ranges instead of the block queue
-              "f16split_agg16": _lib.GPDE_FWD_F16SPLIT | 16,  # aggregation on split f16 regardless of size
-              "f16split_agg32": _lib.GPDE_FWD_F16SPLIT | 32,  # aggregation on fp32 MFMA regardless of size
-              "f16split_noedge": _lib.GPDE_FWD_F16SPLIT | 64}  # never the per-edge last layer of low in-degree graphs
+              "f16split_8wave": _lib.GPDE_FWD_F16SPLIT | _lib.GPDE_FWD_F16SPLIT_8WAVE,   # force the 8-wave kernel (small-graph path) everywhere
+              "f16split_static": _lib.GPDE_FWD_F16SPLIT | _lib.GPDE_FWD_STATIC_RANGES,  # v6 with static per-wave ranges instead of the block queue
+              "f16split_agg16": _lib.GPDE_FWD_F16SPLIT | _lib.GPDE_FWD_AGG_F16,  # aggregation on split f16 regardless of size
+              "f16split_agg32": _lib.GPDE_FWD_F16SPLIT | _lib.GPDE_FWD_AGG_F32,  # aggregation on fp32 MFMA regardless of size
+              "f16split_noedge": _lib.GPDE_FWD_F16SPLIT | _lib.GPDE_FWD_NO_EDGE_PATH}  # never the per-edge last layer of low in-degree graphs
 DEFAULT_PRECISION = os.environ.get("GPDE_PRECISION", "f16split")
 
 

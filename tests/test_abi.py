@@ -111,3 +111,18 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgpde.so")
     with pytest.raises(_lib.GpdeError):
         _lib.lib()
+
+
+def test_forward_flags_of_the_binding_match_the_header():
+    """The A/B flags the host layer ORs into `flags` (ops._PRECISION) are the enum values of include/gpde.h."""
+    import os
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "gpde.h")).read()
+    vals = {m.group(1): int(m.group(2)) for m in re.finditer(r"(GPDE_FWD_\w+)\s*=\s*(\d+)", hdr)}
+    for name in ("GPDE_FWD_DEFAULT", "GPDE_FWD_F16SPLIT", "GPDE_FWD_F16SPLIT_8WAVE", "GPDE_FWD_STATIC_RANGES",
+                 "GPDE_FWD_AGG_F16", "GPDE_FWD_AGG_F32", "GPDE_FWD_NO_EDGE_PATH"):
+        assert vals[name] == getattr(_lib, name), name
+    from graph_pde_amd import ops
+    assert ops._PRECISION["f32"] == 0 and ops._PRECISION["f16split"] == vals["GPDE_FWD_F16SPLIT"]
+    assert ops._PRECISION["f16split_noedge"] == vals["GPDE_FWD_F16SPLIT"] | vals["GPDE_FWD_NO_EDGE_PATH"]
+    assert len(set(ops._PRECISION.values())) == len(ops._PRECISION)
