@@ -786,7 +786,12 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     auto mlp_backward = [&](const float* dUlast, int rows) -> int {
         const float* dUc = dUlast;
         float* bufs[2] = {F(P.off_dU[0]), F(P.off_dU[1])};
-        int nb_ = 0;
+        // The layer GEMMs below read every row of dU_l from all their column-slice workgroups and write dU_{l-1}
+        // rows of the same indices: the output must never be the buffer the input lives in.  In the FULL phase
+        // dU_last IS bufs[0] (the per-edge kernel wrote it there), so the first output goes to bufs[1].  (Rounds 1-2
+        // started at bufs[0]: a workgroup that finished its tile early overwrote rows a sibling slice was still
+        // reading - the intermittent 1e-3 error in grad_W1)
+        int nb_ = dUlast == bufs[0] ? 1 : 0;
         for (int l = n - 1; l >= 1; --l) {
             const int Kl = P.KP[l], Kin = P.KP[l - 1];
             int rc2;

@@ -20,6 +20,14 @@ constexpr int GP_BS_STRIDE = 36;   // LDS row stride (floats) of a [128][32] W2 
 
 static inline int gp_round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// byte ranges [a, a + na) and [b, b + nb) intersect (the GEMM launchers refuse an output that overlaps an operand:
+// their column-slice workgroups read the same operand rows at different times)
+static inline bool gp_overlap(const void* a, size_t na, const void* b, size_t nb) {
+    if (!a || !b || !na || !nb) return false;
+    const uintptr_t a0 = (uintptr_t)a, b0 = (uintptr_t)b;
+    return a0 < b0 + nb && b0 < a0 + na;
+}
+
 // ---- packed MLP layout (all offsets in floats from the start of `packed`) --------------------
 //  mode 0: n_layers == 2            H = relu(L1(attr))                      (K2 = k1)
 //  mode 1: n_layers == 3            H = relu(L2(relu(L1(attr))))            (K1 = k1, K2 = k2)
@@ -213,7 +221,19 @@ struct GpdeGemmArgs {
     int accumulate;                 // C += result (after bias/relu/mask)
     int batches; size_t strideA, strideB, strideC;
     int splits; size_t strideSplit; // split-K: partial s written at C + s*strideSplit
+    int skew_us;                    // test hook (GPDE_DEBUG_SKEW_US): odd column tiles start this many us late
 };
+// Test hook shared by the GEMM kernels: with GPDE_DEBUG_SKEW_US=<n> in the environment, workgroups of odd column
+// slices spin n microseconds before their first load.  Sibling slices read the same operand rows; a buffer plan that
+// lets one slice's output land in rows another slice still has to read then fails deterministically instead of once
+// in a dozen runs (tests/test_gpu_repeat.py).  0 / unset: one scalar compare per workgroup.
+int gpde_debug_skew_us();
+__device__ __forceinline__ void gp_debug_skew(int us) {
+    if (us > 0) {
+        const unsigned long long t0 = wall_clock64();                // 100 MHz
+        while (wall_clock64() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(64);
+    }
+}
 int gpde_launch_gemm(const GpdeGemmArgs& g, hipStream_t stream);
 int gpde_launch_reduce_splits(const float* P, size_t n, int splits, size_t stride, float* C,
                               int accumulate, hipStream_t stream);
@@ -229,6 +249,7 @@ struct GpdeGemmF16sArgs {
     int n_groups;
     int ksplits; size_t cstride;        // split-K (> 1): partial s at C + s * cstride; M <= 4 * 64 * n per launch group
     const float* xc_x; const int32_t* xc_src;   // contract epilogue (per-edge last layer): C = P[N/128][M][64], see the kernel
+    int skew_us;                        // test hook (GPDE_DEBUG_SKEW_US): odd column slices start this many us late
 };
 bool gpde_gemm_f16s_supported(int M, int N, int K, int lda);
 int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a, float* row_scale_ws /* 2 * M floats */, hipStream_t stream);

@@ -13,6 +13,7 @@
 // permutation k = 8q + 4h + t (both operands use the same k for the same MFMA step); an operand
 // with K as the slow index is stored [k][132] and read per k with lanes along the row index.
 #include "gpde_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -37,6 +38,7 @@ __global__ __launch_bounds__(256) void gpde_gemm_kernel(GpdeGemmArgs g) {
     const int batch = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
     const float* A = g.A + (size_t)batch * g.strideA;
     const float* B = g.B + (size_t)batch * g.strideB;
+    if (blockIdx.y & 1) gp_debug_skew(g.skew_us);
     // K range of this split, in chunks of 32
     const int nchunks = (g.K + GK - 1) / GK;
     const int cps = (nchunks + g.splits - 1) / g.splits;
@@ -183,7 +185,27 @@ __global__ void gpde_reduce_splits_kernel(const float* __restrict__ P, size_t n,
 
 }  // namespace
 
-int gpde_launch_gemm(const GpdeGemmArgs& g, hipStream_t stream) {
+int gpde_debug_skew_us() {
+    const char* e = getenv("GPDE_DEBUG_SKEW_US");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? (v < 100000 ? v : 100000) : 0;
+}
+
+int gpde_launch_gemm(const GpdeGemmArgs& g_in, hipStream_t stream) {
+    GpdeGemmArgs g = g_in;
+    g.skew_us = gpde_debug_skew_us();
+    {   // C must not overlap an operand or the mask: several workgroups read the same operand rows at different times
+        const size_t nb = (size_t)(g.batches > 0 ? g.batches - 1 : 0);
+        const size_t ca = ((size_t)(g.splits > 1 ? g.splits - 1 : 0) * g.strideSplit + nb * g.strideC + (size_t)(g.M - 1) * g.ldc + g.N) * 4;
+        const size_t aa = (nb * g.strideA + (g.a_kcontig ? (size_t)(g.M - 1) * g.lda + g.K : (size_t)(g.K - 1) * g.lda + g.M)) * 4;
+        const size_t ba = (nb * g.strideB + (g.b_kcontig ? (size_t)(g.N - 1) * g.ldb + g.K : (size_t)(g.K - 1) * g.ldb + g.N)) * 4;
+        const size_t ma = g.mask ? ((size_t)(g.M - 1) * g.ldmask + g.N) * 4 : 0;
+        if (g.M > 0 && g.N > 0 && g.K > 0 &&
+            (gp_overlap(g.C, ca, g.A, aa) || gp_overlap(g.C, ca, g.B, ba) || gp_overlap(g.C, ca, g.mask, ma))) {
+            gpde_set_error("gpde_gemm: output overlaps an operand (internal buffer plan error)");
+            return GPDE_EINVAL;
+        }
+    }
     const dim3 grid((g.M + GT - 1) / GT, (g.N + GT - 1) / GT, g.batches * g.splits), block(256);
     if (g.a_kcontig && g.b_kcontig) hipLaunchKernelGGL((gpde_gemm_kernel<true, true>), grid, block, 0, stream, g);
     else if (g.a_kcontig && !g.b_kcontig) hipLaunchKernelGGL((gpde_gemm_kernel<true, false>), grid, block, 0, stream, g);

@@ -90,6 +90,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
         slice = blockIdx.x % ns;
         group = blockIdx.x / ns;
     }
+    if (slice & 1) gp_debug_skew(a.skew_us);
     const int NKCT = a.K / GP_BK;                   // chunks of the whole K (the B image's row of tiles)
     const int ntile = (a.M + TE - 1) / TE;
     // split-K (ksplits > 1: the weight-gradient use, few rows and a very long K): group = (K split, row quad), one
@@ -386,9 +387,21 @@ bool gpde_gemm_f16s_supported(int M, int N, int K, int lda) {
 int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a_in, float* row_scale_ws, hipStream_t stream) {
     GpdeGemmF16sArgs a = a_in;
     if (a.ksplits < 1) a.ksplits = 1;
+    a.skew_us = gpde_debug_skew_us();
     if (!gpde_gemm_f16s_supported(a.M, a.N, a.K, a.lda) || a.K % (64 * a.ksplits) != 0 || a.K / a.ksplits < 256) {
         gpde_set_error("gpde_gemm_f16s_nt: unsupported shape M=%d N=%d K=%d ksplits=%d", a.M, a.N, a.K, a.ksplits);
         return GPDE_EUNSUPPORTED;
+    }
+    {   // C must not overlap A or the mask: the N / 128 column-slice workgroups of a row tile read the same A rows at
+        // different times (rounds 1-2 ran dU_1 in place over dU_2: the intermittent wrong grad_W1)
+        const size_t ca = a.xc_x ? (size_t)(a.N / GP_TN) * a.M * GP_W * 4
+                                 : ((size_t)(a.ksplits - 1) * a.cstride + (size_t)(a.M - 1) * a.ldc + a.N) * 4;
+        const size_t aa = ((size_t)(a.M - 1) * a.lda + a.K) * 4;
+        const size_t ma = a.mask ? ((size_t)(a.M - 1) * a.ldmask + a.N) * 4 : 0;
+        if (gp_overlap(a.C, ca, a.A, aa) || gp_overlap(a.C, ca, a.mask, ma)) {
+            gpde_set_error("gpde_gemm_f16s_nt: output overlaps an operand (internal buffer plan error)");
+            return GPDE_EINVAL;
+        }
     }
     if (row_scale_ws) {                      // per-row scales from one read of A; otherwise the caller filled sc / isc
         float* sc = row_scale_ws;

@@ -73,3 +73,90 @@ def test_hidden_activation_build_and_cached_forward_are_reproducible_under_memor
             _repeat(lambda: conv(x, ei, ea), d, 24)        # the direct path (block-queue kernel)
     finally:
         hidden_cache.MODE = mode0
+
+
+# ---- backward (row f1) ---------------------------------------------------------------------------------------------
+# Round 2 saw grad_W1 differ by 1e-3 between two identical calls once in ~15 full-tier runs.  Root cause:
+# the dU_1 GEMM wrote its output into the buffer its input dU_2 lived in; the column-slice workgroups of a row tile read
+# the same dU_2 rows, and a slice that finished early overwrote rows a sibling still had to read.  Two kinds of test:
+# repeats under memory pressure (the generic net), and the workgroup-skew hook GPDE_DEBUG_SKEW_US, which delays odd
+# column slices of every GEMM launch and makes exactly that kind of race deterministic.
+def _flat(o):
+    return [o[0]] + list(o[1]) + list(o[2]) + [o[3], o[4]]
+
+
+_GRAD_NAMES = ["grad_x", "grad_W1", "grad_W2", "grad_W3", "grad_b1", "grad_b2", "grad_b3", "grad_root", "grad_bias"]
+
+
+def _bwd_case_random(dev):
+    from tests.test_gpu_bwd import _case
+    x, ei, ea, ws_, bs_, root, bias, gout = _case([6, 256, 256, 4096], 200, 9000, 5)
+    csr = ops.build_csr(ei.to(dev), x.shape[0])
+    return (x.to(dev), csr, ea.to(dev), [w.to(dev) for w in ws_], [b.to(dev) for b in bs_], root.to(dev), gout.to(dev))
+
+
+def _bwd_case_lattice(dev, s=41):
+    from tests.test_host_logic import DenseNet
+    torch.manual_seed(41)
+    ei = synth.lattice_radius_graph(s, 0.10, dev)
+    pos = synth.lattice_positions(s, dev)
+    ea = synth.darcy_edge_attr(ei, pos, synth.darcy_coefficient(s, 3).to(dev))
+    n = s * s
+    lin = ops.mlp_linears(DenseNet([6, 1024, 1024, 4096], torch.nn.ReLU))
+    ws_ = [l.weight.detach().to(dev) for l in lin]
+    bs_ = [l.bias.detach().to(dev) for l in lin]
+    root = torch.empty(64, 64).uniform_(-0.125, 0.125).to(dev)
+    csr = ops.build_csr(ei, n)
+    return (torch.randn(n, 64, device=dev), csr, ea, ws_, bs_, root, torch.randn(n, 64, device=dev))
+
+
+def _bwd(case):
+    x, csr, ea, ws_, bs_, root, gout = case
+    out = ops.nnconv_backward_raw(x, csr, ea, ws_, bs_, root, "mean", gout)
+    torch.cuda.synchronize()
+    return _flat(out)
+
+
+def _assert_same(ref, cur, what):
+    for nm, a, b in zip(_GRAD_NAMES, ref, cur):
+        if not torch.equal(a, b):
+            dif = (a != b).nonzero()
+            raise AssertionError(f"{what}: {nm}: {dif.shape[0]} of {a.numel()} entries differ, first {dif[:6].tolist()}, "
+                                 f"rel-L2 {float((a - b).norm() / a.norm()):.2e}")
+
+
+@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("which", ["random_256", "lattice41_1024"])
+def test_backward_is_reproducible_under_memory_pressure(which, variant, monkeypatch):
+    """gpde_nnconv_bwd_ordered, both per-edge kernels, 200 repeats with 1 GiB fills (constants incl. NaN / -3e38, and
+    random data) between calls: every gradient identical to the first call, bit for bit."""
+    d = torch.device("cuda:0")
+    monkeypatch.setenv("GPDE_EDGE_BWD", variant)
+    case = _bwd_case_random(d) if which == "random_256" else _bwd_case_lattice(d)
+    ref = [t.clone() for t in _bwd(case)]
+    for it in range(200):
+        if it % 2:
+            t = torch.randn(256 << 20, device=d) * (10.0 ** ((it % 7) - 3))
+            del t
+        else:
+            _poison(d, FILLS[(it // 2) % len(FILLS)])
+        _assert_same(ref, _bwd(case), f"run {it}")
+
+
+@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("which", ["random_256", "lattice41_1024"])
+@pytest.mark.parametrize("f32", [False, True])
+def test_backward_does_not_depend_on_workgroup_timing(which, variant, f32, monkeypatch):
+    """Odd column slices of every GEMM launch start 150 us late (GPDE_DEBUG_SKEW_US): sibling workgroups that read the
+    same operand rows now run far apart in time.  Any output that aliases an operand - the round-2 defect - turns
+    into O(1) errors here; a correct buffer plan gives the bits of the unskewed run."""
+    d = torch.device("cuda:0")
+    monkeypatch.setenv("GPDE_EDGE_BWD", variant)
+    if f32:
+        monkeypatch.setenv("GPDE_BWD_GEMM_F32", "1")
+    case = _bwd_case_random(d) if which == "random_256" else _bwd_case_lattice(d, 31)
+    monkeypatch.delenv("GPDE_DEBUG_SKEW_US", raising=False)
+    ref = [t.clone() for t in _bwd(case)]
+    monkeypatch.setenv("GPDE_DEBUG_SKEW_US", "150")
+    for it in range(3):
+        _assert_same(ref, _bwd(case), f"skewed run {it}")
