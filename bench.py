@@ -246,9 +246,10 @@ def train_mode(args, rank, world, dev, use_dist, barrier):
         "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 (hidden layer + aggregation: 2-term f16-split MFMA, f32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": f"one training step per GPU and step: KernelNN stack (fc1, {args.depth} x relu(NNConv_old), fc2) on "
-                               f"the {s}x{s} r={r} radius graph (N={n}, E={e}), kernel MLP [6,{args.kernel_width},"
-                               f"{args.kernel_width},4096], L1 loss, Adam(1e-4, wd 5e-4); one sample per GPU per step",
+        "rccl_ranks": world if use_dist else 0,
+        "config": {"workload": f"one training step per GPU and step: KernelNN stack fc1 + {args.depth} x relu(NNConv_old) + fc2 on "
+                               f"the {s}x{s} r={r} radius graph N={n} E={e}; kernel MLP 6-{args.kernel_width}-"
+                               f"{args.kernel_width}-4096; L1 loss; Adam lr 1e-4 wd 5e-4; one sample per GPU per step",
                    "graph": args.config, "depth": args.depth, "hidden_cache": hidden_cache.MODE,
                    "parallelism": f"dp{world} (independent samples, one flat gradient all-reduce)"},
         "M_edge_applications_per_s": round(world * args.depth * e / (ms * 1e-3) / 1e6, 2),
@@ -283,10 +284,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            log(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}`")
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # started as plain `python bench.py --gpus N`: re-exec under torch.distributed.run, one rank per GPU over RCCL
+        # (the same command line the driver's launcher uses)
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            log(f"--gpus {args.gpus}: only {have} GPU(s) visible on this node")
             sys.exit(2)
+        import socket
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    if args.gpus != world:
+        log(f"--gpus {args.gpus} but WORLD_SIZE={world}: the two must agree")
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -574,9 +585,9 @@ def main():
         "dtype": "f32" if precision == "f32" else "f32 (hidden layer + aggregation: 2-term f16-split MFMA, f32 accumulate)",
         "precision": precision, "data": "synthetic",
         "median_step_ms": round(med, 3), "value_at_median": round(world * e / med / 1e3, 3),
-        "config": {"workload": f"GKN Darcy-2D {s}x{s} lattice radius graph r={r} "
-                               f"(N={n}, E={e} per sample), NNConv_old fwd width=64, kernel MLP "
-                               f"[6,{kw},{kw},4096], aggr=mean, root+bias; one sample per GPU",
+        "rccl_ranks": world if use_dist else 0,
+        "config": {"workload": f"GKN Darcy-2D {s}x{s} lattice radius graph r={r} N={n} E={e} per sample; NNConv_old fwd "
+                               f"width=64; kernel MLP 6-{kw}-{kw}-4096; aggr=mean root+bias; one sample per GPU",
                    "graph": args.config, "edges_per_sample": e, "nodes_per_sample": n,
                    "plan": plan},
         "rel_l2_sample": rel,

@@ -21,7 +21,8 @@ class NNConvFunction(torch.autograd.Function):
         weights = list(params[:n_layers])
         biases = list(params[n_layers:])
         ops._require_cuda(x, "x")
-        csr = ops.csr_for(edge_index, x.size(0))
+        # a prebuilt ops.Csr (message() / update(): one-off graphs that must not enter the CSR cache) or edge_index
+        csr = edge_index if isinstance(edge_index, ops.Csr) else ops.csr_for(edge_index, x.size(0))
         pm = ops.pack_mlp(weights, biases)
         out = ops.nnconv_forward_raw(x.detach(), csr, edge_attr.detach(), pm, root, bias, aggr)
         ctx.csr, ctx.aggr, ctx.n_layers = csr, aggr, n_layers

@@ -41,10 +41,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+LAST_REPORT = {"compiled": [], "reused": [], "linked": False}      # what the last build() call did
+
+
 def _compile(src, force, extra):
     obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
-    if force or _stale(obj, [path] + _deps()):
+    if not (force or _stale(obj, [path] + _deps())):
+        LAST_REPORT["reused"].append(src)
+    else:
+        LAST_REPORT["compiled"].append(src)
         cmd = [HIPCC] + FLAGS + list(extra) + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -56,6 +62,7 @@ def _compile(src, force, extra):
 
 def build(force: bool = False, extra_flags=()) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
+    LAST_REPORT.update(compiled=[], reused=[], linked=False)
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, extra_flags), SOURCES))
     if force or _stale(LIB, objs):
@@ -63,6 +70,7 @@ def build(force: bool = False, extra_flags=()) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        LAST_REPORT["linked"] = True
     return LIB
 
 

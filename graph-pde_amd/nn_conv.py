@@ -23,6 +23,7 @@ from torch.nn import Parameter
 
 from . import hidden_cache, ops
 from .autograd import NNConvFunction, NNConvHiddenFunction
+from .message_passing import MessagePassing
 
 
 def _reset(nn):
@@ -50,23 +51,24 @@ def _uniform(size, tensor):
             tensor.uniform_(-bound, bound)
 
 
-class NNConv_old(torch.nn.Module):
+class NNConv_old(MessagePassing):
     r"""x'_i = Theta x_i + aggr_{j in N(i)} x_j . h_Theta(e_ij)   with h_Theta a kernel MLP emitting
-    in_channels*out_channels values per edge (nn_conv.py:197-232)."""
+    in_channels*out_channels values per edge (nn_conv.py:197-232).  Derives `MessagePassing` like the reference
+    (nn_conv.py:197, 242) and overrides `propagate` with the fused HIP operator."""
 
     def __init__(self, in_channels, out_channels, nn, aggr="add", root_weight=True, bias=True,
                  **kwargs):
-        super().__init__()
         flow = kwargs.pop("flow", "source_to_target")
         if flow != "source_to_target":
             raise NotImplementedError("only flow='source_to_target' (the reference default) is built")
         if kwargs:
             raise TypeError(f"unexpected arguments {sorted(kwargs)}")
+        if aggr not in ("add", "mean", "max"):
+            raise ValueError(f"aggr must be 'add', 'mean' or 'max' (nn_conv.py:222-224), got {aggr!r}")
+        super().__init__(aggr=aggr, flow=flow)                     # nn_conv.py:242
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.nn = nn
-        self.aggr = aggr
-        self.flow = flow
         if root_weight:
             self.root = Parameter(torch.Tensor(in_channels, out_channels))
         else:
@@ -76,6 +78,14 @@ class NNConv_old(torch.nn.Module):
         else:
             self.register_parameter("bias", None)
         self.reset_parameters()
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """State dicts written by newer PyG releases store the root weight as `lin.weight [out, in]` (a bias-free
+        Linear) instead of `root [in, out]`: accepted and transposed."""
+        k_new, k_old = prefix + "lin.weight", prefix + "root"
+        if k_new in state_dict and k_old not in state_dict:
+            state_dict[k_old] = state_dict.pop(k_new).t().contiguous()
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def reset_parameters(self):                       # nn_conv.py:261-265
         _reset(self.nn)
@@ -101,23 +111,42 @@ class NNConv_old(torch.nn.Module):
             # the default f16-split kernel; anything else takes the tensor the reference would build.
             lin = ops.mlp_linears(self.nn)
             needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-            if not needs_grad and len(lin) == 3 and ops.DEFAULT_PRECISION == "f16split" and \
+            if not needs_grad and self.aggr != "max" and len(lin) == 3 and ops.DEFAULT_PRECISION == "f16split" and \
                     self.in_channels == ops.WIDTH and self.out_channels == ops.WIDTH:
                 csr = ops.csr_for(edge_index, x.size(0))
                 pm = ops.pack_mlp([l.weight for l in lin], [l.bias for l in lin])
                 return ops.nnconv_forward_nodeattr_raw(x, csr, edge_attr, pm, self.root, self.bias, self.aggr)
             edge_attr = edge_attr.materialize(edge_index)
         pseudo = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
+        return self.propagate(edge_index, x=x, pseudo=pseudo)                            # nn_conv.py:271
+
+    def propagate(self, edge_index, size=None, **kwargs):
+        """`propagate(edge_index, x=x, pseudo=pseudo)` (the reference's call, nn_conv.py:271): gather x_j, `message`,
+        aggregate over `edge_index[1]`, `update` - as ONE native operator (gpde_nnconv_fwd) instead of PyG's
+        index_select / message / scatter / update chain.  `size` may only restate the node count."""
+        if set(kwargs) != {"x", "pseudo"}:
+            raise TypeError(f"propagate() takes x= and pseudo= (nn_conv.py:271), got {sorted(kwargs)}")
+        x, pseudo = kwargs["x"], kwargs["pseudo"]
+        x = x.unsqueeze(-1) if x.dim() == 1 else x
+        pseudo = pseudo.unsqueeze(-1) if pseudo.dim() == 1 else pseudo
+        if size is not None:
+            sz = list(size) if isinstance(size, (list, tuple)) else [size, size]
+            if any(v is not None and int(v) != x.size(0) for v in sz):
+                raise NotImplementedError("bipartite propagate (size != [N, N]) is not built: no graph-pde script uses it")
+        if not x.is_cuda:
+            return self._forward_staged(x, edge_index, pseudo)
         lin = ops.mlp_linears(self.nn)
         weights = [l.weight for l in lin]
         biases = [l.bias for l in lin]
         return self._propagate(x, edge_index, pseudo, weights, biases, self.root, self.bias, use_hidden_cache=True)
 
     def _forward_act(self, x, edge_index, edge_attr, residual, relu):
-        needs_grad = torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad) or
+        attr_grad = (not isinstance(edge_attr, ops.NodeAttr)) and torch.is_tensor(edge_attr) and edge_attr.requires_grad
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or attr_grad or
+                                                  (residual is not None and residual.requires_grad) or
                                                   any(p.requires_grad for p in self.parameters()))
         fusable = x.is_cuda and x.dim() == 2 and not isinstance(edge_attr, ops.NodeAttr) and not needs_grad and \
-            x.dtype == torch.float32
+            x.dtype == torch.float32 and (residual is None or residual.device == x.device)
         if not fusable:
             y = self.forward(x, edge_index, edge_attr)
             if residual is not None:
@@ -166,6 +195,21 @@ class NNConv_old(torch.nn.Module):
         return NNConvFunction.apply(x, edge_index, pseudo, root, bias, self.aggr,
                                     len(weights), *weights, *biases)
 
+    def _params_on(self, dev, need_grad):
+        """The module's parameters as tensors on `dev`: (kernel-MLP weights, biases, root, bias).  Parameters already
+        there are returned AS THEY ARE (same objects: the pack cache of ops.pack_mlp recognises them).  CPU parameters
+        (a model moved back with `model.cpu()`): a differentiable `.to(dev)` when a gradient is needed, otherwise the
+        device copy cached by ops.stage_const on the CPU tensor's storage + version - repeated evaluation calls then
+        share one copy and one pack instead of re-packing 24 MB per call."""
+        def one(t):
+            if t is None or t.device == dev:
+                return t
+            if need_grad and t.requires_grad:
+                return t.to(dev)
+            return ops.stage_const(t, dev)
+        lin = ops.mlp_linears(self.nn)
+        return [one(l.weight) for l in lin], [one(l.bias) for l in lin], one(self.root), one(self.bias)
+
     def _forward_staged(self, x, edge_index, edge_attr):
         """CPU tensors (`model.cpu()` + evaluation, UAI1_full_resolution.py:287-303): inputs and
         parameters are copied to the current HIP device (`.to()` is differentiable, so gradients flow back to
@@ -176,11 +220,7 @@ class NNConv_old(torch.nn.Module):
         pseudo = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
         ei_d = ops.stage_const(edge_index, dev)
         ea_d = pseudo.to(dev) if pseudo.requires_grad else ops.stage_const(pseudo, dev)
-        lin = ops.mlp_linears(self.nn)
-        weights = [l.weight.to(dev) for l in lin]
-        biases = [None if l.bias is None else l.bias.to(dev) for l in lin]
-        root = None if self.root is None else self.root.to(dev)
-        bias = None if self.bias is None else self.bias.to(dev)
+        weights, biases, root, bias = self._params_on(dev, torch.is_grad_enabled())
         out = self._propagate(x.to(dev), ei_d, ea_d, weights, biases, root, bias, use_hidden_cache=False)
         return out.to(x.device)
 
@@ -194,11 +234,10 @@ class NNConv_old(torch.nn.Module):
         dev = x_j.device if x_j.is_cuda else ops.staging_device()
         ar = torch.arange(e, device=dev, dtype=torch.int64)
         ident = torch.stack([ar, ar])
-        lin = ops.mlp_linears(self.nn)
-        weights = [l.weight.to(dev) for l in lin]
-        biases = [None if l.bias is None else l.bias.to(dev) for l in lin]
+        weights, biases, _, _ = self._params_on(dev, torch.is_grad_enabled())
         self._check_width()
-        out = NNConvFunction.apply(x_j.to(dev), ident, pseudo.to(dev), None, None, "add", len(weights), *weights, *biases)
+        out = NNConvFunction.apply(x_j.to(dev), ops.build_csr(ident, e), pseudo.to(dev), None, None, "add", len(weights),
+                                   *weights, *biases)
         return out.to(x_j.device)
 
     def update(self, aggr_out, x):                     # nn_conv.py:277-282
@@ -208,16 +247,18 @@ class NNConv_old(torch.nn.Module):
             return aggr_out
         self._check_width()
         dev = x.device if x.is_cuda else ops.staging_device()
-        n = x.size(0)
         empty = torch.empty(2, 0, dtype=torch.int64, device=dev)
-        lin = ops.mlp_linears(self.nn)
-        weights = [l.weight.detach().to(dev) for l in lin]
-        biases = [None if l.bias is None else l.bias.detach().to(dev) for l in lin]
+        need_grad = torch.is_grad_enabled()
+        weights, biases, root, bias = self._params_on(dev, need_grad)
         k0 = weights[0].size(1)
-        term = NNConvFunction.apply(x.to(dev), empty, torch.empty(0, k0, device=dev),
-                                    None if self.root is None else self.root.to(dev),
-                                    None if self.bias is None else self.bias.to(dev), "add", len(weights),
-                                    *weights, *biases)
+        if not (need_grad and (x.requires_grad or any(t is not None and t.requires_grad for t in (root, bias)))):
+            csr = ops.build_csr(empty, x.size(0))      # edgeless: no sort, nothing cached
+            pm = ops.pack_mlp(weights, biases)
+            term = ops.nnconv_forward_raw(x.to(dev), csr, torch.empty(0, k0, device=dev), pm, root, bias, "add")
+        else:
+            # the kernel MLP takes no part in update(): its (staged) parameters enter detached
+            term = NNConvFunction.apply(x.to(dev), ops.build_csr(empty, x.size(0)), torch.empty(0, k0, device=dev), root, bias, "add", len(weights),
+                                        *[w.detach() for w in weights], *[None if b is None else b.detach() for b in biases])
         return aggr_out + term.to(aggr_out.device)
 
     def __repr__(self):                               # nn_conv.py:284-286

@@ -70,10 +70,24 @@ def _stream_ptr(device) -> int:
     return int(torch.cuda.current_stream(device).cuda_stream)
 
 
-def _ver(t: torch.Tensor) -> int:
-    """In-place version counter for cache keys; inference tensors do not track one (reading `_version`
-    raises) and cannot be modified in place outside inference mode, so 0 is a valid stand-in."""
-    return 0 if t.is_inference() else t._version
+def _ver(t: torch.Tensor):
+    """Cache-key component that changes whenever the tensor's contents may have changed.  Normal tensors: the
+    in-place version counter.  Inference tensors track none (reading `_version` raises) yet CAN be modified in place
+    inside torch.inference_mode() - an `edge_attr.mul_()` between two forwards of an eval loop would hit the CSR /
+    staging / hidden-activation caches with an identical key.  For them the key carries a content
+    checksum instead (one pass over the tensor + one device->host scalar per lookup: inference tensors only)."""
+    if not t.is_inference():
+        return t._version
+    if t.numel() == 0:
+        return ("inference", 0)
+    c = t.contiguous()
+    nb = c.numel() * c.element_size()
+    if nb % 4 == 0:
+        words = c.view(torch.uint8).reshape(-1).view(torch.int32)
+        chk = int(words.sum(dtype=torch.int64).item()) ^ (int(words[::7].sum(dtype=torch.int64).item()) << 1)
+    else:
+        chk = int(c.view(torch.uint8).sum(dtype=torch.int64).item())
+    return ("inference", chk)
 
 
 def staging_device() -> torch.device:

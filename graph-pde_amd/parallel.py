@@ -85,10 +85,27 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], world: int | None 
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
-    """Replicate rank `src`'s weights (start of a data-parallel run).  The broadcast writes into
-    `t.detach()` under no_grad - it shares the parameter's version counter, so the packed-weight / hidden
-    caches of graph_pde_amd.ops see the new values (a write through `.data` would not bump it)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        with torch.no_grad():
-            for t in list(module.parameters()) + list(module.buffers()):
-                dist.broadcast(t.detach(), src=src, group=group)
+    """Replicate rank `src`'s weights (start of a data-parallel run): ONE flat broadcast per (device, dtype), then
+    `t.copy_(...)` under no_grad into every parameter / buffer.  The copy is what bumps the tensors' version counters -
+    a c10d collective writing into `t.detach()` does NOT (`_version` stays put), and the packed-weight /
+    hidden-activation caches of graph_pde_amd.ops key on those counters: a forward that ran before the broadcast would
+    otherwise keep serving the pre-broadcast packed weights on the non-source ranks.  The caches are dropped as well."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    groups = {}
+    for t in list(module.parameters()) + list(module.buffers()):
+        groups.setdefault((t.device, t.dtype), []).append(t)
+    with torch.no_grad():
+        for (dev, dt), ts in groups.items():
+            flat = torch.cat([t.detach().reshape(-1) for t in ts]) if ts else None
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+    try:                                    # belt and braces: nothing packed from the old values survives
+        from . import hidden_cache, ops
+        ops.clear_caches()
+        hidden_cache.clear()
+    except Exception:                       # the helper is also usable on plain modules without the native library
+        pass

@@ -1,5 +1,6 @@
 """Host-side mirror of the reference module surface (no GPU)."""
 import io
+import os
 import pickle
 
 import pytest
@@ -84,7 +85,14 @@ def test_module_surface_has_the_reference_methods():
 def test_version_helper_accepts_inference_tensors():
     with torch.inference_mode():
         t = torch.arange(4)
-    assert ops._ver(t) == 0                      # reading t._version would raise
+        k0 = ops._ver(t)                         # reading t._version would raise: a content checksum stands in
+        assert ops._ver(t) == k0
+        t.mul_(2)                                # in-place writes ARE possible inside inference mode:
+        assert ops._ver(t) != k0                 # the cache key must move with the contents
+        f = torch.ones(5, 3)
+        kf = ops._ver(f)
+        f[2, 1] = 1.0000001
+        assert ops._ver(f) != kf
     u = torch.zeros(3)
     v0 = ops._ver(u)
     u.add_(1)
@@ -260,3 +268,31 @@ def test_bench_refuses_a_traffic_record_of_another_kernel(tmp_path, monkeypatch)
     assert rec["hbm_bytes_per_launch"] == 1.0e11
     rec, why = bench.traffic_record("g121", 1024, "gpde_fused_f16v3_kernel")
     assert rec is None
+
+
+def test_module_derives_message_passing_and_accepts_new_pyg_root_key():
+    """The reference class derives PyG's MessagePassing and calls self.propagate (nn_conv.py:197, 242, 271); newer
+    PyG state dicts name the root weight `lin.weight [out, in]`."""
+    import sys
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "graph-pde_amd", "shims")
+    sys.path.insert(0, shim)
+    try:
+        from torch_geometric.nn.conv import MessagePassing
+    finally:
+        sys.path.remove(shim)
+    conv = gp.NNConv_old(64, 64, DenseNet([6, 32, 64, 4096], torch.nn.ReLU), aggr="mean")
+    assert isinstance(conv, MessagePassing) and isinstance(gp.NNConv(64, 64, torch.nn.Linear(6, 4096)), MessagePassing)
+    assert conv.aggr == "mean" and conv.flow == "source_to_target"
+    assert conv.__message_args__ == ["x_j", "pseudo"] and conv.__update_args__ == ["x"]     # SURVEY.md Appendix B
+    assert callable(conv.propagate)
+    with pytest.raises(TypeError):
+        conv.propagate(torch.zeros(2, 0, dtype=torch.int64), x=torch.zeros(1, 64))          # pseudo= missing
+    sd = conv.state_dict()
+    new = {k: v.clone() for k, v in sd.items() if k != "root"}
+    new["lin.weight"] = sd["root"].t().clone()
+    other = gp.NNConv_old(64, 64, DenseNet([6, 32, 64, 4096], torch.nn.ReLU), aggr="mean")
+    other.load_state_dict(new)
+    assert torch.equal(other.root, conv.root) and torch.equal(other.bias, conv.bias)
+    gp.NNConv_old(64, 64, torch.nn.Linear(6, 4096), aggr="max")                              # constructible (nn_conv.py:222-224)
+    with pytest.raises(ValueError):
+        gp.NNConv_old(64, 64, torch.nn.Linear(6, 4096), aggr="median")

@@ -38,7 +38,14 @@ def _worker(rank, world, port, q):
     # 2. replicated weights + flat gradient all-reduce == gradient of the mean loss over all samples
     torch.manual_seed(100 + rank)                      # deliberately different init per rank
     model = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    v0 = [p._version for p in model.parameters()]
+    before = [p.detach().clone() for p in model.parameters()]
     parallel.broadcast_parameters(model, src=0)
+    # the pack / hidden caches of graph_pde_amd.ops key on the version counters: every tensor the broadcast rewrote
+    # must show a new version (a c10d collective alone leaves `_version` untouched)
+    assert all(p._version > v for p, v in zip(model.parameters(), v0)), [p._version for p in model.parameters()]
+    if rank != 0:
+        assert any(not torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
     g = torch.Generator().manual_seed(0)
     xs = torch.randn(n_samples, 5, 6, generator=g)
     ys = torch.randn(n_samples, 5, 3, generator=g)
