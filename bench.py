@@ -169,10 +169,48 @@ def mgkn_probe(dev, steps=10):
         wl_f = build(dev, fused_glue=True)                        # opt-in: relu(x + conv) inside the last kernel
         y_plain, y_fused = wl.forward(), wl_f.forward()
         ms_fused = median_ms(wl_f.forward, steps, warmup=2)
+        ms_grouped = grouped_diff = None
+        if name == "mgkn_orthogonal_burgers1d":                   # the 13 independent convs of a sweep in one launch
+            wl_g = build(dev, grouped=True)
+            y_g = wl_g.forward()
+            ms_grouped = median_ms(wl_g.forward, steps, warmup=2)
+            grouped_diff = max(float((a_.double() - b_.double()).norm() / a_.double().norm().clamp_min(1e-30))
+                               for a_, b_ in zip(y_fused, y_g))
+        from graph_pde_amd import hidden_cache as hc_
+        # opt-in: plain module calls served from cached per-edge weights where the graph qualifies
+        we0 = hc_.WE_MODE
+        hc_.WE_MODE = "auto"
+        try:
+            wl_w = build(dev, fused_glue=True)
+            y_w = wl_w.forward()
+            ms_we = median_ms(wl_w.forward, steps, warmup=3)
+            y_w = wl_w.forward()
+            we_diff = max(float((a_.double() - b_.double()).norm() / a_.double().norm().clamp_min(1e-30)) for a_, b_ in zip(y_fused, y_w))
+            worst_we = 0.0
+            for conv, x, ei, ea in wl_w.pairs:
+                with torch.no_grad():
+                    for _ in range(4):
+                        y = conv(x, ei, ea)
+                lin = ops.mlp_linears(conv.nn)
+                ref = nnconv_forward(x.cpu(), ei.cpu(), ea.cpu(), [l.weight.detach().cpu() for l in lin],
+                                     [l.bias.detach().cpu() for l in lin],
+                                     None if conv.root is None else conv.root.detach().cpu(),
+                                     None if conv.bias is None else conv.bias.detach().cpu(), aggr=conv.aggr,
+                                     dtype=torch.float64, chunk_edges=8192)
+                worst_we = max(worst_we, rel_l2(y.cpu(), ref))
+        finally:
+            hc_.WE_MODE = we0
         out[name] = {
             "workload": wl.description, "nnconv_calls": wl.calls, "edge_applications": wl.edge_applications,
             "ms_per_forward": round(ms, 3),
             "ms_per_forward_fused_glue": round(ms_fused, 3),
+            "ms_per_forward_grouped": None if ms_grouped is None else round(ms_grouped, 3),
+            "grouped_rel_l2_vs_fused_glue": grouped_diff,
+            "ms_per_forward_edge_weight_cache": round(ms_we, 3),
+            "edge_weight_cache": {"opt_in": "GPDE_EDGE_WEIGHT_CACHE=auto (plain module calls) / nnconv_group (explicit)",
+                                  "hits": hc_.stats["we_hits"], "builds": hc_.stats["we_builds"],
+                                  "rel_l2_vs_default_path": we_diff, "max_rel_l2_vs_oracle": worst_we},
+            "best_ms_per_forward": round(min(v for v in (ms, ms_fused, ms_we, ms_grouped) if v is not None), 3),
             "fused_glue_rel_l2_vs_unfused": max(float((a_.double() - b_.double()).norm() / a_.double().norm().clamp_min(1e-30))
                                                 for a_, b_ in zip(y_plain, y_fused)),
             "M_edge_applications_per_s": round(wl.edge_applications / ms / 1e3, 2),

@@ -7,7 +7,7 @@ neuraloperator/graph-pde — hand-written HIP for gfx950 behind the reference's 
 (The directory is named `graph-pde_amd`; `graph_pde_amd.py` at the repo root makes it importable.)
 """
 from . import _lib, ops, synth          # noqa: F401
-from .nn_conv import ECConv, NNConv, NNConv_old   # noqa: F401
+from .nn_conv import ECConv, NNConv, NNConv_old, nnconv_group   # noqa: F401
 from .ops import NodeAttr                           # noqa: F401  (opt-in: edge attributes from node data)
 
-__all__ = ["NNConv_old", "NNConv", "ECConv", "NodeAttr", "ops", "synth"]
+__all__ = ["NNConv_old", "NNConv", "ECConv", "NodeAttr", "nnconv_group", "ops", "synth"]

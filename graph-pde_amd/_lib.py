@@ -14,7 +14,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPDE_LIB", os.path.join(_PKG, "libgpde.so"))   # GPDE_LIB: experiments
 
 GPDE_OK = 0
-GPDE_AGGR_ADD, GPDE_AGGR_MEAN = 0, 1
+GPDE_AGGR_ADD, GPDE_AGGR_MEAN, GPDE_AGGR_MAX = 0, 1, 2
+GPDE_WECONV_MAX_GROUP = 16
 GPDE_FWD_DEFAULT, GPDE_FWD_F16SPLIT = 0, 1
 # the other forward flags of include/gpde.h (A/B switches; tests/test_abi.py checks these values against the header)
 GPDE_FWD_F16SPLIT_8WAVE, GPDE_FWD_STATIC_RANGES, GPDE_FWD_AGG_F16, GPDE_FWD_AGG_F32, GPDE_FWD_NO_EDGE_PATH = 2, 4, 16, 32, 64
@@ -22,6 +23,15 @@ GPDE_WIDTH = 64
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+class GpdeWeConvDesc(ctypes.Structure):
+    """include/gpde.h `GpdeWeConvDesc`: one NNConv call given its per-edge weights (tests/test_abi.py checks the layout)."""
+    _fields_ = [("x", ctypes.c_void_p), ("edge_weights", ctypes.c_void_p), ("rowptr", ctypes.c_void_p),
+                ("src", ctypes.c_void_p), ("root", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("residual", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n_nodes", ctypes.c_int32),
+                ("aggr", ctypes.c_int32), ("relu", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
 
 # name -> (restype, argtypes); mirrors include/gpde.h one to one (tests check the two agree)
 SIGNATURES = {
@@ -129,6 +139,11 @@ SIGNATURES = {
                                        ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p,
                                        ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "gpde_edge_weights_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, c_i32p]),
+    "gpde_edge_weights_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_i32p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_size_t, ctypes.c_void_p]),
+    "gpde_nnconv_fwd_edgeweights_group": (ctypes.c_int, [ctypes.POINTER(GpdeWeConvDesc), ctypes.c_int, ctypes.c_void_p]),
     "gpde_radius_graph_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
                                                ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     "gpde_radius_graph_fill": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,

@@ -273,10 +273,16 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
     // trip per node - a loss when a node has two or three in-edges (MGKN-orthogonal Burgers: 8192 nodes, 16 k edges,
     // 2 x 2.1 GB of Z per call).  There W_e = W3 . h_e is formed tile by tile on the split-f16 GEMM and contracted
     // with x_j in its epilogue ([E][4096] never exists), messages are summed per destination in CSR order.
+    bool store_ok = false;
+    if (L.mode == 1 && L.k0 + 1 <= 8) {
+        GpdeFusedArgs probe{};
+        probe.k0 = L.k0; probe.K1P = L.K1P; probe.K2P = L.K2P;
+        store_ok = gpde_fused_store_supported(probe);
+    }
     const bool edge_path = ((flags & GPDE_FWD_F16SPLIT) || (hidden && hidden_absmax)) && !mixed && !kt && L.has_w3s && P.n_chunks == 1 &&
                            n_edges >= 4096 && n_edges <= 4 * n_nodes && n_edges < ((int64_t)1 << 24) &&
                            !(flags & GPDE_FWD_NO_EDGE_PATH) &&
-                           (hidden || (L.mode == 1 && L.k0 + 1 <= 8 && ((L.K1P / GP_BK) % 2 == 0 || L.K1P / GP_BK >= 8))) &&   // H by a fused store kernel
+                           (hidden || (L.mode == 1 && store_ok)) &&   // H by a fused store kernel (its own support check: LDS limits, chunk parity)
                            (size_t)(n_edges) * L.K2P + gpde_edge_messages_ws_floats(n_edges, GP_W * GP_W) <=
                                (size_t)n_nodes * GP_W * L.K2P;
     if (edge_path) {

@@ -36,12 +36,22 @@ from .autograd import HiddenFunction, HiddenToken
 MODE = os.environ.get("GPDE_HIDDEN_CACHE", "auto")
 BUDGET_BYTES = int(float(os.environ.get("GPDE_HIDDEN_CACHE_GB", "32")) * (1 << 30))
 PARTIAL = os.environ.get("GPDE_HIDDEN_CACHE_PARTIAL", "1") != "0"
+# Per-edge weight cache: for inference calls on low in-degree / small graphs the whole
+# W_e = view(nn(edge_attr_e), 64, 64) tensor is kept ([E, 4096] fp32 = 16 KiB per edge) and a call is one streaming
+# kernel.  OPT-IN: its summation order differs from the fused kernels' (same accuracy, other last bits), and a module's
+# output should not change bits with its call history.  Used by (a) nn_conv.nnconv_group - the explicit grouped API,
+# always, from the first call; (b) aggr='max', which has no other path; (c) plain module calls when
+# GPDE_EDGE_WEIGHT_CACHE=auto (default off).  Budget per module: GPDE_EDGE_WEIGHT_CACHE_GB (default 4).
+WE_MODE = os.environ.get("GPDE_EDGE_WEIGHT_CACHE", "off")
+WE_BUDGET_BYTES = int(float(os.environ.get("GPDE_EDGE_WEIGHT_CACHE_GB", "4")) * (1 << 30))
+WE_SMALL_EDGES = 8192          # calls up to this many edges qualify whatever their in-degree
 
-stats = {"hits": 0, "builds": 0, "direct": 0}       # counters for tests / bench
+stats = {"hits": 0, "builds": 0, "direct": 0, "we_hits": 0, "we_builds": 0}       # counters for tests / bench
 
 
 class _Entry:
-    __slots__ = ("key", "hidden", "token", "attr_ref", "csr", "last_key", "repeats", "hits_on_hidden", "hn")
+    __slots__ = ("key", "hidden", "token", "attr_ref", "csr", "last_key", "repeats", "hits_on_hidden", "hn", "we", "we_key",
+                 "we_refs")
 
     def __init__(self):
         self.key = None
@@ -53,6 +63,9 @@ class _Entry:
         self.repeats = False        # this module has been seen repeating a key
         self.hits_on_hidden = 0
         self.hn = 0                 # nodes whose in-edges the cached H covers (all of them unless partial)
+        self.we = None              # per-edge weights [E, 4096] (inference) and the key they were built for
+        self.we_key = None
+        self.we_refs = None         # pins edge_attr / csr behind we_key
 
 
 _entries: "weakref.WeakKeyDictionary[torch.nn.Module, _Entry]" = weakref.WeakKeyDictionary()
@@ -124,3 +137,51 @@ def lookup(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, b
     ent.hits_on_hidden = 0
     stats["builds"] += 1
     return hidden, token.hmax, hn
+
+
+def edge_weights_qualify(csr, force: bool = False, explicit: bool = False) -> bool:
+    """The per-edge weight form pays where the re-association of DESIGN.md §2 does not: mean in-degree <= 4, or a call
+    of at most WE_SMALL_EDGES edges (launch-bound anyway).  `explicit`: the caller opted in (nnconv_group) - WE_MODE is
+    not consulted; `force` (aggr='max': no other path) only needs the budget."""
+    e, n = csr.n_edges, csr.n_nodes
+    if e == 0:
+        return False
+    if force:
+        return e * ops.EDGE_WEIGHT_BYTES <= max(WE_BUDGET_BYTES, BUDGET_BYTES)
+    return (explicit or WE_MODE == "auto") and (e <= 4 * n or e <= WE_SMALL_EDGES) and e * ops.EDGE_WEIGHT_BYTES <= WE_BUDGET_BYTES
+
+
+def lookup_edge_weights(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, biases,
+                        precision: Optional[str] = None, force: bool = False, explicit: bool = False):
+    """W_e [E, 4096] for this call, or None when another path should run.  ONLY for calls that need no gradient at
+    all.  `force` / `explicit`: built at once (H too).  Otherwise (GPDE_EDGE_WEIGHT_CACHE=auto) it is derived from the
+    module's cached hidden activations the first time they are served without gradient - i.e. only for a module that
+    has been seen repeating (edge_attr, weights)."""
+    if not edge_weights_qualify(csr, force, explicit) or edge_attr.requires_grad:
+        return None
+    precision = ops.DEFAULT_PRECISION if precision is None else precision
+    ent = _entries.get(module)
+    w_last, b_last = weights[-1], biases[-1]
+    key = (_key(edge_attr, csr, list(weights[:-1]) + list(biases[:-1]), precision)[:-1],
+           (w_last.data_ptr(), ops._ver(w_last)), (0, 0) if b_last is None else (b_last.data_ptr(), ops._ver(b_last)))
+    if ent is not None and ent.we is not None and ent.we_key == key:
+        stats["we_hits"] += 1
+        return ent.we
+    now = force or explicit
+    if not now:
+        # peek only: the H policy (who repeats, who gets built) is driven by ONE lookup() per call, made by the caller's
+        # ordinary path.  W_e is derived from an H that is already there - i.e. from the call after H was built.
+        hkey = _key(edge_attr, csr, list(weights[:-1]) + list(biases[:-1]), precision)
+        if ent is None or ent.hidden is None or ent.key != hkey or not ent.token.valid or ent.hn != csr.n_nodes:
+            return None
+    hit = lookup(module, edge_attr, csr, pm, weights, biases, precision, mode="on" if now else None, allow_partial=False)
+    ent = _entries.get(module)
+    if hit is None or hit[2] != csr.n_nodes:
+        if ent is not None:
+            ent.we, ent.we_key, ent.we_refs = None, None, None
+        return None
+    ent.we = None                       # release the previous tensor before allocating the next one
+    ent.we = ops.edge_weights_raw(hit[0].detach(), pm, w_last, b_last)
+    ent.we_key, ent.we_refs = key, (edge_attr, csr)
+    stats["we_builds"] += 1
+    return ent.we

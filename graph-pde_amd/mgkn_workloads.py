@@ -23,7 +23,7 @@ import torch
 import torch.nn.functional as F
 
 from . import synth
-from .nn_conv import NNConv
+from .nn_conv import NNConv, nnconv_group
 
 
 def dense_net(layers: List[int]) -> torch.nn.Sequential:
@@ -48,7 +48,7 @@ class Workload:
 
 
 def orthogonal_burgers(device, s: int = 8192, depth: int = 4, ker_width: int = 1024, seed: int = 0,
-                       fused_glue: bool = False) -> Workload:
+                       fused_glue: bool = False, grouped: bool = False) -> Workload:
     torch.manual_seed(seed)
     graphs = [(ei.to(device), ea.to(device), n) for ei, ea, n in synth.burgers_multipole_graphs(s, seed=seed)]
     nlev = len(graphs)                              # level + 1 graphs: nearest neighbours + one per level
@@ -61,6 +61,11 @@ def orthogonal_burgers(device, s: int = 8192, depth: int = 4, ker_width: int = 1
         with torch.no_grad():
             xs = [p.clone() for p in phis]
             for _ in range(depth):                  # MGKN_orthogonal_burgers1d.py:65-82
+                if grouped:
+                    # the 13 convs of a sweep read phi[l], fixed by the downward pass (:67-71): independent calls,
+                    # one grouped launch (nn_conv.nnconv_group), the relu(x + conv) glue inside it
+                    xs = nnconv_group([(convs[l], phis[l], graphs[l][0], graphs[l][1], xs[l], "relu") for l in range(nlev)])
+                    continue
                 for l in reversed(range(nlev)):
                     if fused_glue:      # opt-in: the relu(x + conv) glue inside the operator's last kernel
                         xs[l] = convs[l](phis[l], graphs[l][0], graphs[l][1], residual=xs[l], activation="relu")

@@ -159,6 +159,9 @@ class NNConv_old(MessagePassing):
         biases = [l.bias for l in lin]
         csr = ops.csr_for(edge_index, x.size(0))
         pm = ops.pack_mlp(weights, biases)
+        call = self._edge_weights_call(x, csr, pseudo, pm, weights, biases, self.root, self.bias, residual, relu)
+        if call is not None:
+            return ops.nnconv_forward_edgeweights_group([call])[0]
         if hidden_cache.MODE != "off" and self.aggr in ("add", "mean") and pseudo.dtype == torch.float32:
             hit = hidden_cache.lookup(self, pseudo, csr, pm, weights, biases, allow_partial=False)
             if hit is not None and hit[2] == csr.n_nodes:
@@ -176,14 +179,29 @@ class NNConv_old(MessagePassing):
         """propagate() of the reference (gather, message, aggregate, update) as ONE native operator on device
         tensors; `weights / biases / root / bias` are the tensors to use (the module's own, or staged copies)."""
         self._check_width()
+        no_grad = not (torch.is_grad_enabled() and
+                       (x.requires_grad or pseudo.requires_grad or any(p.requires_grad for p in self.parameters())))
+        if self.aggr == "max" and not no_grad:
+            raise NotImplementedError("aggr='max' is built for inference (per-edge weight kernel); its gradient is not "
+                                      "built - no graph-pde script uses 'max'")
+        if no_grad and pseudo.dtype == torch.float32 and x.dtype == torch.float32 and (use_hidden_cache or self.aggr == "max"):
+            # inference on a low in-degree / small graph (or aggr='max'): one streaming kernel over the cached per-edge
+            # weights (hidden_cache.lookup_edge_weights, DESIGN.md §6d)
+            csr = ops.csr_for(edge_index, x.size(0))
+            pm = ops.pack_mlp(weights, biases)
+            call = self._edge_weights_call(x, csr, pseudo, pm, weights, biases, root, bias, None, False)
+            if call is not None:
+                return ops.nnconv_forward_edgeweights_group([call])[0]
+        if self.aggr == "max":
+            raise NotImplementedError(
+                f"aggr='max': the per-edge weights of this call ({ops.csr_for(edge_index, x.size(0)).n_edges} edges x 16 KiB) "
+                "exceed the cache budget (GPDE_HIDDEN_CACHE_GB / GPDE_EDGE_WEIGHT_CACHE_GB)")
         # cross-depth reuse (hidden_cache.py): this module applied again with the same edge_attr and
         # weights shares one hidden-activation tensor with the earlier applications
         if use_hidden_cache and hidden_cache.MODE != "off" and self.aggr in ("add", "mean") and \
                 pseudo.dtype == torch.float32 and x.dtype == torch.float32:
             csr = ops.csr_for(edge_index, x.size(0))
             pm = ops.pack_mlp(weights, biases)
-            no_grad = not (torch.is_grad_enabled() and
-                           (x.requires_grad or any(p.requires_grad for p in self.parameters())))
             hit = hidden_cache.lookup(self, pseudo, csr, pm, weights, biases, allow_partial=no_grad)
             if hit is not None:
                 hidden, hmax, hn = hit
@@ -194,6 +212,18 @@ class NNConv_old(MessagePassing):
                                                   root, bias, self.aggr, hmax)
         return NNConvFunction.apply(x, edge_index, pseudo, root, bias, self.aggr,
                                     len(weights), *weights, *biases)
+
+    def _edge_weights_call(self, x, csr, pseudo, pm, weights, biases, root, bias, residual, relu, explicit=False):
+        """Descriptor of this call for ops.nnconv_forward_edgeweights_group, or None when the per-edge weight form does
+        not apply (graph too dense / too large; not opted in - hidden_cache.WE_MODE - or, in `auto`, module not seen
+        repeating yet).  `explicit`: the caller opted in (nnconv_group).  Callers need NO gradient."""
+        force = self.aggr == "max"
+        if not hidden_cache.edge_weights_qualify(csr, force, explicit):
+            return None
+        we = hidden_cache.lookup_edge_weights(self, pseudo, csr, pm, weights, biases, force=force, explicit=explicit)
+        if we is None:
+            return None
+        return dict(x=x, csr=csr, edge_weights=we, root=root, bias=bias, aggr=self.aggr, residual=residual, relu=relu)
 
     def _params_on(self, dev, need_grad):
         """The module's parameters as tensors on `dev`: (kernel-MLP weights, biases, root, bias).  Parameters already
@@ -274,3 +304,43 @@ class NNConv(NNConv_old):
 
 
 ECConv = NNConv
+
+
+def nnconv_group(calls):
+    """Run several INDEPENDENT NNConv calls - e.g. the 13 `conv_list[l](phi[l], ...)` of one upward sweep of the
+    MGKN-orthogonal V-cycle, whose inputs the downward pass fixed beforehand (MGKN_orthogonal_burgers1d.py:65-82) - and
+    return their outputs in order.  `calls`: sequence of (conv, x, edge_index, edge_attr[, residual[, activation]]).
+    Calls that can run from cached per-edge weights (inference, low in-degree / small graphs: DESIGN.md §6d) share ONE
+    kernel launch per 16 (gpde_nnconv_fwd_edgeweights_group); every other call runs as `conv(x, edge_index, edge_attr,
+    residual=, activation=)`.  The result of each call is bit-identical to calling the module on its own."""
+    outs = [None] * len(calls)
+    batch, where = [], []
+    for k, c in enumerate(calls):
+        conv, x, edge_index, edge_attr = c[0], c[1], c[2], c[3]
+        residual = c[4] if len(c) > 4 else None
+        activation = c[5] if len(c) > 5 else None
+        if activation not in (None, "relu"):
+            raise ValueError(f"activation must be None or 'relu', got {activation!r}")
+        call = None
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad) or
+                                                  (torch.is_tensor(edge_attr) and edge_attr.requires_grad) or
+                                                  any(p.requires_grad for p in conv.parameters()))
+        if not needs_grad and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and torch.is_tensor(edge_attr) and \
+                edge_attr.dtype == torch.float32 and (residual is None or residual.device == x.device):
+            conv._check_width()
+            pseudo = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
+            lin = ops.mlp_linears(conv.nn)
+            weights, biases = [l.weight for l in lin], [l.bias for l in lin]
+            csr = ops.csr_for(edge_index, x.size(0))
+            call = conv._edge_weights_call(x, csr, pseudo, ops.pack_mlp(weights, biases), weights, biases, conv.root, conv.bias,
+                                           residual, activation == "relu", explicit=True)
+        if call is not None:
+            batch.append(call)
+            where.append(k)
+        elif residual is not None or activation is not None:
+            outs[k] = conv(x, edge_index, edge_attr, residual=residual, activation=activation)
+        else:
+            outs[k] = conv(x, edge_index, edge_attr)
+    for k, o in zip(where, ops.nnconv_forward_edgeweights_group(batch)):
+        outs[k] = o
+    return outs

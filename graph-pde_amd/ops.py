@@ -619,6 +619,92 @@ def nnconv_forward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, p
     return out
 
 
+# ----------------------------------------------------------------------------------------------
+# the operator given the per-edge weights (include/gpde.h gpde_edge_weights_fwd / gpde_nnconv_fwd_edgeweights_group)
+# ----------------------------------------------------------------------------------------------
+EDGE_WEIGHT_BYTES = WIDTH * WIDTH * 4         # 16 KiB per edge
+
+
+def edge_weights_raw(hidden: torch.Tensor, pm: PackedMlp, w_last: torch.Tensor, b_last: Optional[torch.Tensor]) -> torch.Tensor:
+    """gpde_edge_weights_fwd: W_e = view(nn(pseudo_e), 64, 64) for every CSR slot ([E, 4096] fp32, the last Linear's
+    bias folded in) from the hidden activations of hidden_forward_raw - the reference's nn_conv.py:274 tensor, built
+    once per (edge_attr, weights) instead of once per call."""
+    lib = _lib.lib()
+    _require_cuda(hidden, "hidden")
+    e, dev = int(hidden.size(0)), hidden.device
+    if hidden.dtype != torch.float32 or hidden.dim() != 2 or hidden.size(1) != hidden_width(pm.dims) or not hidden.is_contiguous():
+        raise ValueError(f"hidden must be contiguous float32 [E,{hidden_width(pm.dims)}]")
+    if tuple(w_last.shape) != (WIDTH * WIDTH, pm.dims[-2]):
+        raise ValueError(f"w_last must be [{WIDTH * WIDTH},{pm.dims[-2]}], got {tuple(w_last.shape)}")
+    w_c = w_last.detach().contiguous()
+    b_c = None if b_last is None else b_last.detach().contiguous()
+    we = torch.empty(e, WIDTH * WIDTH, dtype=torch.float32, device=dev)
+    nl = len(pm.dims) - 1
+    ws = torch.empty(max(int(lib.gpde_edge_weights_workspace_bytes(e, nl, pm.dims_c)), 1), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gpde_edge_weights_fwd(hidden.data_ptr(), e, nl, pm.dims_c, pm.packed.data_ptr(), w_c.data_ptr(),
+                                       None if b_c is None else b_c.data_ptr(), we.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       _stream_ptr(dev))
+    _lib.check(rc, "gpde_edge_weights_fwd")
+    _lib.n_native_calls += 1
+    return we
+
+
+_AGGR_WE = {"add": _lib.GPDE_AGGR_ADD, "mean": _lib.GPDE_AGGR_MEAN, "max": _lib.GPDE_AGGR_MAX}
+
+
+def nnconv_forward_edgeweights_group(calls: Sequence[dict]) -> List[torch.Tensor]:
+    """gpde_nnconv_fwd_edgeweights_group: INDEPENDENT NNConv calls, each given its per-edge weights, in one launch per
+    16 calls.  Every call is a dict: x [N,64], csr, edge_weights [E,4096], root, bias, aggr ('add' | 'mean' | 'max'),
+    optional residual [N,64], relu (bool), out.  Returns the outputs in order."""
+    lib = _lib.lib()
+    if not calls:
+        return []
+    dev = calls[0]["x"].device
+    descs = (_lib.GpdeWeConvDesc * len(calls))()
+    outs, keep = [], []
+    for k, c in enumerate(calls):
+        x, csr, we = c["x"], c["csr"], c["edge_weights"]
+        _require_cuda(x, "x")
+        n, e = csr.n_nodes, csr.n_edges
+        if x.device != dev:
+            raise ValueError("all calls of a group must live on one device")
+        if x.dtype != torch.float32 or x.dim() != 2 or tuple(x.shape) != (n, WIDTH):
+            raise ValueError(f"x must be float32 [{n},{WIDTH}], got {x.dtype} {tuple(x.shape)}")
+        if we.dtype != torch.float32 or tuple(we.shape) != (e, WIDTH * WIDTH) or not we.is_contiguous() or we.device != dev:
+            raise ValueError(f"edge_weights must be contiguous float32 [{e},{WIDTH * WIDTH}] on {dev}")
+        aggr = c.get("aggr", "mean")
+        if aggr not in _AGGR_WE:
+            raise NotImplementedError(f"aggr={aggr!r}")
+        x_c = x.detach().contiguous()
+        root, bias = c.get("root"), c.get("bias")
+        root_c = None if root is None else root.detach().contiguous()
+        bias_c = None if bias is None else bias.detach().contiguous()
+        res = _check_residual(c.get("residual"), x_c, n)
+        out = c.get("out")
+        if out is None:
+            out = torch.empty(n, WIDTH, dtype=torch.float32, device=dev)
+        keep.append((x_c, root_c, bias_c, res, we, csr))
+        outs.append(out)
+        d = descs[k]
+        d.x, d.edge_weights, d.rowptr, d.src = x_c.data_ptr(), we.data_ptr(), csr.rowptr.data_ptr(), csr.src.data_ptr()
+        d.root = None if root_c is None else root_c.data_ptr()
+        d.bias = None if bias_c is None else bias_c.data_ptr()
+        d.residual = None if res is None else res.data_ptr()
+        d.out, d.n_nodes, d.aggr, d.relu, d.reserved = out.data_ptr(), n, _AGGR_WE[aggr], 1 if c.get("relu") else 0, 0
+    with torch.cuda.device(dev):
+        rc = lib.gpde_nnconv_fwd_edgeweights_group(descs, len(calls), _stream_ptr(dev))
+    _lib.check(rc, "gpde_nnconv_fwd_edgeweights_group")
+    _lib.n_native_calls += len(calls)
+    return outs
+
+
+def nnconv_forward_edgeweights_raw(x, csr, edge_weights, root, bias, aggr, residual=None, relu=False, out=None):
+    """One call of the group entry point."""
+    return nnconv_forward_edgeweights_group([dict(x=x, csr=csr, edge_weights=edge_weights, root=root, bias=bias, aggr=aggr,
+                                                  residual=residual, relu=relu, out=out)])[0]
+
+
 def nnconv_forward_mixed_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor, hidden: torch.Tensor,
                              hmax: Optional[torch.Tensor], hidden_nodes: int, pm: PackedMlp,
                              root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,

@@ -37,7 +37,8 @@ enum {
     GPDE_EHIP = -4          /* a HIP runtime call / kernel launch failed */
 };
 
-enum { GPDE_AGGR_ADD = 0, GPDE_AGGR_MEAN = 1 };
+enum { GPDE_AGGR_ADD = 0, GPDE_AGGR_MEAN = 1,
+       GPDE_AGGR_MAX = 2 /* gpde_nnconv_fwd_edgeweights_group only: 'max' cannot use the re-associated contraction */ };
 
 /* gpde_nnconv_fwd flags */
 enum {
@@ -264,6 +265,38 @@ int gpde_hidden_bwd(const float* edge_attr, int64_t n_edges, const int32_t* perm
                     const int32_t* dims, const float* const* W, const float* const* b,
                     const float* grad_hidden, float* const* grad_W, float* const* grad_b, void* ws,
                     size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The operator given the PER-EDGE WEIGHTS (second half; row a6 'max').
+ * `weight = self.nn(pseudo).view(-1, in, out)` (nn_conv.py:274) is what the reference forms on every call.  For the
+ * MGKN V-cycles' low in-degree / small graphs (MGKN_orthogonal_burgers1d.py:73-82: 2-3 in-edges per node;
+ * MGKN_general_darcy2d.py:76-90: coarse levels of a few thousand edges) the same module runs `depth` times per forward
+ * with the same edge_attr and weights, so that tensor is the same in every call: gpde_edge_weights_fwd builds it once
+ * from the hidden activations of gpde_hidden_fwd ([E][4096] fp32 in CSR slot order, the last Linear's bias folded in),
+ * and gpde_nnconv_fwd_edgeweights_group then runs any number of INDEPENDENT calls in one launch each doing gather,
+ * message (nn_conv.py:275), aggregation (add / mean / max) and update() (nn_conv.py:277-282; + opt-in residual and
+ * ReLU, the callers' `relu(x + conv(x))` glue) in a single streaming kernel.  Inference only (no backward). */
+size_t gpde_edge_weights_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims);
+int gpde_edge_weights_fwd(const float* hidden /* [E][K2P], gpde_hidden_fwd */, int64_t n_edges, int n_layers,
+                          const int32_t* dims, const void* packed /* gpde_mlp_pack image (k2 padded >= 256), else unused */,
+                          const float* w_last /* [4096][k2] */, const float* b_last /* [4096] or NULL */,
+                          float* edge_weights /* [E][4096] */, void* ws, size_t ws_bytes, void* stream);
+#define GPDE_WECONV_MAX_GROUP 16 /* descriptors per launch; longer lists take several launches */
+typedef struct GpdeWeConvDesc {
+    const float* x;            /* [n_nodes][64] */
+    const float* edge_weights; /* [E][4096] from gpde_edge_weights_fwd, CSR slot order */
+    const int32_t* rowptr;     /* [n_nodes + 1] destination CSR (gpde_csr_from_coo) */
+    const int32_t* src;        /* [E] source node per CSR slot */
+    const float* root;         /* [64][64] or NULL */
+    const float* bias;         /* [64] or NULL */
+    const float* residual;     /* [n_nodes][64] or NULL: out = act(residual + NNConv(x)) */
+    float* out;                /* [n_nodes][64] */
+    int32_t n_nodes;
+    int32_t aggr;              /* GPDE_AGGR_ADD | GPDE_AGGR_MEAN | GPDE_AGGR_MAX */
+    int32_t relu;              /* 1: ReLU on the result */
+    int32_t reserved;
+} GpdeWeConvDesc;
+int gpde_nnconv_fwd_edgeweights_group(const GpdeWeConvDesc* descs /* HOST array */, int n_descs, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Edge attributes on the fly (opt-in).  The reference materialises

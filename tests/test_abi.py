@@ -126,3 +126,23 @@ def test_forward_flags_of_the_binding_match_the_header():
     assert ops._PRECISION["f32"] == 0 and ops._PRECISION["f16split"] == vals["GPDE_FWD_F16SPLIT"]
     assert ops._PRECISION["f16split_noedge"] == vals["GPDE_FWD_F16SPLIT"] | vals["GPDE_FWD_NO_EDGE_PATH"]
     assert len(set(ops._PRECISION.values())) == len(ops._PRECISION)
+
+
+def test_weconv_descriptor_layout_matches_the_header():
+    """ctypes mirror of `GpdeWeConvDesc` (include/gpde.h): field order, 8 pointers + 4 int32 = 80 bytes; the group entry
+    point validates its descriptors on the host (no GPU needed)."""
+    src = open(os.path.join(REPO, "include", "gpde.h")).read()
+    body = re.search(r"typedef struct GpdeWeConvDesc \{(.*?)\} GpdeWeConvDesc;", src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"(\w+);", body)
+    assert names == [f[0] for f in _lib.GpdeWeConvDesc._fields_]
+    assert ctypes.sizeof(_lib.GpdeWeConvDesc) == 80
+    assert int(re.search(r"#define GPDE_WECONV_MAX_GROUP (\d+)", src).group(1)) == _lib.GPDE_WECONV_MAX_GROUP
+    assert re.search(r"GPDE_AGGR_MAX = (\d+)", src).group(1) == str(_lib.GPDE_AGGR_MAX)
+    l = _lib.lib()
+    assert l.gpde_nnconv_fwd_edgeweights_group(None, 0, None) == 0
+    d = (_lib.GpdeWeConvDesc * 1)()
+    d[0].n_nodes, d[0].aggr = 4, 7
+    assert l.gpde_nnconv_fwd_edgeweights_group(d, 1, None) == -1 and b"descriptor 0" in l.gpde_last_error()
+    assert l.gpde_edge_weights_fwd(None, -1, 3, _lib.dims_array([6, 8, 8, 4096]), None, None, None, None, None, 0, None) == -1
+    assert l.gpde_edge_weights_workspace_bytes(1000, 3, _lib.dims_array([6, 256, 256, 4096])) >= 8000
