@@ -310,6 +310,7 @@ def main():
                     help="skip the depth x module probe of the cross-depth hidden-activation reuse")
     ap.add_argument("--no-backward-probe", action="store_true", help="skip the single-call backward timing (g121)")
     ap.add_argument("--no-mgkn", action="store_true", help="skip the MGKN configurations (BASELINE configs 3, 4)")
+    ap.add_argument("--no-g241-train", action="store_true", help="skip the G241 backward / depth-6 training-step figures")
     ap.add_argument("--no-alt", action="store_true", help="skip the exact-fp32 leg")
     ap.add_argument("--precision", default=None, choices=["f32", "f16split", "f16split_8wave", "f16split_static", "f16split_agg16", "f16split_agg32", "f16split_noedge"],
                     help="arithmetic of the hidden layer (default: graph_pde_amd.ops.DEFAULT_PRECISION)")
@@ -610,6 +611,54 @@ def main():
                                 "against float64 autograd: tests/test_gpu_bwd.py, tests/test_gpu_parity.py"}
             log(f"[bench] backward g121: {backward['ms']} ms, {backward['M_edges_per_s']} M-edges/s")
             del eib, eab, xb, yb, lossb
+            # ---- the same at the headline size, and BASELINE config 5's per-GPU unit of work: one training step of the
+            #      depth-6 GKN on ONE 241^2 sample (UAI1_full_resolution.py:258-273: forward, L1 loss, backward, Adam).
+            #      H of this graph is 391 GB (> HBM): nothing is cached, every layer recomputes its hidden chain.
+            if args.config == "g241" and not args.no_g241_train:
+                torch.cuda.empty_cache()
+                xg = x.detach().clone().requires_grad_(True)
+                tg = []
+                for it in range(2):
+                    conv.zero_grad(set_to_none=True)
+                    xg.grad = None
+                    yg = conv(xg, ei, ea)
+                    lg = yg.square().mean()
+                    torch.cuda.synchronize()
+                    tq = time.perf_counter()
+                    lg.backward()
+                    torch.cuda.synchronize()
+                    tg.append(time.perf_counter() - tq)
+                backward["g241_one_layer"] = {"ms": round(1e3 * tg[-1], 1), "M_edges_per_s": round(e / tg[-1] / 1e6, 2),
+                                              "grads_finite": bool(torch.isfinite(xg.grad).all()),
+                                              "note": "second of two backward passes of one NNConv call on the headline graph"}
+                log(f"[bench] backward g241: {backward['g241_one_layer']['ms']} ms, {backward['g241_one_layer']['M_edges_per_s']} M-edges/s")
+                del yg, lg
+                fc1 = torch.nn.Linear(6, 64).to(dev)
+                fc2 = torch.nn.Linear(64, 1).to(dev)
+                params = list(conv.parameters()) + list(fc1.parameters()) + list(fc2.parameters())
+                opt = torch.optim.Adam(params, lr=1e-4, weight_decay=5e-4)
+                a_in = torch.randn(n, 6, device=dev)
+                y_t = torch.randn(n, device=dev)
+                depth = 6
+                torch.cuda.synchronize()
+                tq = time.perf_counter()
+                opt.zero_grad(set_to_none=True)
+                hcur = fc1(a_in)
+                for _ in range(depth):
+                    hcur = torch.relu(conv(hcur, ei, ea))
+                loss_t = torch.norm(fc2(hcur).view(-1) - y_t, 1)
+                loss_t.backward()
+                opt.step()
+                torch.cuda.synchronize()
+                t_step = time.perf_counter() - tq
+                backward["g241_depth6_train_step"] = {
+                    "s": round(t_step, 2), "M_edge_applications_per_s": round(depth * e / t_step / 1e6, 2),
+                    "loss_finite": bool(torch.isfinite(loss_t)),
+                    "note": "ONE step (no warm-up beyond the passes above): fc1 + 6 x relu(NNConv_old) + fc2, L1 loss, backward, "
+                            "Adam - BASELINE config 5's unit of work per GPU and sample; hidden activations of this graph "
+                            "(391 GB) do not fit HBM, so nothing is cached across the layers"}
+                log(f"[bench] g241 depth-6 train step: {t_step:.2f} s")
+                del hcur, loss_t, opt, xg
         finally:
             hidden_cache.MODE = mode0
             hidden_cache.clear()

@@ -561,6 +561,8 @@ struct BwdPlan {
     bool f16s_du1;
     size_t off_dxe;                   // per-edge dx contributions of a chunk (ordered mode)
     bool f16s_dw2; size_t off_tnws;   // dW_2 on the split-f16 GEMM: transposed dU_2 + split image of H_1^T per edge chunk
+    size_t off_dubits;                // column maxima of |dU_2| as bit patterns [kmax]
+    size_t off_maskbits;              // ReLU mask of the first hidden layer as bits [Ec][KP1 / 32] (H_1 itself is not materialised)
     size_t total;
 };
 
@@ -605,7 +607,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     // per-chunk buffers: per edge (hsum + 2*kmax) floats (+ KP1 + KP2 for the transposed operands of dW_2), per node
     // (2*64*K2P + 3*64) floats
     const size_t tn_edge = P->f16s_dw2 ? (size_t)P->KP[1] + P->KP[2] : 0;
-    const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0) + tn_edge + GP_W) * 4, per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4;
+    const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0) + tn_edge + GP_W) * 4 + (P->f16s_dw2 ? P->KP[1] / 8 : 0), per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4;
     int64_t Ec, Nc;
     // alignment of the per-chunk buffers below + the K padding of the transposed operands
     const size_t slack = 64 * 256 + (P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats(0, P->KP[2], P->KP[1], BWD_TN_KSPLITS) * 4 : 0);
@@ -631,6 +633,8 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     P->off_rowsc = take(P->f16s_du1 ? (size_t)2 * Ec : 1);
     P->off_dxe = take((size_t)Ec * GP_W);
     P->off_tnws = take(P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats((int)Ec, P->KP[2], P->KP[1], BWD_TN_KSPLITS) : 1);
+    P->off_dubits = take((size_t)(kmax > 0 ? kmax : 1));
+    P->off_maskbits = take(P->f16s_dw2 ? (size_t)Ec * (P->KP[1] / 32) : 1);
     P->total = off + 256 + (sizing ? slack : 0);
     if (!sizing && P->total > ws_bytes) { gpde_set_error("gpde_nnconv_bwd: internal plan %zu > workspace %zu", P->total, ws_bytes); return GPDE_EWORKSPACE; }
     return GPDE_OK;
@@ -743,6 +747,12 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             fast_last = true;
         }
     }
+    // 3-Linear kernels on the split-f16 GEMMs: the first hidden layer H_1 is never written.  Its only consumers in the
+    // backward are dW_2 = dU_2^T . H_1 (operand image generated straight from the 8 attribute slots, k_first_layer_pack)
+    // and the ReLU mask of dU_1 (128 bytes of bits per edge instead of 4 KiB).  GPDE_BWD_H1_MATERIALIZE=1: the tensor (A/B).
+    const bool h1_on_the_fly = n == 3 && f16s_du1 && f16s_dw2 && dims[0] <= 8 && P.KP[0] >= 8 && !getenv("GPDE_BWD_H1_MATERIALIZE") &&
+                               !getenv("GPDE_BWD_H1_GEMM");
+    auto skip_h1 = [&](int rows) { return h1_on_the_fly && rows >= 8192; };
     // recompute of the hidden chain for rows [e0, e0 + rows) = in-edges of nodes [na_, nb_): layers 1 .. last
     int rc_na = 0, rc_nb = 0;
     auto recompute = [&](int e0, int rows, int last) -> int {
@@ -765,6 +775,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             last = n - 2;
         }
         for (int l = 1; l <= last; ++l) {
+            if (l == 1 && last == 1 && skip_h1(rows)) continue;
             if (l == 1 && dims[0] <= 8 && P.KP[0] >= 8 && P.KP[1] % 4 == 0 && rows >= 1024 && !getenv("GPDE_BWD_H1_GEMM")) {
                 const int cb = (P.KP[1] + 255) / 256;
                 int rb = rows / 64; if (rb > 4096 / cb) rb = 4096 / cb; if (rb < 1) rb = 1;
@@ -808,7 +819,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 }
             }
             const bool tn_split = l == 2 && f16s_dw2 && rows >= 8192;
-            unsigned* du_bits = tn_split ? (unsigned*)F(P.off_rowsc) : nullptr;   // free until the dU_1 GEMM below
+            unsigned* du_bits = tn_split ? (unsigned*)F(P.off_dubits) : nullptr;
             {   // db_l = column sums of dU_l; the same pass collects the column maxima the split dW_2 GEMM scales with
                 const int cb = (Kl + 255) / 256;
                 int splits = 1; while (splits < 512 && cb * splits < 2048 && rows / (splits * 2) >= 64) splits *= 2;
@@ -819,8 +830,9 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             }
             if (tn_split) {
                 // dW_2 += dU_2^T . H_1 on the split-f16 GEMM (contraction over the edges: both operands transposed)
+                GpdeFirstLayerSpec fl{F(P.off_H[0]), P.KP[0], F(P.off_wp[1]), P.KP[0], F(P.off_bp[1]), (uint32_t*)F(P.off_maskbits)};
                 if ((rc2 = gpde_launch_gemm_f16s_tn(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, BWD_TN_KSPLITS,
-                                                    F(P.off_tnws), F(P.off_part), st, du_bits)) != GPDE_OK) return rc2;
+                                                    F(P.off_tnws), F(P.off_part), st, du_bits, skip_h1(rows) ? &fl : nullptr)) != GPDE_OK) return rc2;
                 if ((rc2 = gpde_launch_reduce_splits(F(P.off_part), (size_t)Kl * Kin, BWD_TN_KSPLITS, (size_t)Kl * Kin,
                                                      F(P.off_dwp[l]), 1, st)) != GPDE_OK) return rc2;
             } else if ((rc2 = gemm_tn_acc(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, F(P.off_dwp[l]), Kin,
@@ -830,6 +842,9 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 GpdeGemmF16sArgs g{};
                 g.A = dUc; g.lda = Kl; g.M = rows; g.bsplit = F(P.off_w2ts); g.ucol = F(P.off_ucol2);
                 g.mask = F(P.off_H[l - 1]); g.ldmask = Kin; g.C = dUo; g.ldc = Kin; g.K = Kl; g.N = Kin;
+                if (tn_split && skip_h1(rows)) { g.mask = nullptr; g.ldmask = 0; g.maskbits = (const uint32_t*)F(P.off_maskbits); g.ldmb = Kin / 32; }
+                // (row scales: a pass over dU_2, 3.9 ms at s=121.  Collecting the row maxima inside gpde_edge_bwd2_kernel was
+                // tried in round 3: 16 more registers spill 15 VGPRs of a kernel that sits at its 256-register limit, +5 ms.)
                 if ((rc2 = gpde_launch_gemm_f16s_nt(g, F(P.off_rowsc), st)) != GPDE_OK) return rc2;
                 dUc = dUo;
             } else if (l > 1) {

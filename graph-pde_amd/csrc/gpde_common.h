@@ -243,6 +243,7 @@ struct GpdeGemmF16sArgs {
     const float* A; int lda; int M;
     const void* bsplit; const float* ucol;
     const float* mask; int ldmask;      // optional [M][ldmask]
+    const uint32_t* maskbits; int ldmb; // optional instead of `mask`: bit (n & 31) of maskbits[m * ldmb + n / 32] = "keep"
     float* C; int ldc;
     int K, N;                           // padded sizes: K % 128 == 0, N % 128 == 0
     const float* sc; const float* isc;  // per-row scales (filled by the launcher's pre-pass)
@@ -261,9 +262,20 @@ int gpde_launch_edge_messages(const float* H, int K2P, int64_t n_edges, const vo
 // weight-gradient form: part[s] = partial sums over K split s of dU^T . H (dU [rows][n_out], H [rows][n_in], fp32,
 // contraction over the rows); ws = gpde_gemm_f16s_tn_ws_floats(...) floats, part = ksplits * n_out * n_in floats
 size_t gpde_gemm_f16s_tn_ws_floats(int rows_max, int n_out, int n_in, int ksplits);
+// H given NOT as a tensor but as the first hidden layer of the kernel MLP over gathered attributes:
+// H[e][n] = relu(bp[n] + sum_{d < 8} Wp[n][d] * H0[e][d])  (DenseNet's first Linear + ReLU, utilities.py:223-227).  The
+// launcher writes the split tile image of H^T straight from H0 (no [rows][n_in] tensor, no column-maximum pass: the
+// scales come from the bound |bp[n]| + sum_d |Wp[n][d]| * amax[d]) and the ReLU mask as bits for the dU_1 epilogue.
+struct GpdeFirstLayerSpec {
+    const float* H0; int ld0;            // gathered attributes [rows][ld0], slots >= k0 zero (ld0 >= 8)
+    const float* Wp; int ldw;            // padded first-layer weight [n_in][ldw] (ldw >= 8), bias bp [n_in]
+    const float* bp;
+    uint32_t* maskbits;                  // out: [rows][n_in / 32]
+};
 int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H, int ldh, int n_in, int rows,
                              int ksplits, float* ws, float* part, hipStream_t stream,
-                             const unsigned* du_absmax_bits = nullptr /* [n_out] column maxima of |dU| as bit patterns */);
+                             const unsigned* du_absmax_bits = nullptr /* [n_out] column maxima of |dU| as bit patterns */,
+                             const GpdeFirstLayerSpec* first_layer = nullptr /* non-null: H is this layer (H / ldh unused) */);
 // split tile image of a row-major [n][k] matrix (ld = k): the W2 layout of gpde_mlp_pack for any operand
 int gpde_pack_split_nk(const float* Wnk, int n, int k, int NP, int KP, void* out, float* ucol, hipStream_t stream);
 int gpde_num_cus();

@@ -335,11 +335,21 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
             }
             continue;
         }
-        const bool has_mask = a.mask != nullptr;
+        const bool has_mask = a.mask != nullptr || a.maskbits != nullptr;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             float mk[16][4];
-            if (has_mask) {
+            if (a.maskbits) {
+                // ReLU mask as bits (the first hidden layer is never materialised, GpdeFirstLayerSpec): one 16-byte load
+                // per row (the slice's 128 columns = 4 words, the same address in all lanes)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(r0 + 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h, a.M - 1);
+                    const u4 wv = *(const u4*)(a.maskbits + (size_t)row * a.ldmb + slice * (GP_TN / 32));
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) mk[r][nb] = ((wv[nb] >> l31) & 1u) ? 1.f : 0.f;
+                }
+            } else if (has_mask) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = min(r0 + 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h, a.M - 1);
@@ -398,7 +408,9 @@ int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a_in, float* row_scale_ws, 
                                  : ((size_t)(a.ksplits - 1) * a.cstride + (size_t)(a.M - 1) * a.ldc + a.N) * 4;
         const size_t aa = ((size_t)(a.M - 1) * a.lda + a.K) * 4;
         const size_t ma = a.mask ? ((size_t)(a.M - 1) * a.ldmask + a.N) * 4 : 0;
-        if (gp_overlap(a.C, ca, a.A, aa) || gp_overlap(a.C, ca, a.mask, ma)) {
+        const size_t mba = a.maskbits ? ((size_t)(a.M - 1) * a.ldmb + a.N / 32) * 4 : 0;
+        if (a.maskbits && (a.ldmb % 4 != 0 || a.mask)) { gpde_set_error("gpde_gemm_f16s_nt: maskbits rows must be 16-byte multiples and exclude `mask`"); return GPDE_EINVAL; }
+        if (gp_overlap(a.C, ca, a.A, aa) || gp_overlap(a.C, ca, a.mask, ma) || gp_overlap(a.C, ca, a.maskbits, mba)) {
             gpde_set_error("gpde_gemm_f16s_nt: output overlaps an operand (internal buffer plan error)");
             return GPDE_EINVAL;
         }
@@ -565,6 +577,86 @@ __global__ __launch_bounds__(256) void k_pack_split_kn(const float* __restrict__
 #pragma unroll
     for (int q = 0; q < 4; ++q) dst[q * 256 + threadIdx.x] = srcl[q * 256 + threadIdx.x];
 }
+// ---- the first hidden layer as an operand generator (GpdeFirstLayerSpec) ------------------------------------------
+// amax[d] = max over rows of |H0[row][d]| (d < 8) as fp32 bit patterns (zeroed by the caller)
+__global__ __launch_bounds__(256) void k_attr_absmax8(const float* __restrict__ H0, int rows, int ld0, unsigned* __restrict__ amax) {
+    const int d = threadIdx.x & 7;
+    unsigned m = 0;
+    for (int r = blockIdx.x * 32 + (threadIdx.x >> 3); r < rows; r += gridDim.x * 32)
+        m = max(m, __float_as_uint(H0[(size_t)r * ld0 + d]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) < 8 && m) atomicMax(amax + d, m);
+}
+// column scales from the a-priori bound H[e][n] <= |bp[n]| + sum_d |Wp[n][d]| * amax[d]: sc = 2^(13 - E(bound)), usc = 1 / sc
+__global__ void k_first_layer_scales(const float* __restrict__ Wp, int ldw, const float* __restrict__ bp,
+                                     const unsigned* __restrict__ amax, int n, float* __restrict__ sc, float* __restrict__ usc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float b = fabsf(bp[i]);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) b = fmaf(fabsf(Wp[(size_t)i * ldw + d]), __uint_as_float(amax[d]), b);
+    const int eb = (int)((__float_as_uint(b) >> 23) & 0xff);
+    const bool ok = eb >= 20 && eb <= 230;
+    sc[i] = ok ? __int_as_float((267 - eb) << 23) : 1.f;
+    usc[i] = ok ? __int_as_float((eb - 13) << 23) : 1.f;
+}
+// k_pack_split_kn with H computed on the fly: B[n][k = edge] = relu(bp[n] + sum_d Wp[n][d] H0[edge][d]) * sc[n], plus
+// the ReLU mask bits [rows][n_in / 32].  Workgroup = one 16 KiB tile (slice of 128 n, chunk of 32 edges), thread =
+// (n, k16 step m).  The fp32 fmaf chain is the one k_first_layer / the fp32 GEMM path evaluate (d ascending from the bias).
+__global__ __launch_bounds__(256) void k_first_layer_pack(GpdeFirstLayerSpec f, int rows, int n_in, const float* __restrict__ sc,
+                                                          int nkct, _Float16* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) _Float16 img[128 * 64];      // the 16 KiB tile, final layout
+    __shared__ __attribute__((aligned(16))) float h0s[32][8];
+    const int n = threadIdx.x & 127, m = threadIdx.x >> 7;
+    const int kcn = blockIdx.x, slice = blockIdx.y;
+    {
+        const int e = kcn * 32 + (threadIdx.x >> 3), d = threadIdx.x & 7;
+        h0s[threadIdx.x >> 3][d] = e < rows ? f.H0[(size_t)e * f.ld0 + d] : 0.f;
+    }
+    const int col = slice * 128 + n;
+    const float s = sc[col], b = f.bp[col];
+    float wd[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) wd[d] = f.Wp[(size_t)col * f.ldw + d];
+    __syncthreads();
+    const int e0 = kcn * 32 + 16 * m;
+    float w[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float t = b;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) t = fmaf(wd[d], h0s[16 * m + k][d], t);
+        t = fmaxf(t, 0.f);
+        // mask bits of edge e0 + k: one 64-bit ballot per wave = columns n & ~63 .. +63 -> two words
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(t > 0.f);
+        if ((threadIdx.x & 63) == 0 && e0 + k < rows) {
+            uint32_t* mp = f.maskbits + (size_t)(e0 + k) * (n_in / 32) + slice * 4 + ((n >> 6) << 1);
+            mp[0] = (uint32_t)bal;
+            mp[1] = (uint32_t)(bal >> 32);
+        }
+        w[k] = (e0 + k < rows) ? t * s : 0.f;
+    }
+    const int sw = (n >> 1) & 7;
+    _Float16* row = img + n * 64;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        h8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = w[8 * (j >> 2) + 4 * hh + (j & 3)];
+            hi[j] = (_Float16)v;
+            lo[j] = (_Float16)(v - (float)hi[j]);
+        }
+        *(h8*)(row + (((m * 2 + hh) ^ sw) << 3)) = hi;
+        *(h8*)(row + (((4 + m * 2 + hh) ^ sw) << 3)) = lo;
+    }
+    __syncthreads();
+    h8* dst = (h8*)(out + ((size_t)slice * (size_t)nkct + kcn) * (128 * 64));
+    const h8* srcl = (const h8*)img;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q * 256 + threadIdx.x] = srcl[q * 256 + threadIdx.x];
+}
 }  // namespace
 
 size_t gpde_gemm_f16s_tn_ws_floats(int rows_max, int n_out, int n_in, int ksplits) {
@@ -574,7 +666,13 @@ size_t gpde_gemm_f16s_tn_ws_floats(int rows_max, int n_out, int n_in, int ksplit
 
 // part[s][n_out][n_in] (s < ksplits, stride n_out * n_in) = partial sums of dU^T . H over the K splits
 int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H, int ldh, int n_in, int rows,
-                             int ksplits, float* ws, float* part, hipStream_t stream, const unsigned* du_absmax_bits) {
+                             int ksplits, float* ws, float* part, hipStream_t stream, const unsigned* du_absmax_bits,
+                             const GpdeFirstLayerSpec* fl) {
+    if (fl && (!fl->H0 || !fl->Wp || !fl->bp || !fl->maskbits || fl->ld0 < 8 || fl->ldw < 8)) {
+        gpde_set_error("gpde_gemm_f16s_tn: incomplete first-layer spec");
+        return GPDE_EINVAL;
+    }
+    if (fl) ldh = 4;
     if (rows < 1 || n_out % 64 != 0 || n_in % GP_TN != 0 || ldu % 4 != 0 || ldh % 4 != 0 || ksplits < 1) {
         gpde_set_error("gpde_gemm_f16s_tn: unsupported shape rows=%d n_out=%d n_in=%d", rows, n_out, n_in);
         return GPDE_EUNSUPPORTED;
@@ -595,11 +693,19 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
     // column maxima of dU: given by the caller when another pass over dU has already collected them (k_colsum)
     if (du_absmax_bits) GP_HIP_CHECK(hipMemcpyAsync(bits, du_absmax_bits, (size_t)n_out * 4, hipMemcpyDeviceToDevice, stream));
     else hipLaunchKernelGGL(k_colabsmax, dim3((n_out + 255) / 256, splits), dim3(256), 0, stream, dU, rows, n_out, ldu, splits, bits);
-    hipLaunchKernelGGL(k_colabsmax, dim3((n_in + 255) / 256, splits), dim3(256), 0, stream, H, rows, n_in, ldh, splits, bits + n_out);
     hipLaunchKernelGGL(k_scales_from_max, dim3((n_out + 255) / 256), dim3(256), 0, stream, bits, n_out, sca, isca);
-    hipLaunchKernelGGL(k_scales_from_max, dim3((n_in + 255) / 256), dim3(256), 0, stream, bits + n_out, n_in, scb, ucolb);
     hipLaunchKernelGGL(k_transpose_pad, dim3(epad / 64, n_out / 64), dim3(256), 0, stream, dU, rows, ldu, At, epad);
-    hipLaunchKernelGGL(k_pack_split_kn, dim3(epad / 32, n_in / 128), dim3(256), 0, stream, H, rows, ldh, scb, epad / 32, Bimg);
+    if (fl) {
+        int nb = (rows + 31) / 32; if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(k_attr_absmax8, dim3(nb), dim3(256), 0, stream, fl->H0, rows, fl->ld0, bits + n_out);
+        hipLaunchKernelGGL(k_first_layer_scales, dim3((n_in + 255) / 256), dim3(256), 0, stream, fl->Wp, fl->ldw, fl->bp,
+                           bits + n_out, n_in, scb, ucolb);
+        hipLaunchKernelGGL(k_first_layer_pack, dim3(epad / 32, n_in / 128), dim3(256), 0, stream, *fl, rows, n_in, scb, epad / 32, Bimg);
+    } else {
+        hipLaunchKernelGGL(k_colabsmax, dim3((n_in + 255) / 256, splits), dim3(256), 0, stream, H, rows, n_in, ldh, splits, bits + n_out);
+        hipLaunchKernelGGL(k_scales_from_max, dim3((n_in + 255) / 256), dim3(256), 0, stream, bits + n_out, n_in, scb, ucolb);
+        hipLaunchKernelGGL(k_pack_split_kn, dim3(epad / 32, n_in / 128), dim3(256), 0, stream, H, rows, ldh, scb, epad / 32, Bimg);
+    }
     GP_LAUNCH_CHECK("gpde_gemm_f16s_tn operand kernels");
     GpdeGemmF16sArgs g{};
     g.A = At; g.lda = epad; g.M = n_out; g.bsplit = Bimg; g.ucol = ucolb; g.mask = nullptr; g.ldmask = 0;

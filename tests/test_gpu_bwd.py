@@ -137,3 +137,31 @@ def test_dw2_split_gemm_at_headline_widths_agrees_with_fp32(monkeypatch):
     assert not torch.equal(gW[1], fW[1])
     assert rel_l2(gW[1].cpu(), fW[1].cpu()) <= 2e-6, rel_l2(gW[1].cpu(), fW[1].cpu())
     assert torch.isfinite(gW[1]).all()
+
+
+def test_first_hidden_layer_is_not_materialised_and_changes_only_the_dw2_rounding(monkeypatch):
+    """Round 3: from 8192 edges per chunk on, H_1 is never written - dW_2's operand image is generated from the attribute
+    slots (k_first_layer_pack, scales from an a-priori bound instead of measured column maxima) and the ReLU mask of dU_1
+    travels as bits.  Same fmaf chain as the tensor it replaces: the mask, hence dU_1, dW_1, db_1, are bit-identical;
+    dW_2 differs only by the rounding of differently scaled operands."""
+    dims, n, e = [6, 256, 384, 4096], 300, 21000
+    x, ei, ea, ws_, bs_, root, bias, gout = _case(dims, n, e, 81)
+    rx, rW, rb, rroot, rbias = _oracle_grads(x, ei, ea, ws_, bs_, root, bias, "mean", gout)
+    monkeypatch.delenv("GPDE_BWD_H1_MATERIALIZE", raising=False)
+    gx, gW, gb, groot, gbias = _native(x, ei, ea, ws_, bs_, root, gout)
+    monkeypatch.setenv("GPDE_BWD_H1_MATERIALIZE", "1")
+    fx, fW, fb, froot, fbias = _native(x, ei, ea, ws_, bs_, root, gout)
+    assert torch.equal(gx, fx)
+    for l in (0, 2):
+        assert torch.equal(gW[l], fW[l]) and torch.equal(gb[l], fb[l]), l
+    assert torch.equal(gb[1], fb[1])
+    assert rel_l2(gW[1].cpu(), fW[1].cpu()) <= 2e-6
+    rows = ((gW[1].cpu().double() - rW[1].double()).norm(dim=1) / rW[1].double().norm(dim=1))
+    assert int((rows > TOL).sum()) <= 4 and float(rows.median()) <= 2e-6, (rows.max(), rows.median())
+    # wide dynamic range of the attributes: the bound-based column scales must still leave every H_1 column its accuracy
+    ea2 = ea * torch.logspace(-2, 2, dims[0]).view(1, -1)
+    r2 = _oracle_grads(x, ei, ea2, ws_, bs_, root, bias, "mean", gout)[1]
+    monkeypatch.delenv("GPDE_BWD_H1_MATERIALIZE", raising=False)
+    g2 = _native(x, ei, ea2, ws_, bs_, root, gout)[1]
+    rows2 = ((g2[1].cpu().double() - r2[1].double()).norm(dim=1) / r2[1].double().norm(dim=1))
+    assert int((rows2 > TOL).sum()) <= 4 and float(rows2.median()) <= 2e-6, (rows2.max(), rows2.median())
