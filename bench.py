@@ -467,6 +467,28 @@ def main():
         "hbm_note": "BASELINE.json's HBM target is not the binding bound: >= 205 FLOP/B against a machine balance of 19.7",
     }
 
+    # ---- row f3 on the headline kernel: attributes read from the node table (no [E, 6] tensor, no perm) -----------
+    nodeattr = None
+    if not args.no_alt and kernel == "gpde_fused_f16v6_kernel":
+        try:
+            pos_n = synth.lattice_positions(s, dev)
+            a_n = synth.darcy_coefficient(s, rank).to(dev)
+            na = ops.NodeAttr.darcy(pos_n, a_n)
+            same_attr = bool(torch.equal(na.materialize(ei[:, :4096]), ea[:4096]))
+            out_n = torch.empty_like(out)
+            fn_n = lambda: ops.nnconv_forward_nodeattr_raw(x, csr, na, pm, conv.root, conv.bias, "mean", out=out_n, ws=ws, precision=precision)
+            ms_n = median_ms(fn_n, 3, warmup=1)
+            step()
+            nodeattr = {"ms_per_forward": round(ms_n, 2), "M_edges_per_s": round(e / ms_n / 1e3, 2),
+                        "bitwise_equal_to_tensor_path": bool(torch.equal(out_n, out)) if same_attr else None,
+                        "attr_tensor_bytes_not_read": int(ea.numel() * 4 + e * 4),
+                        "note": "gpde_nnconv_fwd_nodeattr on gpde_fused_f16v6_kernel<false, NODEATTR>: slot d of edge (j -> i) from "
+                                "node_table[(j or i)][col] (SquareMeshGenerator.attributes recipe, utilities.py:274-277)"}
+            log(f"[bench] node-table attributes: {nodeattr['ms_per_forward']} ms, {nodeattr['M_edges_per_s']} M-edges/s, "
+                f"bitwise equal: {nodeattr['bitwise_equal_to_tensor_path']}")
+        except Exception as ex:        # recorded, not fatal for the headline line
+            nodeattr = {"error": repr(ex)}
+
     # ---- the exact-fp32 arithmetic on the same inputs: median of >= 5 steps -------------------------
     alt = None
     if world == 1 and not args.no_alt:
@@ -679,6 +701,7 @@ def main():
                    "plan": plan},
         "rel_l2_sample": rel,
         "alt_precision": alt,
+        "node_table_attributes": nodeattr,
         "roofline": roofline,
         "cpu_baseline": cpu,
         "mgkn": mgkn,

@@ -63,7 +63,11 @@ constexpr int NW = 4;                      // waves per workgroup
 // WRITE_H: the store variant (gpde_hidden_fwd, the backward's recompute of H_2, the per-edge path of gpde_api.hip): the
 // hidden activations of the tile go to a.hout ([CSR slot][K2P] fp32) instead of into the aggregation; no x_j, no Z, static
 // edge ranges (rows are independent).
-template <bool WRITE_H>
+// NODEATTR (gpde_nnconv_fwd_nodeattr): the edge attributes are not a tensor - slot d of edge
+// (j -> i) is table[(sel[d] >> 8 ? i : j) * kt + (sel[d] & 255)], read from the node table (a.attr) with the tile's
+// source / destination ids (the reference builds the [E, 6] tensor from node data, utilities.py:274-277).  No `perm`,
+// no per-edge attribute traffic: the table (N x kt floats) lives in L2.
+template <bool WRITE_H, bool NODEATTR = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // ONE LDS object (cdna guide, glds trap a)
@@ -175,13 +179,27 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
     // lane l owns edge (tile start + l): its edge id, source node and 8 attribute slots; the MFMA operand
     // layout needs edge 32 b + (l & 31) in BOTH lane halves - exchanged by v_permlane32_swap in the prologue
     int perm_n = 0;
+    [[maybe_unused]] int dst_n = 0;     // NODEATTR: perm_n holds the SOURCE node of the next tile's edge, dst_n its destination
     int src_l = 0;                      // source node of edge (tile start + lane), for the x_j row DMA
     float attr_n[8];
-    auto load_perm = [&](int e0n) { perm_n = a.perm[min(e0n + lane, e_clamp)]; };
+    auto load_perm = [&](int e0n) {
+        if constexpr (NODEATTR) {
+            perm_n = a.src[min(e0n + lane, e_clamp)];
+            dst_n = a.dst[min(e0n + lane, e_clamp)];
+        } else perm_n = a.perm[min(e0n + lane, e_clamp)];
+    };
     auto load_attr = [&]() {
-        const float* ap = a.attr + (size_t)perm_n * a.k0;
+        if constexpr (NODEATTR) {
 #pragma unroll
-        for (int d = 0; d < 8; ++d) attr_n[d] = ap[min(d, a.k0 - 1)];
+            for (int d = 0; d < 8; ++d) {
+                const int sd = a.sel[d];                                     // scalar (kernel argument)
+                attr_n[d] = a.attr[(size_t)((sd >> 8) ? dst_n : perm_n) * a.kt + (sd & 255)];
+            }
+        } else {
+            const float* ap = a.attr + (size_t)perm_n * a.k0;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) attr_n[d] = ap[min(d, a.k0 - 1)];
+        }
     };
     // x_j rows of this tile: piece i = rows 4i .. 4i+3 (lane >> 4 picks the row, lane & 15 its 16-byte unit).
     // The source node comes from the lane that loaded that edge's src (ds_bpermute) at the START of a chunk,
@@ -380,6 +398,7 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
         // its four W2 pieces, and the closing wait is vmcnt(<side loads of this chunk>): the W2 pieces are
         // retired, the side loads fly for a whole chunk and are retired by the next chunk's closing wait.
         //   PH 0: next tile's edge ids, this tile's source nodes, 4 segment-end nodes (6 loads)   -> vmcnt(6)
+        //         (NODEATTR: next tile's source AND destination ids instead of the edge ids: 7 loads -> vmcnt(7))
         //   PH 1: nothing (the three loads land)                                                   -> vmcnt(0)
         //   PH 2: next tile's attributes (8 loads) + x_j rows 0..15 (4 DMA)                        -> vmcnt(12)
         //   PH 3/4/5: x_j rows 16..31 / 32..47 / 48..63 (4 DMA each)                               -> vmcnt(4)
@@ -468,7 +487,8 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                     nf_v[b] = a.dst[min(s0, e_clamp)];
                     nl_v[b] = a.dst[min(max(s1 - 1, s0), e_clamp)];
                 }
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                if constexpr (NODEATTR) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             } else if constexpr (PH == 2) {
                 load_attr();
                 x_issue(0);
@@ -664,7 +684,7 @@ extern "C" int gpde_debug_v6_timing(unsigned long long* out4, int reset) {
 // 3-Linear kernels with at least 8 k1 chunks (the side loads of a tile are spread over its first seven), attributes +
 // bias slot within one K = 8 group, split-x input (a.xs) present
 bool gpde_fused_f16v6_supported(const GpdeFusedArgs& a) {
-    return a.K1P / GP_BK >= 8 && a.k0 + 1 <= 8 && v6_lds_bytes(a.K1P) <= 160 * 1024 && a.kt == 0 &&
+    return a.K1P / GP_BK >= 8 && a.k0 + 1 <= 8 && v6_lds_bytes(a.K1P) <= 160 * 1024 && (a.kt == 0 || a.hout == nullptr) &&
            (a.hout != nullptr || a.xs != nullptr);
 }
 
@@ -673,12 +693,13 @@ int gpde_launch_fused_f16v6(const GpdeFusedArgs& a, hipStream_t stream) {
     const dim3 grid(a.n_groups * ns), block(256);
     const size_t lds = v6_lds_bytes(a.K1P);
     static GpdeLdsOnce once;
-    if (int rc = once.ensure(gpde_fused_f16v6_kernel<false>, gpde_fused_f16v6_kernel<true>)) return rc;
+    if (int rc = once.ensure(gpde_fused_f16v6_kernel<false, false>, gpde_fused_f16v6_kernel<true, false>, gpde_fused_f16v6_kernel<false, true>)) return rc;
     if (a.hout) {
         GpdeFusedArgs b = a;
         b.blk = nullptr; b.qn = nullptr; b.qctr = nullptr;             // rows are independent: static ranges
-        hipLaunchKernelGGL(gpde_fused_f16v6_kernel<true>, grid, block, lds, stream, b);
-    } else hipLaunchKernelGGL(gpde_fused_f16v6_kernel<false>, grid, block, lds, stream, a);
+        hipLaunchKernelGGL((gpde_fused_f16v6_kernel<true, false>), grid, block, lds, stream, b);
+    } else if (a.kt) hipLaunchKernelGGL((gpde_fused_f16v6_kernel<false, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((gpde_fused_f16v6_kernel<false, false>), grid, block, lds, stream, a);
     GP_LAUNCH_CHECK("gpde_fused_f16v6_kernel");
     return GPDE_OK;
 }

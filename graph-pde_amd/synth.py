@@ -82,15 +82,18 @@ def darcy_coefficient(s: int, seed: int = 0) -> torch.Tensor:
 
 
 def darcy_edge_attr(edge_index: torch.Tensor, pos: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
-    """float32 [E, 6] = [pos_src(2), pos_dst(2), a_src, a_dst]  (utilities.py:269-277)."""
+    """float32 [E, 6] = [pos_src(2), pos_dst(2), a_src, a_dst]  (utilities.py:269-277).
+
+    Built column by column from 1-D gathers.  Rounds 1-2 wrote `out[:, 0:2] = pos[src].to(float32)` (a [E, 2] float64
+    gather copied into a strided slice): on torch 2.10 + ROCm 7 that leaves ZEROS in the position columns of every row
+    past the first E - 2^26 once E exceeds 2^26 - found in round 3 when the node-table kernel (row f3), which reads the
+    positions itself, disagreed with the tensor path on the 241^2 graph (95.5 M edges).  tests/test_gpu_headline.py now
+    checks the headline tensor against the node table over ALL edges."""
     src, dst = edge_index[0], edge_index[1]
-    a = a.to(pos.device)
-    out = torch.empty(src.numel(), 6, dtype=torch.float32, device=pos.device)
-    out[:, 0:2] = pos[src].to(torch.float32)
-    out[:, 2:4] = pos[dst].to(torch.float32)
-    out[:, 4] = a[src]
-    out[:, 5] = a[dst]
-    return out
+    p32 = pos.to(torch.float32)
+    a = a.to(pos.device, torch.float32)
+    cols = [p32[src, 0], p32[src, 1], p32[dst, 0], p32[dst, 1], a[src], a[dst]]
+    return torch.stack(cols, dim=1)
 
 
 def darcy_graph(s: int, r: float, device="cpu", seed: int = 0

@@ -5,7 +5,8 @@ invariance to node chunking, bit determinism).  Tolerance: 1e-5 relative L2 (BAS
 import pytest
 import torch
 
-from graph_pde_amd import _lib, ops
+import graph_pde_amd as gp
+from graph_pde_amd import _lib, ops, synth
 from oracle.nnconv_oracle import nnconv_forward, rel_l2
 from tests.test_gpu_parity import run_native
 
@@ -94,3 +95,41 @@ def test_v6_deterministic_linear_and_chunk_invariant():
     full = ops.workspace_bytes(1200, 45000, pm)
     y_c = run_native(x, ei, ea, ws_, bs_, None, None, "add", ws_bytes=full // 3)
     assert rel_l2(y_c, y_a) <= 5e-7
+
+
+def test_node_table_attributes_in_the_one_wave_per_simd_kernel():
+    """SURVEY.md §8 row f3 on the headline kernel (round 3): gpde_fused_f16v6_kernel<false, NODEATTR> reads the attribute
+    slots from the node table through the tile's source / destination ids (no `perm`, no [E, 6] tensor) - bitwise the
+    result of the same kernel on the materialised tensor (the attribute values are the same floats), queue and static
+    ranges, and within the bar of the float64 oracle."""
+    from tests.test_host_logic import DenseNet
+    from oracle.nnconv_oracle import nnconv_forward
+    d = torch.device("cuda:0")
+    torch.manual_seed(12)
+    s, r = 61, 0.10
+    ei = synth.lattice_radius_graph(s, r, d)
+    pos = synth.lattice_positions(s, d)
+    a = synth.darcy_coefficient(s, 5).to(d)
+    ea = synth.darcy_edge_attr(ei, pos, a)
+    n = s * s
+    na = gp.NodeAttr.darcy(pos, a)
+    x = torch.randn(n, 64, device=d)
+    csr = ops.csr_for(ei, n)
+    for dims in ([6, 256, 256, 4096], [6, 1024, 1024, 4096]):
+        conv = gp.NNConv_old(64, 64, DenseNet(dims, torch.nn.ReLU), aggr="mean").to(d)
+        lin = ops.mlp_linears(conv.nn)
+        pm = ops.pack_mlp([l.weight for l in lin], [l.bias for l in lin])
+        assert ops.fused_kernel_name(n, csr.n_edges, pm, "f16split") == "gpde_fused_f16v6_kernel"
+        for prec in ("f16split", "f16split_static"):
+            y_t = ops.nnconv_forward_raw(x, csr, ea, pm, conv.root, conv.bias, "mean", precision=prec)
+            y_n = ops.nnconv_forward_nodeattr_raw(x, csr, na, pm, conv.root, conv.bias, "mean", precision=prec)
+            torch.cuda.synchronize()
+            assert torch.equal(y_t, y_n), (dims, prec, rel_l2(y_n.cpu(), y_t.cpu()))
+        y8 = ops.nnconv_forward_nodeattr_raw(x, csr, na, pm, conv.root, conv.bias, "mean", precision="f16split_8wave")
+        assert rel_l2(y8.cpu(), y_n.cpu()) <= 1e-6                     # the round-1/2 node-table kernel (8 waves)
+    rows = torch.arange(0, n, 37)
+    sel = torch.isin(ei[1].cpu(), rows)
+    ei_s, ea_s = ei[:, sel.to(d)], ea[sel.to(d)]
+    ref = nnconv_forward(x.cpu(), ei_s.cpu(), ea_s.cpu(), [l.weight.detach().cpu() for l in lin], [l.bias.detach().cpu() for l in lin],
+                         conv.root.detach().cpu(), conv.bias.detach().cpu(), aggr="mean", dtype=torch.float64, chunk_edges=8192)
+    assert rel_l2(y_n.cpu()[rows], ref[rows]) <= 1e-5
