@@ -1,0 +1,78 @@
+"""GPU tier: the N > 1 path of SURVEY.md §8(e) on hardware, as far as a 1-GPU box allows.
+
+* `python -m torch.distributed.run --nproc-per-node 1` + RCCL (backend "nccl"): process-group init on the device, the flat
+  broadcast, one NNConv training step, the flat gradient all-reduce - gradients bit-equal to the single-process step.
+* world size 2 on the ONE GPU over gloo (RCCL refuses two ranks on one device): each rank packs its own weights first, then
+  takes rank 0's through `broadcast_parameters`; the averaged gradients must be those of the two samples under rank 0's
+  weights - i.e. the pack / hidden caches did not serve pre-broadcast weights, and sharding + all-reduce
+  compose with the native operator.
+No scaling figure is measured here (one GPU)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(REPO, "tests", "helpers", "ddp_step.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(nproc, backend, out):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPDE_HIDDEN_CACHE="off")   # one backward path on both sides
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), WORKER, "--backend", backend, "--out", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return torch.load(out, weights_only=False)
+
+
+def _reference(world):
+    from graph_pde_amd import hidden_cache, ops
+    from tests.helpers import ddp_step
+    dev = torch.device("cuda:0")
+    ops.clear_caches()
+    hidden_cache.clear()
+    mode0, hidden_cache.MODE = hidden_cache.MODE, "off"
+    model = ddp_step.build(1000, dev)
+    grads, losses = None, []
+    for k in range(world):
+        ei, ea, a_in, y = ddp_step.sample(k, dev)
+        model.zero_grad(set_to_none=True)
+        loss = torch.norm(ddp_step.forward(model, a_in, ei, ea) - y, 1)
+        loss.backward()
+        losses.append(float(loss))
+        g = {n_: p.grad.detach().clone() for n_, p in model.named_parameters()}
+        grads = g if grads is None else {n_: grads[n_] + g[n_] for n_ in g}
+    hidden_cache.MODE = mode0
+    if world > 1:
+        grads = {n_: v / world for n_, v in grads.items()}
+    return {n_: v.cpu() for n_, v in grads.items()}, losses
+
+
+def test_torchrun_one_rank_over_rccl_matches_single_process(tmp_path):
+    got = _run(1, "nccl", str(tmp_path / "g.pt"))
+    ref, losses = _reference(1)
+    assert got["world"] == 1 and got["backend"] == "nccl"
+    assert got["losses"] == losses
+    for k, v in ref.items():
+        assert torch.equal(got["grads"][k], v), k
+
+
+def test_two_ranks_share_the_gpu_over_gloo_broadcast_then_allreduce(tmp_path):
+    got = _run(2, "gloo", str(tmp_path / "g2.pt"))
+    ref, losses = _reference(2)
+    assert got["world"] == 2
+    assert got["losses"] == losses                       # both ranks computed with rank 0's weights, not their own packs
+    for k, v in ref.items():
+        assert torch.equal(got["grads"][k], v), k
