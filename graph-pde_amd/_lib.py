@@ -154,6 +154,16 @@ SIGNATURES = {
     "gpde_radius_graph2_fill": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
                                                ctypes.c_double, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.c_int64, ctypes.c_void_p]),
+    "gpde_radius_csr_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "gpde_radius_csr_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                             ctypes.c_double, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double),
+                                             ctypes.POINTER(ctypes.c_double), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                             ctypes.c_void_p]),
+    "gpde_radius_csr_fill": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                            ctypes.c_double, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(ctypes.c_double), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "gpde_profile_begin": (ctypes.c_int, []),
     "gpde_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), c_i32p,
                                         ctypes.POINTER(ctypes.c_double)]),

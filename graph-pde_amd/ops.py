@@ -55,6 +55,12 @@ class Csr:
         return self._src_order
 
     @property
+    def edge_index(self) -> torch.Tensor:
+        """int64 [2, E] (source, target) in CSR SLOT order - the edge list to build per-edge tensors from when the graph
+        came from `radius_csr` (perm = identity: edge_attr rows are addressed by CSR slot)."""
+        return torch.stack([self.src.long(), self.dst.long()])
+
+    @property
     def rowptr_host(self) -> torch.Tensor:
         """Host copy of rowptr (int32, pinned lifetime = the CSR): the backward plans its edge
         chunks on the host.  One device->host copy per graph."""
@@ -849,6 +855,63 @@ def radius_graph(pos: torch.Tensor, r: float, reference_ties: bool = False,
                                                offs.data_ptr(), ei.data_ptr(), e, _stream_ptr(dev)),
                    "gpde_radius_graph2_fill")
     return ei
+
+
+def radius_csr_raw(pos: torch.Tensor, r: float, reference_ties: bool = False, pos_dst: Optional[torch.Tensor] = None):
+    """Cell-list radius graph emitted directly as a destination CSR (gpde_radius_csr_count / _fill): returns
+    (rowptr int32 [n_dst + 1], src int32 [E], dst int32 [E]) - edge (src[s] in pos -> dst[s] in pos_dst), rows in
+    ascending source order.  One sync (the edge count) per graph."""
+    lib = _lib.lib()
+    _require_cuda(pos, "pos")
+    pos = (pos.unsqueeze(1) if pos.dim() == 1 else pos).detach().to(torch.float64).contiguous()
+    if pos_dst is None:
+        pd = pos
+    else:
+        _require_cuda(pos_dst, "pos_dst")
+        pd = (pos_dst.unsqueeze(1) if pos_dst.dim() == 1 else pos_dst).detach().to(torch.float64).contiguous()
+        if pd.size(1) != pos.size(1):
+            raise ValueError("pos and pos_dst must have the same dimension")
+    n, nd, dim = int(pos.size(0)), int(pd.size(0)), int(pos.size(1))
+    dev = pos.device
+    if n == 0 or nd == 0:
+        z = torch.zeros(0, dtype=torch.int32, device=dev)
+        return torch.zeros(nd + 1, dtype=torch.int32, device=dev), z, z.clone()
+    both = pos if pd is pos else torch.cat([pos, pd])
+    lo_t, hi_t = both.min(dim=0).values.cpu(), both.max(dim=0).values.cpu()       # host bounds (one small copy)
+    lo = (ctypes.c_double * dim)(*[float(v) for v in lo_t])
+    hi = (ctypes.c_double * dim)(*[float(v) for v in hi_t])
+    flags = 1 if reference_ties else 0
+    nbytes = int(lib.gpde_radius_csr_workspace_bytes(n, dim, float(r), lo, hi))
+    if nbytes == 0:
+        _lib.check(-1, "gpde_radius_csr_workspace_bytes")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    deg = torch.empty(nd, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gpde_radius_csr_count(pos.data_ptr(), n, pd.data_ptr(), nd, dim, float(r), flags, lo, hi, deg.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), _stream_ptr(dev)), "gpde_radius_csr_count")
+    rowptr64 = torch.zeros(nd + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(deg, 0, out=rowptr64[1:])
+    e = int(rowptr64[-1].item())
+    if e >= (1 << 31) - 64:
+        raise NotImplementedError(f"{e} edges exceed the int32 CSR")
+    rowptr = rowptr64.to(torch.int32)
+    src = torch.empty(e, dtype=torch.int32, device=dev)
+    dst = torch.empty(e, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gpde_radius_csr_fill(pos.data_ptr(), n, pd.data_ptr(), nd, dim, float(r), flags, lo, hi, rowptr.data_ptr(),
+                                            src.data_ptr(), dst.data_ptr(), e, ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
+                   "gpde_radius_csr_fill")
+    return rowptr, src, dst
+
+
+def radius_csr(pos: torch.Tensor, r: float, reference_ties: bool = False) -> Csr:
+    """The radius graph of one point set as the `Csr` the operator consumes (no edge_index, no sort): rowptr / src / dst
+    are what `csr_for(radius_graph(pos, r), n)` builds - bit for bit - and `perm` is the identity: per-edge tensors for
+    this graph are laid out by CSR slot (`csr.edge_index` is the edge list in that order), or not needed at all
+    (`NodeAttr`).  Replaces ball_connectivity + the per-call index handling of PyG (utilities.py:250-255, nn_conv.py:271)."""
+    rowptr, src, dst = radius_csr_raw(pos, r, reference_ties)
+    e = int(src.numel())
+    return Csr(int(rowptr.numel()) - 1, e, rowptr, src, dst, torch.arange(e, dtype=torch.int32, device=src.device))
 
 
 def multilevel_radius_graphs(pos_levels: Sequence[torch.Tensor], radii_inner: Sequence[float],

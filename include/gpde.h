@@ -343,6 +343,22 @@ int gpde_radius_graph2_fill(const double* pos_src, int64_t n_src, const double* 
                             double r, uint32_t flags, const int64_t* offsets, int64_t* edge_index, int64_t n_edges,
                             void* stream);
 
+/* The same graphs by CELL LIST, emitted directly as the destination-sorted CSR the operator consumes (no int64 COO list,
+ * no sort by destination; O(N * neighbourhood) tests instead of O(N^2)): the source points are binned into cells of
+ * edge >= r, one wave per destination point walks the 3^dim neighbouring cells.  Pass 1 (count) builds the cell
+ * structure in `ws` and writes the in-degree of every destination; the caller forms rowptr = exclusive scan (int32
+ * [n_dst + 1]) and allocates src / dst int32 [E]; pass 2 (fill, same arguments, same untouched `ws`) writes them, each
+ * row in ascending source order - exactly what gpde_csr_from_coo makes of the reference's source-major edge list
+ * (rows longer than 4096 edges keep cell order).  lo / hi: HOST arrays [dim], a bounding box of both point sets.
+ * Edge attributes for such a graph are addressed by CSR slot (perm = identity). */
+size_t gpde_radius_csr_workspace_bytes(int64_t n_src, int dim, double r, const double* lo, const double* hi);
+int gpde_radius_csr_count(const double* pos_src, int64_t n_src, const double* pos_dst, int64_t n_dst, int dim, double r,
+                          uint32_t flags, const double* lo, const double* hi, int32_t* deg, void* ws, size_t ws_bytes,
+                          void* stream);
+int gpde_radius_csr_fill(const double* pos_src, int64_t n_src, const double* pos_dst, int64_t n_dst, int dim, double r,
+                         uint32_t flags, const double* lo, const double* hi, const int32_t* rowptr, int32_t* src,
+                         int32_t* dst, int64_t n_edges, void* ws, size_t ws_bytes, void* stream);
+
 /* HIP-event timing of the kernels launched by gpde_nnconv_fwd on the calling thread (used by
  * bench.py for the roofline figure; events are recorded on the same stream as the kernels).
  * gpde_profile_begin() arms it; gpde_profile_end() disarms it, SYNCHRONISES on the recorded

@@ -146,3 +146,15 @@ def test_weconv_descriptor_layout_matches_the_header():
     assert l.gpde_nnconv_fwd_edgeweights_group(d, 1, None) == -1 and b"descriptor 0" in l.gpde_last_error()
     assert l.gpde_edge_weights_fwd(None, -1, 3, _lib.dims_array([6, 8, 8, 4096]), None, None, None, None, None, 0, None) == -1
     assert l.gpde_edge_weights_workspace_bytes(1000, 3, _lib.dims_array([6, 256, 256, 4096])) >= 8000
+
+
+def test_cell_list_queries_validate_on_the_host():
+    l = _lib.lib()
+    D = ctypes.c_double * 2
+    lo, hi = D(0.0, 0.0), D(1.0, 1.0)
+    assert l.gpde_radius_csr_workspace_bytes(58081, 2, 0.1, lo, hi) > 4 * 4 * 58081
+    assert l.gpde_radius_csr_workspace_bytes(10, 4, 0.1, lo, hi) == 0                     # dim 1..3
+    # an absurdly fine grid is coarsened instead of allocating 1e12 cells
+    assert l.gpde_radius_csr_workspace_bytes(10, 2, 1e-9, lo, hi) < (1 << 28)
+    assert l.gpde_radius_csr_count(None, 5, None, 5, 2, 0.1, 0, lo, hi, None, None, 0, None) == -1
+    assert l.gpde_radius_csr_fill(None, 5, None, 5, 2, 0.1, 7, lo, hi, None, None, None, 0, None, 0, None) == -1

@@ -65,3 +65,78 @@ def test_multilevel_graphs_on_the_gpu_match_the_reference_generator():
         lo, hi = g["range_down"][l]
         assert np.array_equal(out["down"][l].cpu().numpy() + np.array([[offs[l]], [offs[l + 1]]]), g["edge_index_down"][:, lo:hi]), l
         assert np.array_equal(out["up"][l].cpu().numpy() + np.array([[offs[l + 1]], [offs[l]]]), g["edge_index_up"][:, lo:hi]), l
+
+
+# ---- cell-list radius graph emitted as the destination CSR (gpde_radius_csr_*, round 3) ----------------------------------
+@pytest.mark.parametrize("ties", [False, True])
+@pytest.mark.parametrize("case", ["lattice31", "lattice61", "random2d", "random3d", "line1d", "clustered"])
+def test_cell_list_csr_is_the_csr_of_the_brute_force_graph(case, ties):
+    """rowptr / src / dst of ops.radius_csr == ops.csr_for(ops.radius_graph(...)) bit for bit (rows in ascending source
+    order = a stable sort by destination of the reference's source-major list), for both distance arithmetics - the
+    reference-ties one decides the lattice pairs at exactly distance r (tests/golden/mesh_ties.npz pins radius_graph)."""
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    if case.startswith("lattice"):
+        s = int(case[7:])
+        pos, r = synth.lattice_positions(s, d), 0.10
+    elif case == "random2d":
+        pos, r = torch.rand(3000, 2, generator=g, dtype=torch.float64).to(d), 0.07
+    elif case == "random3d":
+        pos, r = torch.rand(2500, 3, generator=g, dtype=torch.float64).to(d), 0.16
+    elif case == "line1d":
+        pos, r = torch.rand(4000, 1, generator=g, dtype=torch.float64).to(d) * 3.0 - 1.0, 0.011
+    else:                                                    # most points in one cell, a few far away; a radius above the extent
+        pos = torch.cat([torch.rand(900, 2, generator=g, dtype=torch.float64) * 0.01, torch.rand(40, 2, generator=g, dtype=torch.float64) * 50.0]).to(d)
+        r = 0.004
+    n = pos.shape[0]
+    ei = ops.radius_graph(pos, r, reference_ties=ties)
+    ref = ops.build_csr(ei, n)
+    got = ops.radius_csr(pos, r, reference_ties=ties)
+    assert got.n_edges == ref.n_edges and got.n_nodes == n
+    assert torch.equal(got.rowptr, ref.rowptr) and torch.equal(got.src, ref.src) and torch.equal(got.dst, ref.dst)
+    assert torch.equal(got.perm.long(), torch.arange(got.n_edges, device=d))
+    assert torch.equal(got.edge_index, ei[:, ref.perm.long()])
+    if case == "clustered":
+        big = ops.radius_csr(pos, 100.0)                     # every pair: one cell
+        assert big.n_edges == n * n
+
+
+def test_cell_list_two_point_sets_and_long_rows():
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    ps = torch.rand(5000, 2, generator=g, dtype=torch.float64).to(d)
+    pd = torch.rand(300, 2, generator=g, dtype=torch.float64).to(d)
+    r = 0.35                                                  # rows of ~1700 sources; one destination gets > 4096 with r = 2
+    rowptr, src, dst = ops.radius_csr_raw(ps, r, pos_dst=pd)
+    ei = ops.radius_graph(ps, r, pos_dst=pd)                  # (source in ps, target in pd), source-major
+    order = torch.argsort(ei[1] * 5000 + ei[0])
+    assert int(rowptr[-1]) == ei.shape[1]
+    assert torch.equal(src.long(), ei[0][order]) and torch.equal(dst.long(), ei[1][order])
+    rowptr2, src2, dst2 = ops.radius_csr_raw(ps, 2.0, pos_dst=pd[:3])      # rows of 5000 > 4096: cell order, complete
+    assert rowptr2.tolist() == [0, 5000, 10000, 15000]
+    for k in range(3):
+        assert torch.equal(torch.sort(src2[5000 * k:5000 * (k + 1)]).values.long(), torch.arange(5000, device=d))
+
+
+def test_operator_on_the_cell_list_csr_matches_the_edge_index_path_bit_for_bit():
+    """The headline recipe end to end without an edge list: positions -> radius_csr -> attributes by CSR slot -> NNConv."""
+    from tests.test_host_logic import DenseNet
+    import graph_pde_amd as gp
+    d = torch.device("cuda:0")
+    torch.manual_seed(4)
+    s, r = 41, 0.10
+    pos = synth.lattice_positions(s, d)
+    a = synth.darcy_coefficient(s, 1).to(d)
+    n = s * s
+    ei = ops.radius_graph(pos, r)
+    ea = synth.darcy_edge_attr(ei, pos, a)
+    csr = ops.radius_csr(pos, r)
+    ea_csr = synth.darcy_edge_attr(csr.edge_index, pos, a)
+    conv = gp.NNConv_old(64, 64, DenseNet([6, 256, 256, 4096], torch.nn.ReLU), aggr="mean").to(d)
+    lin = ops.mlp_linears(conv.nn)
+    pm = ops.pack_mlp([l.weight for l in lin], [l.bias for l in lin])
+    x = torch.randn(n, 64, device=d)
+    y_ref = ops.nnconv_forward_raw(x, ops.csr_for(ei, n), ea, pm, conv.root, conv.bias, "mean")
+    y_csr = ops.nnconv_forward_raw(x, csr, ea_csr, pm, conv.root, conv.bias, "mean")
+    y_na = ops.nnconv_forward_nodeattr_raw(x, csr, gp.NodeAttr.darcy(pos, a), pm, conv.root, conv.bias, "mean")
+    assert torch.equal(y_ref, y_csr) and torch.equal(y_ref, y_na)
