@@ -49,7 +49,7 @@ __device__ __forceinline__ int lower_bound_node(const int32_t* __restrict__ rowp
 }
 
 #ifdef GPDE_V6_TIMING      // developer probe (scripts/v6_timing.py): cycles per phase summed over waves, wave-tiles
-__device__ unsigned long long gpde_v6_tm[4];
+__device__ unsigned long long gpde_v6_tm[8];      // prologue, K loop, post, tiles, peeled chunks 0-5 (part of the K loop)
 #define TM_MARK(acc) do { const long long tm1_ = clock64(); acc += tm1_ - tm0_; tm0_ = tm1_; } while (0)
 #else
 #define TM_MARK(acc) do { } while (0)
@@ -188,31 +188,25 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
             dst_n = a.dst[min(e0n + lane, e_clamp)];
         } else perm_n = a.perm[min(e0n + lane, e_clamp)];
     };
-    auto load_attr = [&]() {
+    auto load_attr_d = [&](int d) {             // one attribute slot (the K loop issues them one per MFMA gap)
         if constexpr (NODEATTR) {
-#pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                const int sd = a.sel[d];                                     // scalar (kernel argument)
-                attr_n[d] = a.attr[(size_t)((sd >> 8) ? dst_n : perm_n) * a.kt + (sd & 255)];
-            }
+            const int sd = a.sel[d];                                         // scalar (kernel argument)
+            attr_n[d] = a.attr[(size_t)((sd >> 8) ? dst_n : perm_n) * a.kt + (sd & 255)];
         } else {
-            const float* ap = a.attr + (size_t)perm_n * a.k0;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) attr_n[d] = ap[min(d, a.k0 - 1)];
+            attr_n[d] = a.attr[(size_t)perm_n * a.k0 + min(d, a.k0 - 1)];
         }
+    };
+    auto load_attr = [&]() {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) load_attr_d(d);
     };
     // x_j rows of this tile: piece i = rows 4i .. 4i+3 (lane >> 4 picks the row, lane & 15 its 16-byte unit).
     // The source node comes from the lane that loaded that edge's src (ds_bpermute) at the START of a chunk,
     // the four DMA are issued at its END, behind the chunk's W2 pieces (see the K loop).
     int xsidx[4];
-    auto x_addr = [&](int i0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xsidx[i] = __builtin_amdgcn_ds_bpermute((4 * (i0 + i) + (lane >> 4)) * 4, src_l);
-    };
-    auto x_issue = [&](int i0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            GPDE_GLDS(a.xs + (size_t)xsidx[i] * GP_W + (lane & 15) * 4, Xs + (i0 + i) * 4 * GP_W, 0);
+    auto x_addr1 = [&](int i0, int i) { xsidx[i] = __builtin_amdgcn_ds_bpermute((4 * (i0 + i) + (lane >> 4)) * 4, src_l); };
+    auto x_issue1 = [&](int i0, int i) {
+        GPDE_GLDS(a.xs + (size_t)xsidx[i] * GP_W + (lane & 15) * 4, Xs + (i0 + i) * 4 * GP_W, 0);
     };
 
     // ---- conversions and H1 generation (asm: see the header) ----------------------------------------------
@@ -293,7 +287,7 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
     int slot = 0;           // ring slot of the current chunk
 
 #ifdef GPDE_V6_TIMING
-    long long tm_pro = 0, tm_loop = 0, tm_post = 0, tm0_ = clock64();
+    long long tm_pro = 0, tm_loop = 0, tm_post = 0, tm_peel = 0, tm0_ = clock64();
 #endif
     int e0 = have ? blk_a : e_hi;
     int n_rounds = 0;
@@ -419,7 +413,6 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
             int c1 = c + 2;                                               // (W1|b1) rows read in this chunk: chunk c + 2
             if (c1 >= NKC) c1 -= NKC;
             const char* w1n = w1s + (size_t)(c1 * GP_BK + l31) * 32;
-            if constexpr (!WRITE_H && PH >= 2 && PH <= 5) x_addr(4 * (PH - 2));      // consumes src_l (loaded two chunks ago)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int cbuf = m;                                       // operand buffer of this step
@@ -457,6 +450,34 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                             if (i == 14) GPDE_GLDS(gsrc, ldst, 2048);
                             if (i == 20) GPDE_GLDS(gsrc, ldst, 3072);
                         }
+                        // The tile's side loads, ONE PER MFMA GAP of step 1 - i.e. behind the chunk's four W2 pieces, so
+                        // that the counted wait at the chunk end retires exactly those (round 3: issued as one block after
+                        // the last MFMA they cost ~570 cycles in each of the six peeled chunks, the matrix pipe idling
+                        // while ~60 address / load instructions went out).  The x_j row addresses (ds_bpermute of the
+                        // source ids loaded two chunks earlier) go into the gaps of step 0.
+                        if constexpr (!WRITE_H && PH == 0) {
+                            if (m == 1) {
+                                if (i == 2) load_perm(e0n);
+                                if (i == 5) src_l = a.src[min(e0 + lane, e_clamp)];
+                                if (i == 8) nf_v[0] = a.dst[min(e0, e_clamp)];
+                                if (i == 11) nl_v[0] = a.dst[min(max(min(e0 + 32, eb) - 1, e0), e_clamp)];
+                                if (i == 14) nf_v[1] = a.dst[min(e0 + 32, e_clamp)];
+                                if (i == 17) nl_v[1] = a.dst[min(max(min(e0 + 64, eb) - 1, e0 + 32), e_clamp)];
+                            }
+                        } else if constexpr (WRITE_H && PH == 0) {
+                            if (m == 1 && i == 2) load_perm(e0n);
+                        }
+                        if constexpr (PH == 2) {
+                            if (m == 1 && (i & 1) == 1 && i < 16) load_attr_d(i >> 1);
+                        }
+                        if constexpr (!WRITE_H && PH >= 2 && PH <= 5) {
+                            if (m == 0 && (i == 1 || i == 4 || i == 7 || i == 10)) x_addr1(4 * (PH - 2), (i - 1) / 3);
+                            if constexpr (PH == 2) {
+                                if (m == 1 && (i == 17 || i == 19 || i == 21 || i == 23)) x_issue1(0, (i - 17) / 2);
+                            } else {
+                                if (m == 1 && (i == 3 || i == 9 || i == 15 || i == 21)) x_issue1(4 * (PH - 2), (i - 3) / 6);
+                            }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -470,35 +491,15 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if constexpr (WRITE_H && PH == 0) {
-                load_perm(e0n);
-                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            } else if constexpr (WRITE_H && PH == 2) {
-                load_attr();
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            } else if constexpr (WRITE_H) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else if constexpr (PH == 0) {
-                load_perm(e0n);
-                src_l = a.src[min(e0 + lane, e_clamp)];
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int s0 = e0 + 32 * b, s1 = min(s0 + 32, eb);
-                    nf_v[b] = a.dst[min(s0, e_clamp)];
-                    nl_v[b] = a.dst[min(max(s1 - 1, s0), e_clamp)];
-                }
-                if constexpr (NODEATTR) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            } else if constexpr (PH == 2) {
-                load_attr();
-                x_issue(0);
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            } else if constexpr (PH >= 3 && PH <= 5) {
-                x_issue(4 * (PH - 2));
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            // closing wait: the chunk's W2 pieces are retired, its side loads (issued behind them, above) stay in flight
+            if constexpr (WRITE_H && PH == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if constexpr (WRITE_H && PH == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (WRITE_H) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (PH == 0 && NODEATTR) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else if constexpr (PH == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (PH == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if constexpr (PH >= 3 && PH <= 5) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             slot = slot1;
@@ -509,6 +510,9 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
         chunk(std::integral_constant<int, 3>{}, 3);
         chunk(std::integral_constant<int, 4>{}, 4);
         chunk(std::integral_constant<int, 5>{}, 5);
+#ifdef GPDE_V6_TIMING
+        tm_peel += clock64() - tm0_;
+#endif
         for (int c = 6; c < NKC; ++c) chunk(std::integral_constant<int, 6>{}, c);
 
 
@@ -660,6 +664,7 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
         atomicAdd(&gpde_v6_tm[1], (unsigned long long)tm_loop);
         atomicAdd(&gpde_v6_tm[2], (unsigned long long)tm_post);
         atomicAdd(&gpde_v6_tm[3], (unsigned long long)n_rounds);
+        atomicAdd(&gpde_v6_tm[4], (unsigned long long)tm_peel);
     }
 #endif
 }
@@ -671,11 +676,11 @@ size_t v6_lds_bytes(int K1P) {
 }  // namespace
 
 #ifdef GPDE_V6_TIMING
-extern "C" int gpde_debug_v6_timing(unsigned long long* out4, int reset) {
-    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(gpde_v6_tm), 32) != hipSuccess) return -1;
+extern "C" int gpde_debug_v6_timing(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gpde_v6_tm), 64) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[4] = {0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(gpde_v6_tm), z, 32) != hipSuccess) return -1;
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gpde_v6_tm), z, 64) != hipSuccess) return -1;
     }
     return 0;
 }

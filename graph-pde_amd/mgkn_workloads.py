@@ -116,7 +116,9 @@ def general_darcy(device, s: int = 421, depth: int = 5, ker_width: int = 256, se
                         xx = F.relu(xx + down[l](xx, gd[l][0], gd[l][1]))
                 for l in reversed(range(L)):
                     a, b = offs[l], offs[l + 1]
-                    xx = xx.clone()
+                    if xx is x0:                    # never write into the caller's tensor (the script's x is its own fc_in output)
+                        xx = xx.clone()
+                    # in place on the running state, input slice cloned - as the script does (MGKN_general_darcy2d.py:84-86)
                     xx[a:b] = inner[l](xx[a:b].clone(), g["inner"][l][0], g["inner"][l][1])
                     if l > 0:
                         if fused_glue:

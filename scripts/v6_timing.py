@@ -29,7 +29,7 @@ out = torch.empty(n, 64, device=dev)
 lib = _lib.lib()
 fn = lib.gpde_debug_v6_timing
 fn.restype, fn.argtypes = ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
-buf = (ctypes.c_ulonglong * 4)()
+buf = (ctypes.c_ulonglong * 8)()
 for _ in range(2):
     ops.nnconv_forward_raw(x, csr, ea, pm, conv.root, conv.bias, "mean", out=out, ws=ws, precision="f16split")
 torch.cuda.synchronize()
@@ -40,9 +40,10 @@ ops.nnconv_forward_raw(x, csr, ea, pm, conv.root, conv.bias, "mean", out=out, ws
 t1.record()
 torch.cuda.synchronize()
 fn(buf, 1)
-pro, loop, post, tiles = [int(v) for v in buf]
+pro, loop, post, tiles, peel = [int(v) for v in buf][:5]
 tot = pro + loop + post
 nkc = (kw + 31) // 32
 print(f"{cfg} k={kw}: {t0.elapsed_time(t1):.2f} ms  wave-tiles {tiles}  ticks per wave-tile: prologue {pro/tiles:.0f}  "
       f"K-loop {loop/tiles:.0f} ({loop/tiles/nkc:.0f} per chunk; MFMA floor 1664)  un-scale+aggregation {post/tiles:.0f}  total {tot/tiles:.0f}")
+print(f"K loop split: peeled chunks 0-5 {peel/tiles/6:.0f} per chunk, steady chunks {(loop-peel)/tiles/(nkc-6):.0f} per chunk")
 print(f"shares: prologue {pro/tot:.3f}  K-loop {loop/tot:.3f}  post {post/tot:.3f}")
