@@ -22,7 +22,7 @@ for the median).  Objects on the line:
                 `algorithmic_ratio` = the reference formulation's FLOPs (10,506,304 per edge at 1024^2) at the
                 same duration / the fp32 MFMA peak - above 1 because the kernel re-associates the last layer
                  and runs the hidden layer on the f16 pipe; NOT a roofline fraction.  `traffic` =
-                HBM-side bytes per launch from the PMC record of THIS kernel symbol in profiles/traffic_r02.json
+                HBM-side bytes per launch from the PMC record of THIS kernel symbol in profiles/traffic_r03.json
                 (null when the record is of another kernel), next to the algorithmic bytes per launch.
   alt_precision the exact-fp32 arithmetic (every contraction on fp32 MFMA) on the same inputs: median of >= 5
                 steps, and the distance between the two outputs.
@@ -64,7 +64,11 @@ CONFIGS = {
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_FILE = os.path.join(REPO, "profiles", "traffic_r02.json")
+# What a bare v_mfma_f32_32x32x16_f16 stream sustains on this chip (scripts/ubench/kloop_model_v6.hip, "48 MFMA only" /
+# full K-loop model rows of profiles/r03_kloop_model_power.txt: 1.64 - 1.76 PFLOP/s, the clock falling to ~1.6 GHz under a
+# 100 % busy matrix pipe).  Reported NEXT TO `frac` (which stays against the nominal dense peak), never instead of it.
+SUSTAINED_F16_MFMA_TFLOPS = 1700.0
+TRAFFIC_FILE = os.path.join(REPO, "profiles", "traffic_r03.json")
 
 
 def log(*a):
@@ -102,7 +106,7 @@ def executed_flops_per_edge(dims, kernel, agg_f16, w=64):
 def traffic_record(config, kw, kernel):
     """HBM-side traffic of `kernel` from the committed PMC record, or (None, reason)."""
     if not os.path.exists(TRAFFIC_FILE):
-        return None, "no profiles/traffic_r02.json"
+        return None, "no profiles/traffic_r03.json"
     try:
         tj = json.load(open(TRAFFIC_FILE))
     except Exception as ex:       # noqa: BLE001
@@ -445,6 +449,11 @@ def main():
     roofline = {
         "kernel": kernel, "bound": "mfma", "pipe": "f16 MFMA (2-term split operands, fp32 accumulate)" if on_f16 else "fp32 MFMA",
         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+        "sustained_mfma_tflops": SUSTAINED_F16_MFMA_TFLOPS if on_f16 else None,
+        "frac_of_sustained": round(achieved / SUSTAINED_F16_MFMA_TFLOPS, 4) if on_f16 else None,
+        "sustained_note": "power-governed chip: a bare f16 MFMA stream measures 1.64-1.76 PFLOP/s here (profiles/r03_kloop_model_power.txt); "
+                          "removing 3.2 % of this kernel's cycles changed its time by 0.0 % (profiles/r03_fwd_sideload_interleave_ab.txt)"
+                          if on_f16 else None,
         "traffic": traffic, "traffic_source": src if rec is not None else None,
         "traffic_note": None if rec is not None else src,
         "traffic_detail": rec,
