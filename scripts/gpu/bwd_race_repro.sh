@@ -1,3 +1,9 @@
+# Round 3: proof of the root cause of round 2's intermittent wrong grad_W1 - record: profiles/r03_bwd_race_repro.log.
+# libgpde_repro.so was a one-off build of the ROUND-2 buffer plan (csrc/gpde_bwd.hip: `int nb_ = 0;` in mlp_backward, the
+# overlap guards of gpde_launch_gemm / gpde_launch_gemm_f16s_nt disabled) made with
+#     GPDE_BUILD_SUFFIX=_repro python graph-pde_amd/build.py
+# from a temporarily edited tree; it is not kept.  With GPDE_DEBUG_SKEW_US (odd column slices start 150 us late) that build
+# fails 8 of 8 cases; the fixed library returns the bits of the unskewed run.
 O=gpurun_out/r3_01
 mkdir -p $O
 echo "== repro lib (round-2 buffer plan, guards off) under skew" > $O/repro.log

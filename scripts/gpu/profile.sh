@@ -4,7 +4,7 @@
 # gpurun_out/prof_<tag>/; scripts/collect_profiles.py turns it into the committed profiles/ files.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r02}
+TAG=${1:-r03}
 B="python $R/bench.py --no-cpu-baseline --no-reuse-probe --no-mgkn --no-alt --no-backward-probe"
 mkdir -p $R/gpurun_out/prof_$TAG
 cd $R

@@ -3,7 +3,7 @@
 #   smoke() -> full GPU test tier -> default bench line -> the bench under torch.distributed.run (N = 1) ->
 #   rocprofv3 passes of scripts/gpu/profile.sh -> kernel trace of the backward probe -> per-level MGKN times.
 # Raw output: gpurun_out/validate/ and gpurun_out/prof_<tag>/; scripts/collect_profiles.py makes the profiles/ files.
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=gpurun_out/validate
 mkdir -p $O
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 < /dev/null | grep -v amdgpu.ids | tail -2
