@@ -607,7 +607,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     // per-chunk buffers: per edge (hsum + 2*kmax) floats (+ KP1 + KP2 for the transposed operands of dW_2), per node
     // (2*64*K2P + 3*64) floats
     const size_t tn_edge = P->f16s_dw2 ? (size_t)P->KP[1] + P->KP[2] : 0;
-    const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0) + tn_edge + GP_W) * 4 + (P->f16s_dw2 ? P->KP[1] / 8 : 0), per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4;
+    const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0) + tn_edge + GP_W) * 4 + (P->f16s_dw2 ? P->KP[1] / 8 + (P->KP[2] / 64 + 2) * 4 + 8 : 0), per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4;
     int64_t Ec, Nc;
     // alignment of the per-chunk buffers below + the K padding of the transposed operands
     const size_t slack = 64 * 256 + (P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats(0, P->KP[2], P->KP[1], BWD_TN_KSPLITS) * 4 : 0);
@@ -819,8 +819,11 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 }
             }
             const bool tn_split = l == 2 && f16s_dw2 && rows >= 8192;
+            // one pass over dU_2 for its transposed copy, db_2, and the row scales of the dU_1 GEMM (GPDE_BWD_DU_PASSES=1:
+            // the separate k_colsum / k_row_scale_kernel passes of round 2, A/B)
+            const bool du_one_pass = tn_split && f16s_du1 && !getenv("GPDE_BWD_DU_PASSES");
             unsigned* du_bits = tn_split ? (unsigned*)F(P.off_dubits) : nullptr;
-            {   // db_l = column sums of dU_l; the same pass collects the column maxima the split dW_2 GEMM scales with
+            if (!du_one_pass) {   // db_l = column sums of dU_l; the same pass collects the column maxima the split dW_2 GEMM scales with
                 const int cb = (Kl + 255) / 256;
                 int splits = 1; while (splits < 512 && cb * splits < 2048 && rows / (splits * 2) >= 64) splits *= 2;
                 while (splits > 1 && (size_t)splits * Kl > P.part_floats) splits /= 2;
@@ -831,8 +834,10 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             if (tn_split) {
                 // dW_2 += dU_2^T . H_1 on the split-f16 GEMM (contraction over the edges: both operands transposed)
                 GpdeFirstLayerSpec fl{F(P.off_H[0]), P.KP[0], F(P.off_wp[1]), P.KP[0], F(P.off_bp[1]), (uint32_t*)F(P.off_maskbits)};
+                GpdeDuStats dst_{F(P.off_dbp[l]), F(P.off_rowsc), F(P.off_rowsc) + rows};
                 if ((rc2 = gpde_launch_gemm_f16s_tn(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, BWD_TN_KSPLITS,
-                                                    F(P.off_tnws), F(P.off_part), st, du_bits, skip_h1(rows) ? &fl : nullptr)) != GPDE_OK) return rc2;
+                                                    F(P.off_tnws), F(P.off_part), st, du_one_pass ? nullptr : du_bits,
+                                                    skip_h1(rows) ? &fl : nullptr, du_one_pass ? &dst_ : nullptr)) != GPDE_OK) return rc2;
                 if ((rc2 = gpde_launch_reduce_splits(F(P.off_part), (size_t)Kl * Kin, BWD_TN_KSPLITS, (size_t)Kl * Kin,
                                                      F(P.off_dwp[l]), 1, st)) != GPDE_OK) return rc2;
             } else if ((rc2 = gemm_tn_acc(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, F(P.off_dwp[l]), Kin,
@@ -845,7 +850,10 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 if (tn_split && skip_h1(rows)) { g.mask = nullptr; g.ldmask = 0; g.maskbits = (const uint32_t*)F(P.off_maskbits); g.ldmb = Kin / 32; }
                 // (row scales: a pass over dU_2, 3.9 ms at s=121.  Collecting the row maxima inside gpde_edge_bwd2_kernel was
                 // tried in round 3: 16 more registers spill 15 VGPRs of a kernel that sits at its 256-register limit, +5 ms.)
-                if ((rc2 = gpde_launch_gemm_f16s_nt(g, F(P.off_rowsc), st)) != GPDE_OK) return rc2;
+                if (du_one_pass) {                    // row scales left in off_rowsc by the transposing pass above
+                    g.sc = F(P.off_rowsc); g.isc = F(P.off_rowsc) + rows;
+                    if ((rc2 = gpde_launch_gemm_f16s_nt(g, nullptr, st)) != GPDE_OK) return rc2;
+                } else if ((rc2 = gpde_launch_gemm_f16s_nt(g, F(P.off_rowsc), st)) != GPDE_OK) return rc2;
                 dUc = dUo;
             } else if (l > 1) {
                 float* dUo = bufs[nb_]; nb_ ^= 1;

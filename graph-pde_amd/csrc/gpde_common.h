@@ -272,10 +272,17 @@ struct GpdeFirstLayerSpec {
     const float* bp;
     uint32_t* maskbits;                  // out: [rows][n_in / 32]
 };
+// Optional by-products of the pass that transposes dU (it reads every element once): the bias gradient and the per-row
+// scales the NEXT GEMM over dU (dU_1 = dU . W^T) needs - instead of two more passes over dU (k_colsum, k_row_scale_kernel).
+struct GpdeDuStats {
+    float* db_accumulate;                // [n_out] += column sums of dU (ordered: 64-row blocks ascending)
+    float* row_sc; float* row_isc;       // [rows] 2^(13 - E(max_k |dU[row][k]|)) and its inverse
+};
 int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H, int ldh, int n_in, int rows,
                              int ksplits, float* ws, float* part, hipStream_t stream,
                              const unsigned* du_absmax_bits = nullptr /* [n_out] column maxima of |dU| as bit patterns */,
-                             const GpdeFirstLayerSpec* first_layer = nullptr /* non-null: H is this layer (H / ldh unused) */);
+                             const GpdeFirstLayerSpec* first_layer = nullptr /* non-null: H is this layer (H / ldh unused) */,
+                             const GpdeDuStats* du_stats = nullptr);
 // split tile image of a row-major [n][k] matrix (ld = k): the W2 layout of gpde_mlp_pack for any operand
 int gpde_pack_split_nk(const float* Wnk, int n, int k, int NP, int KP, void* out, float* ucol, hipStream_t stream);
 int gpde_num_cus();

@@ -542,6 +542,64 @@ __global__ __launch_bounds__(256) void k_transpose_pad(const float* __restrict__
         dst[(size_t)c * ldd + e0 + tx] = tile[tx][ty + 4 * i];
     }
 }
+// k_transpose_pad + everything else a single read of dU can give.  A workgroup walks a strip of 1024 rows x 64 columns in
+// 16 tiles: transposed copy; column sums and maxima of the strip (registers of wave 0; one partial sum per strip, reduced
+// in strip order by the caller: deterministic; maxima by atomicMax: order-free, 1024 x strips of them); row maxima of
+// every tile into rowpart[column block][row] (no atomics: 16 partial maxima per row, folded by k_row_scales_from_parts).
+// (First version, round 3: one tile per workgroup with atomics for all three - 9.5 M atomicMax on 1024 addresses per edge
+// chunk made the backward 35 ms SLOWER than the three separate passes.)
+constexpr int TS_STRIP = 1024;
+__global__ __launch_bounds__(256) void k_transpose_stats(const float* __restrict__ src, int rows, int ld, float* __restrict__ dst,
+                                                         int ldd, int n_out, float* __restrict__ csum_part,
+                                                         unsigned* __restrict__ colbits, unsigned* __restrict__ rowpart) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c0 = blockIdx.y * 64;
+    float sacc = 0.f;
+    unsigned cm = 0u;
+    for (int e0 = blockIdx.x * TS_STRIP; e0 < min((int)(blockIdx.x + 1) * TS_STRIP, ldd); e0 += 64) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = e0 + ty + 4 * i;
+            tile[ty + 4 * i][tx] = e < rows ? src[(size_t)e * ld + c0 + tx] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = c0 + ty + 4 * i;
+            dst[(size_t)c * ldd + e0 + tx] = tile[tx][ty + 4 * i];
+        }
+        if (ty == 0) {                   // column tx: running sum (rows ascending) and maximum
+#pragma unroll 16
+            for (int r = 0; r < 64; ++r) {
+                const float v = tile[r][tx];
+                sacc += v;
+                cm = max(cm, __float_as_uint(v) & 0x7fffffffu);
+            }
+        } else if (ty == 1) {            // row tx: maximum over the tile's 64 columns
+            unsigned m = 0u;
+#pragma unroll 16
+            for (int c = 0; c < 64; ++c) m = max(m, __float_as_uint(tile[tx][c]) & 0x7fffffffu);
+            rowpart[(size_t)blockIdx.y * ldd + e0 + tx] = m;
+        }
+        __syncthreads();
+    }
+    if (ty == 0) {
+        csum_part[(size_t)blockIdx.x * n_out + c0 + tx] = sacc;
+        if (cm) atomicMax(colbits + c0 + tx, cm);
+    }
+}
+__global__ void k_row_scales_from_parts(const unsigned* __restrict__ rowpart, int nparts, int ldd, int rows, float* __restrict__ sc,
+                                        float* __restrict__ isc) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows) return;
+    unsigned m = 0u;
+    for (int p = 0; p < nparts; ++p) m = max(m, rowpart[(size_t)p * ldd + e]);
+    const int eb = (int)((m >> 23) & 0xff);
+    const bool ok = eb >= 20 && eb <= 230;
+    sc[e] = ok ? __int_as_float((267 - eb) << 23) : 1.f;
+    isc[e] = ok ? __int_as_float((eb - 13) << 23) : 1.f;
+}
 // The split tile image of gpde_pack.hip's pack_w2_f16split_kernel for B[n][k] = H[k][n] * sc[n] (H row-major [rows][ld],
 // k = the edge): workgroup = one 16 KiB tile (slice of 128 n, chunk of 32 k), thread = (n, k16 step m).
 __global__ __launch_bounds__(256) void k_pack_split_kn(const float* __restrict__ H, int rows, int ld,
@@ -661,13 +719,15 @@ __global__ __launch_bounds__(256) void k_first_layer_pack(GpdeFirstLayerSpec f, 
 
 size_t gpde_gemm_f16s_tn_ws_floats(int rows_max, int n_out, int n_in, int ksplits) {
     const size_t epad = (size_t)rows_max + 64 * (size_t)ksplits;
-    return epad * n_out + epad * n_in + 3 * (size_t)(n_out + n_in) + 64;
+    return epad * n_out + epad * n_in + 3 * (size_t)(n_out + n_in) + 64 +
+           (epad / 1024 + 2) * (size_t)n_out + (size_t)(n_out / 64 + 1) * epad + 64;   // GpdeDuStats: column-sum partials per
+                                                                                          // 1024-row strip, row maxima per column block
 }
 
 // part[s][n_out][n_in] (s < ksplits, stride n_out * n_in) = partial sums of dU^T . H over the K splits
 int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H, int ldh, int n_in, int rows,
                              int ksplits, float* ws, float* part, hipStream_t stream, const unsigned* du_absmax_bits,
-                             const GpdeFirstLayerSpec* fl) {
+                             const GpdeFirstLayerSpec* fl, const GpdeDuStats* st_) {
     if (fl && (!fl->H0 || !fl->Wp || !fl->bp || !fl->maskbits || fl->ld0 < 8 || fl->ldw < 8)) {
         gpde_set_error("gpde_gemm_f16s_tn: incomplete first-layer spec");
         return GPDE_EINVAL;
@@ -687,14 +747,28 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
     float* scb = isca + n_out;
     float* ucolb = scb + n_in;
     unsigned* bits = (unsigned*)(ucolb + n_in);                // [n_out + n_in]
+    const int nstrip = (epad + TS_STRIP - 1) / TS_STRIP;
+    float* csum_part = (float*)(bits + n_out + n_in) + 16;    // [nstrip][n_out]   (GpdeDuStats)
+    unsigned* rowpart = (unsigned*)(csum_part + (size_t)nstrip * n_out);        // [n_out / 64][epad]
     GP_HIP_CHECK(hipMemsetAsync(bits, 0, (size_t)(n_out + n_in) * 4, stream));
     int splits = 1;
     while (splits < 256 && rows / (splits * 2) >= 64) splits *= 2;
     // column maxima of dU: given by the caller when another pass over dU has already collected them (k_colsum)
-    if (du_absmax_bits) GP_HIP_CHECK(hipMemcpyAsync(bits, du_absmax_bits, (size_t)n_out * 4, hipMemcpyDeviceToDevice, stream));
-    else hipLaunchKernelGGL(k_colabsmax, dim3((n_out + 255) / 256, splits), dim3(256), 0, stream, dU, rows, n_out, ldu, splits, bits);
-    hipLaunchKernelGGL(k_scales_from_max, dim3((n_out + 255) / 256), dim3(256), 0, stream, bits, n_out, sca, isca);
-    hipLaunchKernelGGL(k_transpose_pad, dim3(epad / 64, n_out / 64), dim3(256), 0, stream, dU, rows, ldu, At, epad);
+    if (st_) {
+        // ONE pass over dU: transposed copy, column sums (-> bias gradient), column maxima (-> scales of the A rows here),
+        // row maxima (-> row scales of the dU . W^T GEMM that follows)
+        hipLaunchKernelGGL(k_transpose_stats, dim3(nstrip, n_out / 64), dim3(256), 0, stream, dU, rows, ldu, At, epad, n_out,
+                           csum_part, bits, rowpart);
+        if (int rc = gpde_launch_reduce_splits(csum_part, (size_t)n_out, nstrip, (size_t)n_out, st_->db_accumulate, 1, stream)) return rc;
+        hipLaunchKernelGGL(k_row_scales_from_parts, dim3((rows + 255) / 256), dim3(256), 0, stream, rowpart, n_out / 64, epad, rows,
+                           st_->row_sc, st_->row_isc);
+        hipLaunchKernelGGL(k_scales_from_max, dim3((n_out + 255) / 256), dim3(256), 0, stream, bits, n_out, sca, isca);
+    } else {
+        if (du_absmax_bits) GP_HIP_CHECK(hipMemcpyAsync(bits, du_absmax_bits, (size_t)n_out * 4, hipMemcpyDeviceToDevice, stream));
+        else hipLaunchKernelGGL(k_colabsmax, dim3((n_out + 255) / 256, splits), dim3(256), 0, stream, dU, rows, n_out, ldu, splits, bits);
+        hipLaunchKernelGGL(k_scales_from_max, dim3((n_out + 255) / 256), dim3(256), 0, stream, bits, n_out, sca, isca);
+        hipLaunchKernelGGL(k_transpose_pad, dim3(epad / 64, n_out / 64), dim3(256), 0, stream, dU, rows, ldu, At, epad);
+    }
     if (fl) {
         int nb = (rows + 31) / 32; if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(k_attr_absmax8, dim3(nb), dim3(256), 0, stream, fl->H0, rows, fl->ld0, bits + n_out);
