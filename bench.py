@@ -478,7 +478,7 @@ def main():
 
     # ---- row f3 on the headline kernel: attributes read from the node table (no [E, 6] tensor, no perm) -----------
     nodeattr = None
-    if not args.no_alt and kernel == "gpde_fused_f16v6_kernel":
+    if world == 1 and not args.no_alt and kernel == "gpde_fused_f16v6_kernel":
         try:
             pos_n = synth.lattice_positions(s, dev)
             a_n = synth.darcy_coefficient(s, rank).to(dev)

@@ -296,3 +296,34 @@ def test_module_derives_message_passing_and_accepts_new_pyg_root_key():
     gp.NNConv_old(64, 64, torch.nn.Linear(6, 4096), aggr="max")                              # constructible (nn_conv.py:222-224)
     with pytest.raises(ValueError):
         gp.NNConv_old(64, 64, torch.nn.Linear(6, 4096), aggr="median")
+
+
+def test_edge_weight_cache_policy_is_opt_in_and_bounded(monkeypatch):
+    """hidden_cache.edge_weights_qualify: off by default for plain module calls; the explicit grouped API
+    and aggr='max' do not consult the switch; low in-degree or small calls only; byte budget."""
+    from graph_pde_amd import hidden_cache
+
+    class C:
+        def __init__(self, n, e):
+            self.n_nodes, self.n_edges = n, e
+    assert hidden_cache.WE_MODE in ("off", "auto")
+    monkeypatch.setattr(hidden_cache, "WE_MODE", "off")
+    assert not hidden_cache.edge_weights_qualify(C(8192, 16384))
+    assert hidden_cache.edge_weights_qualify(C(8192, 16384), explicit=True)              # in-degree 2: Burgers level 0
+    assert hidden_cache.edge_weights_qualify(C(400, 7732), explicit=True)                # <= 8192 edges whatever the degree
+    assert not hidden_cache.edge_weights_qualify(C(2400, 131904), explicit=True)         # Darcy inner level 0: Z path
+    assert not hidden_cache.edge_weights_qualify(C(10, 0), explicit=True, force=True)
+    monkeypatch.setattr(hidden_cache, "WE_MODE", "auto")
+    assert hidden_cache.edge_weights_qualify(C(8192, 16384))
+    monkeypatch.setattr(hidden_cache, "WE_BUDGET_BYTES", 16384 * 1000)
+    assert not hidden_cache.edge_weights_qualify(C(8192, 16384)) and hidden_cache.edge_weights_qualify(C(500, 1000))
+    monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", 16384 * 2000)
+    assert hidden_cache.edge_weights_qualify(C(10, 2000), force=True) and not hidden_cache.edge_weights_qualify(C(10, 2001), force=True)
+
+
+def test_nnconv_group_argument_checks_without_a_gpu():
+    conv = gp.NNConv(64, 64, DenseNet([4, 16, 16, 4096], torch.nn.ReLU), aggr="mean")
+    x, ei, ea = torch.randn(5, 64), torch.tensor([[0, 1], [1, 2]]), torch.randn(2, 4)
+    with pytest.raises(ValueError, match="activation"):
+        gp.nnconv_group([(conv, x, ei, ea, None, "tanh")])
+    assert gp.nnconv_group([]) == []
