@@ -152,7 +152,10 @@ int gpde_nnconv_fwd_plan(int64_t n_nodes, int64_t n_edges, int n_layers, const i
  * `n_edges` edges, this kernel MLP and these flags: "gpde_fused_f16v6_kernel" (one wave per SIMD, 64 x 128
  * wave tile; GPDE_FWD_F16SPLIT from 32768 edges on), "gpde_fused_f16v3_kernel" (8 waves; smaller graphs,
  * GPDE_FWD_F16SPLIT_8WAVE) or "gpde_fused_kernel" (fp32 MFMA; 2-Linear and >= 4-Linear kernels).  Host-side
- * query, no device work; static storage.  bench.py keys its rocprofv3 / PMC records on this name. */
+ * query, no device work; static storage.  bench.py keys its rocprofv3 / PMC records on this name.
+ * It names the kernel of the RE-ASSOCIATED path; a low in-degree graph (mean in-degree <= 4, >= 4096 edges, k2 >= 256,
+ * one node chunk: DESIGN.md §3e) runs the store variant of the same kernel family plus gpde_gemm_f16s_nt_kernel instead -
+ * whether it does depends on the node count and the workspace, which this query does not see. */
 const char* gpde_nnconv_fwd_kernel(int64_t n_edges, int n_layers, const int32_t* dims, uint32_t flags);
 
 /* ---------------------------------------------------------------------------------------------
