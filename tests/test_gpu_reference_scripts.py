@@ -40,7 +40,7 @@ def _run(name, sets, timeout=1500):
 
 def _floats_after(line, key):
     tail = line.split(key, 1)[1].replace(",", " ").split()
-    return float(tail[0])
+    return float(tail[0].replace("tensor(", "").rstrip(")"))          # the script prints CPU tensors as `tensor(0.0398)`
 
 
 @pytest.mark.skipif(not _have("UAI1_full_resolution.py"), reason="reference scripts not staged on this box")
