@@ -133,3 +133,42 @@ def test_node_table_attributes_in_the_one_wave_per_simd_kernel():
     ref = nnconv_forward(x.cpu(), ei_s.cpu(), ea_s.cpu(), [l.weight.detach().cpu() for l in lin], [l.bias.detach().cpu() for l in lin],
                          conv.root.detach().cpu(), conv.bias.detach().cpu(), aggr="mean", dtype=torch.float64, chunk_edges=8192)
     assert rel_l2(y_n.cpu()[rows], ref[rows]) <= 1e-5
+
+
+def test_attributes_in_slot_order_are_a_pure_layout_change(monkeypatch):
+    """ops.attr_in_slot_order (round 3): edge_attr rows gathered into CSR slot order once per (graph, edge_attr), perm -> identity.
+    Same values, same summation order: forward and every gradient are bit-identical to the indirect addressing; the copy is
+    cached on the CSR and follows in-place changes of edge_attr (version counter)."""
+    from tests.test_host_logic import DenseNet
+    d = torch.device("cuda:0")
+    torch.manual_seed(21)
+    ei, ea, n = synth.darcy_graph(61, 0.10, device=d, seed=3)
+    x = torch.randn(n, 64, device=d)
+    conv = gp.NNConv_old(64, 64, DenseNet([6, 256, 256, 4096], torch.nn.ReLU), aggr="mean").to(d)
+    lin = ops.mlp_linears(conv.nn)
+    ws_, bs_ = [l.weight.detach() for l in lin], [l.bias.detach() for l in lin]
+    pm = ops.pack_mlp(ws_, bs_)
+    g = torch.randn(n, 64, device=d)
+
+    def run():
+        csr = ops.build_csr(ei, n)
+        y = ops.nnconv_forward_raw(x, csr, ea, pm, conv.root, conv.bias, "mean")
+        gr = ops.nnconv_backward_raw(x, csr, ea, ws_, bs_, conv.root.detach(), "mean", g)
+        return csr, y, gr
+    monkeypatch.setattr(ops, "ATTR_SLOT_ORDER", False)
+    _, y0, g0 = run()
+    monkeypatch.setattr(ops, "ATTR_SLOT_ORDER", True)
+    csr, y1, g1 = run()
+    assert csr._attr_sorted is not None and len(csr._attr_sorted) == 1
+    assert torch.equal(y0, y1) and torch.equal(g0[0], g1[0])
+    for l in range(3):
+        assert torch.equal(g0[1][l], g1[1][l]) and torch.equal(g0[2][l], g1[2][l])
+    srt = next(iter(csr._attr_sorted.values()))[1]
+    assert torch.equal(srt, ea[csr.perm.long()])
+    ea2 = ea.clone()
+    y_a = ops.nnconv_forward_raw(x, csr, ea2, pm, conv.root, conv.bias, "mean")
+    ea2.mul_(1.5)                                             # in place: new version -> new gathered copy
+    y_b = ops.nnconv_forward_raw(x, csr, ea2, pm, conv.root, conv.bias, "mean")
+    monkeypatch.setattr(ops, "ATTR_SLOT_ORDER", False)
+    y_c = ops.nnconv_forward_raw(x, csr, ea2, pm, conv.root, conv.bias, "mean")
+    assert torch.equal(y_a, y1) and torch.equal(y_b, y_c) and not torch.equal(y_a, y_b)
