@@ -24,7 +24,9 @@ class NNConvFunction(torch.autograd.Function):
         # a prebuilt ops.Csr (message() / update(): one-off graphs that must not enter the CSR cache) or edge_index
         csr = edge_index if isinstance(edge_index, ops.Csr) else ops.csr_for(edge_index, x.size(0))
         pm = ops.pack_mlp(weights, biases)
-        out = ops.nnconv_forward_raw(x.detach(), csr, edge_attr.detach(), pm, root, bias, aggr)
+        # training: keep Z for the backward's dW_3 (ops.z_buffer: None when it does not pay / fit)
+        ctx.z = ops.z_buffer(csr, pm.dims, x.device) if any(ctx.needs_input_grad) and aggr in ("add", "mean") else None
+        out = ops.nnconv_forward_raw(x.detach(), csr, edge_attr.detach(), pm, root, bias, aggr, z_keep=ctx.z)
         ctx.csr, ctx.aggr, ctx.n_layers = csr, aggr, n_layers
         ctx.has_bias = bias is not None
         ctx.attr_needs_grad = edge_attr.requires_grad
@@ -42,7 +44,8 @@ class NNConvFunction(torch.autograd.Function):
         weights, biases = list(params[:n]), list(params[n:])
         gx, gW, gb, groot, gbias = ops.nnconv_backward_raw(
             x, ctx.csr, edge_attr, weights, biases, root, ctx.aggr, grad_out,
-            need_root=root is not None, need_bias=ctx.has_bias)
+            need_root=root is not None, need_bias=ctx.has_bias, z_saved=ctx.z)
+        ctx.z = None
         return (gx, None, None, groot, gbias if ctx.has_bias else None, None, None, *gW, *gb)
 
 
@@ -89,7 +92,8 @@ class NNConvHiddenFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, hidden, csr, pm, w_last, b_last, root, bias, aggr, hmax=None):
-        out = ops.nnconv_forward_hidden_raw(x.detach(), csr, hidden.detach(), pm, root, bias, aggr, hmax=hmax)
+        ctx.z = ops.z_buffer(csr, pm.dims, x.device) if any(ctx.needs_input_grad) else None
+        out = ops.nnconv_forward_hidden_raw(x.detach(), csr, hidden.detach(), pm, root, bias, aggr, hmax=hmax, z_keep=ctx.z)
         ctx.csr, ctx.dims, ctx.aggr = csr, tuple(pm.dims), aggr
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, hidden, w_last, b_last, root)
@@ -101,5 +105,6 @@ class NNConvHiddenFunction(torch.autograd.Function):
         x, hidden, w_last, b_last, root = ctx.saved_tensors
         gx, gh, gw, gb, groot, gbias = ops.nnconv_backward_hidden_raw(
             x, ctx.csr, hidden, ctx.dims, w_last, b_last, root, ctx.aggr, grad_out,
-            need_root=root is not None, need_bias=ctx.has_bias)
+            need_root=root is not None, need_bias=ctx.has_bias, z_saved=ctx.z)
+        ctx.z = None
         return (gx, gh, None, None, gw, gb, groot, gbias if ctx.has_bias else None, None, None)

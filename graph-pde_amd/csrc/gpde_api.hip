@@ -222,7 +222,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
              const float* bias, int aggr, uint32_t flags, const float* hidden, float* out, void* ws,
              size_t ws_bytes, hipStream_t stream, int kt = 0, const int* sel = nullptr,
              const float* hidden_absmax = nullptr, int64_t hidden_nodes = -1, const float* residual = nullptr,
-             int relu_out = 0) {
+             int relu_out = 0, float* z_keep = nullptr) {
     // hidden_nodes in [0, n_nodes): MIXED call (gpde_nnconv_fwd_mixed) -- `hidden` covers the in-edges of
     // nodes [0, hidden_nodes) only (a graph whose H does not fit memory, e.g. 391 GB at the 241^2 graph);
     // those nodes aggregate from it, the others run the fused kernel on edge_attr
@@ -279,7 +279,9 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
         probe.k0 = L.k0; probe.K1P = L.K1P; probe.K2P = L.K2P;
         store_ok = gpde_fused_store_supported(probe);
     }
-    const bool edge_path = ((flags & GPDE_FWD_F16SPLIT) || (hidden && hidden_absmax)) && !mixed && !kt && L.has_w3s && P.n_chunks == 1 &&
+    // z_keep: the caller wants Z_i = sum_e x_j (x) H_e of EVERY node ([N][64][K2P], zero-initialised by the caller: nodes
+    // without in-edges are not written) - the backward's dW_3 reads it instead of re-aggregating (gpde_nnconv_fwd_keepz)
+    const bool edge_path = !z_keep && ((flags & GPDE_FWD_F16SPLIT) || (hidden && hidden_absmax)) && !mixed && !kt && L.has_w3s && P.n_chunks == 1 &&
                            n_edges >= 4096 && n_edges <= 4 * n_nodes && n_edges < ((int64_t)1 << 24) &&
                            !(flags & GPDE_FWD_NO_EDGE_PATH) &&
                            (hidden || (L.mode == 1 && store_ok)) &&   // H by a fused store kernel (its own support check: LDS limits, chunk parity)
@@ -358,7 +360,8 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
             f.w1 = pk + L.off_w1; f.w2t = pk + L.off_w2t; f.b2 = pk + L.off_b2;
             f.w2h = pk + L.off_w2h; f.ucol = pk + L.off_ucol;
             f.w1h = pk + L.off_w1h; f.fcol = pk + L.off_fcol;
-            f.hbuf = hfinal; f.zbuf = zbuf; f.xs = xs; f.scal = scal;
+            float* zc = z_keep ? z_keep + (size_t)nc0 * GP_W * L.K2P : zbuf;
+            f.hbuf = hfinal; f.zbuf = zc; f.xs = xs; f.scal = scal;
             f.kt = kt; f.hmax = (from_h && xs) ? (const unsigned*)hidden_absmax : nullptr;
             for (int d = 0; d < 8; ++d) f.sel[d] = (kt && sel) ? sel[d < L.k0 ? d : L.k0 - 1] : 0;
             f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
@@ -380,7 +383,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
             if (rc != GPDE_OK) return rc;
             ProfScope ps1(GPDE_PROF_GEMM3, stream);
             GpdeGemm3Args g;
-            g.zbuf = zbuf; g.w3q = pk + L.off_w3q; g.part = part; g.nn = nn; g.K2P = L.K2P;
+            g.zbuf = zc; g.w3q = pk + L.off_w3q; g.part = part; g.nn = nn; g.K2P = L.K2P;
             g.splits = splits; g.rowptr = rowptr; g.nc0 = (int)nc0;
             rc = gpde_launch_gemm3(g, stream);
             if (rc != GPDE_OK) return rc;
@@ -500,6 +503,23 @@ extern "C" int gpde_nnconv_fwd_hidden_act(const float* x, int64_t n_nodes, const
     return fwd_impl(x, n_nodes, nullptr, n_edges, rowptr, src, dst, nullptr, n_layers, dims, packed, root, bias,
                     aggr, 0, hidden, out, ws, ws_bytes, (hipStream_t)stream_, 0, nullptr, hidden_absmax, -1, residual,
                     relu_out);
+}
+
+extern "C" int gpde_nnconv_fwd_keepz(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
+                                     const float* hidden_absmax, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
+                                     const int32_t* dst, const int32_t* perm, int n_layers, const int32_t* dims,
+                                     const void* packed, const float* root, const float* bias, int aggr, uint32_t flags,
+                                     float* z_keep, float* out, void* ws, size_t ws_bytes, void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || !dims || !packed || !rowptr || (n_nodes > 0 && (!x || !out || !z_keep)) ||
+        (n_edges > 0 && (!src || !dst || (!hidden && (!edge_attr || !perm))))) {
+        gpde_set_error("gpde_nnconv_fwd_keepz: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (hidden)
+        return fwd_impl(x, n_nodes, nullptr, n_edges, rowptr, src, dst, nullptr, n_layers, dims, packed, root, bias, aggr, 0,
+                        hidden, out, ws, ws_bytes, (hipStream_t)stream_, 0, nullptr, hidden_absmax, -1, nullptr, 0, z_keep);
+    return fwd_impl(x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, n_layers, dims, packed, root, bias, aggr, flags,
+                    nullptr, out, ws, ws_bytes, (hipStream_t)stream_, 0, nullptr, nullptr, -1, nullptr, 0, z_keep);
 }
 
 extern "C" int gpde_profile_begin(void) {

@@ -692,7 +692,8 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
              const float* const* b, const float* root, int aggr, const float* grad_out, float* grad_x,
              float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias,
              const float* hidden, float* grad_hidden_out, const float* grad_hidden_in, void* ws,
-             size_t ws_bytes, hipStream_t st, const int32_t* src_rowptr = nullptr, const int32_t* src_slots = nullptr) {
+             size_t ws_bytes, hipStream_t st, const int32_t* src_rowptr = nullptr, const int32_t* src_slots = nullptr,
+             const float* z_saved = nullptr) {
     const bool do_conv = phase != BWD_MLP, do_mlp = phase != BWD_CONV;
     BwdPlan P;
     int rc = make_bwd_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P);
@@ -905,9 +906,11 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             // hidden activations of the chunk's edges: recomputed, or rows of the given cache
             if (phase == BWD_FULL) { rc_na = na; rc_nb = nb; if ((rc = recompute(e0, rows, n - 1)) != GPDE_OK) return rc; }
             const float* Hlast = phase == BWD_FULL ? F(P.off_H[n - 1]) : hidden + (size_t)e0 * K2P;
-            // Z of the chunk's nodes from the recomputed activations (mode-2 fused kernel)
-            GP_HIP_CHECK(hipMemsetAsync(Z, 0, (size_t)nn * GP_W * K2P * 4, st));
-            {
+            // Z of the chunk's nodes: kept by the forward (gpde_nnconv_fwd_keepz), else re-aggregated from the recomputed /
+            // given activations
+            if (z_saved) Z = const_cast<float*>(z_saved) + (size_t)na * GP_W * K2P;      // read only below
+            else GP_HIP_CHECK(hipMemsetAsync(Z, 0, (size_t)nn * GP_W * K2P * 4, st));
+            if (!z_saved) {
                 GpdeFusedArgs f{};
                 f.x = x; f.attr = edge_attr; f.rowptr = rowptr; f.src = src; f.dst = dst; f.perm = perm;
                 f.hbuf = Hlast; f.zbuf = Z; f.k0 = dims[0]; f.K1P = 32; f.K2P = K2P;
@@ -1015,6 +1018,31 @@ extern "C" int gpde_nnconv_bwd_ordered(const float* x, int64_t n_nodes, const fl
     return bwd_impl(BWD_FULL, x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims,
                     W, b, root, aggr, grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, nullptr, nullptr,
                     nullptr, ws, ws_bytes, (hipStream_t)stream_, src_rowptr, src_slots);
+}
+
+// The same with Z saved by the forward (gpde_nnconv_fwd_keepz): z_saved [N][64][K2P]; `hidden` != NULL selects the
+// given-activations form (gpde_nnconv_bwd_hidden_ordered's arguments: edge_attr / perm / W / b of the hidden layers unused).
+extern "C" int gpde_nnconv_bwd_z(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden, int64_t n_edges,
+                                 const int32_t* rowptr, const int32_t* src, const int32_t* dst, const int32_t* perm,
+                                 const int32_t* rowptr_host, const int32_t* src_rowptr, const int32_t* src_slots, int n_layers,
+                                 const int32_t* dims, const float* const* W, const float* const* b, const float* root, int aggr,
+                                 const float* grad_out, const float* z_saved, float* grad_x, float* grad_hidden,
+                                 float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias, void* ws,
+                                 size_t ws_bytes, void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || !dims || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws || !z_saved || !grad_W || !grad_b ||
+        n_layers < 2 || n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x || !grad_x)) ||
+        (n_edges > 0 && (!src || !dst || (hidden ? !grad_hidden : (!edge_attr || !perm))))) {
+        gpde_set_error("gpde_nnconv_bwd_z: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_z: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
+    if (hidden)
+        return bwd_impl(BWD_CONV, x, n_nodes, nullptr, n_edges, rowptr, src, dst, nullptr, rowptr_host, n_layers, dims, W, b, root,
+                        aggr, grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, hidden, grad_hidden, nullptr, ws, ws_bytes,
+                        (hipStream_t)stream_, src_rowptr, src_slots, z_saved);
+    return bwd_impl(BWD_FULL, x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims, W, b, root, aggr,
+                    grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes,
+                    (hipStream_t)stream_, src_rowptr, src_slots, z_saved);
 }
 
 extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,

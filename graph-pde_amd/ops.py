@@ -359,6 +359,20 @@ def workspace_bytes(n_nodes: int, n_edges: int, pm: PackedMlp) -> int:
     return int(_lib.lib().gpde_nnconv_fwd_workspace_bytes(n_nodes, n_edges, len(pm.dims) - 1, pm.dims_c))
 
 
+SAVE_Z_BYTES = int(float(os.environ.get("GPDE_SAVE_Z_GB", "16")) * (1 << 30))     # per call; 0 disables
+
+
+def z_buffer(csr: Csr, dims: Sequence[int], device) -> Optional[torch.Tensor]:
+    """Zeroed [N, 64 * K2P] buffer for the keep-Z forward (gpde_nnconv_fwd_keepz), or None when it does not pay / fit:
+    the forward forms Z_i = sum_e x_j (x) h_e anyway and the backward's dW_3 needs exactly that - keeping it
+    (256 KiB per node at k2 = 1024: 15 GB on the 241^2 graph) saves the backward one aggregation pass over the 4 KiB-per-edge
+    hidden activations.  Graphs of low in-degree (the per-edge last layer, §3e) and buffers above GPDE_SAVE_Z_GB are skipped."""
+    nbytes = csr.n_nodes * WIDTH * hidden_width(dims) * 4
+    if SAVE_Z_BYTES <= 0 or nbytes > SAVE_Z_BYTES or csr.n_edges < 32 * csr.n_nodes:
+        return None
+    return torch.zeros(csr.n_nodes, WIDTH * hidden_width(dims), dtype=torch.float32, device=device)
+
+
 def _check_residual(residual, x, n):
     if residual is None:
         return None
@@ -372,10 +386,11 @@ def nnconv_forward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor, pm: P
                        root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,
                        out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
                        precision: Optional[str] = None, residual: Optional[torch.Tensor] = None,
-                       relu: bool = False) -> torch.Tensor:
+                       relu: bool = False, z_keep: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One gpde_nnconv_fwd call on the current stream. x [N,64] f32, edge_attr [E,k0] f32.
     `residual` / `relu` (opt-in): out = act(residual + NNConv(x)) in the last kernel
-    (gpde_nnconv_fwd_act)."""
+    (gpde_nnconv_fwd_act).  `z_keep` (zeros [N, 64 * K2P]): gpde_nnconv_fwd_keepz - Z of every node is left there for
+    the backward (`z_buffer`)."""
     lib = _lib.lib()
     _require_cuda(x, "x")
     _require_cuda(edge_attr, "edge_attr")
@@ -405,8 +420,16 @@ def nnconv_forward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor, pm: P
     if ws is None:
         ws = torch.empty(max(workspace_bytes(n, e, pm), 1), dtype=torch.uint8, device=x.device)
     residual = _check_residual(residual, x, n)
+    if z_keep is not None and (residual is not None or relu):
+        raise ValueError("z_keep cannot be combined with the fused glue")
     with torch.cuda.device(x.device):
-        if residual is None and not relu:
+        if z_keep is not None:
+            rc = lib.gpde_nnconv_fwd_keepz(x.data_ptr(), n, edge_attr.data_ptr(), None, None, e, csr.rowptr.data_ptr(),
+                                           csr.src.data_ptr(), csr.dst.data_ptr(), perm.data_ptr(), len(pm.dims) - 1, pm.dims_c,
+                                           pm.packed.data_ptr(), None if root_c is None else root_c.data_ptr(),
+                                           None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr], _PRECISION[precision],
+                                           z_keep.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
+        elif residual is None and not relu:
             rc = lib.gpde_nnconv_fwd(x.data_ptr(), n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(),
                                      csr.src.data_ptr(), csr.dst.data_ptr(), perm.data_ptr(),
                                      len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(),
@@ -522,8 +545,8 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
                         weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
                         root: Optional[torch.Tensor], aggr: str, grad_out: torch.Tensor,
                         need_root: bool = True, need_bias: bool = True,
-                        ws: Optional[torch.Tensor] = None):
-    """One gpde_nnconv_bwd call on the current stream.
+                        ws: Optional[torch.Tensor] = None, z_saved: Optional[torch.Tensor] = None):
+    """One gpde_nnconv_bwd call on the current stream (`z_saved`: the keep-Z forward's buffer -> gpde_nnconv_bwd_z).
     Returns (grad_x, [grad_W_l], [grad_b_l or None], grad_root or None, grad_bias or None)."""
     lib = _lib.lib()
     for t, nm in ((x, "x"), (edge_attr, "edge_attr"), (grad_out, "grad_out")):
@@ -554,6 +577,18 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     rph = csr.rowptr_host
     srp, ssl = csr.src_order
+    if z_saved is not None:
+        with torch.cuda.device(dev):
+            rc = lib.gpde_nnconv_bwd_z(x.data_ptr(), n, edge_attr.data_ptr(), None, e, csr.rowptr.data_ptr(), csr.src.data_ptr(),
+                                       csr.dst.data_ptr(), perm.data_ptr(), rph.data_ptr(), None if srp is None else srp.data_ptr(),
+                                       None if ssl is None else ssl.data_ptr(), nl, dims_c, arr(ws_), arr(bs_),
+                                       None if root_c is None else root_c.data_ptr(), _AGGR[aggr], grad_out.data_ptr(),
+                                       z_saved.data_ptr(), gx.data_ptr(), None, arr(gW), arr(gb),
+                                       None if groot is None else groot.data_ptr(), None if gbias is None else gbias.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "gpde_nnconv_bwd_z")
+        _lib.n_native_calls += 1
+        return gx, gW, gb, groot, gbias
     with torch.cuda.device(dev):
         rc = lib.gpde_nnconv_bwd_ordered(x.data_ptr(), n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(),
                                  csr.src.data_ptr(), csr.dst.data_ptr(), perm.data_ptr(),
@@ -631,7 +666,7 @@ def nnconv_forward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, p
                               root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,
                               out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
                               hmax: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                              relu: bool = False) -> torch.Tensor:
+                              relu: bool = False, z_keep: Optional[torch.Tensor] = None) -> torch.Tensor:
     """gpde_nnconv_fwd_hidden: aggregation + last Linear + update() from given hidden activations
     (`hmax`: the max |H| scalar hidden_forward_raw returned; enables the split-f16 aggregation)."""
     lib = _lib.lib()
@@ -653,6 +688,18 @@ def nnconv_forward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, p
     if ws is None:
         ws = torch.empty(max(workspace_bytes(n, e, pm), 1), dtype=torch.uint8, device=x.device)
     residual = _check_residual(residual, x, n)
+    if z_keep is not None:
+        if residual is not None or relu:
+            raise ValueError("z_keep cannot be combined with the fused glue")
+        with torch.cuda.device(x.device):
+            rc = lib.gpde_nnconv_fwd_keepz(x.data_ptr(), n, None, hidden.data_ptr(), None if hmax is None else hmax.data_ptr(), e,
+                                           csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), None, len(pm.dims) - 1,
+                                           pm.dims_c, pm.packed.data_ptr(), None if root_c is None else root_c.data_ptr(),
+                                           None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr], 0, z_keep.data_ptr(),
+                                           out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
+        _lib.check(rc, "gpde_nnconv_fwd_keepz")
+        _lib.n_native_calls += 1
+        return out
     with torch.cuda.device(x.device):
         rc = lib.gpde_nnconv_fwd_hidden_act(x.data_ptr(), n, hidden.data_ptr(),
                                             None if hmax is None else hmax.data_ptr(), e, csr.rowptr.data_ptr(),
@@ -789,8 +836,8 @@ def nnconv_forward_mixed_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
 def nnconv_backward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, dims: Sequence[int],
                                w_last: torch.Tensor, b_last: Optional[torch.Tensor],
                                root: Optional[torch.Tensor], aggr: str, grad_out: torch.Tensor,
-                               need_root: bool = True, need_bias: bool = True):
-    """gpde_nnconv_bwd_hidden.  Returns (grad_x, grad_hidden [E,K2P], grad_w_last, grad_b_last or None,
+                               need_root: bool = True, need_bias: bool = True, z_saved: Optional[torch.Tensor] = None):
+    """gpde_nnconv_bwd_hidden (`z_saved`: gpde_nnconv_bwd_z).  Returns (grad_x, grad_hidden [E,K2P], grad_w_last, grad_b_last or None,
     grad_root or None, grad_bias or None)."""
     lib = _lib.lib()
     n, e, dev = csr.n_nodes, csr.n_edges, x.device
@@ -813,6 +860,20 @@ def nnconv_backward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, 
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     p = lambda t: None if t is None else t.data_ptr()
     srp, ssl = csr.src_order
+    if z_saved is not None:
+        P_ = ctypes.c_void_p
+        Wa = (P_ * nl)(*([None] * (nl - 1) + [w_last.data_ptr()]))
+        Ba = (P_ * nl)(*([None] * (nl - 1) + [p(b_c)]))
+        gWa = (P_ * nl)(*([None] * (nl - 1) + [gw.data_ptr()]))
+        gBa = (P_ * nl)(*([None] * (nl - 1) + [p(gb)]))
+        with torch.cuda.device(dev):
+            rc = lib.gpde_nnconv_bwd_z(x.data_ptr(), n, None, hidden.data_ptr(), e, csr.rowptr.data_ptr(), csr.src.data_ptr(),
+                                       csr.dst.data_ptr(), None, csr.rowptr_host.data_ptr(), p(srp), p(ssl), nl, dims_c, Wa, Ba,
+                                       p(root_c), _AGGR[aggr], grad_out.data_ptr(), z_saved.data_ptr(), gx.data_ptr(), gh.data_ptr(),
+                                       gWa, gBa, p(groot), p(gbias), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "gpde_nnconv_bwd_z")
+        _lib.n_native_calls += 1
+        return gx, gh, gw, gb, groot, gbias
     with torch.cuda.device(dev):
         rc = lib.gpde_nnconv_bwd_hidden_ordered(x.data_ptr(), n, hidden.data_ptr(), e, csr.rowptr.data_ptr(),
                                         csr.src.data_ptr(), csr.dst.data_ptr(), csr.rowptr_host.data_ptr(),

@@ -270,6 +270,27 @@ int gpde_hidden_bwd(const float* edge_attr, int64_t n_edges, const int32_t* perm
                     size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Keep-Z pair (training): the forward already forms Z_i = sum_{e -> i} x_j (x) h_e for every node and the
+ * backward's dW_3 = sum_i gT_i (x) Z_i needs exactly that; without these two entry points the backward re-aggregates it from
+ * the recomputed (or given) hidden activations.  gpde_nnconv_fwd_keepz = gpde_nnconv_fwd (hidden == NULL) or
+ * gpde_nnconv_fwd_hidden (hidden != NULL; edge_attr / perm unused) writing Z into z_keep [N][64][K2P] (K2P = last hidden
+ * width padded to 128; ZERO-INITIALISED by the caller: nodes without in-edges are not written); the per-edge last layer of
+ * low in-degree graphs is not taken.  gpde_nnconv_bwd_z = gpde_nnconv_bwd_ordered / gpde_nnconv_bwd_hidden_ordered with
+ * that Z (W / b: all n_layers entries for the full form; only the last for the hidden form). */
+int gpde_nnconv_fwd_keepz(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
+                          const float* hidden_absmax, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
+                          const int32_t* dst, const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
+                          const float* root, const float* bias, int aggr, uint32_t flags, float* z_keep, float* out,
+                          void* ws, size_t ws_bytes, void* stream);
+int gpde_nnconv_bwd_z(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden, int64_t n_edges,
+                      const int32_t* rowptr, const int32_t* src, const int32_t* dst, const int32_t* perm,
+                      const int32_t* rowptr_host, const int32_t* src_rowptr, const int32_t* src_slots, int n_layers,
+                      const int32_t* dims, const float* const* W, const float* const* b, const float* root, int aggr,
+                      const float* grad_out, const float* z_saved, float* grad_x, float* grad_hidden,
+                      float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias, void* ws,
+                      size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The operator given the PER-EDGE WEIGHTS (second half; row a6 'max').
  * `weight = self.nn(pseudo).view(-1, in, out)` (nn_conv.py:274) is what the reference forms on every call.  For the
  * MGKN V-cycles' low in-degree / small graphs (MGKN_orthogonal_burgers1d.py:73-82: 2-3 in-edges per node;

@@ -169,3 +169,54 @@ def test_first_hidden_layer_is_not_materialised_and_changes_only_the_dw2_roundin
     g2 = _native(x, ei, ea2, ws_, bs_, root, gout)[1]
     rows2 = row_err(g2[1], r2[1])
     assert int((rows2 > TOL).sum()) <= 4 and float(rows2.median()) <= 2e-6, (rows2.max(), rows2.median())
+
+
+@pytest.mark.parametrize("cached", [False, True])
+def test_keep_z_forward_feeds_the_backward(cached, monkeypatch):
+    """gpde_nnconv_fwd_keepz / gpde_nnconv_bwd_z (round 3): the forward leaves Z_i = sum_e x_j (x) h_e of every node for the
+    backward's dW_3 instead of the backward re-aggregating it.  Through the module (direct operator and the hidden-activation
+    split): output bit-identical, every gradient within rounding of the path without it and within the tolerance of float64
+    autograd; nodes without in-edges and a 2-chunk-sized graph included."""
+    import graph_pde_amd as gp
+    from graph_pde_amd import hidden_cache
+    from tests.test_host_logic import DenseNet
+    d = dev()
+    torch.manual_seed(31)
+    n, e = 220, 9000                                            # >= 32 edges per node: the buffer is used
+    ei = torch.stack([torch.randint(0, n, (e,)), torch.randint(0, n - 7, (e,))]).to(d)       # the last 7 nodes have no in-edge
+    ea, x0 = torch.randn(e, 6, device=d), torch.randn(n, 64, device=d)
+    conv = gp.NNConv_old(64, 64, DenseNet([6, 256, 256, 4096], torch.nn.ReLU), aggr="mean").to(d)
+    gout = torch.randn(n, 64, device=d)
+    monkeypatch.setattr(hidden_cache, "MODE", "on" if cached else "off")
+
+    def run(save_bytes):
+        monkeypatch.setattr(ops, "SAVE_Z_BYTES", save_bytes)
+        hidden_cache.clear()
+        conv.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y = conv(x, ei, ea)
+        (y * gout).sum().backward()
+        return y.detach(), [x.grad.clone()] + [p.grad.clone() for p in conv.parameters()]
+    seen = []
+    for name in ("nnconv_backward_raw", "nnconv_backward_hidden_raw"):
+        orig = getattr(ops, name)
+        monkeypatch.setattr(ops, name, (lambda f: lambda *a, **k: (seen.append(k.get("z_saved") is not None), f(*a, **k))[1])(orig))
+    y0, g0 = run(0)
+    assert seen and not any(seen)
+    del seen[:]
+    y1, g1 = run(16 << 30)
+    assert seen and all(seen)                                     # the backward did read the forward's Z
+    assert torch.equal(y0, y1)
+    for a, b in zip(g0, g1):       # (at this size both Z come from the same fp32-MFMA aggregation order: often the same bits)
+        assert rel_l2(a.cpu(), b.cpu()) <= 2e-6, rel_l2(a.cpu(), b.cpu())
+    lin = ops.mlp_linears(conv.nn)
+    rx, rW, rb, rroot, rbias = _oracle_grads(x0.cpu(), ei.cpu(), ea.cpu(), [l.weight.detach().cpu() for l in lin],
+                                             [l.bias.detach().cpu() for l in lin], conv.root.detach().cpu(), conv.bias.detach().cpu(),
+                                             "mean", gout.cpu())
+    assert rel_l2(g1[0].cpu(), rx) <= TOL
+    names = dict(conv.named_parameters())
+    assert rel_l2(names["nn.layers.4.weight"].grad.cpu(), rW[2]) <= TOL and rel_l2(names["root"].grad.cpu(), rroot) <= TOL
+    assert ops.z_buffer(ops.csr_for(ei, n), [6, 256, 256, 4096], d) is not None
+    monkeypatch.setattr(ops, "SAVE_Z_BYTES", 1 << 20)
+    assert ops.z_buffer(ops.csr_for(ei, n), [6, 256, 256, 4096], d) is None     # over budget -> the backward aggregates itself
+    hidden_cache.clear()
