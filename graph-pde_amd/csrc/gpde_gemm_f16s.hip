@@ -662,58 +662,62 @@ __global__ void k_first_layer_scales(const float* __restrict__ Wp, int ldw, cons
 // k_pack_split_kn with H computed on the fly: B[n][k = edge] = relu(bp[n] + sum_d Wp[n][d] H0[edge][d]) * sc[n], plus
 // the ReLU mask bits [rows][n_in / 32].  Workgroup = one 16 KiB tile (slice of 128 n, chunk of 32 edges), thread =
 // (n, k16 step m).  The fp32 fmaf chain is the one k_first_layer / the fp32 GEMM path evaluate (d ascending from the bias).
+constexpr int FLP_TILES = 8;            // 32-edge tiles per workgroup: the column's weights / bias / scale are loaded once for all
 __global__ __launch_bounds__(256) void k_first_layer_pack(GpdeFirstLayerSpec f, int rows, int n_in, const float* __restrict__ sc,
                                                           int nkct, _Float16* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) _Float16 img[128 * 64];      // the 16 KiB tile, final layout
     __shared__ __attribute__((aligned(16))) float h0s[32][8];
     const int n = threadIdx.x & 127, m = threadIdx.x >> 7;
-    const int kcn = blockIdx.x, slice = blockIdx.y;
-    {
-        const int e = kcn * 32 + (threadIdx.x >> 3), d = threadIdx.x & 7;
-        h0s[threadIdx.x >> 3][d] = e < rows ? f.H0[(size_t)e * f.ld0 + d] : 0.f;
-    }
+    const int slice = blockIdx.y;
     const int col = slice * 128 + n;
     const float s = sc[col], b = f.bp[col];
     float wd[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) wd[d] = f.Wp[(size_t)col * f.ldw + d];
-    __syncthreads();
-    const int e0 = kcn * 32 + 16 * m;
-    float w[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        float t = b;
-#pragma unroll
-        for (int d = 0; d < 8; ++d) t = fmaf(wd[d], h0s[16 * m + k][d], t);
-        t = fmaxf(t, 0.f);
-        // mask bits of edge e0 + k: one 64-bit ballot per wave = columns n & ~63 .. +63 -> two words
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(t > 0.f);
-        if ((threadIdx.x & 63) == 0 && e0 + k < rows) {
-            uint32_t* mp = f.maskbits + (size_t)(e0 + k) * (n_in / 32) + slice * 4 + ((n >> 6) << 1);
-            mp[0] = (uint32_t)bal;
-            mp[1] = (uint32_t)(bal >> 32);
-        }
-        w[k] = (e0 + k < rows) ? t * s : 0.f;
-    }
     const int sw = (n >> 1) & 7;
     _Float16* row = img + n * 64;
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        h8 hi, lo;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = w[8 * (j >> 2) + 4 * hh + (j & 3)];
-            hi[j] = (_Float16)v;
-            lo[j] = (_Float16)(v - (float)hi[j]);
+    for (int kcn = blockIdx.x * FLP_TILES; kcn < min((int)(blockIdx.x + 1) * FLP_TILES, nkct); ++kcn) {
+        {
+            const int e = kcn * 32 + (threadIdx.x >> 3), d = threadIdx.x & 7;
+            h0s[threadIdx.x >> 3][d] = e < rows ? f.H0[(size_t)e * f.ld0 + d] : 0.f;
         }
-        *(h8*)(row + (((m * 2 + hh) ^ sw) << 3)) = hi;
-        *(h8*)(row + (((4 + m * 2 + hh) ^ sw) << 3)) = lo;
-    }
-    __syncthreads();
-    h8* dst = (h8*)(out + ((size_t)slice * (size_t)nkct + kcn) * (128 * 64));
-    const h8* srcl = (const h8*)img;
+        __syncthreads();
+        const int e0 = kcn * 32 + 16 * m;
+        float w[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q * 256 + threadIdx.x] = srcl[q * 256 + threadIdx.x];
+        for (int k = 0; k < 16; ++k) {
+            float t = b;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) t = fmaf(wd[d], h0s[16 * m + k][d], t);
+            t = fmaxf(t, 0.f);
+            // mask bits of edge e0 + k: one 64-bit ballot per wave = columns n & ~63 .. +63 -> two words
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(t > 0.f);
+            if ((threadIdx.x & 63) == 0 && e0 + k < rows) {
+                uint32_t* mp = f.maskbits + (size_t)(e0 + k) * (n_in / 32) + slice * 4 + ((n >> 6) << 1);
+                mp[0] = (uint32_t)bal;
+                mp[1] = (uint32_t)(bal >> 32);
+            }
+            w[k] = (e0 + k < rows) ? t * s : 0.f;
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            h8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = w[8 * (j >> 2) + 4 * hh + (j & 3)];
+                hi[j] = (_Float16)v;
+                lo[j] = (_Float16)(v - (float)hi[j]);
+            }
+            *(h8*)(row + (((m * 2 + hh) ^ sw) << 3)) = hi;
+            *(h8*)(row + (((4 + m * 2 + hh) ^ sw) << 3)) = lo;
+        }
+        __syncthreads();
+        h8* dst = (h8*)(out + ((size_t)slice * (size_t)nkct + kcn) * (128 * 64));
+        const h8* srcl = (const h8*)img;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q * 256 + threadIdx.x] = srcl[q * 256 + threadIdx.x];
+        __syncthreads();                     // img / h0s are rewritten by the next tile
+    }
 }
 }  // namespace
 
@@ -774,7 +778,7 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
         hipLaunchKernelGGL(k_attr_absmax8, dim3(nb), dim3(256), 0, stream, fl->H0, rows, fl->ld0, bits + n_out);
         hipLaunchKernelGGL(k_first_layer_scales, dim3((n_in + 255) / 256), dim3(256), 0, stream, fl->Wp, fl->ldw, fl->bp,
                            bits + n_out, n_in, scb, ucolb);
-        hipLaunchKernelGGL(k_first_layer_pack, dim3(epad / 32, n_in / 128), dim3(256), 0, stream, *fl, rows, n_in, scb, epad / 32, Bimg);
+        hipLaunchKernelGGL(k_first_layer_pack, dim3((epad / 32 + FLP_TILES - 1) / FLP_TILES, n_in / 128), dim3(256), 0, stream, *fl, rows, n_in, scb, epad / 32, Bimg);
     } else {
         hipLaunchKernelGGL(k_colabsmax, dim3((n_in + 255) / 256, splits), dim3(256), 0, stream, H, rows, n_in, ldh, splits, bits + n_out);
         hipLaunchKernelGGL(k_scales_from_max, dim3((n_in + 255) / 256), dim3(256), 0, stream, bits + n_out, n_in, scb, ucolb);
