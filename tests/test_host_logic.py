@@ -327,3 +327,41 @@ def test_nnconv_group_argument_checks_without_a_gpu():
     with pytest.raises(ValueError, match="activation"):
         gp.nnconv_group([(conv, x, ei, ea, None, "tanh")])
     assert gp.nnconv_group([]) == []
+
+
+def test_attr_slot_order_cache_and_keep_z_policy_host_logic(monkeypatch):
+    """ops.attr_in_slot_order (layout-only copy of edge_attr in CSR slot order, cached per graph + edge_attr version) and
+    ops.z_buffer (when the keep-Z training pair is used) - pure host logic, exercised here on CPU tensors."""
+    e, n = 40000, 50
+    g = torch.Generator().manual_seed(0)
+    perm = torch.randperm(e, generator=g).to(torch.int32)
+    dst = torch.sort(torch.randint(0, n, (e,), generator=g)).values.to(torch.int32)
+    rowptr = torch.searchsorted(dst.long(), torch.arange(n + 1)).to(torch.int32)
+    csr = ops.Csr(n, e, rowptr, torch.zeros(e, dtype=torch.int32), dst, perm)
+    ea = torch.randn(e, 6, generator=g)
+    monkeypatch.setattr(ops, "ATTR_SLOT_ORDER", True)
+    s1, p1 = ops.attr_in_slot_order(csr, ea)
+    assert torch.equal(s1, ea[perm.long()]) and torch.equal(p1, torch.arange(e, dtype=torch.int32))
+    s2, _ = ops.attr_in_slot_order(csr, ea)
+    assert s2 is s1                                               # cached
+    ea.mul_(2.0)                                                  # in place: version moves, a new copy is gathered
+    s3, _ = ops.attr_in_slot_order(csr, ea)
+    assert s3 is not s1 and torch.equal(s3, ea[perm.long()])
+    monkeypatch.setattr(ops, "ATTR_SLOT_ORDER", False)
+    s4, p4 = ops.attr_in_slot_order(csr, ea)
+    assert s4 is ea and p4 is perm
+    monkeypatch.setattr(ops, "ATTR_SLOT_ORDER", True)
+    small = ops.Csr(n, 100, rowptr, torch.zeros(100, dtype=torch.int32), dst[:100], perm[:100])
+    assert ops.attr_in_slot_order(small, ea[:100])[0].data_ptr() == ea[:100].data_ptr()      # below 32768 edges: not worth a copy
+    ident = ops.Csr(n, e, rowptr, torch.zeros(e, dtype=torch.int32), dst, torch.arange(e, dtype=torch.int32))
+    assert ops.attr_in_slot_order(ident, ea)[0] is ea            # a graph from radius_csr is in slot order already
+    # keep-Z: only with >= 32 edges per node and within the byte budget
+    dims = [6, 1024, 1024, 4096]
+    monkeypatch.setattr(ops, "SAVE_Z_BYTES", 16 << 30)
+    z = ops.z_buffer(csr, dims, "cpu")
+    assert z is not None and tuple(z.shape) == (n, 64 * 1024) and float(z.abs().sum()) == 0.0
+    assert ops.z_buffer(ops.Csr(2000, e, rowptr, perm, dst, perm), dims, "cpu") is None          # 20 edges per node
+    monkeypatch.setattr(ops, "SAVE_Z_BYTES", n * 64 * 1024 * 4 - 1)
+    assert ops.z_buffer(csr, dims, "cpu") is None
+    monkeypatch.setattr(ops, "SAVE_Z_BYTES", 0)
+    assert ops.z_buffer(csr, dims, "cpu") is None
