@@ -3,6 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config g241|g121|g61|g16] [--kernel-width 1024]
     python bench.py --train [--gpus N] ...          # training-step mode (BASELINE config 5 shape, see below)
+    python bench.py --split-graph [--gpus N] ...    # ONE graph split by destination rows over the ranks (strong scaling)
 
 One "step" = one `conv(x, edge_index, edge_attr)` forward of the headline operator on one PDE sample: the
 Darcy-241^2 r=0.10 lattice radius graph (N = 58,081 nodes, E = 95,539,625 edges, BASELINE.json configs[1])
@@ -38,6 +39,10 @@ for the median).  Objects on the line:
 KernelNN-shaped stack on the rank's own sample + ONE flat RCCL gradient all-reduce (parallel.allreduce_gradients)
 + Adam; reports samples/s, ms/step and the all-reduce share.  Default graph g61 (the reference's own training
 resolution, UAI1_full_resolution.py:39-46).
+
+--split-graph: the exchange step of SURVEY.md §8(e): every rank holds the same graph, keeps the in-edges of its block of
+destination rows (balanced on in-edges), a step = its rows of one NNConv forward + the RCCL all-gather of the [rows, 64]
+blocks (15 MB in total at G241); `value` = the graph's edges / step time, `scaling` = "strong".
 """
 from __future__ import annotations
 
@@ -300,6 +305,60 @@ def train_mode(args, rank, world, dev, use_dist, barrier):
     }
 
 
+def split_graph_mode(args, rank, world, dev, use_dist, barrier):
+    """`--split-graph`: ONE graph (the same on every rank) split by destination rows over the ranks, a step = one NNConv
+    forward of the WHOLE graph: each rank its rows, then the all-gather of the row blocks (parallel.nnconv_rows,
+    SURVEY.md §8e way 2).  Strong scaling: total work fixed.  Not the default line (that one is one sample per GPU)."""
+    import torch.distributed as dist
+    from graph_pde_amd import parallel, synth
+    s, r = CONFIGS[args.config]
+    conv = make_conv(args.kernel_width, dev)
+    ei, ea, n = synth.darcy_graph(s, r, device=dev, seed=0)
+    e = int(ei.shape[1])
+    x = torch.randn(n, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(1000))
+    part = parallel.partition_rows(ei, ea, n, rank=rank, world=world)
+    del ei, ea
+    torch.cuda.empty_cache()
+
+    def step():
+        with torch.no_grad():
+            if use_dist and world == 1:           # one rank under torchrun: still through the collective (RCCL)
+                return parallel._gather_blocks(conv(x, part.edge_index, part.edge_attr)[part.lo:part.hi].contiguous(), part)
+            return parallel.nnconv_rows(conv, x, part)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    edges = [None] * world
+    if use_dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.all_gather_object(edges, part.n_edges)
+    else:
+        edges = [part.n_edges]
+    if rank != 0:
+        return None
+    ms = 1e3 * elapsed / args.steps
+    return {
+        "metric": "M-edges/s through fused NNConv fwd (width=64)", "value": round(e / (ms * 1e-3) / 1e6, 3), "unit": "M-edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32 (hidden layer + aggregation: 2-term f16-split MFMA, f32 accumulate)", "data": "synthetic",
+        "rccl_ranks": world if use_dist else 0,
+        "config": {"workload": f"one NNConv forward of ONE {s}x{s} r={r} radius graph N={n} E={e} split by destination rows over "
+                               f"{world} rank(s); kernel MLP 6-{args.kernel_width}-{args.kernel_width}-4096; all-gather of the "
+                               f"[rows x 64] blocks inside the timed step", "graph": args.config,
+                   "parallelism": f"rows{world} (destination-row blocks balanced on in-edges; x replicated)"},
+        "edges_per_rank": edges, "row_bounds": part.bounds, "all_finite": bool(torch.isfinite(out).all()),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -320,6 +379,8 @@ def main():
                     help="arithmetic of the hidden layer (default: graph_pde_amd.ops.DEFAULT_PRECISION)")
     ap.add_argument("--train", action="store_true", help="training-step mode (see the module docstring)")
     ap.add_argument("--depth", type=int, default=6, help="--train: NNConv applications per forward")
+    ap.add_argument("--split-graph", action="store_true",
+                    help="strong-scaling mode: ONE graph split by destination rows over the ranks (all-gather per forward)")
     args = ap.parse_args()
     if args.config is None:
         args.config = "g61" if args.train else "g241"
@@ -358,8 +419,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.train:
-        line = train_mode(args, rank, world, dev, use_dist, barrier)
+    if args.train or args.split_graph:
+        line = (train_mode if args.train else split_graph_mode)(args, rank, world, dev, use_dist, barrier)
         if line is not None:
             print(json.dumps(line), flush=True)
         if use_dist:

@@ -109,3 +109,138 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
         hidden_cache.clear()
     except Exception:                       # the helper is also usable on plain modules without the native library
         pass
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ONE graph over several GPUs: the exchange step of SURVEY.md §8(e), way 2
+# ----------------------------------------------------------------------------------------------------------------------
+# A single sample too slow (or too big) for one GPU - the 241^2 graph is 95.5 M edges, 0.5 s per NNConv layer on one
+# MI355X - is split by DESTINATION rows: rank r owns a contiguous node range [lo_r, hi_r) holding ~E / world in-edges
+# (balanced on the in-degree prefix sum, not on node counts: boundary nodes of a radius graph have half the in-edges).
+# x [N, 64] is replicated (15 MB at N = 58,081); a layer is: NNConv over the rank's own in-edges -> its rows of the
+# result -> ONE all-gather of the [hi_r - lo_r, 64] blocks (RCCL over xGMI: 15 MB in total per layer at G241, ~0.1 ms
+# against 63 ms of compute per rank at world 8) -> the next layer's replicated x.  The per-node arithmetic is the
+# single-GPU operator's: a node's in-edges stay together, in the caller's order.
+#
+# Training: everything outside the conv (fc1 / fc2 / loss of the GKN stack, UAI1_full_resolution.py:27-33) is computed
+# redundantly on every rank, so d loss / d (gathered rows) is the same tensor everywhere.  `_GatherRows.backward` hands
+# the conv `world` x its own rows of it, `_ReplicatedInput.backward` all-reduces the dx contributions of the ranks' edge
+# sets and divides by `world`: conv parameter gradients are then `world` x this rank's part, replicated parameters carry
+# the full gradient on every rank, and the SAME `allreduce_gradients(average=True)` call as in the sample-sharded run
+# turns both into the exact gradient (sum of parts / identical copies).
+
+
+class RowPartition:
+    """This rank's destination-row block of one graph (make it with `partition_rows`)."""
+
+    def __init__(self, n_nodes, bounds, rank, edge_index, edge_attr, group=None):
+        self.n_nodes = int(n_nodes)
+        self.bounds = [int(b) for b in bounds]          # world + 1 node offsets, bounds[0] = 0, bounds[-1] = N
+        self.rank = int(rank)
+        self.world = len(self.bounds) - 1
+        self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+        self.edge_index = edge_index                    # [2, E_r] global node ids, the caller's edge order
+        self.edge_attr = edge_attr                      # [E_r, k0]
+        self.group = group
+
+    @property
+    def n_edges(self) -> int:
+        return int(self.edge_index.shape[1])
+
+    def __repr__(self):
+        return (f"RowPartition(rank {self.rank}/{self.world}, rows [{self.lo}, {self.hi}) of {self.n_nodes}, "
+                f"{self.n_edges} in-edges)")
+
+
+def row_bounds(edge_index: torch.Tensor, n_nodes: int, world: int) -> List[int]:
+    """Node offsets of `world` contiguous destination ranges with (nearly) equal in-edge counts: range r ends at the
+    first node where the in-degree prefix sum reaches (r + 1) E / world.  Deterministic in (edge_index, n_nodes, world):
+    every rank computes the same list.  Ranges may be empty (more ranks than nodes with in-edges)."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    e = int(edge_index.shape[1])
+    if e == 0 or world == 1:
+        return [min(n_nodes, -(-n_nodes * r // world)) for r in range(world)] + [n_nodes] if world > 1 else [0, n_nodes]
+    deg = torch.bincount(edge_index[1].reshape(-1).to(torch.int64), minlength=n_nodes)
+    cum = torch.cumsum(deg, 0)
+    targets = torch.tensor([-(-e * r // world) for r in range(1, world)], dtype=cum.dtype, device=cum.device)
+    cuts = (torch.searchsorted(cum, targets, right=False) + 1).clamp(max=n_nodes).tolist()
+    bounds = [0]
+    for c in cuts:
+        bounds.append(max(int(c), bounds[-1]))
+    return bounds + [n_nodes]
+
+
+def partition_rows(edge_index: torch.Tensor, edge_attr: torch.Tensor, n_nodes: int, rank: int | None = None,
+                   world: int | None = None, group=None) -> RowPartition:
+    """Keep the edges whose DESTINATION lies in this rank's row block (order preserved: a node's in-edges are summed in
+    the order the single-GPU operator sums them).  `edge_index` [2, E] with row 1 = target i (nn_conv.py:271 /
+    SURVEY.md App. B), `edge_attr` [E] or [E, k0].  Called with the full graph on every rank."""
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world {world}")
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2 or edge_attr.shape[0] != edge_index.shape[1]:
+        raise ValueError(f"edge_index [2, E] and edge_attr [E, ...] expected, got {tuple(edge_index.shape)} / {tuple(edge_attr.shape)}")
+    bounds = row_bounds(edge_index, n_nodes, world)
+    if world == 1:
+        return RowPartition(n_nodes, bounds, 0, edge_index, edge_attr, group)
+    dst = edge_index[1]
+    keep = ((dst >= bounds[rank]) & (dst < bounds[rank + 1])).nonzero().reshape(-1)
+    return RowPartition(n_nodes, bounds, rank, edge_index.index_select(1, keep).contiguous(),
+                        edge_attr.index_select(0, keep).contiguous(), group)
+
+
+def _gather_blocks(local: torch.Tensor, part: RowPartition) -> torch.Tensor:
+    sizes = [part.bounds[r + 1] - part.bounds[r] for r in range(part.world)]
+    mx = max(sizes)
+    pad = local.new_zeros((mx,) + tuple(local.shape[1:]))            # equal-size pieces: one plain (RCCL) all-gather
+    pad[:local.shape[0]].copy_(local)
+    bufs = [torch.empty_like(pad) for _ in range(part.world)]
+    dist.all_gather(bufs, pad, group=part.group)
+    return torch.cat([bufs[r][:sizes[r]] for r in range(part.world)], 0)
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, local, part):
+        ctx.part = part
+        return _gather_blocks(local.contiguous(), part)
+
+    @staticmethod
+    def backward(ctx, grad_full):
+        p = ctx.part
+        return grad_full[p.lo:p.hi] * float(p.world), None
+
+
+class _ReplicatedInput(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, part):
+        ctx.part = part
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, grad):
+        p = ctx.part
+        g = grad.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=p.group)
+        return g / float(p.world), None
+
+
+def nnconv_rows(conv, x: torch.Tensor, part: RowPartition) -> torch.Tensor:
+    """One NNConv layer of a row-partitioned graph: `x` [N, in] replicated on every rank -> `conv` over this rank's
+    in-edges -> its rows [lo, hi) -> all-gather -> the full [N, out] on every rank.  `conv` is called as the reference
+    calls it, `conv(x, edge_index, edge_attr)` (nn_conv.py:267); rows outside the block have no in-edge in the rank's
+    edge set (their `x . root + bias` is computed and dropped: 64 x 64 per node).  Differentiable; with world 1 (or no
+    process group) it is `conv(x, edge_index, edge_attr)`."""
+    if x.shape[0] != part.n_nodes:
+        raise ValueError(f"x has {x.shape[0]} rows, the partitioned graph {part.n_nodes} nodes")
+    if part.world == 1:
+        return conv(x, part.edge_index, part.edge_attr)
+    if not dist.is_initialized():
+        raise RuntimeError("nnconv_rows with world > 1 needs an initialised process group (parallel.init_from_env)")
+    x_in = _ReplicatedInput.apply(x, part) if (torch.is_grad_enabled() and x.requires_grad) else x
+    out = conv(x_in, part.edge_index, part.edge_attr)
+    return _GatherRows.apply(out[part.lo:part.hi], part)

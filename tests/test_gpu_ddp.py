@@ -6,6 +6,8 @@
   takes rank 0's through `broadcast_parameters`; the averaged gradients must be those of the two samples under rank 0's
   weights - i.e. the pack / hidden caches did not serve pre-broadcast weights, and sharding + all-reduce
   compose with the native operator.
+* ONE graph split by destination rows over two ranks (parallel.partition_rows / nnconv_rows, the exchange step of §8e):
+  all-gathered result and all-reduced gradients against the single-process step on the whole graph.
 No scaling figure is measured here (one GPU)."""
 import os
 import socket
@@ -28,10 +30,10 @@ def _free_port():
     return p
 
 
-def _run(nproc, backend, out):
+def _run(nproc, backend, out, worker=WORKER):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPDE_HIDDEN_CACHE="off")   # one backward path on both sides
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), WORKER, "--backend", backend, "--out", out]
+           "127.0.0.1", "--master-port", str(_free_port()), worker, "--backend", backend, "--out", out]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return torch.load(out, weights_only=False)
@@ -76,3 +78,33 @@ def test_two_ranks_share_the_gpu_over_gloo_broadcast_then_allreduce(tmp_path):
     assert got["losses"] == losses                       # both ranks computed with rank 0's weights, not their own packs
     for k, v in ref.items():
         assert torch.equal(got["grads"][k], v), k
+
+
+def test_one_graph_split_by_rows_over_two_ranks_matches_the_whole_graph(tmp_path):
+    from graph_pde_amd import hidden_cache, ops
+    from tests.helpers import ddp_step, rows_step
+    got = _run(2, "gloo", str(tmp_path / "rows.pt"), worker=os.path.join(REPO, "tests", "helpers", "rows_step.py"))
+    dev = torch.device("cuda:0")
+    ops.clear_caches()
+    hidden_cache.clear()
+    mode0, hidden_cache.MODE = hidden_cache.MODE, "off"
+    try:
+        model = ddp_step.build(1000, dev)
+        ei, ea, a_in, y = ddp_step.sample(0, dev)
+        out = rows_step.forward(model, a_in, lambda h: model["conv"](h, ei, ea))
+        loss = torch.norm(out - y, 1)
+        loss.backward()
+    finally:
+        hidden_cache.MODE = mode0
+    (lo0, hi0, e0), (lo1, hi1, e1) = got["parts"]
+    assert got["world"] == 2 and (lo0, hi1) == (0, a_in.size(0)) and hi0 == lo1 and e0 + e1 == ei.shape[1]
+    assert min(e0, e1) > 0.4 * ei.shape[1]                               # balanced on in-edges
+    ref = out.detach().cpu()
+    rel = float(torch.norm(got["out"] - ref) / torch.norm(ref))
+    assert rel <= 1e-6, rel                       # a node's in-edges are summed in the same order; only the f16-split scales
+    assert torch.equal(got["out"], got["out_inference"]) or \
+        float(torch.norm(got["out"] - got["out_inference"]) / torch.norm(ref)) <= 1e-6      # (per-call maxima) may differ
+    assert abs(got["loss"] - float(loss)) <= 1e-5 * abs(float(loss))
+    for k, p in model.named_parameters():
+        g, r = got["grads"][k], p.grad.detach().cpu()
+        assert float(torch.norm(g - r) / torch.norm(r)) <= 2e-5, k
