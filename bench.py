@@ -33,7 +33,8 @@ for the median).  Objects on the line:
   mgkn          BASELINE configs 3 and 4 (MGKN-orthogonal Burgers-1D s=8192, MGKN-general Darcy-2D L=5):
                 ms per model forward, NNConv calls, M-edge-applications/s, max rel-L2 of the distinct NNConv
                 applications vs the fp64 oracle on the same tensors, time share per kernel kind.
-  depth_reuse   cross-depth reuse probe (s=61, depth 6).
+  depth_reuse   cross-depth reuse probe (s=61, depth 6; and the headline graph with the partial H the device-sized
+                budget allows).
 
 --train: one training step per rank and step = forward + native backward (gpde_nnconv_bwd) of a depth-`--depth`
 KernelNN-shaped stack on the rank's own sample + ONE flat RCCL gradient all-reduce (parallel.allreduce_gradients)
@@ -667,6 +668,40 @@ def main():
                  "rel_l2_between_paths": d6,
                  "note": "forward: fixed weights, H built once and reused by all later calls; "
                          "forward_backward: new weight version every step, H rebuilt once per step"}
+        if args.config == "g241":
+            # the headline graph itself: H (391 GB) does not fit, the default budget (hidden_cache.budget_bytes: sized to
+            # the device) keeps the in-edges of the leading ~44 % of the nodes; the others are recomputed per layer
+            def g_fwd():
+                with torch.no_grad():
+                    hcur = x
+                    for _ in range(depth):
+                        hcur = torch.relu(conv(hcur, ei, ea))
+                    return hcur
+            gres = {}
+            for mode in ("off", "auto"):
+                hidden_cache.MODE = mode
+                hidden_cache.clear()
+                torch.cuda.empty_cache()
+                budget = hidden_cache.budget_bytes(dev)
+                g_fwd()
+                torch.cuda.synchronize()
+                tq = time.perf_counter()
+                yg = g_fwd()
+                torch.cuda.synchronize()
+                ent = hidden_cache._entries.get(conv)
+                gres[mode] = (time.perf_counter() - tq, yg, budget, 0 if ent is None or ent.hidden is None else ent.hn)
+            hidden_cache.MODE = mode0
+            dg = float((gres["off"][1].double() - gres["auto"][1].double()).norm() / gres["off"][1].double().norm())
+            reuse["g241_depth6_forward"] = {
+                "direct_ms": round(1e3 * gres["off"][0], 1), "reuse_ms": round(1e3 * gres["auto"][0], 1),
+                "M_edge_applications_per_s": {"direct": round(depth * e / gres["off"][0] / 1e6, 1),
+                                              "reuse": round(depth * e / gres["auto"][0] / 1e6, 1)},
+                "budget_GiB": round(gres["auto"][2] / 2 ** 30, 1), "nodes_served_from_H": gres["auto"][3], "nodes": n,
+                "rel_l2_between_paths": dg,
+                "note": "partial H: inference only (gpde_nnconv_fwd_mixed); budget = 60 % of HBM, at most free - 48 GB"}
+            del gres, yg, ent                            # `ent` holds the 170 GB partial H: it must not outlive this probe
+            hidden_cache.clear()
+            torch.cuda.empty_cache()
 
     # ---- backward of ONE NNConv call on the s=121 graph: what `loss.backward()` costs per
     #      edge through the same operator (dx, dW_1..3, db_1..3, droot, dbias), hidden-activation cache off so that the

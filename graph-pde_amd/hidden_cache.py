@@ -8,7 +8,8 @@ the same tensor in every one of those calls.  This module decides, per NNConv in
 materialise H (one `HiddenFunction` node) and serve the remaining calls from it
 (`NNConvHiddenFunction`): the hidden layer and its backward then run once per step.
 
-Policy (`GPDE_HIDDEN_CACHE` = auto | on | off, default auto; budget `GPDE_HIDDEN_CACHE_GB`, default 32):
+Policy (`GPDE_HIDDEN_CACHE` = auto | on | off, default auto; budget `GPDE_HIDDEN_CACHE_GB`, default: sized to the device -
+60 % of its HBM, at most what is free now minus a 48 GB reserve for workspaces, i.e. ~170 GB on an idle 288 GB MI355X):
   * a call whose (edge_attr memory + version, CSR, hidden-layer parameter versions, precision, grad
     mode) matches the cached H is a hit;
   * "auto" materialises H only for a module that has been SEEN repeating a key (the second call of
@@ -34,7 +35,25 @@ from . import ops
 from .autograd import HiddenFunction, HiddenToken
 
 MODE = os.environ.get("GPDE_HIDDEN_CACHE", "auto")
-BUDGET_BYTES = int(float(os.environ.get("GPDE_HIDDEN_CACHE_GB", "32")) * (1 << 30))
+_env_gb = os.environ.get("GPDE_HIDDEN_CACHE_GB", "")
+# None = sized to the device at the moment H is built (budget_bytes); a number pins it (tests / A-B runs set this variable)
+BUDGET_BYTES: Optional[int] = None if _env_gb in ("", "auto") else int(float(_env_gb) * (1 << 30))
+AUTO_FRACTION = 0.6                  # of the device's HBM
+AUTO_RESERVE_BYTES = 48 << 30        # left free for workspaces (Z of the 241^2 graph: 15 GB), the caller's tensors, RCCL
+
+
+def budget_bytes(device=None, releasing: int = 0) -> int:
+    """Bytes the hidden activations of ONE module may take.  With GPDE_HIDDEN_CACHE_GB unset the budget follows the
+    device: min(60 % of its memory, free now + `releasing` (the H about to be dropped) - reserve).  On the 241^2 graph
+    (H = 391 GB) that caches the in-edges of ~44 % of the nodes instead of none, 1.64 x on a depth-6 inference forward
+    (scripts/time_g241_depth6_reuse.py)."""
+    if BUDGET_BYTES is not None:
+        return BUDGET_BYTES
+    dev = None if device is None else torch.device(device)
+    if dev is None or dev.type != "cuda":
+        return 32 << 30
+    free, total = torch.cuda.mem_get_info(dev)
+    return max(0, min(int(AUTO_FRACTION * total), free + releasing - AUTO_RESERVE_BYTES))
 PARTIAL = os.environ.get("GPDE_HIDDEN_CACHE_PARTIAL", "1") != "0"
 # Per-edge weight cache (DESIGN.md §6d): for inference calls on low in-degree / small graphs the whole
 # W_e = view(nn(edge_attr_e), 64, 64) tensor is kept ([E, 4096] fp32 = 16 KiB per edge) and a call is one streaming
@@ -77,6 +96,20 @@ def clear():
         stats[k] = 0
 
 
+def release_all() -> bool:
+    """Drop every cached H / W_e tensor (the entries and what they learnt about their modules stay): called by
+    ops._alloc_ws when a workspace does not fit.  Returns whether anything was released."""
+    freed = False
+    for ent in list(_entries.values()):
+        if ent.hidden is not None or ent.we is not None:
+            freed = True
+        ent.hidden, ent.key, ent.token, ent.attr_ref, ent.csr = None, None, None, None, None
+        ent.we, ent.we_key, ent.we_refs = None, None, None
+    if freed:
+        stats["released"] = stats.get("released", 0) + 1
+    return freed
+
+
 def _key(edge_attr: torch.Tensor, csr, hidden_params: List[Optional[torch.Tensor]], precision: str):
     st = edge_attr.untyped_storage()
     grad = torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in hidden_params)
@@ -116,13 +149,14 @@ def lookup(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, b
     nbytes = csr.n_edges * row_bytes
     want = mode == "on" or (mode == "auto" and ent.repeats)
     hn = csr.n_nodes
-    if want and nbytes > BUDGET_BYTES and PARTIAL and allow_partial and len(pm.dims) == 4:
+    budget = budget_bytes(edge_attr.device, 0 if ent.hidden is None else ent.hidden.numel() * ent.hidden.element_size()) if want else 0
+    if want and nbytes > budget and PARTIAL and allow_partial and len(pm.dims) == 4:
         # the leading nodes whose in-edges fit the budget, in whole 64-node tiles; worth it from 1/8 on
         rp = csr.rowptr_host
-        hn = int(torch.searchsorted(rp.to(torch.int64), torch.tensor(BUDGET_BYTES // row_bytes), right=True)) - 1
+        hn = int(torch.searchsorted(rp.to(torch.int64), torch.tensor(budget // row_bytes), right=True)) - 1
         hn = hn // 64 * 64
-        nbytes = int(rp[hn]) * row_bytes if hn >= csr.n_nodes // 8 and hn > 0 else BUDGET_BYTES + 1
-    if not want or nbytes > BUDGET_BYTES or csr.n_edges == 0 or edge_attr.requires_grad:
+        nbytes = int(rp[hn]) * row_bytes if hn >= csr.n_nodes // 8 and hn > 0 else budget + 1
+    if not want or nbytes > budget or csr.n_edges == 0 or edge_attr.requires_grad:
         ent.hidden, ent.key, ent.token, ent.attr_ref, ent.csr = None, None, None, None, None
         stats["direct"] += 1
         return None
@@ -147,7 +181,7 @@ def edge_weights_qualify(csr, force: bool = False, explicit: bool = False) -> bo
     if e == 0:
         return False
     if force:
-        return e * ops.EDGE_WEIGHT_BYTES <= max(WE_BUDGET_BYTES, BUDGET_BYTES)
+        return e * ops.EDGE_WEIGHT_BYTES <= max(WE_BUDGET_BYTES, budget_bytes(getattr(getattr(csr, "rowptr", None), "device", None)))
     return (explicit or WE_MODE == "auto") and (e <= 4 * n or e <= WE_SMALL_EDGES) and e * ops.EDGE_WEIGHT_BYTES <= WE_BUDGET_BYTES
 
 

@@ -49,7 +49,7 @@ class Csr:
             srp = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
             ssl = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
             nbytes = int(lib.gpde_csr_workspace_bytes(self.n_edges, self.n_nodes))
-            ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+            ws = _alloc_ws(nbytes, dev)
             with torch.cuda.device(dev):
                 rc = lib.gpde_csr_source_order(self.src.data_ptr(), self.n_edges, self.n_nodes, srp.data_ptr(),
                                                ssl.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
@@ -362,6 +362,20 @@ def workspace_bytes(n_nodes: int, n_edges: int, pm: PackedMlp) -> int:
 SAVE_Z_BYTES = int(float(os.environ.get("GPDE_SAVE_Z_GB", "16")) * (1 << 30))     # per call; 0 disables
 
 
+def _alloc_ws(nbytes: int, dev) -> torch.Tensor:
+    """Workspace of a native call.  The hidden-activation / per-edge-weight caches may hold most of the device (their
+    budget follows the HBM size: hidden_cache.budget_bytes) - they are recomputable, a workspace is not optional: when the
+    allocation fails they are dropped and it is retried once."""
+    try:
+        return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+    except torch.OutOfMemoryError:
+        from . import hidden_cache
+        if not hidden_cache.release_all():
+            raise
+        torch.cuda.empty_cache()
+        return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+
+
 def z_buffer(csr: Csr, dims: Sequence[int], device) -> Optional[torch.Tensor]:
     """Zeroed [N, 64 * K2P] buffer for the keep-Z forward (gpde_nnconv_fwd_keepz), or None when it does not pay / fit:
     the forward forms Z_i = sum_e x_j (x) h_e anyway and the backward's dW_3 needs exactly that - keeping it
@@ -370,7 +384,10 @@ def z_buffer(csr: Csr, dims: Sequence[int], device) -> Optional[torch.Tensor]:
     nbytes = csr.n_nodes * WIDTH * hidden_width(dims) * 4
     if SAVE_Z_BYTES <= 0 or nbytes > SAVE_Z_BYTES or csr.n_edges < 32 * csr.n_nodes:
         return None
-    return torch.zeros(csr.n_nodes, WIDTH * hidden_width(dims), dtype=torch.float32, device=device)
+    try:
+        return torch.zeros(csr.n_nodes, WIDTH * hidden_width(dims), dtype=torch.float32, device=device)
+    except torch.OutOfMemoryError:       # keeping Z is an optimisation: without it the backward re-aggregates
+        return None
 
 
 def _check_residual(residual, x, n):
@@ -418,7 +435,7 @@ def nnconv_forward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor, pm: P
     if out is None:
         out = torch.empty(n, WIDTH, dtype=torch.float32, device=x.device)
     if ws is None:
-        ws = torch.empty(max(workspace_bytes(n, e, pm), 1), dtype=torch.uint8, device=x.device)
+        ws = _alloc_ws(workspace_bytes(n, e, pm), x.device)
     residual = _check_residual(residual, x, n)
     if z_keep is not None and (residual is not None or relu):
         raise ValueError("z_keep cannot be combined with the fused glue")
@@ -506,7 +523,7 @@ def nnconv_forward_nodeattr_raw(x: torch.Tensor, csr: Csr, na: NodeAttr, pm: Pac
     if out is None:
         out = torch.empty(n, WIDTH, dtype=torch.float32, device=x.device)
     if ws is None:
-        ws = torch.empty(max(workspace_bytes(n, e, pm), 1), dtype=torch.uint8, device=x.device)
+        ws = _alloc_ws(workspace_bytes(n, e, pm), x.device)
     with torch.cuda.device(x.device):
         rc = lib.gpde_nnconv_fwd_nodeattr(x.data_ptr(), n, na.table.data_ptr(), na.table.size(1), sel_c, e,
                                           csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(),
@@ -574,7 +591,7 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
         nbytes = int(lib.gpde_nnconv_bwd_workspace_bytes(n, e, nl, dims_c))
         if nbytes == 0:
             _lib.check(-2, "gpde_nnconv_bwd_workspace_bytes")
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = _alloc_ws(nbytes, dev)
     rph = csr.rowptr_host
     srp, ssl = csr.src_order
     if z_saved is not None:
@@ -651,7 +668,7 @@ def hidden_forward_raw(csr: Csr, edge_attr: torch.Tensor, pm: PackedMlp,
                                  hidden.data_ptr(), None if hmax is None else hmax.data_ptr(),
                                  ws.data_ptr(), ws.numel(), _stream_ptr(dev))
         if rc in (-1, -3) and fast:    # shape not covered by the fused kernel: the general path needs ws
-            ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+            ws = _alloc_ws(nbytes, dev)
             hmax = None                # ... and does not record max |H|
             rc = lib.gpde_hidden_fwd(edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), n_lim,
                                      perm.data_ptr(), nl, pm.dims_c, pm.packed.data_ptr(),
@@ -686,7 +703,7 @@ def nnconv_forward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, p
     if out is None:
         out = torch.empty(n, WIDTH, dtype=torch.float32, device=x.device)
     if ws is None:
-        ws = torch.empty(max(workspace_bytes(n, e, pm), 1), dtype=torch.uint8, device=x.device)
+        ws = _alloc_ws(workspace_bytes(n, e, pm), x.device)
     residual = _check_residual(residual, x, n)
     if z_keep is not None:
         if residual is not None or relu:
@@ -818,7 +835,7 @@ def nnconv_forward_mixed_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
     root_c = None if root is None else root.detach().contiguous()
     bias_c = None if bias is None else bias.detach().contiguous()
     out = torch.empty(n, WIDTH, dtype=torch.float32, device=x.device)
-    ws = torch.empty(max(workspace_bytes(n, e, pm), 1), dtype=torch.uint8, device=x.device)
+    ws = _alloc_ws(workspace_bytes(n, e, pm), x.device)
     with torch.cuda.device(x.device):
         rc = lib.gpde_nnconv_fwd_mixed(x.data_ptr(), n, edge_attr.data_ptr(), hidden.data_ptr(),
                                        None if hmax is None else hmax.data_ptr(), hidden_nodes, e,
@@ -857,7 +874,7 @@ def nnconv_backward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, 
     nbytes = int(lib.gpde_nnconv_bwd_workspace_bytes(n, e, nl, dims_c))
     if nbytes == 0:
         _lib.check(-2, "gpde_nnconv_bwd_workspace_bytes")
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws = _alloc_ws(nbytes, dev)
     p = lambda t: None if t is None else t.data_ptr()
     srp, ssl = csr.src_order
     if z_saved is not None:
@@ -906,7 +923,7 @@ def hidden_backward_raw(csr: Csr, edge_attr: torch.Tensor, dims: Sequence[int],
     nbytes = int(lib.gpde_nnconv_bwd_workspace_bytes(0, e, nl, dims_c))
     if nbytes == 0:
         _lib.check(-2, "gpde_nnconv_bwd_workspace_bytes")
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws = _alloc_ws(nbytes, dev)
     with torch.cuda.device(dev):
         rc = lib.gpde_hidden_bwd(edge_attr.data_ptr(), e, perm.data_ptr(), nl, dims_c,
                                  _ptr_array(ws_), _ptr_array(bs_), grad_hidden.data_ptr(),
@@ -987,7 +1004,7 @@ def radius_csr_raw(pos: torch.Tensor, r: float, reference_ties: bool = False, po
     nbytes = int(lib.gpde_radius_csr_workspace_bytes(n, dim, float(r), lo, hi))
     if nbytes == 0:
         _lib.check(-1, "gpde_radius_csr_workspace_bytes")
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws = _alloc_ws(nbytes, dev)
     deg = torch.empty(nd, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.gpde_radius_csr_count(pos.data_ptr(), n, pd.data_ptr(), nd, dim, float(r), flags, lo, hi, deg.data_ptr(),

@@ -365,3 +365,50 @@ def test_attr_slot_order_cache_and_keep_z_policy_host_logic(monkeypatch):
     assert ops.z_buffer(csr, dims, "cpu") is None
     monkeypatch.setattr(ops, "SAVE_Z_BYTES", 0)
     assert ops.z_buffer(csr, dims, "cpu") is None
+
+
+def test_hidden_cache_budget_follows_the_device_unless_pinned(monkeypatch):
+    """hidden_cache.budget_bytes: GPDE_HIDDEN_CACHE_GB pins it; unset -> min(60 % of the device's memory, free now + what
+    is about to be released - the 48 GB reserve), never negative; CPU tensors (tests) get the old fixed 32 GB."""
+    from graph_pde_amd import hidden_cache
+    gb = 1 << 30
+    monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", 5 * gb)
+    assert hidden_cache.budget_bytes("cuda:0") == 5 * gb and hidden_cache.budget_bytes(None) == 5 * gb
+    monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", None)
+    assert hidden_cache.budget_bytes(None) == 32 * gb and hidden_cache.budget_bytes(torch.device("cpu")) == 32 * gb
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (280 * gb, 288 * gb))
+    assert hidden_cache.budget_bytes("cuda:0") == int(0.6 * 288 * gb)                  # idle device: the fraction binds
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (100 * gb, 288 * gb))
+    assert hidden_cache.budget_bytes("cuda:0") == 52 * gb                               # busy device: free - reserve
+    assert hidden_cache.budget_bytes("cuda:0", releasing=20 * gb) == 72 * gb            # the H being replaced counts as free
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (10 * gb, 288 * gb))
+    assert hidden_cache.budget_bytes("cuda:0") == 0
+
+
+def test_workspace_allocation_drops_the_caches_once_when_the_device_is_full(monkeypatch):
+    """ops._alloc_ws: the hidden-activation cache may hold most of the HBM (budget sized to the device); a workspace that
+    does not fit makes it let go and is retried ONCE; with nothing to release the error is the caller's."""
+    from graph_pde_amd import hidden_cache
+
+    class M(torch.nn.Module):
+        pass
+    m = M()
+    ent = hidden_cache._Entry()
+    ent.hidden, ent.key, ent.repeats = torch.zeros(4), ("k",), True
+    hidden_cache._entries[m] = ent
+    real_empty, calls = torch.empty, {"n": 0}
+
+    def flaky_empty(*a, **k):
+        calls["n"] += 1
+        if calls["n"] == 1:
+            raise torch.OutOfMemoryError("HIP out of memory (test)")
+        return real_empty(*a, **k)
+    monkeypatch.setattr(torch, "empty", flaky_empty)
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
+    ws = ops._alloc_ws(100, "cpu")
+    assert ws.numel() == 100 and calls["n"] == 2
+    assert ent.hidden is None and ent.key is None and ent.repeats       # tensors gone, what was learnt about the module stays
+    calls["n"] = 0                                                        # nothing cached any more: the error propagates
+    with pytest.raises(torch.OutOfMemoryError):
+        ops._alloc_ws(100, "cpu")
+    hidden_cache.clear()
