@@ -159,8 +159,10 @@ def row_bounds(edge_index: torch.Tensor, n_nodes: int, world: int) -> List[int]:
     if world < 1:
         raise ValueError("world must be >= 1")
     e = int(edge_index.shape[1])
-    if e == 0 or world == 1:
-        return [min(n_nodes, -(-n_nodes * r // world)) for r in range(world)] + [n_nodes] if world > 1 else [0, n_nodes]
+    if world == 1:
+        return [0, n_nodes]
+    if e == 0:                                      # nothing to balance: equal node counts
+        return [min(n_nodes, -(-n_nodes * r // world)) for r in range(world)] + [n_nodes]
     deg = torch.bincount(edge_index[1].reshape(-1).to(torch.int64), minlength=n_nodes)
     cum = torch.cumsum(deg, 0)
     targets = torch.tensor([-(-e * r // world) for r in range(1, world)], dtype=cum.dtype, device=cum.device)
