@@ -1,28 +1,48 @@
 #!/usr/bin/env python3
 """Stage / unstage the reference's own script files for a GPU-box run of the UNMODIFIED scripts.
 
-    python scripts/stage_reference.py            # copy /root/reference/*/*.py -> oracle/_ref/ (git-ignored)
+    python scripts/stage_reference.py [--all]    # copy the needed (all) /root/reference/*/*.py -> oracle/_ref/ (git-ignored)
     python scripts/stage_reference.py --remove   # delete the staged copies again
 
-The GPU box has no /root/reference; the gpurun snapshot carries git-ignored files, so the byte-identical
-copies travel with it.  They are never committed, and they are removed after the run: the repo holds no
-reference source (the logs of the runs are kept under profiles/)."""
+The GPU box has no /root/reference; the gpurun snapshot (and the driver's round-end snapshot) carries git-ignored
+files, so the byte-identical copies travel with it exactly like the built libgpde.so does.  They are never committed:
+the repo holds no reference source.  `__graft_entry__.build()` calls `stage()` on the build container, where
+/root/reference exists, so that tests/test_gpu_reference_scripts.py runs on the GPU box instead of skipping."""
 import os
 import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DST = os.path.join(REPO, "oracle", "_ref")
-if "--remove" in sys.argv:
-    shutil.rmtree(DST, ignore_errors=True)
-    print("removed", DST)
-    sys.exit(0)
-n = 0
-for proj in ("graph-neural-operator", "multipole-graph-neural-operator"):
-    src = os.path.join("/root/reference", proj)
-    os.makedirs(os.path.join(DST, proj), exist_ok=True)
-    for f in sorted(os.listdir(src)):
-        if f.endswith(".py"):
-            shutil.copyfile(os.path.join(src, f), os.path.join(DST, proj, f))
-            n += 1
-print(f"staged {n} files under {DST}")
+SRC = "/root/reference"
+PROJECTS = ("graph-neural-operator", "multipole-graph-neural-operator")
+# what the three unmodified-script tests execute: the scripts themselves and the `utilities` module each imports
+# (nn_conv / torch_geometric / h5py resolve to graph-pde_amd/shims and are NOT staged)
+NEEDED = {"graph-neural-operator": ("UAI1_full_resolution.py", "utilities.py"),
+          "multipole-graph-neural-operator": ("MGKN_general_darcy2d.py", "MGKN_orthogonal_burgers1d.py", "utilities.py")}
+
+
+def stage(src_root: str = SRC, dst: str = DST, everything: bool = False) -> int:
+    """Copy the reference's *.py files (both projects) under oracle/_ref/.  Returns the number of files staged;
+    0 when the reference is not on this machine (the GPU box: nothing to do, the snapshot brought them)."""
+    if not os.path.isdir(src_root):
+        return 0
+    n = 0
+    for proj in PROJECTS:
+        src = os.path.join(src_root, proj)
+        if not os.path.isdir(src):
+            continue
+        os.makedirs(os.path.join(dst, proj), exist_ok=True)
+        for f in sorted(os.listdir(src)):
+            if f.endswith(".py") and (everything or f in NEEDED[proj]):
+                shutil.copyfile(os.path.join(src, f), os.path.join(dst, proj, f))
+                n += 1
+    return n
+
+
+if __name__ == "__main__":
+    if "--remove" in sys.argv:
+        shutil.rmtree(DST, ignore_errors=True)
+        print("removed", DST)
+        sys.exit(0)
+    print(f"staged {stage(everything='--all' in sys.argv)} files under {DST}")
