@@ -6,6 +6,12 @@ Cross-depth reuse: `HiddenFunction` mater
 activations H(edge_attr; hidden layers) once, `NNConvHiddenFunction` is the operator given H.  When a
 module is applied `depth` times with the same edge_attr and weights, all `depth` applications share
 one H node: autograd sums their dL/dH and `HiddenFunction.backward` runs the MLP backward once.
+
+Depth-deferred backward: when H does not fit memory (the 241^2 graph: 391 GB) the same sharing is done
+WITHOUT the tensor.  `DeferredHiddenFunction` returns a one-element "virtual H" tensor that every application of the module
+takes as an input (`NNConvDeferredFunction`); their backward passes compute grad_x and the node-side gradients only
+(gpde_nnconv_bwd_light) and leave (x, grad_out) on the shared token; autograd runs the virtual node's backward after all of
+them, and that ONE gpde_nnconv_bwd_deferred pass forms the hidden layers' gradients of all applications.
 """
 from __future__ import annotations
 
@@ -108,3 +114,81 @@ class NNConvHiddenFunction(torch.autograd.Function):
             need_root=root is not None, need_bias=ctx.has_bias, z_saved=ctx.z)
         ctx.z = None
         return (gx, gh, None, None, gw, gb, groot, gbias if ctx.has_bias else None, None, None)
+
+
+class DeferredToken:
+    """Shared by the virtual-H node and the applications hanging on it: the (input, output gradient) pairs the light
+    backward passes leave for the deferred pass, and the validity flag of the cached virtual H (as HiddenToken)."""
+    __slots__ = ("valid", "stash")
+
+    def __init__(self):
+        self.valid = True
+        self.stash = []
+
+
+class DeferredHiddenFunction(torch.autograd.Function):
+    """The "virtual H" of a module whose hidden activations do not fit memory: a one-element tensor standing for
+    H(edge_attr; hidden layers).  Its backward - run by autograd after every application's backward - is ONE
+    gpde_nnconv_bwd_deferred pass over the edges for all applications."""
+
+    @staticmethod
+    def forward(ctx, edge_attr, csr, aggr, token, n_layers, *params):
+        ctx.csr, ctx.aggr, ctx.token, ctx.n_layers = csr, aggr, token, n_layers
+        ctx.attr_needs_grad = edge_attr.requires_grad
+        ctx.save_for_backward(edge_attr, *params)
+        return torch.zeros(1, dtype=torch.float32, device=edge_attr.device)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_virtual):
+        if ctx.attr_needs_grad:
+            raise NotImplementedError(
+                "gradient with respect to edge_attr is not built (no reference script needs it)")
+        token = ctx.token
+        token.valid = False
+        stash, token.stash = token.stash, []
+        edge_attr, *params = ctx.saved_tensors
+        n = ctx.n_layers
+        weights, biases = list(params[:n]), list(params[n:])
+        if not stash:                   # no application took part in this backward: the hidden layers get zero
+            gW = [torch.zeros_like(w) for w in weights[:-1]]
+            gb = [None if b is None else torch.zeros_like(b) for b in biases[:-1]]
+        else:
+            gW, gb = ops.nnconv_backward_deferred_raw([s[0] for s in stash], [s[1] for s in stash], ctx.csr, edge_attr,
+                                                      weights, biases, ctx.aggr)
+        return (None, None, None, None, None, *gW, None, *gb, None)
+
+
+class NNConvDeferredFunction(torch.autograd.Function):
+    """One application of a depth-shared module whose hidden layers are differentiated by the shared virtual-H node:
+    forward = gpde_nnconv_fwd (as NNConvFunction), backward = gpde_nnconv_bwd_light."""
+
+    @staticmethod
+    def forward(ctx, x, virtual_h, csr, edge_attr, root, bias, aggr, token, n_layers, *params):
+        # params: the Linear layers' weights then biases (the module's own tensors: the pack cache recognises them).  This
+        # node returns a gradient for the LAST Linear only; the hidden layers' flows through virtual_h.
+        weights = list(params[:n_layers])
+        biases = list(params[n_layers:])
+        ops._require_cuda(x, "x")
+        pm = ops.pack_mlp(weights, biases)
+        ctx.z = ops.z_buffer(csr, pm.dims, x.device) if aggr in ("add", "mean") else None
+        out = ops.nnconv_forward_raw(x.detach(), csr, edge_attr.detach(), pm, root, bias, aggr, z_keep=ctx.z)
+        ctx.csr, ctx.aggr, ctx.n_layers, ctx.token = csr, aggr, n_layers, token
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, edge_attr, root, *params)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        x, edge_attr, root, *params = ctx.saved_tensors
+        n = ctx.n_layers
+        weights, biases = list(params[:n]), list(params[n:])
+        gx, gw, gb, groot, gbias = ops.nnconv_backward_light_raw(
+            x, ctx.csr, edge_attr, weights, biases, root, ctx.aggr, grad_out,
+            need_root=root is not None, need_bias=ctx.has_bias, z_saved=ctx.z)
+        ctx.z = None
+        ctx.token.stash.append((x, grad_out.detach().contiguous()))
+        gv = torch.zeros(1, dtype=torch.float32, device=x.device)        # the virtual H carries no numbers, only the dependency
+        return (gx, gv, None, None, groot, gbias if ctx.has_bias else None, None, None, None,
+                *([None] * (n - 1)), gw, *([None] * (n - 1)), gb)

@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd_kernel(EdgeBwdArgs a) {
             const int seg_end = min(a.rowptr[node + 1], t1);
             const float* dZi = a.dZ + (size_t)(node - a.n0) * GP_W * a.K2P + nc;
             const bool mine = (t0 + l31 >= e_seg) && (t0 + l31 < seg_end);     // lane's edge in segment
-            // dH[e][n] += sum_c x[e][c] dZ_i[c][n]      (A = x from LDS, B = dZ_i from L2)
+            // dH[e][n] += sum_c x[e][c] dZ_i[c][n]      (A = x from LDS, B = dZ_i from L2); skipped without a dU output
+            if (a.dU) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd_kernel(EdgeBwdArgs a) {
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) dh[nb] = mfma32(av, zp[nb * 32], dh[nb]);
                 }
+            }
             // dXg^T[c][e] += sum_n dZ_i[c][n] H[e][n]   (A = dZ_i rows c, B = H^T from LDS)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd_kernel(EdgeBwdArgs a) {
             e_seg = seg_end;
         }
         // dU = dH * (H > 0)
+        if (a.dU)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -459,7 +462,8 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd2_kernel(EdgeBwdArgs a) {
             if (nd == 0 ? !anyA : !anyB) continue;
             const bool in = nd == 0 ? inA : inB;
             const float* zb = dZs + buf * EB2_DZ + nd * 64 * EB2_NC;
-            // product (1): k = c = 8q + 4h + t
+            // product (1): k = c = 8q + 4h + t   (skipped without a dU output: the light pass of the depth-deferred backward)
+            if (a.dU) {
 #pragma unroll
             for (int q = 0; q < 8; ++q)
 #pragma unroll
@@ -468,6 +472,7 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd2_kernel(EdgeBwdArgs a) {
                     const float bv = zb[c * EB2_NC + ((((l31 >> 2) ^ (c & 7)) << 2) | (l31 & 3))];
                     dh = mfma32(in ? xr[q][t] : 0.f, bv, dh);
                 }
+            }
             // product (2): k = n = 8q + 4h + t, B row c = l31 (+32)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
@@ -481,6 +486,7 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd2_kernel(EdgeBwdArgs a) {
             }
         }
         // dU rows of this pass's nodes: dH * (H > 0); lane = column nc + l31, rows (r, h)
+        if (a.dU)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int er = (r & 3) + 8 * (r >> 2) + 4 * h, e = t0 + er;
@@ -563,11 +569,14 @@ struct BwdPlan {
     bool f16s_dw2; size_t off_tnws;   // dW_2 on the split-f16 GEMM: transposed dU_2 + split image of H_1^T per edge chunk
     size_t off_dubits;                // column maxima of |dU_2| as bit patterns [kmax]
     size_t off_maskbits;              // ReLU mask of the first hidden layer as bits [Ec][KP1 / 32] (H_1 itself is not materialised)
+    // depth-deferred form (gpde_nnconv_bwd_deferred): L = n_defer layers share one pass over the hidden layers
+    int L, Lp;                        // Lp = K / 64 of the gather GEMM: L rounded up to an even count >= 4 (zero layers)
+    size_t off_dzstack, off_dzimg, off_nbits, off_nscale, off_tiles, off_xsc;
     size_t total;
 };
 
 int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws_bytes, bool sizing,
-                  BwdPlan* P) {
+                  BwdPlan* P, int n_defer = 0) {
     if (n_layers < 2 || n_layers > GPDE_MAX_LAYERS) { gpde_set_error("kernel MLP must have 2..%d Linear layers", GPDE_MAX_LAYERS); return GPDE_EUNSUPPORTED; }
     if (dims[n_layers] != GP_W * GP_W) { gpde_set_error("last layer must emit %d values", GP_W * GP_W); return GPDE_EUNSUPPORTED; }
     P->n_layers = n_layers; P->nh = n_layers - 1;
@@ -603,11 +612,16 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
         P->off_ucol2 = take(P->KP[1]);
     }
     P->f16s_dw2 = P->f16s_du1 && P->KP[2] % 64 == 0 && P->KP[1] % GP_TN == 0;
+    P->L = n_defer; P->Lp = n_defer > 0 ? (n_defer + 1) / 2 * 2 : 0;
+    if (n_defer > 0 && P->Lp < 4) P->Lp = 4;
+    P->off_xsc = take(n_defer > 0 ? (size_t)2 * (N > 0 ? N : 1) : 1);      // per source node row scales of the layer-input stack
     const size_t fixed = off;
     // per-chunk buffers: per edge (hsum + 2*kmax) floats (+ KP1 + KP2 for the transposed operands of dW_2), per node
     // (2*64*K2P + 3*64) floats
     const size_t tn_edge = P->f16s_dw2 ? (size_t)P->KP[1] + P->KP[2] : 0;
-    const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0) + tn_edge + GP_W) * 4 + (P->f16s_dw2 ? P->KP[1] / 8 + (P->KP[2] / 64 + 2) * 4 + 8 : 0), per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4;
+    const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0) + tn_edge + GP_W) * 4 + (P->f16s_dw2 ? P->KP[1] / 8 + (P->KP[2] / 64 + 2) * 4 + 8 : 0) + (n_defer > 0 ? 1 : 0),
+                 per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4 +
+                            (n_defer > 0 ? (size_t)(P->L + P->Lp) * GP_W * P->K2P * 4 + 64 : 0);   // dZ of every deferred layer (fp32) + the node's split image + tile records
     int64_t Ec, Nc;
     // alignment of the per-chunk buffers below + the K padding of the transposed operands
     const size_t slack = 64 * 256 + (P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats(0, P->KP[2], P->KP[1], BWD_TN_KSPLITS) * 4 : 0);
@@ -635,6 +649,11 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     P->off_tnws = take(P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats((int)Ec, P->KP[2], P->KP[1], BWD_TN_KSPLITS) : 1);
     P->off_dubits = take((size_t)(kmax > 0 ? kmax : 1));
     P->off_maskbits = take(P->f16s_dw2 ? (size_t)Ec * (P->KP[1] / 32) : 1);
+    P->off_dzstack = take(n_defer > 0 ? (size_t)P->L * Nc * GP_W * P->K2P : 1);
+    P->off_dzimg = take(n_defer > 0 ? (size_t)P->Lp * Nc * GP_W * P->K2P : 1);
+    P->off_nbits = take(n_defer > 0 ? (size_t)Nc : 1);
+    P->off_nscale = take(n_defer > 0 ? (size_t)2 * Nc : 1);
+    P->off_tiles = take(n_defer > 0 ? (size_t)4 * (Ec / 256 + Nc + 8) : 1);
     P->total = off + 256 + (sizing ? slack : 0);
     if (!sizing && P->total > ws_bytes) { gpde_set_error("gpde_nnconv_bwd: internal plan %zu > workspace %zu", P->total, ws_bytes); return GPDE_EWORKSPACE; }
     return GPDE_OK;
@@ -684,7 +703,11 @@ namespace {
 //   BWD_CONV  gpde_nnconv_bwd_hidden  H given ([CSR slot][K2P]); grads of x, W3, b3, root, bias and
 //                                     dL/dU of the last hidden layer ([CSR slot][K2P]) written out
 //   BWD_MLP   gpde_hidden_bwd         H and dL/dU given; grads of the hidden Linear layers
-enum BwdPhase { BWD_FULL = 0, BWD_CONV = 1, BWD_MLP = 2 };
+//   BWD_LIGHT gpde_nnconv_bwd_light     one application of a depth-shared module: everything BUT the hidden layers' gradients
+//                                       (grad_x, last Linear, root, bias); the last hidden layer is recomputed, never differentiated
+//   BWD_DEFER gpde_nnconv_bwd_deferred  the hidden layers' gradients of ALL those applications in one pass over the edges:
+//                                       dU_2 = (sum_l x_j^(l) . dZ_i^(l)) (.) [H_2 > 0]  (a K = 64 L contraction), then ONE MLP backward
+enum BwdPhase { BWD_FULL = 0, BWD_CONV = 1, BWD_MLP = 2, BWD_LIGHT = 3, BWD_DEFER = 4 };
 
 int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
              const int32_t* rowptr, const int32_t* src, const int32_t* dst, const int32_t* perm,
@@ -693,10 +716,10 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
              float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias,
              const float* hidden, float* grad_hidden_out, const float* grad_hidden_in, void* ws,
              size_t ws_bytes, hipStream_t st, const int32_t* src_rowptr = nullptr, const int32_t* src_slots = nullptr,
-             const float* z_saved = nullptr) {
-    const bool do_conv = phase != BWD_MLP, do_mlp = phase != BWD_CONV;
+             const float* z_saved = nullptr, int n_defer = 0, const float* x_stack = nullptr, const float* g_stack = nullptr) {
+    const bool do_conv = phase != BWD_MLP && phase != BWD_DEFER, do_mlp = phase != BWD_CONV && phase != BWD_LIGHT;
     BwdPlan P;
-    int rc = make_bwd_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P);
+    int rc = make_bwd_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P, phase == BWD_DEFER ? n_defer : 0);
     if (rc != GPDE_OK) return rc;
     const int n = n_layers, K2P = P.K2P;
     const int N = (int)n_nodes;
@@ -723,6 +746,9 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         if ((rc = gpde_pack_split_nk(F(P.off_w2t), P.KP[1], P.KP[2], P.KP[1], P.KP[2], F(P.off_w2ts), F(P.off_ucol2), st)) != GPDE_OK) return rc;
     }
     const size_t w3n = (size_t)GP_W * GP_W * K2P;
+    if (phase == BWD_DEFER)
+        hipLaunchKernelGGL(k_pad_mat, dim3(nblk(w3n)), dim3(T), 0, st, W[n - 1], GP_W * GP_W, dims[n - 1], dims[n - 1],
+                           GP_W * GP_W, K2P, F(P.off_w3p));
     if (do_conv) {
         hipLaunchKernelGGL(k_pad_mat, dim3(nblk(w3n)), dim3(T), 0, st, W[n - 1], GP_W * GP_W, dims[n - 1], dims[n - 1],
                            GP_W * GP_W, K2P, F(P.off_w3p));
@@ -739,7 +765,8 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     // still needed in memory (dW_2 = dU_2^T H_1) and comes from the GEMM below
     GpdePackLayout PL;
     bool fast_last = false;
-    if (phase == BWD_FULL && P.pack_bytes && rowptr && !getenv("GPDE_BWD_RECOMPUTE_F32") &&
+    const bool recomputes = phase == BWD_FULL || phase == BWD_LIGHT || phase == BWD_DEFER;
+    if (recomputes && P.pack_bytes && rowptr && (phase != BWD_FULL || !getenv("GPDE_BWD_RECOMPUTE_F32")) &&
         gpde_pack_layout(n, dims, &PL) == GPDE_OK && PL.mode == 1) {
         GpdeFusedArgs probe{};
         probe.k0 = PL.k0; probe.K1P = PL.K1P; probe.K2P = PL.K2P;
@@ -754,11 +781,18 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     const bool h1_on_the_fly = n == 3 && f16s_du1 && f16s_dw2 && dims[0] <= 8 && P.KP[0] >= 8 && !getenv("GPDE_BWD_H1_MATERIALIZE") &&
                                !getenv("GPDE_BWD_H1_GEMM");
     auto skip_h1 = [&](int rows) { return h1_on_the_fly && rows >= 8192; };
+    if ((phase == BWD_LIGHT && !fast_last) || (phase == BWD_DEFER && !(fast_last && f16s_du1 && f16s_dw2 && n == 3))) {
+        gpde_set_error("gpde_nnconv_bwd_%s: kernel MLP outside the depth-deferred form (3 Linear layers of widths that are multiples of 128, "
+                       "k0 <= 7): use gpde_nnconv_bwd", phase == BWD_LIGHT ? "light" : "deferred");
+        return GPDE_EUNSUPPORTED;
+    }
+    const bool light = phase == BWD_LIGHT;
     // recompute of the hidden chain for rows [e0, e0 + rows) = in-edges of nodes [na_, nb_): layers 1 .. last
     int rc_na = 0, rc_nb = 0;
     auto recompute = [&](int e0, int rows, int last) -> int {
-        hipLaunchKernelGGL(k_gather_attr, dim3(nblk((size_t)rows * P.KP[0])), dim3(T), 0, st, edge_attr, perm, e0,
-                           rows, dims[0], P.KP[0], F(P.off_H[0]));
+        if (!light)      // (the light pass needs the last hidden layer only, which the fused kernel forms from the attributes itself)
+            hipLaunchKernelGGL(k_gather_attr, dim3(nblk((size_t)rows * P.KP[0])), dim3(T), 0, st, edge_attr, perm, e0,
+                               rows, dims[0], P.KP[0], F(P.off_H[0]));
         if (fast_last && last == n - 1) {
             const float* pk = F(P.off_pack);
             GpdeFusedArgs f{};
@@ -775,6 +809,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             if (rc2 != GPDE_OK) return rc2;
             last = n - 2;
         }
+        if (light) return GPDE_OK;
         for (int l = 1; l <= last; ++l) {
             if (l == 1 && last == 1 && skip_h1(rows)) continue;
             if (l == 1 && dims[0] <= 8 && P.KP[0] >= 8 && P.KP[1] % 4 == 0 && rows >= 1024 && !getenv("GPDE_BWD_H1_GEMM")) {
@@ -882,8 +917,10 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     }
 
     // ---- node-aligned chunks ----------------------------------------------------------------------------------
+    if (phase == BWD_DEFER && n_edges > 0)
+        if ((rc = gpde_launch_xstack_scales(x_stack, (size_t)N * GP_W, P.L, N, F(P.off_xsc), F(P.off_xsc) + N, st)) != GPDE_OK) return rc;
     int na = 0;
-    while (do_conv && na < N && n_edges > 0) {
+    while ((do_conv || phase == BWD_DEFER) && na < N && n_edges > 0) {
         // largest nb with (nb - na) <= Nc and edges <= Ec (at least one node)
         int lo = na + 1, hi = (int)((int64_t)na + P.Nc < N ? na + P.Nc : N);
         const int64_t ebase = rowptr_host[na];
@@ -901,11 +938,39 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         const int e0 = (int)ebase, e1 = rowptr_host[nb], rows = e1 - e0;
         float* gT = F(P.off_gT); float* S = F(P.off_S); float* dS = F(P.off_dS);
         float* Z = F(P.off_Z); float* dZ = F(P.off_dZ);
+        if (phase == BWD_DEFER) {
+            if (rows > 0) {
+                rc_na = na; rc_nb = nb;
+                if ((rc = recompute(e0, rows, n - 1)) != GPDE_OK) return rc;
+                // dZ^(l)[i][c][k] = sum_o gT^(l)[i][o] W3[c*64+o][k] of every deferred layer, then the nodes' split images
+                const size_t dzl = (size_t)P.Nc * GP_W * K2P;
+                for (int l = 0; l < P.L; ++l) {
+                    hipLaunchKernelGGL(k_scale_g, dim3((nn + 3) / 4), dim3(T), 0, st, g_stack + (size_t)l * N * GP_W, rowptr, aggr, na, nn, gT);
+                    GpdeGemmArgs g = gemm0();
+                    g.A = gT; g.lda = GP_W; g.B = F(P.off_w3p); g.ldb = K2P; g.b_kcontig = 0;
+                    g.C = F(P.off_dzstack) + (size_t)l * dzl; g.ldc = GP_W * K2P; g.M = nn; g.N = K2P; g.K = GP_W;
+                    g.batches = GP_W; g.strideA = 0; g.strideB = (size_t)GP_W * K2P; g.strideC = K2P;
+                    if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
+                }
+                if ((rc = gpde_launch_dz_image(F(P.off_dzstack), dzl, P.L, P.Lp, nn, K2P, (unsigned*)F(P.off_nbits), F(P.off_nscale),
+                                               F(P.off_nscale) + P.Nc, F(P.off_dzimg), st)) != GPDE_OK) return rc;
+                const int ntiles = gpde_tile_count(rowptr_host, na, nb);
+                int32_t* tiles = (int32_t*)F(P.off_tiles);
+                if ((rc = gpde_launch_tile_list(rowptr, na, nn, e0, tiles, st)) != GPDE_OK) return rc;
+                // dU_2 of the chunk's edges: (sum over the layers of x_j . dZ_i) masked by the recomputed H_2 > 0
+                float* dU2 = F(P.off_dU[0]);
+                if ((rc = gpde_launch_gemm_f16s_gather(x_stack, (size_t)N * GP_W, P.Lp, F(P.off_xsc), F(P.off_xsc) + N, src + e0, rows, tiles, ntiles,
+                                                       F(P.off_dzimg), F(P.off_nscale) + P.Nc, F(P.off_H[n - 1]), K2P, dU2, K2P, K2P, st)) != GPDE_OK) return rc;
+                if ((rc = mlp_backward(dU2, rows)) != GPDE_OK) return rc;
+            }
+            na = nb;
+            continue;
+        }
         hipLaunchKernelGGL(k_scale_g, dim3((nn + 3) / 4), dim3(T), 0, st, grad_out, rowptr, aggr, na, nn, gT);
         if (rows > 0) {
             // hidden activations of the chunk's edges: recomputed, or rows of the given cache
-            if (phase == BWD_FULL) { rc_na = na; rc_nb = nb; if ((rc = recompute(e0, rows, n - 1)) != GPDE_OK) return rc; }
-            const float* Hlast = phase == BWD_FULL ? F(P.off_H[n - 1]) : hidden + (size_t)e0 * K2P;
+            if (phase == BWD_FULL || light) { rc_na = na; rc_nb = nb; if ((rc = recompute(e0, rows, n - 1)) != GPDE_OK) return rc; }
+            const float* Hlast = (phase == BWD_FULL || light) ? F(P.off_H[n - 1]) : hidden + (size_t)e0 * K2P;
             // Z of the chunk's nodes: kept by the forward (gpde_nnconv_fwd_keepz), else re-aggregated from the recomputed /
             // given activations
             if (z_saved) Z = const_cast<float*>(z_saved) + (size_t)na * GP_W * K2P;      // read only below
@@ -944,7 +1009,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 if ((rc = gpde_launch_gemm(s2, st)) != GPDE_OK) return rc;
             }
             // per-edge backward through the aggregation -> dU_{n-1}, dx_j
-            float* dUc = phase == BWD_FULL ? F(P.off_dU[0]) : grad_hidden_out + (size_t)e0 * K2P;
+            float* dUc = phase == BWD_FULL ? F(P.off_dU[0]) : light ? nullptr : grad_hidden_out + (size_t)e0 * K2P;   // light: dx only
             {
                 const bool ordered = src_rowptr && src_slots;
                 EdgeBwdArgs ea{x, rowptr, src, dst, dZ, dS, Hlast, dUc, dx, e0, e1, na, K2P, ordered ? F(P.off_dxe) : nullptr};
@@ -1043,6 +1108,66 @@ extern "C" int gpde_nnconv_bwd_z(const float* x, int64_t n_nodes, const float* e
     return bwd_impl(BWD_FULL, x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims, W, b, root, aggr,
                     grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes,
                     (hipStream_t)stream_, src_rowptr, src_slots, z_saved);
+}
+
+// ---- depth-deferred backward: a module applied `depth` times with the same edge_attr and weights ----------------------
+// (KernelNN.forward applies ONE conv1 `depth` times, /root/reference/graph-neural-operator/UAI1_full_resolution.py:29-30, and
+// loss.backward(), :266, sums the kernel MLP's gradients over those uses.)  When the hidden activations do not fit memory
+// every application runs gpde_nnconv_bwd_light (grad_x and the node-side gradients only) and ONE gpde_nnconv_bwd_deferred
+// pass forms the hidden layers' gradients of all of them.
+extern "C" int gpde_nnconv_bwd_deferred_supported(int n_layers, const int32_t* dims) {
+    BwdPlan P;
+    GpdePackLayout PL;
+    if (!dims || n_layers != 3 || make_bwd_plan(1, 1, n_layers, dims, 0, true, &P, 2) != GPDE_OK) return 0;
+    if (!(P.f16s_du1 && P.f16s_dw2 && P.pack_bytes) || dims[0] > 7 || gpde_pack_layout(n_layers, dims, &PL) != GPDE_OK || PL.mode != 1) return 0;
+    GpdeFusedArgs probe{};
+    probe.k0 = PL.k0; probe.K1P = PL.K1P; probe.K2P = PL.K2P;
+    return gpde_fused_store_supported(probe) ? 1 : 0;
+}
+
+extern "C" size_t gpde_nnconv_bwd_deferred_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers, const int32_t* dims,
+                                                           int n_defer) {
+    BwdPlan P;
+    if (!dims || n_nodes < 0 || n_edges < 0 || n_defer < 1) return 0;
+    if (make_bwd_plan(n_nodes, n_edges, n_layers, dims, 0, true, &P, n_defer) != GPDE_OK) return 0;
+    return P.total;
+}
+
+extern "C" int gpde_nnconv_bwd_light(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges, const int32_t* rowptr,
+                                     const int32_t* src, const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host,
+                                     const int32_t* src_rowptr, const int32_t* src_slots, int n_layers, const int32_t* dims,
+                                     const float* const* W, const float* const* b, const float* root, int aggr, const float* grad_out,
+                                     const float* z_saved, float* grad_x, float* grad_w_last, float* grad_b_last, float* grad_root,
+                                     float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || !dims || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws || n_layers < 2 ||
+        n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x || !grad_x)) || (n_edges > 0 && (!edge_attr || !src || !dst || !perm))) {
+        gpde_set_error("gpde_nnconv_bwd_light: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_light: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
+    float* gW[GPDE_MAX_LAYERS] = {};
+    float* gb[GPDE_MAX_LAYERS] = {};
+    gW[n_layers - 1] = grad_w_last; gb[n_layers - 1] = grad_b_last;
+    return bwd_impl(BWD_LIGHT, x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims, W, b, root, aggr,
+                    grad_out, grad_x, gW, gb, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream_,
+                    src_rowptr, src_slots, z_saved);
+}
+
+extern "C" int gpde_nnconv_bwd_deferred(const float* x_stack, const float* grad_out_stack, int n_defer, int64_t n_nodes,
+                                        const float* edge_attr, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
+                                        const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host, int n_layers,
+                                        const int32_t* dims, const float* const* W, const float* const* b, int aggr,
+                                        float* const* grad_W, float* const* grad_b, void* ws, size_t ws_bytes, void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || n_defer < 1 || !dims || !W || !b || !grad_W || !grad_b || !rowptr || !rowptr_host || !ws ||
+        n_layers < 2 || n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x_stack || !grad_out_stack)) ||
+        (n_edges > 0 && (!edge_attr || !src || !dst || !perm))) {
+        gpde_set_error("gpde_nnconv_bwd_deferred: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_deferred: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
+    return bwd_impl(BWD_DEFER, nullptr, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims, W, b, nullptr,
+                    aggr, nullptr, nullptr, grad_W, grad_b, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
+                    (hipStream_t)stream_, nullptr, nullptr, nullptr, n_defer, x_stack, grad_out_stack);
 }
 
 extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,

@@ -251,6 +251,13 @@ struct GpdeGemmF16sArgs {
     int ksplits; size_t cstride;        // split-K (> 1): partial s at C + s * cstride; M <= 4 * 64 * n per launch group
     const float* xc_x; const int32_t* xc_src;   // contract epilogue (per-edge last layer): C = P[N/128][M][64], see the kernel
     int skew_us;                        // test hook (GPDE_DEBUG_SKEW_US): odd column slices start this many us late
+    // gather form (gpde_launch_gemm_f16s_gather; set by that launcher only): A = stack of node tables, B per destination node
+    const int32_t* g_src;               // [M] source node of each row (CSR slot)
+    const int32_t* g_tile;              // [g_ntiles][4]: destination node (chunk-local), first row, end row, 0
+    int g_ntiles;
+    size_t g_layer_stride;              // floats between the node tables of consecutive layers (K = 64 * layers)
+    size_t g_bnode_bytes;               // bytes of one node's split tile image [N/128][K/32][16 KiB]
+    const float* g_unscale;             // [nodes] 2^-t of the node's image
 };
 bool gpde_gemm_f16s_supported(int M, int N, int K, int lda);
 int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a, float* row_scale_ws /* 2 * M floats */, hipStream_t stream);
@@ -283,6 +290,21 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
                              const unsigned* du_absmax_bits = nullptr /* [n_out] column maxima of |dU| as bit patterns */,
                              const GpdeFirstLayerSpec* first_layer = nullptr /* non-null: H is this layer (H / ldh unused) */,
                              const GpdeDuStats* du_stats = nullptr);
+// ---- depth-deferred backward (gpde_nnconv_bwd_deferred): dU_2 of the edges of a node chunk from the stacked layer inputs ----
+// dU[e][n] = (sum_{l < Lp, c < 64} xstack[l][src[e]][c] * dZ^(l)[dst e][c][n]) (.) [mask[e][n] > 0]   for the chunk's rows.
+//   tiles   [ntiles][4] from gpde_launch_tile_list (host count: gpde_tile_count)
+//   bimg    per chunk node the split tile image of B_i[n][(l, c)] = dZ^(l)_i[c][n] (gpde_launch_dz_image), unscale [nodes]
+//   sc/isc  [N] per source node (gpde_launch_xstack_scales)
+int gpde_launch_gemm_f16s_gather(const float* xstack, size_t layer_stride, int Lp, const float* sc_src, const float* isc_src,
+                                 const int32_t* src_rows, int rows, const int32_t* tiles, int ntiles, const void* bimg,
+                                 const float* unscale, const float* mask, int ldmask, float* C, int ldc, int N, hipStream_t stream);
+size_t gpde_dz_image_bytes_per_node(int Lp, int K2P);
+// dZ [L][nn_alloc][64][K2P] fp32 (layer stride dz_layer_stride floats) -> per node image + scales; bits [nn] scratch
+int gpde_launch_dz_image(const float* dZ, size_t dz_layer_stride, int L, int Lp, int nn, int K2P, unsigned* bits, float* scale,
+                         float* unscale, void* img, hipStream_t stream);
+int gpde_launch_xstack_scales(const float* xstack, size_t layer_stride, int L, int64_t n_nodes, float* sc, float* isc, hipStream_t stream);
+int gpde_tile_count(const int32_t* rowptr_host, int na, int nb);          // sum over nodes of ceil(deg / 256)
+int gpde_launch_tile_list(const int32_t* rowptr, int na, int nn, int e0, int32_t* tiles, hipStream_t stream);
 // split tile image of a row-major [n][k] matrix (ld = k): the W2 layout of gpde_mlp_pack for any operand
 int gpde_pack_split_nk(const float* Wnk, int n, int k, int NP, int KP, void* out, float* ucol, hipStream_t stream);
 int gpde_num_cus();

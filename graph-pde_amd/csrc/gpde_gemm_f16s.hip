@@ -63,6 +63,12 @@ __global__ void k_row_scale_kernel(const float* __restrict__ A, int M, int K, in
 
 constexpr int A_SLOT = NW * TE * 128;      // 32 KiB: one 32-k chunk of the workgroup's 256 rows (fp32)
 
+// GATHER (the depth-deferred backward's dU_2 = (sum_l x_j^(l) . dZ_i^(l)) (.) [H_2 > 0], gpde_launch_gemm_f16s_gather): row = CSR
+// slot e (j -> i); A[e][(l, c)] = x^(l)[j][c] is gathered through g_src from the stack of node tables (chunk = one half row of
+// one layer, a full 128-byte line); B depends on the destination node: a workgroup tile is 256 consecutive slots of ONE node
+// (g_tile), its four waves share that node's image through the ring.  Row scales are per SOURCE node (sc / isc indexed by
+// g_src), the image carries one scale per node (g_unscale).
+template <bool GATHER>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -92,7 +98,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
     }
     if (slice & 1) gp_debug_skew(a.skew_us);
     const int NKCT = a.K / GP_BK;                   // chunks of the whole K (the B image's row of tiles)
-    const int ntile = (a.M + TE - 1) / TE;
+    const int ntile = GATHER ? a.g_ntiles : (a.M + TE - 1) / TE;      // GATHER: workgroup tiles (<= 256 slots of one node)
     // split-K (ksplits > 1: the weight-gradient use, few rows and a very long K): group = (K split, row quad), one
     // tile per wave, partial products of split s at C + s * cstride
     int NKC = NKCT, kc0 = 0, rounds, tgroup = group, tstride = a.n_groups;
@@ -108,21 +114,41 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
         rounds = 1;
         Cout += (size_t)ks * a.cstride;
     } else {
-        const int stride = a.n_groups * NW;
+        const int stride = a.n_groups * (GATHER ? 1 : NW);
         rounds = (ntile + stride - 1) / stride;
         if (rounds == 0) return;
     }
     auto kc = [&](int c) { return kc0 + c; };
-    const unsigned long long bbase = (unsigned long long)a.bsplit + (size_t)slice * NKCT * TILE_B + wave * 4096;
+    // GATHER: workgroup tile of round t.  The groups of one XCD (group & 7) take CONSECUTIVE tiles - the row tiles of one
+    // destination node read the same image slice and neighbouring source rows: one L2 serves them
+    const int gu = (GATHER && a.n_groups % 8 == 0) ? (group >> 3) + (group & 7) * (a.n_groups >> 3) : group;
+    auto tile_rec = [&](int t, int& node, int& rs, int& re_load, int& re_store) {
+        const int wt = t * a.n_groups + gu;
+        const int wc = min(wt, ntile - 1);
+        node = __builtin_amdgcn_readfirstlane(a.g_tile[4 * wc]);
+        rs = __builtin_amdgcn_readfirstlane(a.g_tile[4 * wc + 1]);
+        re_load = __builtin_amdgcn_readfirstlane(a.g_tile[4 * wc + 2]);
+        re_store = wt < ntile ? re_load : rs;                     // a workgroup beyond the list computes and stores nothing
+    };
+    const unsigned long long bbase0 = (unsigned long long)a.bsplit + (size_t)slice * NKCT * TILE_B + wave * 4096;
+    unsigned long long bbase = bbase0, nbbase = bbase0;             // GATHER: image of this / the next tile's node
+    int g_node = 0, g_rs = 0, g_rel = 1, g_res = 0;
+    if (GATHER) {
+        tile_rec(0, g_node, g_rs, g_rel, g_res);
+        bbase = bbase0 + (size_t)g_node * a.g_bnode_bytes;
+    }
     const unsigned lane16 = lane * 16;
-    auto b_src = [&](int chunk) {
-        unsigned long long gb = bbase + (size_t)chunk * TILE_B;
+    auto b_src = [&](int chunk, unsigned long long base) {
+        unsigned long long gb = base + (size_t)chunk * TILE_B;
         asm volatile("" : "+s"(gb));
         return (const char*)(gb + lane16);
     };
+    auto aofs = [&](int chunk) -> size_t {
+        return GATHER ? (size_t)(chunk >> 1) * a.g_layer_stride + (size_t)(chunk & 1) * GP_BK : (size_t)chunk * GP_BK;
+    };
     float ucv[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) ucv[nb] = a.ucol[slice * GP_TN + nb * 32 + l31];
+    for (int nb = 0; nb < 4; ++nb) ucv[nb] = GATHER ? 1.f : a.ucol[slice * GP_TN + nb * 32 + l31];
     const int sw = (l31 >> 1) & 7;
     const int boff[2] = {l31 * 128 + (((0 + h) ^ sw) << 4), l31 * 128 + (((2 + h) ^ sw) << 4)};
 
@@ -140,10 +166,10 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
     };
 
     {   // chunks 0 and 1 of this slice's B
-        const char* g0 = b_src(kc(0));
+        const char* g0 = b_src(kc(0), bbase);
         char* l0 = ring + wave * 4096;
         GPDE_GLDS(g0, l0, 0); GPDE_GLDS(g0, l0, 1024); GPDE_GLDS(g0, l0, 2048); GPDE_GLDS(g0, l0, 3072);
-        const char* g1 = b_src(kc(1));
+        const char* g1 = b_src(kc(1), bbase);
         char* l1 = ring + TILE_B + wave * 4096;
         GPDE_GLDS(g1, l1, 0); GPDE_GLDS(g1, l1, 1024); GPDE_GLDS(g1, l1, 2048); GPDE_GLDS(g1, l1, 3072);
     }
@@ -161,14 +187,31 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
     int aslot = 0;          // A ring slot of the current chunk
 
     for (int t = 0; t < rounds; ++t) {
-        const int tile = (t * tstride + tgroup) * NW + wave;
-        const int r0 = tile * TE;                                  // may lie beyond M: loads clamp, stores are masked
+        int r0, rmax, rend;                                        // first row, last loadable row, end of the stored rows
+        if (GATHER) {
+            if (t > 0) { g_node = 0; tile_rec(t, g_node, g_rs, g_rel, g_res); bbase = nbbase; }
+            int nn_, nrs_, nrl_, nre_;
+            tile_rec(t + 1, nn_, nrs_, nrl_, nre_);
+            nbbase = bbase0 + (size_t)nn_ * a.g_bnode_bytes;
+            r0 = g_rs + wave * TE; rmax = g_rel - 1; rend = g_res;
+            const float un = a.g_unscale[g_node];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) ucv[nb] = un;
+        } else {
+            const int tile = (t * tstride + tgroup) * NW + wave;
+            r0 = tile * TE; rmax = a.M - 1; rend = a.M;            // may lie beyond M: loads clamp, stores are masked
+        }
+        // GATHER: the source nodes of the wave tile's 64 rows in ONE load (lane = row), handed round by ds_bpermute - ten
+        // dependent index loads per tile otherwise
+        int srcv = 0;
+        if (GATHER) srcv = a.g_src[min(r0 + lane, rmax)];
         float sc[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int row = min(r0 + 32 * e + l31, a.M - 1);
-            sc[e] = a.sc[row];
-            if (h == 0) Es[32 * e + l31] = a.isc[row];
+            const int row = min(r0 + 32 * e + l31, rmax);
+            const int srow = GATHER ? __shfl(srcv, 32 * e + l31) : row;
+            sc[e] = a.sc[srow];
+            if (h == 0) Es[32 * e + l31] = a.isc[srow];
         }
         // A chunk DMA: piece j = rows 8j .. 8j+7 of the wave's tile in FULL 128-byte lines (8 lanes per row), the
         // 16-byte units of a row XOR-swizzled through the SOURCE address (unit u of row r is stored at u ^ ((r>>1)&7):
@@ -177,13 +220,15 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int r = 8 * j + (lane >> 3);
-            const int row = min(r0 + r, a.M - 1);
-            apiece[j] = a.A + (size_t)row * a.lda + 4 * ((lane & 7) ^ ((r >> 1) & 7));
+            const int row = min(r0 + r, rmax);
+            const size_t arow = GATHER ? (size_t)__shfl(srcv, r) * GP_W : (size_t)row * a.lda;
+            apiece[j] = a.A + arow + 4 * ((lane & 7) ^ ((r >> 1) & 7));
         }
         auto issue_a = [&](int as, int chunk) {
             char* l = awave + as * A_SLOT;
+            const size_t co = aofs(chunk);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) GPDE_GLDS(apiece[j] + chunk * GP_BK, l + j * 1024, 0);
+            for (int j = 0; j < 8; ++j) GPDE_GLDS(apiece[j] + co, l + j * 1024, 0);
         };
         // fragment reads: piece q = 2 m + half of edge block e holds k = 16 m + 8 half + 4 h + {0..3} = unit 2 q + h
         auto read_a = [&](int as, f32x4 (&raw)[2][4]) {
@@ -230,12 +275,13 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
             const int slot2 = slot1 + 1 == NS ? 0 : slot1 + 1;
             const int an1 = aslot + 1 == NS ? 0 : aslot + 1;      // A(c + 1): converted during this chunk
             int c2 = c + 2;
-            if (c2 >= NKC) c2 -= NKC;
-            const char* gsrc = b_src(kc(c2));
+            const bool wrap = c2 >= NKC;                              // chunks 0 / 1 of the NEXT tile (GATHER: of its node's image)
+            if (wrap) c2 -= NKC;
+            const char* gsrc = b_src(kc(c2), wrap ? nbbase : bbase);
             char* ldst = ring + slot2 * TILE_B + wave * 4096;
             const char* rb0 = ring + slot * TILE_B;
             const char* rb1 = ring + slot1 * TILE_B;
-            const int c3 = kc(min(c + 3, NKC - 1));                   // A(c + 3) (clamped at the tile's end: unused) -> A(c)'s slot
+            const size_t c3 = aofs(kc(min(c + 3, NKC - 1)));          // A(c + 3) (clamped at the tile's end: unused) -> A(c)'s slot
             char* adst = awave + aslot * A_SLOT;
             read_a(an1, raw);
 #pragma unroll
@@ -277,8 +323,8 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                         // the eight A pieces of chunk c + 3, behind the four B pieces, two per MFMA gap
                         if (m == 1 && (i == 2 || i == 8 || i == 14 || i == 20)) {
                             const int k = (i - 2) / 6;
-                            GPDE_GLDS(apiece[2 * k] + c3 * GP_BK, adst + (2 * k) * 1024, 0);
-                            GPDE_GLDS(apiece[2 * k + 1] + c3 * GP_BK, adst + (2 * k + 1) * 1024, 0);
+                            GPDE_GLDS(apiece[2 * k] + c3, adst + (2 * k) * 1024, 0);
+                            GPDE_GLDS(apiece[2 * k + 1] + c3, adst + (2 * k + 1) * 1024, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -300,7 +346,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
         // ---- un-scale, mask, store --------------------------------------------------------------------------
         // The 64 mask words of an edge block are loaded as ONE batch (rows clamped, no branches) before the first
         // store: a load -> wait -> select -> store chain per element cost 60 us of a 90 us tile.
-        if (a.xc_x) {
+        if (!GATHER && a.xc_x) {
             // Contract epilogue (per-edge last layer of the NNConv forward, gpde_api.hip): row = CSR slot e, column
             // n = c * 64 + o of W_e = W3 . h_e (nn_conv.py:273-274: `weight = self.nn(pseudo).view(-1, 64, 64)`); this
             // slice holds c = 2 * slice + {0, 1}.  m_e[o] += x_j[c] * W_e[c][o] (nn_conv.py:275) is formed here, so the
@@ -310,7 +356,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                 float xv0[16], xv1[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = min(r0 + 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h, a.M - 1);
+                    const int row = min(r0 + 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h, rmax);
                     const float* xp = a.xc_x + (size_t)a.xc_src[row] * GP_W + 2 * slice;
                     xv0[r] = xp[0];
                     xv1[r] = xp[1];
@@ -327,10 +373,10 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
 #pragma unroll
                         for (int nb = 0; nb < 4; ++nb) acc[e][nb][r] = 0.f;
                         float* pp = Cout + ((size_t)slice * a.M + row) * GP_W + l31;
-                        if (FULL || row < a.M) { pp[0] = m0; pp[32] = m1; }
+                        if (FULL || row < rend) { pp[0] = m0; pp[32] = m1; }
                     }
                 };
-                if (r0 + TE <= a.M) store_rows(std::true_type{});
+                if (r0 + TE <= rend) store_rows(std::true_type{});
                 else store_rows(std::false_type{});
             }
             continue;
@@ -344,7 +390,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                 // per row (the slice's 128 columns = 4 words, the same address in all lanes)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = min(r0 + 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h, a.M - 1);
+                    const int row = min(r0 + 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h, rmax);
                     const u4 wv = *(const u4*)(a.maskbits + (size_t)row * a.ldmb + slice * (GP_TN / 32));
 #pragma unroll
                     for (int nb = 0; nb < 4; ++nb) mk[r][nb] = ((wv[nb] >> l31) & 1u) ? 1.f : 0.f;
@@ -352,7 +398,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
             } else if (has_mask) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = min(r0 + 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h, a.M - 1);
+                    const int row = min(r0 + 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h, rmax);
                     const float* mp = a.mask + (size_t)row * a.ldmask + slice * GP_TN + l31;
 #pragma unroll
                     for (int nb = 0; nb < 4; ++nb) mk[r][nb] = mp[nb * 32];
@@ -373,11 +419,11 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                         float v = acc[e][nb][r] * (ie * ucv[nb]);
                         acc[e][nb][r] = 0.f;
                         if (has_mask) v = mk[r][nb] > 0.f ? v : 0.f;
-                        if (FULL || row < a.M) cp[nb * 32] = v;
+                        if (FULL || row < rend) cp[nb * 32] = v;
                     }
                 }
             };
-            if (r0 + TE <= a.M) store_rows(std::true_type{});
+            if (r0 + TE <= rend) store_rows(std::true_type{});
             else store_rows(std::false_type{});
         }
     }
@@ -436,8 +482,8 @@ int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a_in, float* row_scale_ws, 
     a.n_groups = groups;
     const size_t lds = (size_t)NS * TILE_B + (size_t)NS * A_SLOT + NW * TE * 4 + 64;
     static GpdeLdsOnce once;
-    if (int rc = once.ensure(gpde_gemm_f16s_nt_kernel)) return rc;
-    hipLaunchKernelGGL(gpde_gemm_f16s_nt_kernel, dim3(groups * ns), dim3(256), lds, stream, a);
+    if (int rc = once.ensure(gpde_gemm_f16s_nt_kernel<false>, gpde_gemm_f16s_nt_kernel<true>)) return rc;
+    hipLaunchKernelGGL(gpde_gemm_f16s_nt_kernel<false>, dim3(groups * ns), dim3(256), lds, stream, a);
     GP_LAUNCH_CHECK("gpde_gemm_f16s_nt_kernel");
     return GPDE_OK;
 }
@@ -790,4 +836,174 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
     g.C = part; g.ldc = n_in; g.K = epad; g.N = n_in; g.sc = sca; g.isc = isca;
     g.ksplits = ksplits; g.cstride = (size_t)n_out * n_in;
     return gpde_launch_gemm_f16s_nt(g, nullptr, stream);
+}
+
+// ---- gather form: operands and launcher (depth-deferred backward, gpde_bwd.hip) ------------------------------------------
+namespace {
+constexpr int GT_ROWS = NW * TE;        // slots per workgroup tile
+
+// bits[node] = max |dZ[node][..]| over one layer's [64][K2P] block as an fp32 bit pattern (bits zeroed by the caller; the
+// maximum over layers accumulates): one workgroup per node
+__global__ __launch_bounds__(256) void k_node_absmax(const float* __restrict__ dZ, int row_floats, unsigned* __restrict__ bits) {
+    const float* p = dZ + (size_t)blockIdx.x * row_floats;
+    unsigned m = 0;
+    for (int i = threadIdx.x * 4; i < row_floats; i += 1024) {
+        const f32x4 v = *(const f32x4*)(p + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = max(m, __float_as_uint(v[j]) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(bits + blockIdx.x, m);
+}
+// The split tile image (k_pack_split_kn's layout) of B_i[n][K = 64 l + c] = dZ^(l)[i][c][n] * sc[i] for one destination
+// node i: workgroup = one 16 KiB tile (node, slice of 128 n, chunk of 32 K = half the channels of one layer), thread =
+// (n, k16 step m).  Layers l >= L (K padding) are zero tiles.
+__global__ __launch_bounds__(256) void k_pack_dz_image(const float* __restrict__ dZ, size_t dz_layer_stride, int L, int K2P,
+                                                       const float* __restrict__ sc, int nkct, _Float16* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) _Float16 img[128 * 64];
+    const int n = threadIdx.x & 127, m = threadIdx.x >> 7;
+    const int kcn = blockIdx.x, slice = blockIdx.y, node = blockIdx.z;
+    const int l = kcn >> 1, c0 = (kcn & 1) * 32 + 16 * m;
+    const float s = sc[node];
+    float w[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        w[k] = l < L ? dZ[(size_t)l * dz_layer_stride + ((size_t)node * GP_W + c0 + k) * K2P + slice * 128 + n] * s : 0.f;
+    const int sw = (n >> 1) & 7;
+    _Float16* row = img + n * 64;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        h8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = w[8 * (j >> 2) + 4 * hh + (j & 3)];
+            hi[j] = (_Float16)v;
+            lo[j] = (_Float16)(v - (float)hi[j]);
+        }
+        *(h8*)(row + (((m * 2 + hh) ^ sw) << 3)) = hi;
+        *(h8*)(row + (((4 + m * 2 + hh) ^ sw) << 3)) = lo;
+    }
+    __syncthreads();
+    const int ns = K2P / 128;
+    h8* dst = (h8*)(out + (((size_t)node * ns + slice) * (size_t)nkct + kcn) * (128 * 64));
+    const h8* srcl = (const h8*)img;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q * 256 + threadIdx.x] = srcl[q * 256 + threadIdx.x];
+}
+// per source node j: sc = 2^(13 - E(max over the L layers and 64 channels of |xstack[l][j][c]|)), isc = 1 / sc
+__global__ __launch_bounds__(256) void k_xstack_scales(const float* __restrict__ xs, size_t layer_stride, int L, int64_t n_nodes,
+                                                       float* __restrict__ sc, float* __restrict__ isc) {
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= n_nodes) return;
+    unsigned m = 0;
+    for (int l = 0; l < L; ++l) m = max(m, __float_as_uint(xs[(size_t)l * layer_stride + (size_t)j * GP_W + lane]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if (lane == 0) {
+        const int eb = (int)((m >> 23) & 0xff);
+        const bool ok = eb >= 20 && eb <= 230;
+        sc[j] = ok ? __int_as_float((267 - eb) << 23) : 1.f;
+        isc[j] = ok ? __int_as_float((eb - 13) << 23) : 1.f;
+    }
+}
+// tiles[t] = (chunk-local node, first row, end row, 0) for every run of <= 256 in-edges of the nodes na .. na + nn: one
+// workgroup, nodes in batches of 1024 with an LDS scan (a chunk holds a few thousand nodes at most)
+__global__ __launch_bounds__(1024) void k_tile_list(const int32_t* __restrict__ rowptr, int na, int nn, int e0, int32_t* __restrict__ tiles) {
+    __shared__ int scan[1024];
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < nn; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        int r0 = 0, r1 = 0;
+        if (i < nn) { r0 = rowptr[na + i] - e0; r1 = rowptr[na + i + 1] - e0; }
+        const int cnt = (r1 - r0 + GT_ROWS - 1) / GT_ROWS;
+        scan[threadIdx.x] = cnt;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int v = threadIdx.x >= o ? scan[threadIdx.x - o] : 0;
+            __syncthreads();
+            scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const int first = base + scan[threadIdx.x] - cnt;
+        for (int q = 0; q < cnt; ++q) {
+            int32_t* t = tiles + 4 * (size_t)(first + q);
+            t[0] = i; t[1] = r0 + q * GT_ROWS; t[2] = r1; t[3] = 0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) base += scan[1023];
+        __syncthreads();
+    }
+}
+}  // namespace
+
+size_t gpde_dz_image_bytes_per_node(int Lp, int K2P) { return (size_t)(K2P / 128) * (2 * Lp) * TILE_B; }
+
+int gpde_tile_count(const int32_t* rowptr_host, int na, int nb) {
+    long long t = 0;
+    for (int i = na; i < nb; ++i) t += (rowptr_host[i + 1] - rowptr_host[i] + GT_ROWS - 1) / GT_ROWS;
+    return (int)t;
+}
+
+int gpde_launch_tile_list(const int32_t* rowptr, int na, int nn, int e0, int32_t* tiles, hipStream_t stream) {
+    hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, stream, rowptr, na, nn, e0, tiles);
+    GP_LAUNCH_CHECK("k_tile_list");
+    return GPDE_OK;
+}
+
+int gpde_launch_xstack_scales(const float* xstack, size_t layer_stride, int L, int64_t n_nodes, float* sc, float* isc, hipStream_t stream) {
+    if (n_nodes <= 0) return GPDE_OK;
+    hipLaunchKernelGGL(k_xstack_scales, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, stream, xstack, layer_stride, L, n_nodes, sc, isc);
+    GP_LAUNCH_CHECK("k_xstack_scales");
+    return GPDE_OK;
+}
+
+int gpde_launch_dz_image(const float* dZ, size_t dz_layer_stride, int L, int Lp, int nn, int K2P, unsigned* bits, float* scale,
+                         float* unscale, void* img, hipStream_t stream) {
+    if (nn <= 0) return GPDE_OK;
+    if (K2P % 128 != 0 || L < 1 || Lp < L || Lp % 2 != 0) { gpde_set_error("gpde_launch_dz_image: bad shape L=%d Lp=%d K2P=%d", L, Lp, K2P); return GPDE_EINVAL; }
+    GP_HIP_CHECK(hipMemsetAsync(bits, 0, (size_t)nn * 4, stream));
+    for (int l = 0; l < L; ++l)
+        hipLaunchKernelGGL(k_node_absmax, dim3(nn), dim3(256), 0, stream, dZ + (size_t)l * dz_layer_stride, GP_W * K2P, bits);
+    hipLaunchKernelGGL(k_scales_from_max, dim3((nn + 255) / 256), dim3(256), 0, stream, bits, nn, scale, unscale);
+    hipLaunchKernelGGL(k_pack_dz_image, dim3(2 * Lp, K2P / 128, nn), dim3(256), 0, stream, dZ, dz_layer_stride, L, K2P, scale,
+                       2 * Lp, (_Float16*)img);
+    GP_LAUNCH_CHECK("gpde_launch_dz_image kernels");
+    return GPDE_OK;
+}
+
+int gpde_launch_gemm_f16s_gather(const float* xstack, size_t layer_stride, int Lp, const float* sc_src, const float* isc_src,
+                                 const int32_t* src_rows, int rows, const int32_t* tiles, int ntiles, const void* bimg,
+                                 const float* unscale, const float* mask, int ldmask, float* C, int ldc, int N, hipStream_t stream) {
+    if (rows <= 0 || ntiles <= 0) return GPDE_OK;
+    const int K = GP_W * Lp;
+    if (N % GP_TN != 0 || Lp < 4 || Lp % 2 != 0 || !mask) {
+        gpde_set_error("gpde_gemm_f16s_gather: unsupported shape N=%d layers=%d", N, Lp);
+        return GPDE_EUNSUPPORTED;
+    }
+    if (gp_overlap(C, ((size_t)(rows - 1) * ldc + N) * 4, mask, ((size_t)(rows - 1) * ldmask + N) * 4)) {
+        gpde_set_error("gpde_gemm_f16s_gather: output overlaps the mask (internal buffer plan error)");
+        return GPDE_EINVAL;
+    }
+    GpdeGemmF16sArgs a{};
+    a.A = xstack; a.lda = GP_W; a.M = rows; a.bsplit = bimg; a.ucol = nullptr; a.mask = mask; a.ldmask = ldmask;
+    a.C = C; a.ldc = ldc; a.K = K; a.N = N; a.sc = sc_src; a.isc = isc_src; a.ksplits = 1; a.cstride = 0;
+    a.skew_us = gpde_debug_skew_us();
+    a.g_src = src_rows; a.g_tile = tiles; a.g_ntiles = ntiles; a.g_layer_stride = layer_stride;
+    a.g_bnode_bytes = gpde_dz_image_bytes_per_node(Lp, N); a.g_unscale = unscale;
+    const int ns = N / GP_TN;
+    int groups = gpde_num_cus() / ns;
+    if (groups < 1) groups = 1;
+    if (groups > ntiles) groups = ntiles;
+    if (groups >= 8) groups = groups / 8 * 8;                    // whole XCD rounds: consecutive tiles share an L2
+    a.n_groups = groups;
+    const size_t lds = (size_t)NS * TILE_B + (size_t)NS * A_SLOT + NW * TE * 4 + 64;
+    static GpdeLdsOnce once;
+    if (int rc = once.ensure(gpde_gemm_f16s_nt_kernel<true>)) return rc;
+    hipLaunchKernelGGL(gpde_gemm_f16s_nt_kernel<true>, dim3(groups * ns), dim3(256), lds, stream, a);
+    GP_LAUNCH_CHECK("gpde_gemm_f16s_nt_kernel<gather>");
+    return GPDE_OK;
 }

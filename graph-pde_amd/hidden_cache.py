@@ -32,7 +32,7 @@ from typing import List, Optional
 import torch
 
 from . import ops
-from .autograd import HiddenFunction, HiddenToken
+from .autograd import DeferredHiddenFunction, DeferredToken, HiddenFunction, HiddenToken
 
 MODE = os.environ.get("GPDE_HIDDEN_CACHE", "auto")
 _env_gb = os.environ.get("GPDE_HIDDEN_CACHE_GB", "")
@@ -55,6 +55,10 @@ def budget_bytes(device=None, releasing: int = 0) -> int:
     free, total = torch.cuda.mem_get_info(dev)
     return max(0, min(int(AUTO_FRACTION * total), free + releasing - AUTO_RESERVE_BYTES))
 PARTIAL = os.environ.get("GPDE_HIDDEN_CACHE_PARTIAL", "1") != "0"
+# Depth-deferred backward: a module that repeats (edge_attr, weights) within a forward, needs gradients and
+# whose H does NOT fit the budget shares one "virtual H" autograd node - its applications run the light backward and ONE
+# deferred pass differentiates the hidden layers for all of them (autograd.DeferredHiddenFunction).  auto | off.
+DEFER_MODE = os.environ.get("GPDE_DEFERRED_BWD", "auto")
 # Per-edge weight cache: for inference calls on low in-degree / small graphs the whole
 # W_e = view(nn(edge_attr_e), 64, 64) tensor is kept ([E, 4096] fp32 = 16 KiB per edge) and a call is one streaming
 # kernel.  OPT-IN: its summation order differs from the fused kernels' (same accuracy, other last bits), and a module's
@@ -70,7 +74,7 @@ stats = {"hits": 0, "builds": 0, "direct": 0, "we_hits": 0, "we_builds": 0}     
 
 class _Entry:
     __slots__ = ("key", "hidden", "token", "attr_ref", "csr", "last_key", "repeats", "hits_on_hidden", "hn", "we", "we_key",
-                 "we_refs")
+                 "we_refs", "big_key", "dkey", "dtoken", "dvirtual", "dcount", "drefs")
 
     def __init__(self):
         self.key = None
@@ -85,6 +89,12 @@ class _Entry:
         self.we = None              # per-edge weights [E, 4096] (inference) and the key they were built for
         self.we_key = None
         self.we_refs = None         # pins edge_attr / csr behind we_key
+        self.big_key = None         # key of the last call whose H was wanted but exceeded the budget
+        self.dkey = None            # depth-deferred backward: key, token and tensor of the current virtual H,
+        self.dtoken = None          # applications hanging on it, pinned edge_attr / csr
+        self.dvirtual = None
+        self.dcount = 0
+        self.drefs = None
 
 
 _entries: "weakref.WeakKeyDictionary[torch.nn.Module, _Entry]" = weakref.WeakKeyDictionary()
@@ -105,6 +115,8 @@ def release_all() -> bool:
             freed = True
         ent.hidden, ent.key, ent.token, ent.attr_ref, ent.csr = None, None, None, None, None
         ent.we, ent.we_key, ent.we_refs = None, None, None
+        if ent.dtoken is not None and not ent.dtoken.stash:      # (a virtual H holds no memory; one mid-backward is left alone)
+            ent.dkey, ent.dtoken, ent.dvirtual, ent.drefs, ent.dcount = None, None, None, None, 0
     if freed:
         stats["released"] = stats.get("released", 0) + 1
     return freed
@@ -158,6 +170,7 @@ def lookup(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, b
         nbytes = int(rp[hn]) * row_bytes if hn >= csr.n_nodes // 8 and hn > 0 else budget + 1
     if not want or nbytes > budget or csr.n_edges == 0 or edge_attr.requires_grad:
         ent.hidden, ent.key, ent.token, ent.attr_ref, ent.csr = None, None, None, None, None
+        ent.big_key = key if (want and nbytes > budget and csr.n_edges > 0 and not edge_attr.requires_grad) else None
         stats["direct"] += 1
         return None
     token = HiddenToken()
@@ -171,6 +184,42 @@ def lookup(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, b
     ent.hits_on_hidden = 0
     stats["builds"] += 1
     return hidden, token.hmax, hn
+
+
+def lookup_deferred(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, biases, aggr: str,
+                    precision: Optional[str] = None):
+    """(virtual H tensor, token) for a call that needs gradients, right after `lookup` returned None for it - or None when
+    the plain operator (autograd.NNConvFunction: its own full backward) should run.  Deferred when: the module has been seen
+    repeating this (edge_attr, weights) key, its H was wanted but does not fit the budget, the hidden layers require a
+    gradient and the kernel MLP is in the deferred form (ops.deferred_supported).  All applications of one forward share the
+    returned node until its backward has run."""
+    if DEFER_MODE == "off" or aggr not in ("add", "mean") or not torch.is_grad_enabled():
+        return None
+    ent = _entries.get(module)
+    if ent is None:
+        return None
+    precision = ops.DEFAULT_PRECISION if precision is None else precision
+    hw, hb = list(weights[:-1]), list(biases[:-1])
+    if not any(p is not None and p.requires_grad for p in hw + hb) or edge_attr.requires_grad:
+        return None
+    key = _key(edge_attr, csr, hw + hb, precision)
+    if ent.dtoken is not None and ent.dkey == key and ent.dtoken.valid:
+        ent.dcount += 1
+        stats["deferred_hits"] = stats.get("deferred_hits", 0) + 1
+        return ent.dvirtual, ent.dtoken
+    if ent.dtoken is not None and ent.dcount <= 1:
+        ent.repeats = False             # the last virtual H served a single application: stop speculating
+    ent.dkey, ent.dtoken, ent.dvirtual, ent.drefs, ent.dcount = None, None, None, None, 0
+    if not ent.repeats or ent.big_key != key or not ops.deferred_supported(pm.dims):
+        return None
+    token = DeferredToken()
+    n = len(weights)
+    w_last, b_last = weights[-1], biases[-1]
+    virtual = DeferredHiddenFunction.apply(edge_attr, csr, aggr, token, n, *hw, w_last.detach(),
+                                           *hb, None if b_last is None else b_last.detach())
+    ent.dkey, ent.dtoken, ent.dvirtual, ent.drefs, ent.dcount = key, token, virtual, (edge_attr, csr), 1
+    stats["deferred_builds"] = stats.get("deferred_builds", 0) + 1
+    return virtual, token
 
 
 def edge_weights_qualify(csr, force: bool = False, explicit: bool = False) -> bool:

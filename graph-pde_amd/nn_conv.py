@@ -22,7 +22,7 @@ import torch
 from torch.nn import Parameter
 
 from . import hidden_cache, ops
-from .autograd import NNConvFunction, NNConvHiddenFunction
+from .autograd import NNConvDeferredFunction, NNConvFunction, NNConvHiddenFunction
 from .message_passing import MessagePassing
 
 
@@ -210,6 +210,13 @@ class NNConv_old(MessagePassing):
                                                         bias, self.aggr)
                 return NNConvHiddenFunction.apply(x, hidden, csr, pm, weights[-1], biases[-1],
                                                   root, bias, self.aggr, hmax)
+            if not no_grad:
+                # H wanted but too large for the device (the 241^2 graph: 391 GB): the applications of this forward share a
+                # "virtual H" node instead - light backward per application, ONE deferred pass for the hidden layers
+                d = hidden_cache.lookup_deferred(self, pseudo, csr, pm, weights, biases, self.aggr)
+                if d is not None:
+                    return NNConvDeferredFunction.apply(x, d[0], csr, pseudo, root, bias, self.aggr, d[1],
+                                                        len(weights), *weights, *biases)
         return NNConvFunction.apply(x, edge_index, pseudo, root, bias, self.aggr,
                                     len(weights), *weights, *biases)
 

@@ -622,6 +622,101 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
 
 
 # ----------------------------------------------------------------------------------------------
+# depth-deferred backward (include/gpde.h gpde_nnconv_bwd_light / gpde_nnconv_bwd_deferred)
+# ----------------------------------------------------------------------------------------------
+def deferred_supported(dims: Sequence[int]) -> bool:
+    """Whether the kernel MLP `dims` = [k0, k1, k2, 4096] is in the depth-deferred form (gpde_nnconv_bwd_deferred_supported)."""
+    return bool(_lib.lib().gpde_nnconv_bwd_deferred_supported(len(dims) - 1, _lib.dims_array(dims)))
+
+
+def deferred_layers_padded(n_defer: int) -> int:
+    """Lp of include/gpde.h: layers of the x stack handed to gpde_nnconv_bwd_deferred (zero layers appended)."""
+    return max(4, (n_defer + 1) // 2 * 2)
+
+
+def nnconv_backward_light_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
+                              weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
+                              root: Optional[torch.Tensor], aggr: str, grad_out: torch.Tensor,
+                              need_root: bool = True, need_bias: bool = True, z_saved: Optional[torch.Tensor] = None):
+    """gpde_nnconv_bwd_light: one application of a depth-shared module - grad_x, the last Linear's gradients, grad_root,
+    grad_bias; the hidden layers' gradients come from nnconv_backward_deferred_raw.
+    Returns (grad_x, grad_w_last, grad_b_last or None, grad_root or None, grad_bias or None)."""
+    lib = _lib.lib()
+    for t, nm in ((x, "x"), (edge_attr, "edge_attr"), (grad_out, "grad_out")):
+        _require_cuda(t, nm)
+    if aggr not in _AGGR:
+        raise NotImplementedError(f"aggr={aggr!r}")
+    n, e, dev = csr.n_nodes, csr.n_edges, x.device
+    nl = len(weights)
+    dims = [int(weights[0].size(1))] + [int(w.size(0)) for w in weights]
+    dims_c = _lib.dims_array(dims)
+    x = x.detach().contiguous()
+    edge_attr, perm = attr_in_slot_order(csr, edge_attr.detach().contiguous())
+    grad_out = grad_out.detach().contiguous().float()
+    ws_ = [w.detach().contiguous() for w in weights]
+    bs_ = [None if b is None else b.detach().contiguous() for b in biases]
+    root_c = None if root is None else root.detach().contiguous()
+    gx = torch.empty(n, WIDTH, dtype=torch.float32, device=dev)
+    gw = torch.empty_like(ws_[-1])
+    gb = None if bs_[-1] is None else torch.empty_like(bs_[-1])
+    groot = torch.empty(WIDTH, WIDTH, dtype=torch.float32, device=dev) if (need_root and root is not None) else None
+    gbias = torch.empty(WIDTH, dtype=torch.float32, device=dev) if need_bias else None
+    nbytes = int(lib.gpde_nnconv_bwd_workspace_bytes(n, e, nl, dims_c))
+    if nbytes == 0:
+        _lib.check(-2, "gpde_nnconv_bwd_workspace_bytes")
+    ws = _alloc_ws(nbytes, dev)
+    srp, ssl = csr.src_order
+    p = lambda t: None if t is None else t.data_ptr()
+    with torch.cuda.device(dev):
+        rc = lib.gpde_nnconv_bwd_light(x.data_ptr(), n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), csr.src.data_ptr(),
+                                       csr.dst.data_ptr(), perm.data_ptr(), csr.rowptr_host.data_ptr(), p(srp), p(ssl), nl, dims_c,
+                                       _ptr_array(ws_), _ptr_array(bs_), p(root_c), _AGGR[aggr], grad_out.data_ptr(), p(z_saved),
+                                       gx.data_ptr(), gw.data_ptr(), p(gb), p(groot), p(gbias), ws.data_ptr(), ws.numel(),
+                                       _stream_ptr(dev))
+    _lib.check(rc, "gpde_nnconv_bwd_light")
+    _lib.n_native_calls += 1
+    return gx, gw, gb, groot, gbias
+
+
+def nnconv_backward_deferred_raw(xs: Sequence[torch.Tensor], gs: Sequence[torch.Tensor], csr: Csr, edge_attr: torch.Tensor,
+                                 weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], aggr: str):
+    """gpde_nnconv_bwd_deferred: the hidden layers' gradients of ALL the applications (xs[l], gs[l]) = (input, output
+    gradient) of a depth-shared module, in one pass over the edges.  `weights` / `biases`: ALL Linear layers (the last one
+    is read, not differentiated).  Returns ([grad_W_l], [grad_b_l or None]) for the hidden layers."""
+    lib = _lib.lib()
+    L = len(xs)
+    if L < 1 or len(gs) != L:
+        raise ValueError("one (input, output gradient) pair per deferred application")
+    n, e, dev = csr.n_nodes, csr.n_edges, edge_attr.device
+    nl = len(weights)
+    dims = [int(weights[0].size(1))] + [int(w.size(0)) for w in weights]
+    dims_c = _lib.dims_array(dims)
+    Lp = deferred_layers_padded(L)
+    x_stack = torch.zeros(Lp, n, WIDTH, dtype=torch.float32, device=dev)
+    g_stack = torch.empty(L, n, WIDTH, dtype=torch.float32, device=dev)
+    for l in range(L):
+        x_stack[l].copy_(xs[l].detach())
+        g_stack[l].copy_(gs[l].detach())
+    edge_attr, perm = attr_in_slot_order(csr, edge_attr.detach().contiguous())
+    ws_ = [w.detach().contiguous() for w in weights]
+    bs_ = [None if b is None else b.detach().contiguous() for b in biases]
+    gW = [torch.empty_like(w) for w in ws_[:-1]] + [None]
+    gb = [None if b is None else torch.empty_like(b) for b in bs_[:-1]] + [None]
+    nbytes = int(lib.gpde_nnconv_bwd_deferred_workspace_bytes(n, e, nl, dims_c, L))
+    if nbytes == 0:
+        _lib.check(-2, "gpde_nnconv_bwd_deferred_workspace_bytes")
+    ws = _alloc_ws(nbytes, dev)
+    with torch.cuda.device(dev):
+        rc = lib.gpde_nnconv_bwd_deferred(x_stack.data_ptr(), g_stack.data_ptr(), L, n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(),
+                                          csr.src.data_ptr(), csr.dst.data_ptr(), perm.data_ptr(), csr.rowptr_host.data_ptr(), nl, dims_c,
+                                          _ptr_array(ws_), _ptr_array(bs_), _AGGR[aggr], _ptr_array(gW), _ptr_array(gb), ws.data_ptr(),
+                                          ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "gpde_nnconv_bwd_deferred")
+    _lib.n_native_calls += 1
+    return gW[:-1], gb[:-1]
+
+
+# ----------------------------------------------------------------------------------------------
 # cross-depth reuse of the hidden activations (SURVEY.md §8 f4; include/gpde.h gpde_hidden_*)
 # ----------------------------------------------------------------------------------------------
 def hidden_width(dims: Sequence[int]) -> int:

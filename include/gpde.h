@@ -291,6 +291,41 @@ int gpde_nnconv_bwd_z(const float* x, int64_t n_nodes, const float* edge_attr, c
                       size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Depth-deferred backward (SURVEY.md §8 rows f1 x f4 when the hidden activations do NOT fit memory: H of the 241^2 graph is
+ * 391 GB).  `KernelNN.forward` applies the SAME conv1 `depth` times (UAI1_full_resolution.py:29-30) and `loss.backward()`
+ * (:266) sums the kernel MLP's gradients over those applications.  With dU_2^(l)[e] = (x_j^(l) . dZ_i^(l)) (.) [H_2[e] > 0]
+ * and H_2 the same in every application, the sum over l can be taken BEFORE the hidden layers' backward:
+ *   dU_2[e][k] = (sum_l sum_c x_j^(l)[c] dZ_i^(l)[c][k]) (.) [H_2[e][k] > 0]       one K = 64 * depth contraction per edge
+ * so the two 1024 x 1024 GEMMs per edge (dU_1, dW_2), the transposes and dW_1 / db_* run ONCE per step.
+ *   gpde_nnconv_bwd_light     one application: grad_x, grad of the last Linear (grad_w_last [4096][k2], grad_b_last [4096]),
+ *                             grad_root, grad_bias - everything gpde_nnconv_bwd_ordered writes except the hidden layers'
+ *                             gradients.  z_saved: NULL or the keep-Z forward's buffer (gpde_nnconv_fwd_keepz).
+ *                             Workspace: gpde_nnconv_bwd_workspace_bytes.
+ *   gpde_nnconv_bwd_deferred  all applications: x_stack [Lp][N][64] = the inputs x^(l) of the n_defer applications, ZERO
+ *                             layers appended up to Lp = max(4, n_defer rounded up to even); grad_out_stack [n_defer][N][64] =
+ *                             their output gradients (any order, the same in both stacks).  Writes grad_W[l] / grad_b[l] of
+ *                             the hidden layers l = 0 .. n_layers - 2 (the last entries are ignored).  Workspace:
+ *                             gpde_nnconv_bwd_deferred_workspace_bytes.
+ * Built for the kernel MLPs gpde_nnconv_bwd_deferred_supported() accepts (3 Linear layers, hidden widths multiples of 128,
+ * at most 7 attributes: the split-f16 path); others return GPDE_EUNSUPPORTED - use gpde_nnconv_bwd per application.
+ * Results: grad_x etc. of the light pass are the bits of gpde_nnconv_bwd_ordered; the hidden layers' gradients equal the
+ * sum of the per-application ones up to fp32 / split-f16 summation order (tests/test_gpu_deferred.py: <= 2e-5). */
+int gpde_nnconv_bwd_deferred_supported(int n_layers, const int32_t* dims);
+size_t gpde_nnconv_bwd_deferred_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers, const int32_t* dims,
+                                                int n_defer);
+int gpde_nnconv_bwd_light(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges, const int32_t* rowptr,
+                          const int32_t* src, const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host,
+                          const int32_t* src_rowptr, const int32_t* src_slots, int n_layers, const int32_t* dims,
+                          const float* const* W, const float* const* b, const float* root, int aggr, const float* grad_out,
+                          const float* z_saved, float* grad_x, float* grad_w_last, float* grad_b_last, float* grad_root,
+                          float* grad_bias, void* ws, size_t ws_bytes, void* stream);
+int gpde_nnconv_bwd_deferred(const float* x_stack, const float* grad_out_stack, int n_defer, int64_t n_nodes,
+                             const float* edge_attr, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
+                             const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host, int n_layers,
+                             const int32_t* dims, const float* const* W, const float* const* b, int aggr,
+                             float* const* grad_W, float* const* grad_b, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The operator given the PER-EDGE WEIGHTS (second half; row a6 'max').
  * `weight = self.nn(pseudo).view(-1, in, out)` (nn_conv.py:274) is what the reference forms on every call.  For the
  * MGKN V-cycles' low in-degree / small graphs (MGKN_orthogonal_burgers1d.py:73-82: 2-3 in-edges per node;
