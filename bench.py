@@ -698,7 +698,7 @@ def main():
                                               "reuse": round(depth * e / gres["auto"][0] / 1e6, 1)},
                 "budget_GiB": round(gres["auto"][2] / 2 ** 30, 1), "nodes_served_from_H": gres["auto"][3], "nodes": n,
                 "rel_l2_between_paths": dg,
-                "note": "partial H: inference only (gpde_nnconv_fwd_mixed); budget = 60 % of HBM, at most free - 48 GB"}
+                "note": "partial H: inference only (gpde_nnconv_fwd_mixed); budget = 70 % of HBM, at most free - 48 GB"}
             del gres, yg, ent                            # `ent` holds the 170 GB partial H: it must not outlive this probe
             hidden_cache.clear()
             torch.cuda.empty_cache()

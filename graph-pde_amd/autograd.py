@@ -119,11 +119,14 @@ class NNConvHiddenFunction(torch.autograd.Function):
 class DeferredToken:
     """Shared by the virtual-H node and the applications hanging on it: the (input, output gradient) pairs the light
     backward passes leave for the deferred pass, and the validity flag of the cached virtual H (as HiddenToken)."""
-    __slots__ = ("valid", "stash")
+    __slots__ = ("valid", "stash", "hpart")
 
     def __init__(self):
         self.valid = True
         self.stash = []
+        self.hpart = None       # (H rows of the in-edges of nodes [0, hn), max |H| scalar, hn): the cache's partial H, or None.
+                                # Read at call time and droppable at any moment (hidden_cache.release_all): without it
+                                # everything is recomputed - same mathematics
 
 
 class DeferredHiddenFunction(torch.autograd.Function):
@@ -147,6 +150,7 @@ class DeferredHiddenFunction(torch.autograd.Function):
         token = ctx.token
         token.valid = False
         stash, token.stash = token.stash, []
+        hp, token.hpart = token.hpart, None       # the cache builds its next partial H before this token is replaced
         edge_attr, *params = ctx.saved_tensors
         n = ctx.n_layers
         weights, biases = list(params[:n]), list(params[n:])
@@ -155,7 +159,8 @@ class DeferredHiddenFunction(torch.autograd.Function):
             gb = [None if b is None else torch.zeros_like(b) for b in biases[:-1]]
         else:
             gW, gb = ops.nnconv_backward_deferred_raw([s[0] for s in stash], [s[1] for s in stash], ctx.csr, edge_attr,
-                                                      weights, biases, ctx.aggr)
+                                                      weights, biases, ctx.aggr, hidden_part=None if hp is None else hp[0],
+                                                      hidden_nodes=0 if hp is None else hp[2])
         return (None, None, None, None, None, *gW, None, *gb, None)
 
 
@@ -172,7 +177,12 @@ class NNConvDeferredFunction(torch.autograd.Function):
         ops._require_cuda(x, "x")
         pm = ops.pack_mlp(weights, biases)
         ctx.z = ops.z_buffer(csr, pm.dims, x.device) if aggr in ("add", "mean") else None
-        out = ops.nnconv_forward_raw(x.detach(), csr, edge_attr.detach(), pm, root, bias, aggr, z_keep=ctx.z)
+        hp = token.hpart
+        if hp is not None:          # the in-edges of the leading nodes from the kept partial H, the rest through the fused kernel
+            out = ops.nnconv_forward_mixed_raw(x.detach(), csr, edge_attr.detach(), hp[0], hp[1], hp[2], pm, root, bias, aggr,
+                                               z_keep=ctx.z)
+        else:
+            out = ops.nnconv_forward_raw(x.detach(), csr, edge_attr.detach(), pm, root, bias, aggr, z_keep=ctx.z)
         ctx.csr, ctx.aggr, ctx.n_layers, ctx.token = csr, aggr, n_layers, token
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, edge_attr, root, *params)
@@ -184,9 +194,11 @@ class NNConvDeferredFunction(torch.autograd.Function):
         x, edge_attr, root, *params = ctx.saved_tensors
         n = ctx.n_layers
         weights, biases = list(params[:n]), list(params[n:])
+        hp = ctx.token.hpart
         gx, gw, gb, groot, gbias = ops.nnconv_backward_light_raw(
             x, ctx.csr, edge_attr, weights, biases, root, ctx.aggr, grad_out,
-            need_root=root is not None, need_bias=ctx.has_bias, z_saved=ctx.z)
+            need_root=root is not None, need_bias=ctx.has_bias, z_saved=ctx.z,
+            hidden_part=None if hp is None else hp[0], hidden_nodes=0 if hp is None else hp[2])
         ctx.z = None
         ctx.token.stash.append((x, grad_out.detach().contiguous()))
         gv = torch.zeros(1, dtype=torch.float32, device=x.device)        # the virtual H carries no numbers, only the dependency

@@ -461,6 +461,26 @@ extern "C" int gpde_nnconv_fwd_mixed(const float* x, int64_t n_nodes, const floa
                     hidden_nodes);
 }
 
+extern "C" int gpde_nnconv_fwd_mixed_keepz(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
+                                           const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges,
+                                           const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                                           const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
+                                           const float* root, const float* bias, int aggr, uint32_t flags, float* z_keep,
+                                           float* out, void* ws, size_t ws_bytes, void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || !dims || !packed || !rowptr || (n_nodes > 0 && (!x || !out)) ||
+        (n_edges > 0 && (!edge_attr || !src || !dst || !perm)) || hidden_nodes < 0 || hidden_nodes > n_nodes ||
+        (hidden_nodes > 0 && !hidden)) {
+        gpde_set_error("gpde_nnconv_fwd_mixed_keepz: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (hidden_nodes == 0)
+        return fwd_impl(x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, n_layers, dims, packed, root, bias,
+                        aggr, flags, nullptr, out, ws, ws_bytes, (hipStream_t)stream_, 0, nullptr, nullptr, -1, nullptr, 0, z_keep);
+    return fwd_impl(x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, n_layers, dims, packed, root, bias,
+                    aggr, flags, hidden, out, ws, ws_bytes, (hipStream_t)stream_, 0, nullptr, hidden_absmax,
+                    hidden_nodes, nullptr, 0, z_keep);
+}
+
 extern "C" int gpde_nnconv_fwd_hidden(const float* x, int64_t n_nodes, const float* hidden,
                                       const float* hidden_absmax, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
                                       const int32_t* dst, int n_layers, const int32_t* dims,

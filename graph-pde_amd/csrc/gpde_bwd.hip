@@ -716,7 +716,10 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
              float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias,
              const float* hidden, float* grad_hidden_out, const float* grad_hidden_in, void* ws,
              size_t ws_bytes, hipStream_t st, const int32_t* src_rowptr = nullptr, const int32_t* src_slots = nullptr,
-             const float* z_saved = nullptr, int n_defer = 0, const float* x_stack = nullptr, const float* g_stack = nullptr) {
+             const float* z_saved = nullptr, int n_defer = 0, const float* x_stack = nullptr, const float* g_stack = nullptr,
+             const float* hpart = nullptr, int64_t hpart_nodes = 0) {
+    // hpart (BWD_LIGHT / BWD_DEFER): the last hidden activations of the in-edges of nodes [0, hpart_nodes) are GIVEN (a partial
+    // H kept by the caller, CSR slots [0, rowptr[hpart_nodes])): node chunks below that bound read them instead of recomputing
     const bool do_conv = phase != BWD_MLP && phase != BWD_DEFER, do_mlp = phase != BWD_CONV && phase != BWD_LIGHT;
     BwdPlan P;
     int rc = make_bwd_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P, phase == BWD_DEFER ? n_defer : 0);
@@ -789,11 +792,13 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     const bool light = phase == BWD_LIGHT;
     // recompute of the hidden chain for rows [e0, e0 + rows) = in-edges of nodes [na_, nb_): layers 1 .. last
     int rc_na = 0, rc_nb = 0;
+    const float* chunk_h = nullptr;          // the current chunk's last hidden activations when they are given (hpart)
     auto recompute = [&](int e0, int rows, int last) -> int {
         if (!light)      // (the light pass needs the last hidden layer only, which the fused kernel forms from the attributes itself)
             hipLaunchKernelGGL(k_gather_attr, dim3(nblk((size_t)rows * P.KP[0])), dim3(T), 0, st, edge_attr, perm, e0,
                                rows, dims[0], P.KP[0], F(P.off_H[0]));
-        if (fast_last && last == n - 1) {
+        if (fast_last && last == n - 1 && chunk_h) last = n - 2;
+        else if (fast_last && last == n - 1) {
             const float* pk = F(P.off_pack);
             GpdeFusedArgs f{};
             f.attr = edge_attr; f.rowptr = rowptr; f.perm = perm;
@@ -923,6 +928,8 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     while ((do_conv || phase == BWD_DEFER) && na < N && n_edges > 0) {
         // largest nb with (nb - na) <= Nc and edges <= Ec (at least one node)
         int lo = na + 1, hi = (int)((int64_t)na + P.Nc < N ? na + P.Nc : N);
+        const bool from_h = hpart && na < hpart_nodes;
+        if (from_h && hi > hpart_nodes) hi = (int)hpart_nodes;        // a chunk never straddles the end of the given H
         const int64_t ebase = rowptr_host[na];
         if (phase == BWD_CONV) P.Ec = n_edges;       // H and dU live outside the workspace: no edge limit
         if (rowptr_host[lo] - ebase > P.Ec) {
@@ -938,10 +945,12 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         const int e0 = (int)ebase, e1 = rowptr_host[nb], rows = e1 - e0;
         float* gT = F(P.off_gT); float* S = F(P.off_S); float* dS = F(P.off_dS);
         float* Z = F(P.off_Z); float* dZ = F(P.off_dZ);
+        chunk_h = from_h ? hpart + (size_t)e0 * K2P : nullptr;
         if (phase == BWD_DEFER) {
             if (rows > 0) {
                 rc_na = na; rc_nb = nb;
                 if ((rc = recompute(e0, rows, n - 1)) != GPDE_OK) return rc;
+                const float* H2 = chunk_h ? chunk_h : F(P.off_H[n - 1]);
                 // dZ^(l)[i][c][k] = sum_o gT^(l)[i][o] W3[c*64+o][k] of every deferred layer, then the nodes' split images
                 const size_t dzl = (size_t)P.Nc * GP_W * K2P;
                 for (int l = 0; l < P.L; ++l) {
@@ -960,7 +969,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 // dU_2 of the chunk's edges: (sum over the layers of x_j . dZ_i) masked by the recomputed H_2 > 0
                 float* dU2 = F(P.off_dU[0]);
                 if ((rc = gpde_launch_gemm_f16s_gather(x_stack, (size_t)N * GP_W, P.Lp, F(P.off_xsc), F(P.off_xsc) + N, src + e0, rows, tiles, ntiles,
-                                                       F(P.off_dzimg), F(P.off_nscale) + P.Nc, F(P.off_H[n - 1]), K2P, dU2, K2P, K2P, st)) != GPDE_OK) return rc;
+                                                       F(P.off_dzimg), F(P.off_nscale) + P.Nc, H2, K2P, dU2, K2P, K2P, st)) != GPDE_OK) return rc;
                 if ((rc = mlp_backward(dU2, rows)) != GPDE_OK) return rc;
             }
             na = nb;
@@ -970,7 +979,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         if (rows > 0) {
             // hidden activations of the chunk's edges: recomputed, or rows of the given cache
             if (phase == BWD_FULL || light) { rc_na = na; rc_nb = nb; if ((rc = recompute(e0, rows, n - 1)) != GPDE_OK) return rc; }
-            const float* Hlast = (phase == BWD_FULL || light) ? F(P.off_H[n - 1]) : hidden + (size_t)e0 * K2P;
+            const float* Hlast = chunk_h ? chunk_h : (phase == BWD_FULL || light) ? F(P.off_H[n - 1]) : hidden + (size_t)e0 * K2P;
             // Z of the chunk's nodes: kept by the forward (gpde_nnconv_fwd_keepz), else re-aggregated from the recomputed /
             // given activations
             if (z_saved) Z = const_cast<float*>(z_saved) + (size_t)na * GP_W * K2P;      // read only below
@@ -1137,10 +1146,12 @@ extern "C" int gpde_nnconv_bwd_light(const float* x, int64_t n_nodes, const floa
                                      const int32_t* src, const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host,
                                      const int32_t* src_rowptr, const int32_t* src_slots, int n_layers, const int32_t* dims,
                                      const float* const* W, const float* const* b, const float* root, int aggr, const float* grad_out,
-                                     const float* z_saved, float* grad_x, float* grad_w_last, float* grad_b_last, float* grad_root,
+                                     const float* z_saved, const float* hidden_part, int64_t hidden_nodes, float* grad_x,
+                                     float* grad_w_last, float* grad_b_last, float* grad_root,
                                      float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
     if (n_nodes < 0 || n_edges < 0 || !dims || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws || n_layers < 2 ||
-        n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x || !grad_x)) || (n_edges > 0 && (!edge_attr || !src || !dst || !perm))) {
+        n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x || !grad_x)) || (n_edges > 0 && (!edge_attr || !src || !dst || !perm)) ||
+        hidden_nodes < 0 || hidden_nodes > n_nodes || (hidden_nodes > 0 && !hidden_part)) {
         gpde_set_error("gpde_nnconv_bwd_light: null/negative argument");
         return GPDE_EINVAL;
     }
@@ -1150,24 +1161,27 @@ extern "C" int gpde_nnconv_bwd_light(const float* x, int64_t n_nodes, const floa
     gW[n_layers - 1] = grad_w_last; gb[n_layers - 1] = grad_b_last;
     return bwd_impl(BWD_LIGHT, x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims, W, b, root, aggr,
                     grad_out, grad_x, gW, gb, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream_,
-                    src_rowptr, src_slots, z_saved);
+                    src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, hidden_nodes > 0 ? hidden_part : nullptr, hidden_nodes);
 }
 
 extern "C" int gpde_nnconv_bwd_deferred(const float* x_stack, const float* grad_out_stack, int n_defer, int64_t n_nodes,
                                         const float* edge_attr, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
                                         const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host, int n_layers,
                                         const int32_t* dims, const float* const* W, const float* const* b, int aggr,
+                                        const float* hidden_part, int64_t hidden_nodes,
                                         float* const* grad_W, float* const* grad_b, void* ws, size_t ws_bytes, void* stream_) {
     if (n_nodes < 0 || n_edges < 0 || n_defer < 1 || !dims || !W || !b || !grad_W || !grad_b || !rowptr || !rowptr_host || !ws ||
         n_layers < 2 || n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x_stack || !grad_out_stack)) ||
-        (n_edges > 0 && (!edge_attr || !src || !dst || !perm))) {
+        (n_edges > 0 && (!edge_attr || !src || !dst || !perm)) || hidden_nodes < 0 || hidden_nodes > n_nodes ||
+        (hidden_nodes > 0 && !hidden_part)) {
         gpde_set_error("gpde_nnconv_bwd_deferred: null/negative argument");
         return GPDE_EINVAL;
     }
     if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_deferred: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
     return bwd_impl(BWD_DEFER, nullptr, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims, W, b, nullptr,
                     aggr, nullptr, nullptr, grad_W, grad_b, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
-                    (hipStream_t)stream_, nullptr, nullptr, nullptr, n_defer, x_stack, grad_out_stack);
+                    (hipStream_t)stream_, nullptr, nullptr, nullptr, n_defer, x_stack, grad_out_stack,
+                    hidden_nodes > 0 ? hidden_part : nullptr, hidden_nodes);
 }
 
 extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,

@@ -9,7 +9,7 @@ materialise H (one `HiddenFunction` node) and serve the remaining calls from it
 (`NNConvHiddenFunction`): the hidden layer and its backward then run once per step.
 
 Policy (`GPDE_HIDDEN_CACHE` = auto | on | off, default auto; budget `GPDE_HIDDEN_CACHE_GB`, default: sized to the device -
-60 % of its HBM, at most what is free now minus a 48 GB reserve for workspaces, i.e. ~170 GB on an idle 288 GB MI355X):
+70 % of its HBM, at most what is free now minus a 48 GB reserve for workspaces, i.e. ~200 GB on an idle 288 GB MI355X):
   * a call whose (edge_attr memory + version, CSR, hidden-layer parameter versions, precision, grad
     mode) matches the cached H is a hit;
   * "auto" materialises H only for a module that has been SEEN repeating a key (the second call of
@@ -38,13 +38,13 @@ MODE = os.environ.get("GPDE_HIDDEN_CACHE", "auto")
 _env_gb = os.environ.get("GPDE_HIDDEN_CACHE_GB", "")
 # None = sized to the device at the moment H is built (budget_bytes); a number pins it (tests / A-B runs set this variable)
 BUDGET_BYTES: Optional[int] = None if _env_gb in ("", "auto") else int(float(_env_gb) * (1 << 30))
-AUTO_FRACTION = 0.6                  # of the device's HBM
+AUTO_FRACTION = 0.7                  # of the device's HBM
 AUTO_RESERVE_BYTES = 48 << 30        # left free for workspaces (Z of the 241^2 graph: 15 GB), the caller's tensors, RCCL
 
 
 def budget_bytes(device=None, releasing: int = 0) -> int:
     """Bytes the hidden activations of ONE module may take.  With GPDE_HIDDEN_CACHE_GB unset the budget follows the
-    device: min(60 % of its memory, free now + `releasing` (the H about to be dropped) - reserve).  On the 241^2 graph
+    device: min(70 % of its memory, free now + `releasing` (the H about to be dropped) - reserve).  On the 241^2 graph
     (H = 391 GB) that caches the in-edges of ~44 % of the nodes instead of none, 1.64 x on a depth-6 inference forward
     (scripts/time_g241_depth6_reuse.py)."""
     if BUDGET_BYTES is not None:
@@ -52,7 +52,7 @@ def budget_bytes(device=None, releasing: int = 0) -> int:
     dev = None if device is None else torch.device(device)
     if dev is None or dev.type != "cuda":
         return 32 << 30
-    free, total = torch.cuda.mem_get_info(dev)
+    free, total = ops.device_free_bytes(dev)
     return max(0, min(int(AUTO_FRACTION * total), free + releasing - AUTO_RESERVE_BYTES))
 PARTIAL = os.environ.get("GPDE_HIDDEN_CACHE_PARTIAL", "1") != "0"
 # Depth-deferred backward: a module that repeats (edge_attr, weights) within a forward, needs gradients and
@@ -115,8 +115,8 @@ def release_all() -> bool:
             freed = True
         ent.hidden, ent.key, ent.token, ent.attr_ref, ent.csr = None, None, None, None, None
         ent.we, ent.we_key, ent.we_refs = None, None, None
-        if ent.dtoken is not None and not ent.dtoken.stash:      # (a virtual H holds no memory; one mid-backward is left alone)
-            ent.dkey, ent.dtoken, ent.dvirtual, ent.drefs, ent.dcount = None, None, None, None, 0
+        if ent.dtoken is not None:
+            ent.dtoken.hpart = None          # applications still hanging on the virtual H recompute instead (same mathematics)
     if freed:
         stats["released"] = stats.get("released", 0) + 1
     return freed
@@ -150,6 +150,8 @@ def lookup(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, b
         ent.hits_on_hidden += 1
         if ent.hn == csr.n_nodes or allow_partial:
             stats["hits"] += 1
+            if ent.hn < csr.n_nodes:
+                ent.big_key = key
             return ent.hidden, ent.token.hmax, ent.hn
     repeated = ent.last_key == key
     if repeated:
@@ -175,20 +177,41 @@ def lookup(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, b
         return None
     token = HiddenToken()
     ent.hidden = None                # release the previous H before allocating the next one
-    if hn < csr.n_nodes:             # partial: inference only, no autograd node
-        hidden, token.hmax = ops.hidden_forward_raw(csr, edge_attr.detach(), pm, list(weights[:-1]) + [None],
-                                                    list(biases[:-1]) + [None], precision, n_nodes_limit=hn)
-    else:
-        hidden = HiddenFunction.apply(edge_attr, csr, pm, precision, token, len(hw), *hw, *hb)
+    if ent.dtoken is not None:
+        ent.dtoken.hpart = None      # ... also where a finished virtual-H node still points at it
+    try:
+        if hn < csr.n_nodes:         # partial: no autograd node (inference, or training on the virtual-H node: lookup_deferred)
+            hidden, token.hmax = ops.hidden_forward_raw(csr, edge_attr.detach(), pm, list(weights[:-1]) + [None],
+                                                        list(biases[:-1]) + [None], precision, n_nodes_limit=hn)
+        else:
+            hidden = HiddenFunction.apply(edge_attr, csr, pm, precision, token, len(hw), *hw, *hb)
+    except torch.OutOfMemoryError:
+        # the budget was measured a moment ago; another module's cache, another process or the caller's own tensors may have
+        # taken the room since.  H is an optimisation: drop everything cached and run the direct path.
+        ent.hidden, ent.key, ent.token, ent.attr_ref, ent.csr = None, None, None, None, None
+        release_all()
+        torch.cuda.empty_cache()
+        stats["oom_fallbacks"] = stats.get("oom_fallbacks", 0) + 1
+        stats["direct"] += 1
+        return None
     ent.key, ent.hidden, ent.token, ent.attr_ref, ent.csr, ent.hn = key, hidden, token, edge_attr, csr, hn
     ent.hits_on_hidden = 0
+    if hn < csr.n_nodes:
+        ent.big_key = key            # the whole H does not fit: a training call shares a virtual-H node (lookup_deferred)
     stats["builds"] += 1
     return hidden, token.hmax, hn
 
 
+def defer_possible(edge_attr: torch.Tensor, pm, weights, biases, aggr: str) -> bool:
+    """A call that needs gradients could hang on a virtual-H node (lookup_deferred): then `lookup` may hand it a PARTIAL H."""
+    return DEFER_MODE != "off" and aggr in ("add", "mean") and torch.is_grad_enabled() and not edge_attr.requires_grad and \
+        any(p is not None and p.requires_grad for p in list(weights[:-1]) + list(biases[:-1])) and ops.deferred_supported(pm.dims)
+
+
 def lookup_deferred(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, biases, aggr: str,
-                    precision: Optional[str] = None):
-    """(virtual H tensor, token) for a call that needs gradients, right after `lookup` returned None for it - or None when
+                    precision: Optional[str] = None, hpart=None):
+    """(virtual H tensor, token) for a call that needs gradients, right after `lookup` returned None (or a PARTIAL H: `hpart`
+    = its (H, hmax, hn) - the applications then read those rows instead of recomputing them) for it - or None when
     the plain operator (autograd.NNConvFunction: its own full backward) should run.  Deferred when: the module has been seen
     repeating this (edge_attr, weights) key, its H was wanted but does not fit the budget, the hidden layers require a
     gradient and the kernel MLP is in the deferred form (ops.deferred_supported).  All applications of one forward share the
@@ -205,14 +228,18 @@ def lookup_deferred(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, w
     key = _key(edge_attr, csr, hw + hb, precision)
     if ent.dtoken is not None and ent.dkey == key and ent.dtoken.valid:
         ent.dcount += 1
+        ent.dtoken.hpart = hpart
         stats["deferred_hits"] = stats.get("deferred_hits", 0) + 1
         return ent.dvirtual, ent.dtoken
     if ent.dtoken is not None and ent.dcount <= 1:
         ent.repeats = False             # the last virtual H served a single application: stop speculating
+    if ent.dtoken is not None:
+        ent.dtoken.hpart = None
     ent.dkey, ent.dtoken, ent.dvirtual, ent.drefs, ent.dcount = None, None, None, None, 0
     if not ent.repeats or ent.big_key != key or not ops.deferred_supported(pm.dims):
         return None
     token = DeferredToken()
+    token.hpart = hpart
     n = len(weights)
     w_last, b_last = weights[-1], biases[-1]
     virtual = DeferredHiddenFunction.apply(edge_attr, csr, aggr, token, n, *hw, w_last.detach(),

@@ -202,8 +202,9 @@ class NNConv_old(MessagePassing):
                 pseudo.dtype == torch.float32 and x.dtype == torch.float32:
             csr = ops.csr_for(edge_index, x.size(0))
             pm = ops.pack_mlp(weights, biases)
-            hit = hidden_cache.lookup(self, pseudo, csr, pm, weights, biases, allow_partial=no_grad)
-            if hit is not None:
+            defer_ok = (not no_grad) and hidden_cache.defer_possible(pseudo, pm, weights, biases, self.aggr)
+            hit = hidden_cache.lookup(self, pseudo, csr, pm, weights, biases, allow_partial=no_grad or defer_ok)
+            if hit is not None and (hit[2] == csr.n_nodes or no_grad):
                 hidden, hmax, hn = hit
                 if hn < csr.n_nodes:        # H of the leading nodes only: mixed forward (inference)
                     return ops.nnconv_forward_mixed_raw(x, csr, pseudo, hidden, hmax, hn, pm, root,
@@ -212,8 +213,9 @@ class NNConv_old(MessagePassing):
                                                   root, bias, self.aggr, hmax)
             if not no_grad:
                 # H wanted but too large for the device (the 241^2 graph: 391 GB): the applications of this forward share a
-                # "virtual H" node instead - light backward per application, ONE deferred pass for the hidden layers
-                d = hidden_cache.lookup_deferred(self, pseudo, csr, pm, weights, biases, self.aggr)
+                # "virtual H" node instead - light backward per application, ONE deferred pass for the hidden layers; the
+                # part of H that does fit (`hit`: the in-edges of the leading nodes) is read instead of recomputed
+                d = hidden_cache.lookup_deferred(self, pseudo, csr, pm, weights, biases, self.aggr, hpart=hit)
                 if d is not None:
                     return NNConvDeferredFunction.apply(x, d[0], csr, pseudo, root, bias, self.aggr, d[1],
                                                         len(weights), *weights, *biases)

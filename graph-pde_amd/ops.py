@@ -360,6 +360,16 @@ def workspace_bytes(n_nodes: int, n_edges: int, pm: PackedMlp) -> int:
 
 
 SAVE_Z_BYTES = int(float(os.environ.get("GPDE_SAVE_Z_GB", "16")) * (1 << 30))     # per call; 0 disables
+SAVE_Z_RESERVE_BYTES = int(float(os.environ.get("GPDE_SAVE_Z_RESERVE_GB", "48")) * (1 << 30))   # device memory left free by a kept Z
+
+
+def device_free_bytes(dev):
+    """(bytes an allocation can still get, device total): what the driver reports free PLUS what torch's caching allocator
+    holds in freed blocks (it returns them to the driver when a large request needs the room) - after a training step the
+    freed Z buffers and workspaces of the 241^2 graph are ~120 GB of such blocks, invisible to mem_get_info alone."""
+    free, total = torch.cuda.mem_get_info(dev)
+    cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    return free + max(0, cached), total
 
 
 def _alloc_ws(nbytes: int, dev) -> torch.Tensor:
@@ -384,6 +394,12 @@ def z_buffer(csr: Csr, dims: Sequence[int], device) -> Optional[torch.Tensor]:
     nbytes = csr.n_nodes * WIDTH * hidden_width(dims) * 4
     if SAVE_Z_BYTES <= 0 or nbytes > SAVE_Z_BYTES or csr.n_edges < 32 * csr.n_nodes:
         return None
+    if nbytes > (1 << 30):
+        # large buffers (15 GB per call on the 241^2 graph, one per layer until its backward ran): kept only while the device
+        # still has room for the backward's workspace afterwards - keeping Z is an optimisation, the workspace is not
+        free, _ = device_free_bytes(device)
+        if free - nbytes < SAVE_Z_RESERVE_BYTES:
+            return None
     try:
         return torch.zeros(csr.n_nodes, WIDTH * hidden_width(dims), dtype=torch.float32, device=device)
     except torch.OutOfMemoryError:       # keeping Z is an optimisation: without it the backward re-aggregates
@@ -637,9 +653,11 @@ def deferred_layers_padded(n_defer: int) -> int:
 def nnconv_backward_light_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
                               weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
                               root: Optional[torch.Tensor], aggr: str, grad_out: torch.Tensor,
-                              need_root: bool = True, need_bias: bool = True, z_saved: Optional[torch.Tensor] = None):
+                              need_root: bool = True, need_bias: bool = True, z_saved: Optional[torch.Tensor] = None,
+                              hidden_part: Optional[torch.Tensor] = None, hidden_nodes: int = 0):
     """gpde_nnconv_bwd_light: one application of a depth-shared module - grad_x, the last Linear's gradients, grad_root,
-    grad_bias; the hidden layers' gradients come from nnconv_backward_deferred_raw.
+    grad_bias; the hidden layers' gradients come from nnconv_backward_deferred_raw.  `hidden_part` / `hidden_nodes`: the
+    partial H of the mixed forward (rows of the in-edges of nodes [0, hidden_nodes)): read instead of recomputed.
     Returns (grad_x, grad_w_last, grad_b_last or None, grad_root or None, grad_bias or None)."""
     lib = _lib.lib()
     for t, nm in ((x, "x"), (edge_attr, "edge_attr"), (grad_out, "grad_out")):
@@ -671,6 +689,7 @@ def nnconv_backward_light_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor
         rc = lib.gpde_nnconv_bwd_light(x.data_ptr(), n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), csr.src.data_ptr(),
                                        csr.dst.data_ptr(), perm.data_ptr(), csr.rowptr_host.data_ptr(), p(srp), p(ssl), nl, dims_c,
                                        _ptr_array(ws_), _ptr_array(bs_), p(root_c), _AGGR[aggr], grad_out.data_ptr(), p(z_saved),
+                                       p(hidden_part) if hidden_nodes > 0 else None, int(hidden_nodes) if hidden_part is not None else 0,
                                        gx.data_ptr(), gw.data_ptr(), p(gb), p(groot), p(gbias), ws.data_ptr(), ws.numel(),
                                        _stream_ptr(dev))
     _lib.check(rc, "gpde_nnconv_bwd_light")
@@ -679,7 +698,8 @@ def nnconv_backward_light_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor
 
 
 def nnconv_backward_deferred_raw(xs: Sequence[torch.Tensor], gs: Sequence[torch.Tensor], csr: Csr, edge_attr: torch.Tensor,
-                                 weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], aggr: str):
+                                 weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], aggr: str,
+                                 hidden_part: Optional[torch.Tensor] = None, hidden_nodes: int = 0):
     """gpde_nnconv_bwd_deferred: the hidden layers' gradients of ALL the applications (xs[l], gs[l]) = (input, output
     gradient) of a depth-shared module, in one pass over the edges.  `weights` / `biases`: ALL Linear layers (the last one
     is read, not differentiated).  Returns ([grad_W_l], [grad_b_l or None]) for the hidden layers."""
@@ -709,7 +729,10 @@ def nnconv_backward_deferred_raw(xs: Sequence[torch.Tensor], gs: Sequence[torch.
     with torch.cuda.device(dev):
         rc = lib.gpde_nnconv_bwd_deferred(x_stack.data_ptr(), g_stack.data_ptr(), L, n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(),
                                           csr.src.data_ptr(), csr.dst.data_ptr(), perm.data_ptr(), csr.rowptr_host.data_ptr(), nl, dims_c,
-                                          _ptr_array(ws_), _ptr_array(bs_), _AGGR[aggr], _ptr_array(gW), _ptr_array(gb), ws.data_ptr(),
+                                          _ptr_array(ws_), _ptr_array(bs_), _AGGR[aggr],
+                                          hidden_part.data_ptr() if (hidden_part is not None and hidden_nodes > 0) else None,
+                                          int(hidden_nodes) if hidden_part is not None else 0,
+                                          _ptr_array(gW), _ptr_array(gb), ws.data_ptr(),
                                           ws.numel(), _stream_ptr(dev))
     _lib.check(rc, "gpde_nnconv_bwd_deferred")
     _lib.n_native_calls += 1
@@ -915,9 +938,9 @@ def nnconv_forward_edgeweights_raw(x, csr, edge_weights, root, bias, aggr, resid
 def nnconv_forward_mixed_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor, hidden: torch.Tensor,
                              hmax: Optional[torch.Tensor], hidden_nodes: int, pm: PackedMlp,
                              root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,
-                             precision: Optional[str] = None) -> torch.Tensor:
-    """gpde_nnconv_fwd_mixed: nodes [0, hidden_nodes) aggregate from `hidden` (their in-edges' rows), the
-    rest run the fused kernel -- for graphs whose full H does not fit memory.  Forward only."""
+                             precision: Optional[str] = None, z_keep: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gpde_nnconv_fwd_mixed(_keepz): nodes [0, hidden_nodes) aggregate from `hidden` (their in-edges' rows), the
+    rest run the fused kernel -- for graphs whose full H does not fit memory.  `z_keep`: as nnconv_forward_raw."""
     lib = _lib.lib()
     _require_cuda(x, "x")
     precision = DEFAULT_PRECISION if precision is None else precision
@@ -932,14 +955,14 @@ def nnconv_forward_mixed_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
     out = torch.empty(n, WIDTH, dtype=torch.float32, device=x.device)
     ws = _alloc_ws(workspace_bytes(n, e, pm), x.device)
     with torch.cuda.device(x.device):
-        rc = lib.gpde_nnconv_fwd_mixed(x.data_ptr(), n, edge_attr.data_ptr(), hidden.data_ptr(),
-                                       None if hmax is None else hmax.data_ptr(), hidden_nodes, e,
-                                       csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(),
-                                       perm.data_ptr(), len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(),
-                                       None if root_c is None else root_c.data_ptr(),
-                                       None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
-                                       _PRECISION[precision], out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                       _stream_ptr(x.device))
+        rc = lib.gpde_nnconv_fwd_mixed_keepz(x.data_ptr(), n, edge_attr.data_ptr(), hidden.data_ptr(),
+                                             None if hmax is None else hmax.data_ptr(), hidden_nodes, e,
+                                             csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(),
+                                             perm.data_ptr(), len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(),
+                                             None if root_c is None else root_c.data_ptr(),
+                                             None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
+                                             _PRECISION[precision], None if z_keep is None else z_keep.data_ptr(),
+                                             out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
     _lib.check(rc, "gpde_nnconv_fwd_mixed")
     _lib.n_native_calls += 1
     return out

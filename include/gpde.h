@@ -306,6 +306,9 @@ int gpde_nnconv_bwd_z(const float* x, int64_t n_nodes, const float* edge_attr, c
  *                             their output gradients (any order, the same in both stacks).  Writes grad_W[l] / grad_b[l] of
  *                             the hidden layers l = 0 .. n_layers - 2 (the last entries are ignored).  Workspace:
  *                             gpde_nnconv_bwd_deferred_workspace_bytes.
+ * hidden_part / hidden_nodes (both entry points; NULL / 0: none): the last hidden activations of the in-edges of nodes
+ * [0, hidden_nodes) as gpde_hidden_fwd(n_nodes = hidden_nodes) wrote them (the partial H of gpde_nnconv_fwd_mixed) - node
+ * chunks below that bound read them instead of recomputing the hidden chain (the 241^2 graph: 44 % of the edges fit 170 GB).
  * Built for the kernel MLPs gpde_nnconv_bwd_deferred_supported() accepts (3 Linear layers, hidden widths multiples of 128,
  * at most 7 attributes: the split-f16 path); others return GPDE_EUNSUPPORTED - use gpde_nnconv_bwd per application.
  * Results: grad_x etc. of the light pass are the bits of gpde_nnconv_bwd_ordered; the hidden layers' gradients equal the
@@ -317,13 +320,22 @@ int gpde_nnconv_bwd_light(const float* x, int64_t n_nodes, const float* edge_att
                           const int32_t* src, const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host,
                           const int32_t* src_rowptr, const int32_t* src_slots, int n_layers, const int32_t* dims,
                           const float* const* W, const float* const* b, const float* root, int aggr, const float* grad_out,
-                          const float* z_saved, float* grad_x, float* grad_w_last, float* grad_b_last, float* grad_root,
+                          const float* z_saved, const float* hidden_part, int64_t hidden_nodes, float* grad_x,
+                          float* grad_w_last, float* grad_b_last, float* grad_root,
                           float* grad_bias, void* ws, size_t ws_bytes, void* stream);
 int gpde_nnconv_bwd_deferred(const float* x_stack, const float* grad_out_stack, int n_defer, int64_t n_nodes,
                              const float* edge_attr, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
                              const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host, int n_layers,
                              const int32_t* dims, const float* const* W, const float* const* b, int aggr,
+                             const float* hidden_part, int64_t hidden_nodes,
                              float* const* grad_W, float* const* grad_b, void* ws, size_t ws_bytes, void* stream);
+/* The mixed forward (gpde_nnconv_fwd_mixed) that also leaves Z_i for the backward (z_keep as in gpde_nnconv_fwd_keepz; NULL: none). */
+int gpde_nnconv_fwd_mixed_keepz(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
+                                const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges,
+                                const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                                const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
+                                const float* root, const float* bias, int aggr, uint32_t flags, float* z_keep, float* out,
+                                void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The operator given the PER-EDGE WEIGHTS (second half; row a6 'max').

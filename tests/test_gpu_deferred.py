@@ -181,6 +181,62 @@ def test_module_shares_a_virtual_hidden_node_when_h_does_not_fit(monkeypatch):
         assert torch.equal(r, a)
 
 
+def test_partial_hidden_activations_serve_the_light_and_deferred_passes(monkeypatch):
+    """The part of H that fits the budget (in-edges of the leading nodes) is read instead of recomputed: raw calls against the
+    recomputing ones, then the module (mixed forward + light backward + deferred pass on the virtual-H node) against the
+    direct path."""
+    dims, n, deg, L = [6, 256, 256, 4096], 128, 100, 3
+    x0, ei, ea, ws_, bs_, root, bias = _dense_case(dims, n, deg, 31)
+    d = dev()
+    csr = ops.build_csr(ei.to(d), n)
+    ead, wd, bd, rd = _to(d, ea, ws_, bs_, root)
+    pm = ops.pack_mlp(wd, bd)
+    hn = 64
+    hpart, hmax = ops.hidden_forward_raw(csr, ead, pm, wd[:-1] + [None], bd[:-1] + [None], n_nodes_limit=hn)
+    torch.manual_seed(2)
+    xs = [torch.randn(n, 64, device=d) for _ in range(L)]
+    gs = [torch.randn(n, 64, device=d) for _ in range(L)]
+    a = ops.nnconv_backward_light_raw(xs[0], csr, ead, wd, bd, rd, "mean", gs[0])
+    b = ops.nnconv_backward_light_raw(xs[0], csr, ead, wd, bd, rd, "mean", gs[0], hidden_part=hpart, hidden_nodes=hn)
+    for u, v in zip(a, b):
+        assert rel_l2(v.cpu(), u.cpu()) <= 1e-6
+    da = ops.nnconv_backward_deferred_raw(xs, gs, csr, ead, wd, bd, "mean")
+    db = ops.nnconv_backward_deferred_raw(xs, gs, csr, ead, wd, bd, "mean", hidden_part=hpart, hidden_nodes=hn)
+    for k in range(2):
+        assert rel_l2(db[0][k].cpu(), da[0][k].cpu()) <= 2e-6 and rel_l2(db[1][k].cpu(), da[1][k].cpu()) <= 2e-6
+    # module level: budget = about half of H
+    depth = 4
+    torch.manual_seed(0)
+    net = _Net(dims, depth).to(d)
+    x, eid, tgt = x0.to(d), ei.to(d), torch.randn(n, 64, device=d)
+    monkeypatch.setattr(hidden_cache, "MODE", "off")
+    ref, loss_ref = _grads(net, x, eid, ead, tgt)
+    monkeypatch.setattr(hidden_cache, "MODE", "auto")
+    monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", int(csr.n_edges * 256 * 4 * 0.7))        # rows of 64 of the 128 nodes fit
+    hidden_cache.clear()
+    _grads(net, x, eid, ead, tgt)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.0)                                              # an optimizer step: the version counters move
+    got, loss = _grads(net, x, eid, ead, tgt)                      # steady state: partial H from the first call on
+    assert hidden_cache.stats["builds"] >= 2 and hidden_cache.stats.get("deferred_builds", 0) == 2
+    ent = hidden_cache._entries[net.conv1]
+    assert ent.hidden is not None and 0 < ent.hn < n and ent.hn % 64 == 0
+    assert abs(loss - loss_ref) <= 1e-5 * abs(loss_ref)
+    names = ["x"] + [k for k, _ in net.named_parameters()]
+    for name, r, g in zip(names, ref, got):
+        assert rel_l2(g.cpu(), r.cpu()) <= TOL, (name, rel_l2(g.cpu(), r.cpu()))
+    # the cache gives way (ops._alloc_ws on OOM -> release_all): the hanging applications recompute, same gradients
+    net.zero_grad(set_to_none=True)
+    xin = x.clone().requires_grad_(True)
+    loss2 = ((net(xin, eid, ead) - tgt) ** 2).mean()
+    assert hidden_cache.release_all()
+    loss2.backward()
+    torch.cuda.synchronize()
+    for name, r, g in zip(names, ref, [xin.grad] + [p.grad for p in net.parameters()]):
+        assert rel_l2(g.cpu(), r.cpu()) <= TOL, (name, rel_l2(g.cpu(), r.cpu()))
+
+
 def test_unsupported_kernels_keep_the_plain_backward(monkeypatch):
     """Kernel MLPs outside the deferred form ([6, 64, 128, 4096]: the checkpoint's widths) are never deferred."""
     dims = [6, 64, 128, 4096]

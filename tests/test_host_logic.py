@@ -368,21 +368,28 @@ def test_attr_slot_order_cache_and_keep_z_policy_host_logic(monkeypatch):
 
 
 def test_hidden_cache_budget_follows_the_device_unless_pinned(monkeypatch):
-    """hidden_cache.budget_bytes: GPDE_HIDDEN_CACHE_GB pins it; unset -> min(60 % of the device's memory, free now + what
-    is about to be released - the 48 GB reserve), never negative; CPU tensors (tests) get the old fixed 32 GB."""
+    """hidden_cache.budget_bytes: GPDE_HIDDEN_CACHE_GB pins it; unset -> min(70 % of the device's memory, free now (driver +
+    torch's cached free blocks) + what is about to be released - the 48 GB reserve), never negative; CPU tensors (tests) get
+    the old fixed 32 GB."""
     from graph_pde_amd import hidden_cache
     gb = 1 << 30
     monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", 5 * gb)
     assert hidden_cache.budget_bytes("cuda:0") == 5 * gb and hidden_cache.budget_bytes(None) == 5 * gb
     monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", None)
     assert hidden_cache.budget_bytes(None) == 32 * gb and hidden_cache.budget_bytes(torch.device("cpu")) == 32 * gb
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda dev=None: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda dev=None: 0)
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (280 * gb, 288 * gb))
-    assert hidden_cache.budget_bytes("cuda:0") == int(0.6 * 288 * gb)                  # idle device: the fraction binds
+    assert hidden_cache.budget_bytes("cuda:0") == int(0.7 * 288 * gb)                  # idle device: the fraction binds
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (100 * gb, 288 * gb))
     assert hidden_cache.budget_bytes("cuda:0") == 52 * gb                               # busy device: free - reserve
     assert hidden_cache.budget_bytes("cuda:0", releasing=20 * gb) == 72 * gb            # the H being replaced counts as free
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (10 * gb, 288 * gb))
     assert hidden_cache.budget_bytes("cuda:0") == 0
+    # blocks torch's allocator holds free (last step's Z buffers and workspaces) count as free
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda dev=None: 150 * gb)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda dev=None: 30 * gb)
+    assert hidden_cache.budget_bytes("cuda:0") == (10 + 120 - 48) * gb
 
 
 def test_workspace_allocation_drops_the_caches_once_when_the_device_is_full(monkeypatch):
