@@ -23,7 +23,8 @@ for the median).  Objects on the line:
                 `algorithmic_ratio` = the reference formulation's FLOPs (10,506,304 per edge at 1024^2) at the
                 same duration / the fp32 MFMA peak - above 1 because the kernel re-associates the last layer
                  and runs the hidden layer on the f16 pipe; NOT a roofline fraction.  `traffic` =
-                HBM-side bytes per launch from the PMC record of THIS kernel symbol in profiles/traffic_r03.json
+                HBM-side bytes per launch from the PMC record of THIS kernel symbol in profiles/traffic_r0N.json (newest),
+                or measured in this run with --measure-traffic
                 (null when the record is of another kernel), next to the algorithmic bytes per launch.
   alt_precision the exact-fp32 arithmetic (every contraction on fp32 MFMA) on the same inputs: median of >= 5
                 steps, and the distance between the two outputs.
@@ -74,7 +75,8 @@ PEAK_HBM_GBS = 8000.0
 # full K-loop model rows of profiles/r03_kloop_model_power.txt: 1.64 - 1.76 PFLOP/s, the clock falling to ~1.6 GHz under a
 # 100 % busy matrix pipe).  Reported NEXT TO `frac` (which stays against the nominal dense peak), never instead of it.
 SUSTAINED_F16_MFMA_TFLOPS = 1700.0
-TRAFFIC_FILE = os.path.join(REPO, "profiles", "traffic_r03.json")
+TRAFFIC_FILE = next((f for f in (os.path.join(REPO, "profiles", f"traffic_r0{k}.json") for k in (4, 3)) if os.path.exists(f)),
+                    os.path.join(REPO, "profiles", "traffic_r04.json"))      # newest committed PMC record of the headline kernel
 
 
 def log(*a):
@@ -112,7 +114,7 @@ def executed_flops_per_edge(dims, kernel, agg_f16, w=64):
 def traffic_record(config, kw, kernel):
     """HBM-side traffic of `kernel` from the committed PMC record, or (None, reason)."""
     if not os.path.exists(TRAFFIC_FILE):
-        return None, "no profiles/traffic_r03.json"
+        return None, f"no {os.path.relpath(TRAFFIC_FILE, REPO)}"
     try:
         tj = json.load(open(TRAFFIC_FILE))
     except Exception as ex:       # noqa: BLE001
@@ -123,6 +125,48 @@ def traffic_record(config, kw, kernel):
     if rec is None:
         return None, f"PMC record holds {sorted(tj.get('kernels', {}))}, not {kernel}: re-run scripts/gpu/profile.sh"
     return rec, tj.get("source", "")
+
+
+def measure_traffic(args, kernel):
+    """--measure-traffic: HBM-side bytes per launch of `kernel`, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, then
+    WRITE_SIZE: separate passes, --kernel-trace only, as MI355X_MICROARCH.md prescribes) over a one-step child run of this
+    script.  Same correction as scripts/collect_profiles.py: the counters are KiB, gfx950's FETCH_SIZE counts a 128-byte
+    request as 64 (corrected = 2 x raw, an upper bound where part of the traffic is 4-byte loads).  Returns (record, source)
+    or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--config", args.config,
+             "--kernel-width", str(args.kernel_width), "--no-cpu-baseline", "--no-reuse-probe", "--no-mgkn", "--no-alt",
+             "--no-backward-probe"] + (["--precision", args.precision] if args.precision else [])
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="gpde_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            r = subprocess.run(["rocprofv3", "--output-format", "csv", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "run", "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+            fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not fs:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stderr[-300:]}"
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(fs[0]))
+                    if row["Counter_Name"] == ctr and kernel in row["Kernel_Name"]]
+            if not vals:
+                return None, f"no {ctr} rows for {kernel}"
+            got[ctr] = (sum(vals) * 1024 / len(vals), len(vals))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    f_b, w_b = got["FETCH_SIZE"][0], got["WRITE_SIZE"][0]
+    rec = {"launches": got["FETCH_SIZE"][1], "FETCH_SIZE_raw_bytes_per_launch": round(f_b),
+           "FETCH_SIZE_corrected_bytes_per_launch": round(2 * f_b), "WRITE_SIZE_bytes_per_launch": round(w_b),
+           "hbm_bytes_per_launch": round(2 * f_b + w_b)}
+    return rec, "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over a one-step child run of bench.py"
 
 
 def make_conv(kw, dev, k0=6, seed=0):
@@ -210,9 +254,33 @@ def mgkn_probe(dev, steps=10):
                 worst_we = max(worst_we, rel_l2(y.cpu(), ref))
         finally:
             hc_.WE_MODE = we0
+        # one optimisation step of the NNConv stack (forward with autograd + native backward of every call + Adam): the
+        # scripts' inner loop (MGKN_general_darcy2d.py:260-282, MGKN_orthogonal_burgers1d.py:226-242), default policy
+        # (hidden-activation cache `auto`: every module's H is built once per step and its MLP backward runs once)
+        hc_.clear()
+        wl_t = build(dev)
+        for _ in range(3):
+            loss_t = wl_t.train_step()
+        torch.cuda.synchronize()
+        tts = []
+        for _ in range(5):
+            tq = time.perf_counter()
+            loss_t = wl_t.train_step()
+            torch.cuda.synchronize()
+            tts.append(time.perf_counter() - tq)
+        train_ms = 1e3 * statistics.median(tts)
+        train_stats = dict(hc_.stats)
+        hc_.clear()
         out[name] = {
             "workload": wl.description, "nnconv_calls": wl.calls, "edge_applications": wl.edge_applications,
             "ms_per_forward": round(ms, 3),
+            "train_step_ms": round(train_ms, 3),
+            "train_step": {"ms": round(train_ms, 3), "loss_finite": bool(torch.isfinite(loss_t)),
+                           "M_edge_applications_per_s": round(wl.edge_applications / train_ms / 1e3, 2),
+                           "hidden_cache": {k: train_stats.get(k) for k in ("hits", "builds", "direct")},
+                           "note": "median of 5 steps after 3 warm-ups: forward with autograd, squared-norm loss, native backward of "
+                                   "every NNConv call (gpde_nnconv_bwd / _hidden + gpde_hidden_bwd once per module), Adam lr 1e-3 wd 5e-4; "
+                                   "gradient parity of every distinct call at this size: tests/test_gpu_mgkn.py"},
             "ms_per_forward_fused_glue": round(ms_fused, 3),
             "ms_per_forward_grouped": None if ms_grouped is None else round(ms_grouped, 3),
             "grouped_rel_l2_vs_fused_glue": grouped_diff,
@@ -376,6 +444,9 @@ def main():
     ap.add_argument("--no-mgkn", action="store_true", help="skip the MGKN configurations (BASELINE configs 3, 4)")
     ap.add_argument("--no-g241-train", action="store_true", help="skip the G241 backward / depth-6 training-step figures")
     ap.add_argument("--no-alt", action="store_true", help="skip the exact-fp32 leg")
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="re-derive roofline.traffic in THIS run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a one-step "
+                         "child run of this script (needs rocprofv3 on the box; adds ~2 minutes)")
     ap.add_argument("--precision", default=None, choices=["f32", "f16split", "f16split_8wave", "f16split_static", "f16split_agg16", "f16split_agg32", "f16split_noedge"],
                     help="arithmetic of the hidden layer (default: graph_pde_amd.ops.DEFAULT_PRECISION)")
     ap.add_argument("--train", action="store_true", help="training-step mode (see the module docstring)")
@@ -445,9 +516,16 @@ def main():
     csr = ops.csr_for(ei, n)
     torch.cuda.synchronize()
     t2 = time.time()
+    ops.attr_in_slot_order(csr, ea)              # edge_attr rows in CSR slot order (gpde_gather_rows): once per (graph, edge_attr)
+    torch.cuda.synchronize()
+    t3 = time.time()
+    # per-(graph, edge_attr) preparation every NEW sample pays before its first forward; never inside the timed region
+    graph_prep = {"csr_build_ms": round(1e3 * (t2 - t1), 2), "attr_reorder_ms": round(1e3 * (t3 - t2), 2),
+                  "note": "gpde_csr_from_coo (stable sort by destination of the int64 [2,E] list) and gpde_gather_rows (edge_attr into "
+                          "CSR slot order); both cached per tensor + version, `depth` applications and every epoch reuse them"}
     if rank == 0:
         log(f"[bench] graph {args.config}: N={n} E={e} generated in {t1 - t0:.2f}s; "
-            f"dst-CSR build {1e3 * (t2 - t1):.1f} ms (not in the timed region)")
+            f"dst-CSR build {1e3 * (t2 - t1):.1f} ms, attribute reorder {1e3 * (t3 - t2):.1f} ms (not in the timed region)")
 
     lin = ops.mlp_linears(conv.nn)
     pm = ops.pack_mlp([l.weight for l in lin], [l.bias for l in lin])
@@ -504,6 +582,16 @@ def main():
     n_param = sum(p.numel() for p in conv.parameters())
     alg_bytes_per_launch = (40.0 * e + 512.0 * n + 4.0 * n_param) * edges_per_launch / e   # SURVEY §8(d) x units per launch
     rec, src = traffic_record(args.config, kw, kernel)
+    if args.measure_traffic and world == 1:
+        del ws
+        torch.cuda.empty_cache()                      # the child run needs the device's memory
+        rec_m, src_m = measure_traffic(args, kernel)
+        ws = torch.empty(ops.workspace_bytes(n, e, pm), dtype=torch.uint8, device=dev)
+        if rec_m is not None:
+            rec, src = rec_m, src_m
+        else:
+            log(f"[bench] --measure-traffic: {src_m}; keeping the committed record")
+            src = f"{src} (--measure-traffic failed: {src_m})" if rec is not None else src_m
     traffic = None if rec is None else rec.get("hbm_bytes_per_launch")
     other_ms = sum(v[0] for k, v in kinds.items() if k != "fused")
     edges_per_s_rank = e / (elapsed / args.steps)
@@ -728,8 +816,37 @@ def main():
                 tb.append(time.perf_counter() - tq)
             tb_med = sorted(tb[1:])[1]
             eb_ = int(eib.shape[1])
+            # executed MFMA work of one backward per edge (3-Linear kernel, split-f16 GEMMs): recompute of H_2 on the forward's
+            # kernel (3 x hidden + H1 regeneration), dU_1 and dW_2 (3 x hidden each) on the f16 pipe; the per-edge kernel's two
+            # 64 x k2 products on the fp32 pipe (Z comes from the forward: keep-Z)
+            kwp = (kw + 127) // 128 * 128
+            f16_bwd = 3 * (3 * 2 * kwp * kwp) + 2 * 2 * 16 * kwp * (kwp // 128)
+            f32_bwd = 2 * (2 * 64 * kwp)
+            bwd_rate = eb_ / tb_med / 1e12
+            trec = None
+            tfile = os.path.join(REPO, "profiles", "traffic_r04_bwd.json")
+            if os.path.exists(tfile):
+                try:
+                    trec = json.load(open(tfile))
+                except Exception:       # noqa: BLE001
+                    trec = None
+            alg_bwd = 40.0 * eb_ + 3 * 256.0 * nb_ + 8.0 * sum(p_.numel() for p_ in conv.parameters())
             backward = {"graph": "g121 (N=%d, E=%d)" % (nb_, eb_), "ms": round(1e3 * tb_med, 2),
                         "M_edges_per_s": round(eb_ / tb_med / 1e6, 2),
+                        "roofline": {
+                            "bound": "mfma", "pipe": "f16 MFMA (2-term split operands) for the three k1 x k2 products, fp32 MFMA for the per-edge 64 x k2 products",
+                            "executed_flop_per_edge": {"f16_mfma": f16_bwd, "fp32_mfma": f32_bwd},
+                            "achieved": round(f16_bwd * bwd_rate, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(f16_bwd * bwd_rate / PEAK_F16_MFMA_TFLOPS, 4),
+                            "fp32_mfma_tflops": round(f32_bwd * bwd_rate, 2),
+                            "frac_note": "whole backward (all kernels, wall time) against the f16 peak; the fp32-MFMA part adds "
+                                         f"{round(f32_bwd * bwd_rate / PEAK_FP32_MFMA_TFLOPS, 4)} of the fp32 peak on top",
+                            "algorithmic_bytes": round(alg_bwd),
+                            "traffic": None if trec is None else trec.get("hbm_bytes_per_backward"),
+                            "traffic_over_algorithmic": None if trec is None or not trec.get("hbm_bytes_per_backward") else
+                            round(trec["hbm_bytes_per_backward"] / alg_bwd, 1),
+                            "traffic_source": None if trec is None else trec.get("source"),
+                            "traffic_by_kernel": None if trec is None else trec.get("kernels")},
                         "grads_finite": bool(torch.isfinite(xb.grad).all()) and
                         all(bool(torch.isfinite(p_.grad).all()) for p_ in conv.parameters()),
                         "arithmetic": "dU_1 and dW_2 GEMMs on the 2-term f16 split (gpde_gemm_f16s_nt_kernel), "
@@ -767,25 +884,42 @@ def main():
                 a_in = torch.randn(n, 6, device=dev)
                 y_t = torch.randn(n, device=dev)
                 depth = 6
-                torch.cuda.synchronize()
-                tq = time.perf_counter()
-                opt.zero_grad(set_to_none=True)
-                hcur = fc1(a_in)
-                for _ in range(depth):
-                    hcur = torch.relu(conv(hcur, ei, ea))
-                loss_t = torch.norm(fc2(hcur).view(-1) - y_t, 1)
-                loss_t.backward()
-                opt.step()
-                torch.cuda.synchronize()
-                t_step = time.perf_counter() - tq
+                del xg
+                # the module's DEFAULT policy (hidden cache `auto`, deferred backward `auto`): H of this graph (391 GB) does
+                # not fit, so the applications share a virtual-H node - light backward per application, ONE deferred pass for
+                # the hidden layers - and read the part of H that does fit.  Step 1 still sees the first
+                # application as a stranger (own full backward); from step 2 on all six hang on the shared node.
+                hidden_cache.MODE = "auto"
+                hidden_cache.clear()
+                torch.cuda.empty_cache()
+                t_steps = []
+                for it in range(3):
+                    torch.cuda.synchronize()
+                    tq = time.perf_counter()
+                    opt.zero_grad(set_to_none=True)
+                    hcur = fc1(a_in)
+                    for _ in range(depth):
+                        hcur = torch.relu(conv(hcur, ei, ea))
+                    loss_t = torch.norm(fc2(hcur).view(-1) - y_t, 1)
+                    loss_t.backward()
+                    opt.step()
+                    torch.cuda.synchronize()
+                    t_steps.append(time.perf_counter() - tq)
+                t_step = min(t_steps[1:])
+                ent_t = hidden_cache._entries.get(conv)
                 backward["g241_depth6_train_step"] = {
-                    "s": round(t_step, 2), "M_edge_applications_per_s": round(depth * e / t_step / 1e6, 2),
+                    "s": round(t_step, 2), "first_step_s": round(t_steps[0], 2), "steps_s": [round(t_, 2) for t_ in t_steps],
+                    "M_edge_applications_per_s": round(depth * e / t_step / 1e6, 2),
                     "loss_finite": bool(torch.isfinite(loss_t)),
-                    "note": "ONE step (no warm-up beyond the passes above): fc1 + 6 x relu(NNConv_old) + fc2, L1 loss, backward, "
-                            "Adam - BASELINE config 5's unit of work per GPU and sample; hidden activations of this graph "
-                            "(391 GB) do not fit HBM, so nothing is cached across the layers"}
-                log(f"[bench] g241 depth-6 train step: {t_step:.2f} s")
-                del hcur, loss_t, opt, xg
+                    "deferred_backward": {k: hidden_cache.stats.get(k, 0) for k in ("deferred_builds", "deferred_hits", "builds", "hits")},
+                    "nodes_served_from_partial_H": 0 if ent_t is None or ent_t.hidden is None else ent_t.hn, "nodes": n,
+                    "peak_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+                    "note": "three consecutive steps of fc1 + 6 x relu(NNConv_old) + fc2, L1 loss, backward, Adam (UAI1_full_resolution.py:"
+                            "258-273) - BASELINE config 5's unit of work per GPU and sample; `s` = the faster of steps 2 and 3 (steady "
+                            "state: all six applications on the shared virtual-H node), `first_step_s` includes the cold start; "
+                            "round 3 ran every application's own full backward: 18.98 s"}
+                log(f"[bench] g241 depth-6 train step: first {t_steps[0]:.2f} s, steady {t_step:.2f} s")
+                del hcur, loss_t, opt
         finally:
             hidden_cache.MODE = mode0
             hidden_cache.clear()
@@ -804,6 +938,7 @@ def main():
                                f"width=64; kernel MLP 6-{kw}-{kw}-4096; aggr=mean root+bias; one sample per GPU",
                    "graph": args.config, "edges_per_sample": e, "nodes_per_sample": n,
                    "plan": plan},
+        "graph_prep": graph_prep,
         "rel_l2_sample": rel,
         "alt_precision": alt,
         "node_table_attributes": nodeattr,

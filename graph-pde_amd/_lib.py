@@ -43,6 +43,7 @@ SIGNATURES = {
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                          ctypes.c_void_p]),
+    "gpde_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "gpde_mlp_pack_bytes": (ctypes.c_size_t, [ctypes.c_int, c_i32p]),
     "gpde_mlp_pack": (ctypes.c_int, [ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p),
                                      ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p,

@@ -148,3 +148,28 @@ extern "C" int gpde_csr_source_order(const int32_t* src, int64_t n_edges, int64_
     GP_LAUNCH_CHECK("gpde_csr_source_order kernels");
     return GPDE_OK;
 }
+
+// ---- per-edge rows in CSR slot order (ops.attr_in_slot_order) ------------------------------------------------------------
+namespace {
+// one thread per output element: a row is k0 <= 8 floats (24 bytes at k0 = 6), consecutive threads write consecutive
+// floats (full lines out); the reads are the scattered rows - once per (graph, tensor)
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ rows, int k, const int32_t* __restrict__ perm,
+                                                     size_t total, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t s = i / (unsigned)k;
+    const int d = (int)(i - s * (unsigned)k);
+    out[i] = rows[(size_t)perm[s] * k + d];
+}
+}  // namespace
+
+extern "C" int gpde_gather_rows(const float* rows, int k, const int32_t* perm, int64_t n, float* out, void* stream_) {
+    if (n < 0 || k < 1 || (n > 0 && (!rows || !perm || !out))) { gpde_set_error("gpde_gather_rows: null/negative argument"); return GPDE_EINVAL; }
+    if (n == 0) return GPDE_OK;
+    const size_t total = (size_t)n * k;
+    const size_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffull) { gpde_set_error("gpde_gather_rows: %lld rows x %d exceed one launch", (long long)n, k); return GPDE_EUNSUPPORTED; }
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, rows, k, perm, total, out);
+    GP_LAUNCH_CHECK("k_gather_rows");
+    return GPDE_OK;
+}

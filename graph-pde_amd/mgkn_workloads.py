@@ -38,13 +38,16 @@ def dense_net(layers: List[int]) -> torch.nn.Sequential:
 
 class Workload:
     def __init__(self, name: str, calls: int, edge_applications: int, forward: Callable[[], List[torch.Tensor]],
-                 pairs: List[tuple], description: str):
+                 pairs: List[tuple], description: str, train_step: Callable[[], float] = None, modules: List[torch.nn.Module] = None):
         self.name = name
         self.calls = calls                          # NNConv calls per model forward
         self.edge_applications = edge_applications  # sum over the calls of their edge counts
         self.forward = forward                      # runs one model forward (no_grad), returns the final states
         self.pairs = pairs                          # distinct (conv, x, edge_index, edge_attr) of the forward
         self.description = description
+        self.train_step = train_step                # one optimisation step (forward with autograd, loss, backward, Adam): the
+                                                    # scripts' inner loop (MGKN_general_darcy2d.py:260-282, MGKN_orthogonal_burgers1d.py:226-242)
+        self.modules = modules or []                # the NNConv modules (their parameters are what the step updates)
 
 
 def orthogonal_burgers(device, s: int = 8192, depth: int = 4, ker_width: int = 1024, seed: int = 0,
@@ -57,26 +60,38 @@ def orthogonal_burgers(device, s: int = 8192, depth: int = 4, ker_width: int = 1
     phis = [torch.randn(n, 64, device=device) for _, _, n in graphs]
     edges = sum(int(g[0].shape[1]) for g in graphs)
 
+    def sweep_all():
+        xs = [p.clone() for p in phis]
+        for _ in range(depth):                  # MGKN_orthogonal_burgers1d.py:65-82
+            if grouped:
+                # the 13 convs of a sweep read phi[l], fixed by the downward pass (:67-71): independent calls,
+                # one grouped launch (nn_conv.nnconv_group), the relu(x + conv) glue inside it
+                xs = nnconv_group([(convs[l], phis[l], graphs[l][0], graphs[l][1], xs[l], "relu") for l in range(nlev)])
+                continue
+            for l in reversed(range(nlev)):
+                if fused_glue:      # opt-in: the relu(x + conv) glue inside the operator's last kernel
+                    xs[l] = convs[l](phis[l], graphs[l][0], graphs[l][1], residual=xs[l], activation="relu")
+                else:
+                    xs[l] = F.relu(xs[l] + convs[l](phis[l], graphs[l][0], graphs[l][1]))
+        return xs
+
     def forward():
         with torch.no_grad():
-            xs = [p.clone() for p in phis]
-            for _ in range(depth):                  # MGKN_orthogonal_burgers1d.py:65-82
-                if grouped:
-                    # the 13 convs of a sweep read phi[l], fixed by the downward pass (:67-71): independent calls,
-                    # one grouped launch (nn_conv.nnconv_group), the relu(x + conv) glue inside it
-                    xs = nnconv_group([(convs[l], phis[l], graphs[l][0], graphs[l][1], xs[l], "relu") for l in range(nlev)])
-                    continue
-                for l in reversed(range(nlev)):
-                    if fused_glue:      # opt-in: the relu(x + conv) glue inside the operator's last kernel
-                        xs[l] = convs[l](phis[l], graphs[l][0], graphs[l][1], residual=xs[l], activation="relu")
-                    else:
-                        xs[l] = F.relu(xs[l] + convs[l](phis[l], graphs[l][0], graphs[l][1]))
-            return xs
+            return sweep_all()
+
+    opt = torch.optim.Adam([p for c in convs for p in c.parameters()], lr=1e-3, weight_decay=5e-4)   # :209-211
+
+    def train_step():
+        opt.zero_grad(set_to_none=True)
+        loss = sum(x_.square().mean() for x_ in sweep_all())
+        loss.backward()
+        opt.step()
+        return loss
 
     pairs = [(convs[l], phis[l], graphs[l][0], graphs[l][1]) for l in range(nlev)]
     return Workload("mgkn_orthogonal_burgers1d", nlev * depth, edges * depth, forward, pairs,
                     f"MGKN-orthogonal Burgers-1D s={s}: {nlev} levels, depth {depth}, kernel widths "
-                    f"max({ker_width}//2^l,16), {edges} edges per sweep")
+                    f"max({ker_width}//2^l,16), {edges} edges per sweep", train_step, convs)
 
 
 def general_darcy(device, s: int = 421, depth: int = 5, ker_width: int = 256, seed: int = 0,
@@ -105,34 +120,46 @@ def general_darcy(device, s: int = 421, depth: int = 5, ker_width: int = 256, se
     edges = sum(int(g["inner"][l][0].shape[1]) for l in range(L)) + \
         sum(int(gd[l][0].shape[1]) + int(gu[l][0].shape[1]) for l in range(L - 1))
 
+    def sweep_all(train=False):
+        xx = x0
+        for _ in range(depth):                  # MGKN_general_darcy2d.py:76-90
+            for l in range(L - 1):
+                if fused_glue:
+                    xx = down[l](xx, gd[l][0], gd[l][1], residual=xx, activation="relu")
+                else:
+                    xx = F.relu(xx + down[l](xx, gd[l][0], gd[l][1]))
+            for l in reversed(range(L)):
+                a, b = offs[l], offs[l + 1]
+                if xx is x0 or train:           # never write into the caller's tensor (the script's x is its own fc_in output);
+                    xx = xx.clone()             # with autograd: nor into a tensor F.relu saved (torch 2.x saves the OUTPUT)
+                # in place on the running state, input slice cloned - as the script does (MGKN_general_darcy2d.py:84-86)
+                xx[a:b] = inner[l](xx[a:b].clone(), g["inner"][l][0], g["inner"][l][1])
+                if l > 0:
+                    if fused_glue:
+                        xx = up[l - 1](xx, gu[l - 1][0], gu[l - 1][1], residual=xx, activation="relu")
+                    else:
+                        xx = F.relu(xx + up[l - 1](xx, gu[l - 1][0], gu[l - 1][1]))
+        return [xx]
+
     def forward():
         with torch.no_grad():
-            xx = x0
-            for _ in range(depth):                  # MGKN_general_darcy2d.py:76-90
-                for l in range(L - 1):
-                    if fused_glue:
-                        xx = down[l](xx, gd[l][0], gd[l][1], residual=xx, activation="relu")
-                    else:
-                        xx = F.relu(xx + down[l](xx, gd[l][0], gd[l][1]))
-                for l in reversed(range(L)):
-                    a, b = offs[l], offs[l + 1]
-                    if xx is x0:                    # never write into the caller's tensor (the script's x is its own fc_in output)
-                        xx = xx.clone()
-                    # in place on the running state, input slice cloned - as the script does (MGKN_general_darcy2d.py:84-86)
-                    xx[a:b] = inner[l](xx[a:b].clone(), g["inner"][l][0], g["inner"][l][1])
-                    if l > 0:
-                        if fused_glue:
-                            xx = up[l - 1](xx, gu[l - 1][0], gu[l - 1][1], residual=xx, activation="relu")
-                        else:
-                            xx = F.relu(xx + up[l - 1](xx, gu[l - 1][0], gu[l - 1][1]))
-            return [xx]
+            return sweep_all()
+
+    opt = torch.optim.Adam([p for c in inner + down + up for p in c.parameters()], lr=1e-3, weight_decay=5e-4)   # :240-242
+
+    def train_step():
+        opt.zero_grad(set_to_none=True)
+        loss = sweep_all(train=True)[0].square().mean()
+        loss.backward()
+        opt.step()
+        return loss
 
     pairs = [(inner[l], x0[offs[l]:offs[l + 1]].contiguous(), g["inner"][l][0], g["inner"][l][1]) for l in range(L)]
     pairs += [(down[l], x0, gd[l][0], gd[l][1]) for l in range(L - 1)]
     pairs += [(up[l], x0, gu[l][0], gu[l][1]) for l in range(L - 1)]
     return Workload("mgkn_general_darcy2d", (3 * L - 2) * depth, edges * depth, forward, pairs,
                     f"MGKN-general Darcy-2D m={m} of the {s}^2 lattice: L={L}, depth {depth}, kernel widths "
-                    f"{ker_width}//2^l, {edges} edges per sweep")
+                    f"{ker_width}//2^l, {edges} edges per sweep", train_step, inner + down + up)
 
 
 WORKLOADS: Dict[str, Callable] = {"mgkn_orthogonal_burgers1d": orthogonal_burgers,

@@ -129,6 +129,22 @@ def stage_const(t: torch.Tensor, dev: torch.device) -> torch.Tensor:
     return hit[1]
 
 
+def gather_rows(rows: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+    """out[s] = rows[perm[s]] (gpde_gather_rows): one native pass, no int64 index temporaries, no torch advanced indexing
+    (unreliable above 2^26 rows on this torch / ROCm build: synth.darcy_edge_attr)."""
+    _require_cuda(rows, "rows")
+    _require_cuda(perm, "perm")
+    if rows.dtype != torch.float32 or rows.dim() != 2 or not rows.is_contiguous() or perm.dtype != torch.int32:
+        raise ValueError("gather_rows: contiguous float32 [rows, k] and an int32 permutation")
+    n = int(perm.numel())
+    out = torch.empty(n, rows.size(1), dtype=torch.float32, device=rows.device)
+    with torch.cuda.device(rows.device):
+        rc = _lib.lib().gpde_gather_rows(rows.data_ptr(), int(rows.size(1)), perm.data_ptr(), n, out.data_ptr(),
+                                         _stream_ptr(rows.device))
+    _lib.check(rc, "gpde_gather_rows")
+    return out
+
+
 ATTR_SLOT_ORDER = os.environ.get("GPDE_ATTR_SLOT_ORDER", "1") != "0"
 _ATTR_SLOT_ORDER_MIN_EDGES = 32768
 
@@ -143,7 +159,7 @@ def attr_in_slot_order(csr: "Csr", edge_attr: torch.Tensor):
     the side loads become sequential and `perm` an identity.  Same values, same summation order: bit-identical results.
     GPDE_ATTR_SLOT_ORDER=0 keeps the indirect addressing (A/B); graphs built by `radius_csr` already are in slot order."""
     e = csr.n_edges
-    if not ATTR_SLOT_ORDER or e < _ATTR_SLOT_ORDER_MIN_EDGES or edge_attr.requires_grad:
+    if not ATTR_SLOT_ORDER or e < _ATTR_SLOT_ORDER_MIN_EDGES or edge_attr.requires_grad or edge_attr.dtype != torch.float32:
         return edge_attr, csr.perm
     if csr._identity is None:
         csr._identity = torch.arange(e, dtype=torch.int32, device=csr.perm.device)
@@ -156,12 +172,7 @@ def attr_in_slot_order(csr: "Csr", edge_attr: torch.Tensor):
     hit = csr._attr_sorted.get(key)
     if hit is None:
         src = edge_attr.detach()
-        out = torch.empty(e, src.size(1), dtype=src.dtype, device=src.device)
-        step = 1 << 24                                  # row gathers in pieces: torch indexing above 2^26 rows is not trusted (synth.py)
-        for lo in range(0, e, step):
-            idx = csr.perm[lo:lo + step].long()
-            for c in range(src.size(1)):
-                out[lo:lo + step, c] = src[:, c][idx]
+        out = gather_rows(src, csr.perm)
         while len(csr._attr_sorted) >= 2:
             csr._attr_sorted.pop(next(iter(csr._attr_sorted)))
         hit = csr._attr_sorted[key] = (edge_attr, out)  # the source tensor is kept alive: its address is part of the key

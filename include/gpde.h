@@ -84,6 +84,10 @@ int gpde_csr_from_coo(const int64_t* edge_index, int64_t stride_row, int64_t str
                       int64_t n_edges, int64_t n_nodes, int32_t* rowptr, int32_t* src,
                       int32_t* dst, int32_t* perm, int32_t* n_bad, void* ws, size_t ws_bytes,
                       void* stream);
+/* out[s][0..k) = rows[perm[s]][0..k) for the n CSR slots: a per-edge tensor (edge_attr [E][k0], the `pseudo` of
+ * nn_conv.py:271) laid out by CSR slot, once per (graph, tensor), so that the fused kernels stream it instead of chasing
+ * perm (8 column slices x one cache line per edge otherwise).  Same values: results are bit-identical. */
+int gpde_gather_rows(const float* rows, int k, const int32_t* perm, int64_t n, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Kernel-MLP weights, repacked once per parameter update into MFMA-tile order.

@@ -37,6 +37,50 @@ def test_mgkn_forward_calls_match_oracle(name):
     print(name, "max rel-L2 over", len(wl.pairs), "NNConv applications:", f"{worst:.2e}")
 
 
+@pytest.mark.parametrize("name", sorted(mgkn_workloads.WORKLOADS))
+def test_mgkn_gradients_of_every_distinct_call_match_float64_autograd(name):
+    """Both MGKN scripts are TRAINING scripts (MGKN_general_darcy2d.py:260-282, MGKN_orthogonal_burgers1d.py:226-242):
+    every distinct NNConv application of configs 3 / 4 at its full size - grad_x and every parameter gradient of
+    gpde_nnconv_bwd against float64 autograd through the oracle (in edge chunks: the [E, 4096] float64 tensor of the
+    131 k-edge call is 4.3 GB), then one optimisation step of the whole model (finite loss, every parameter moved)."""
+    from oracle.nnconv_oracle import nnconv_grads
+    d = torch.device("cuda:0")
+    wl = mgkn_workloads.WORKLOADS[name](d)
+    torch.manual_seed(5)
+    worst = {}
+    for conv, x, ei, ea in wl.pairs:
+        conv.zero_grad(set_to_none=True)
+        xin = x.clone().requires_grad_(True)
+        gout = torch.randn(x.shape[0], 64, device=d)
+        (conv(xin, ei, ea) * gout).sum().backward()
+        torch.cuda.synchronize()
+        lin = ops.mlp_linears(conv.nn)
+        rx, rW, rb, rroot, rbias = nnconv_grads(x.cpu(), ei.cpu(), ea.cpu(), [l.weight.detach().cpu() for l in lin],
+                                                [l.bias.detach().cpu() for l in lin],
+                                                None if conv.root is None else conv.root.detach().cpu(),
+                                                None if conv.bias is None else conv.bias.detach().cpu(), conv.aggr, gout.cpu(),
+                                                chunk_edges=16384)
+        errs = {"dx": rel_l2(xin.grad.cpu(), rx)}
+        for l, layer in enumerate(lin):
+            errs[f"dW{l}"] = rel_l2(layer.weight.grad.cpu(), rW[l])
+            errs[f"db{l}"] = rel_l2(layer.bias.grad.cpu(), rb[l])
+        if conv.root is not None:
+            errs["droot"] = rel_l2(conv.root.grad.cpu(), rroot)
+        if conv.bias is not None:
+            errs["dbias"] = rel_l2(conv.bias.grad.cpu(), rbias)
+        for k, v in errs.items():
+            assert v <= 2e-5, (name, tuple(ei.shape), k, v)
+            worst[k] = max(worst.get(k, 0.0), v)
+    print(name, "max rel-L2 of the gradients over", len(wl.pairs), "NNConv applications:", {k: f"{v:.1e}" for k, v in worst.items()})
+    before = [p.detach().clone() for m in wl.modules for p in m.parameters()]
+    calls = _lib.n_native_calls
+    loss = wl.train_step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and _lib.n_native_calls - calls >= 2 * wl.calls - 2       # a native forward and backward per application
+    after = [p for m in wl.modules for p in m.parameters()]
+    assert all(torch.isfinite(p).all() for p in after) and sum(int(not torch.equal(a, b)) for a, b in zip(before, after)) == len(after)
+
+
 @pytest.mark.parametrize("mode", ["off", "auto"])
 @pytest.mark.parametrize("name", sorted(mgkn_workloads.WORKLOADS))
 def test_fused_glue_is_bit_identical_to_the_unfused_composition(name, mode):

@@ -340,6 +340,9 @@ def test_attr_slot_order_cache_and_keep_z_policy_host_logic(monkeypatch):
     csr = ops.Csr(n, e, rowptr, torch.zeros(e, dtype=torch.int32), dst, perm)
     ea = torch.randn(e, 6, generator=g)
     monkeypatch.setattr(ops, "ATTR_SLOT_ORDER", True)
+    # the gather itself is a native kernel (gpde_gather_rows, checked on the GPU in tests/test_gpu_v6.py); here a stand-in,
+    # the subject being the cache policy around it
+    monkeypatch.setattr(ops, "gather_rows", lambda rows, pm_: rows[pm_.long()])
     s1, p1 = ops.attr_in_slot_order(csr, ea)
     assert torch.equal(s1, ea[perm.long()]) and torch.equal(p1, torch.arange(e, dtype=torch.int32))
     s2, _ = ops.attr_in_slot_order(csr, ea)

@@ -158,6 +158,26 @@ def test_oracle_gradients_match_autograd_through_the_reference_module(name):
         assert rel_l2(gbias, r["gbias"]) <= tol
 
 
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_oracle_gradients_in_edge_chunks_equal_the_whole(name):
+    """nnconv_grads(chunk_edges=...) - the form the MGKN-scale gradient tests use (the [E, 4096] float64 tensor of a
+    131 k-edge call is 4.3 GB) - is the same sum taken in pieces: equal to the pinned gradients to float64 rounding."""
+    from oracle.nnconv_oracle import nnconv_grads
+    from tests.conftest import load_golden
+    g, r = load_golden(name), load_golden_grads(name)
+    e = g["edge_index"].shape[1]
+    gx, gW, gb, groot, gbias = nnconv_grads(g["x"], g["edge_index"], g["edge_attr"], g["weights"], g["biases"],
+                                            g["root"], g["bias"], g["aggr"], r["gout"], chunk_edges=max(1, e // 3))
+    tol = 1e-12
+    assert rel_l2(gx, r["gx"]) <= tol
+    for l in range(len(gW)):
+        assert rel_l2(gW[l], r["gW"][l]) <= tol and rel_l2(gb[l], r["gb"][l]) <= tol, l
+    if groot is not None:
+        assert rel_l2(groot, r["groot"]) <= tol
+    if gbias is not None:
+        assert rel_l2(gbias, r["gbias"]) <= tol
+
+
 def _lattice(s):
     import numpy as np
     g = np.linspace(0.0, 1.0, s)
