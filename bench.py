@@ -375,44 +375,71 @@ def train_mode(args, rank, world, dev, use_dist, barrier):
 
 
 def split_graph_mode(args, rank, world, dev, use_dist, barrier):
-    """`--split-graph`: ONE graph (the same on every rank) split by destination rows over the ranks, a step = one NNConv
-    forward of the WHOLE graph: each rank its rows, then the all-gather of the row blocks (parallel.nnconv_rows,
-    SURVEY.md §8e way 2).  Strong scaling: total work fixed.  Not the default line (that one is one sample per GPU)."""
+    """`--split-graph`: ONE graph split by destination rows over the ranks, a step = one NNConv forward of the WHOLE graph:
+    each rank its rows, then the all-gather of the row blocks (parallel.nnconv_rows, SURVEY.md §8e way 2).  Strong scaling:
+    total work fixed.  Not the default line (that one is one sample per GPU).  The rank's block is built from the POSITIONS
+    (parallel.partition_rows_by_position: count pass over all nodes, fill pass over its own destinations) - no rank holds
+    the whole edge list; `--split-from-edges` keeps round 3's whole-graph-then-filter path for comparison."""
     import torch.distributed as dist
-    from graph_pde_amd import parallel, synth
+    from graph_pde_amd import ops, parallel, synth
     s, r = CONFIGS[args.config]
     conv = make_conv(args.kernel_width, dev)
-    ei, ea, n = synth.darcy_graph(s, r, device=dev, seed=0)
-    e = int(ei.shape[1])
+    n = s * s
     x = torch.randn(n, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(1000))
-    part = parallel.partition_rows(ei, ea, n, rank=rank, world=world)
-    del ei, ea
+    torch.cuda.synchronize()
+    tq = time.perf_counter()
+    if args.split_from_edges:
+        ei, ea, n = synth.darcy_graph(s, r, device=dev, seed=0)
+        part = parallel.partition_rows(ei, ea, n, rank=rank, world=world)
+        del ei, ea
+    else:
+        pos = synth.lattice_positions(s, dev)
+        a_n = synth.darcy_coefficient(s, 0).to(dev)
+        part = parallel.partition_rows_by_position(pos, r, ops.NodeAttr.darcy(pos, a_n), rank=rank, world=world)
+    torch.cuda.synchronize()
+    build_ms = 1e3 * (time.perf_counter() - tq)
     torch.cuda.empty_cache()
+    graph = part.edge_index if part.csr is None else part.csr
+    ev = []
 
     def step():
         with torch.no_grad():
-            if use_dist and world == 1:           # one rank under torchrun: still through the collective (RCCL)
-                return parallel._gather_blocks(conv(x, part.edge_index, part.edge_attr)[part.lo:part.hi].contiguous(), part)
-            return parallel.nnconv_rows(conv, x, part)
+            a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            a.record()
+            local = conv(x, graph, part.edge_attr)[part.lo:part.hi].contiguous()       # this rank's rows
+            b.record()
+            if use_dist:                              # (one rank under torchrun: still through the collective = RCCL)
+                full = parallel._gather_blocks(local, part)
+            else:
+                full = local
+            c.record()
+            ev.append((a, b, c))
+            return full
 
     for _ in range(args.warmup):
         step()
+    ev.clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    edges = [None] * world
+    block_ms = statistics.median(a.elapsed_time(b) for a, b, _ in ev)
+    gather_ms = statistics.median(b.elapsed_time(c) for _, b, c in ev)
+    mine = {"rank": rank, "rows": [part.lo, part.hi], "edges": part.n_edges, "block_ms": round(block_ms, 3),
+            "gather_ms": round(gather_ms, 3), "graph_build_ms": round(build_ms, 1)}
+    per_rank = [None] * world
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        dist.all_gather_object(edges, part.n_edges)
+        dist.all_gather_object(per_rank, mine)
     else:
-        edges = [part.n_edges]
+        per_rank = [mine]
     if rank != 0:
         return None
+    e = sum(p_["edges"] for p_ in per_rank)
     ms = 1e3 * elapsed / args.steps
     return {
         "metric": "M-edges/s through fused NNConv fwd (width=64)", "value": round(e / (ms * 1e-3) / 1e6, 3), "unit": "M-edges/s",
@@ -423,8 +450,11 @@ def split_graph_mode(args, rank, world, dev, use_dist, barrier):
         "config": {"workload": f"one NNConv forward of ONE {s}x{s} r={r} radius graph N={n} E={e} split by destination rows over "
                                f"{world} rank(s); kernel MLP 6-{args.kernel_width}-{args.kernel_width}-4096; all-gather of the "
                                f"[rows x 64] blocks inside the timed step", "graph": args.config,
-                   "parallelism": f"rows{world} (destination-row blocks balanced on in-edges; x replicated)"},
-        "edges_per_rank": edges, "row_bounds": part.bounds, "all_finite": bool(torch.isfinite(out).all()),
+                   "parallelism": f"rows{world} (destination-row blocks balanced on in-edges; x replicated)",
+                   "partition": "whole edge list on every rank, then filtered (--split-from-edges)" if args.split_from_edges else
+                                "built per rank from the positions: in-degree count pass over all nodes + fill pass over the rank's "
+                                "own destinations (parallel.partition_rows_by_position); no rank holds the whole edge list"},
+        "per_rank": per_rank, "row_bounds": part.bounds, "all_finite": bool(torch.isfinite(out).all()),
     }
 
 
@@ -451,6 +481,9 @@ def main():
                     help="arithmetic of the hidden layer (default: graph_pde_amd.ops.DEFAULT_PRECISION)")
     ap.add_argument("--train", action="store_true", help="training-step mode (see the module docstring)")
     ap.add_argument("--depth", type=int, default=6, help="--train: NNConv applications per forward")
+    ap.add_argument("--split-from-edges", action="store_true",
+                    help="--split-graph: build the whole edge list on every rank and filter it (round 3's path) instead of building "
+                         "each rank's block from the positions")
     ap.add_argument("--split-graph", action="store_true",
                     help="strong-scaling mode: ONE graph split by destination rows over the ranks (all-gather per forward)")
     args = ap.parse_args()

@@ -291,7 +291,13 @@ def lookup_edge_weights(module: torch.nn.Module, edge_attr: torch.Tensor, csr, p
             ent.we, ent.we_key, ent.we_refs = None, None, None
         return None
     ent.we = None                       # release the previous tensor before allocating the next one
-    ent.we = ops.edge_weights_raw(hit[0].detach(), pm, w_last, b_last)
+    try:
+        ent.we = ops.edge_weights_raw(hit[0].detach(), pm, w_last, b_last)
+    except torch.OutOfMemoryError:      # 16 KiB per edge: an optimisation like H - on OOM the ordinary path runs
+        ent.we, ent.we_key, ent.we_refs = None, None, None
+        torch.cuda.empty_cache()
+        stats["oom_fallbacks"] = stats.get("oom_fallbacks", 0) + 1
+        return None
     ent.we_key, ent.we_refs = key, (edge_attr, csr)
     stats["we_builds"] += 1
     return ent.we

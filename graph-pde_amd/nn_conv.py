@@ -101,6 +101,10 @@ class NNConv_old(MessagePassing):
         when a gradient is needed the same value is composed from the unfused operator and torch ops."""
         if activation not in (None, "relu"):
             raise ValueError(f"activation must be None or 'relu', got {activation!r}")
+        with ops.ver_scope():        # (inference tensors: one content checksum per tensor and call, shared by all cache keys)
+            return self._forward(x, edge_index, edge_attr, residual, activation)
+
+    def _forward(self, x, edge_index, edge_attr, residual, activation):
         if residual is not None or activation is not None:
             return self._forward_act(x, edge_index, edge_attr, residual, activation == "relu")
         x = x.unsqueeze(-1) if x.dim() == 1 else x
@@ -116,7 +120,7 @@ class NNConv_old(MessagePassing):
                 csr = ops.csr_for(edge_index, x.size(0))
                 pm = ops.pack_mlp([l.weight for l in lin], [l.bias for l in lin])
                 return ops.nnconv_forward_nodeattr_raw(x, csr, edge_attr, pm, self.root, self.bias, self.aggr)
-            edge_attr = edge_attr.materialize(edge_index)
+            edge_attr = edge_attr.materialize(edge_index.edge_index if isinstance(edge_index, ops.Csr) else edge_index)
         pseudo = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
         return self.propagate(edge_index, x=x, pseudo=pseudo)                            # nn_conv.py:271
 
@@ -182,8 +186,12 @@ class NNConv_old(MessagePassing):
         no_grad = not (torch.is_grad_enabled() and
                        (x.requires_grad or pseudo.requires_grad or any(p.requires_grad for p in self.parameters())))
         if self.aggr == "max" and not no_grad:
-            raise NotImplementedError("aggr='max' is built for inference (per-edge weight kernel); its gradient is not "
-                                      "built - no graph-pde script uses 'max'")
+            # a gradient through 'max' (no graph-pde script uses it; a freshly built module in grad mode lands here): PyG's own
+            # chain - gather, `message`, segment max, `update` - with the native `message()` / `update()`,
+            # both differentiable; the fused inference kernel serves no_grad calls
+            if isinstance(edge_index, ops.Csr):
+                edge_index = edge_index.edge_index
+            return MessagePassing.propagate(self, edge_index, x=x, pseudo=pseudo)
         if no_grad and pseudo.dtype == torch.float32 and x.dtype == torch.float32 and (use_hidden_cache or self.aggr == "max"):
             # inference on a low in-degree / small graph (or aggr='max'): one streaming kernel over the cached per-edge
             # weights (hidden_cache.lookup_edge_weights)
@@ -193,6 +201,8 @@ class NNConv_old(MessagePassing):
             if call is not None:
                 return ops.nnconv_forward_edgeweights_group([call])[0]
         if self.aggr == "max":
+            if pseudo.dtype != torch.float32 or x.dtype != torch.float32:
+                raise NotImplementedError(f"aggr='max': float32 only (got x {x.dtype}, edge_attr {pseudo.dtype})")
             raise NotImplementedError(
                 f"aggr='max': the per-edge weights of this call ({ops.csr_for(edge_index, x.size(0)).n_edges} edges x 16 KiB) "
                 "exceed the cache budget (GPDE_HIDDEN_CACHE_GB / GPDE_EDGE_WEIGHT_CACHE_GB)")
@@ -255,9 +265,9 @@ class NNConv_old(MessagePassing):
         the CPU parameters), the SAME kernels run, the output returns to the caller's device."""
         dev = ops.staging_device()
         if isinstance(edge_attr, ops.NodeAttr):
-            edge_attr = edge_attr.materialize(edge_index)
+            edge_attr = edge_attr.materialize(edge_index.edge_index if isinstance(edge_index, ops.Csr) else edge_index)
         pseudo = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
-        ei_d = ops.stage_const(edge_index, dev)
+        ei_d = edge_index if isinstance(edge_index, ops.Csr) else ops.stage_const(edge_index, dev)
         ea_d = pseudo.to(dev) if pseudo.requires_grad else ops.stage_const(pseudo, dev)
         weights, biases, root, bias = self._params_on(dev, torch.is_grad_enabled())
         out = self._propagate(x.to(dev), ei_d, ea_d, weights, biases, root, bias, use_hidden_cache=False)

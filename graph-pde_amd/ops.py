@@ -79,24 +79,78 @@ def _stream_ptr(device) -> int:
     return int(torch.cuda.current_stream(device).cuda_stream)
 
 
+_ver_memo: "dict | None" = None          # content checksums of inference tensors computed during the current operator call
+
+
+class ver_scope:
+    """Within one operator call an inference tensor's checksum is computed once and reused by every cache key that needs it
+    (CSR, slot-order attributes, hidden activations: up to six lookups per call, each two device passes + a host sync
+    before - ADVICE r3).  Across calls nothing is remembered: such tensors can change in place without a trace."""
+
+    def __enter__(self):
+        global _ver_memo
+        self.outer = _ver_memo
+        if _ver_memo is None:
+            _ver_memo = {}
+        return self
+
+    def __exit__(self, *exc):
+        global _ver_memo
+        _ver_memo = self.outer
+        return False
+
+
+_HASH_W = None
+
+
+def _content_hash(t: torch.Tensor) -> int:
+    """Position-sensitive checksum of a tensor's bytes: 32-bit words in rows of 4096, every word weighted by a fixed odd
+    multiplier of its column, every row sum by an odd multiplier of its row number (float64 arithmetic on the device: exact
+    products, deterministic sums).  A permutation of rows or a sum-preserving edit changes it; one pass, one host sync."""
+    global _HASH_W
+    c = t.contiguous()
+    nb = c.numel() * c.element_size()
+    raw = c.view(torch.uint8).reshape(-1)
+    if nb % 4:
+        raw = torch.cat([raw, raw.new_zeros(4 - nb % 4)])
+    words = raw.view(torch.int32)
+    cols = 4096
+    if _HASH_W is None or _HASH_W.device != words.device:
+        g = torch.Generator().manual_seed(0x9E3779B9)
+        _HASH_W = (torch.randint(1, 1 << 20, (cols,), generator=g, dtype=torch.int64) * 2 + 1).to(torch.float64).to(words.device)
+    total, row0 = 0.0, 0
+    step = cols << 12                                   # 16 Mi words (64 MB) per piece: bounds the float64 temporary
+    for lo in range(0, words.numel(), step):
+        w = words[lo:lo + step]
+        pad = (-w.numel()) % cols
+        if pad:
+            w = torch.cat([w, w.new_zeros(pad)])
+        rows = w.view(-1, cols).to(torch.float64) @ _HASH_W
+        mult = (torch.arange(row0, row0 + rows.numel(), device=rows.device, dtype=torch.float64) * 2 + 1) % 1048573.0
+        total = total + (rows % 2147483647.0 * mult).sum()
+        row0 += rows.numel()
+    return int(float(total) % 9007199254740881.0) ^ (nb << 1)
+
+
 def _ver(t: torch.Tensor):
     """Cache-key component that changes whenever the tensor's contents may have changed.  Normal tensors: the
     in-place version counter.  Inference tensors track none (reading `_version` raises) yet CAN be modified in place
     inside torch.inference_mode() - an `edge_attr.mul_()` between two forwards of an eval loop would hit the CSR /
-    staging / hidden-activation caches with an identical key.  For them the key carries a content
-    checksum instead (one pass over the tensor + one device->host scalar per lookup: inference tensors only)."""
+    staging / hidden-activation caches with an identical key.  For them the key carries a position-sensitive
+    content checksum instead (`_content_hash`: one pass + one device->host scalar), computed once per operator call
+    (`ver_scope`): inference tensors only."""
     if not t.is_inference():
         return t._version
     if t.numel() == 0:
         return ("inference", 0)
-    c = t.contiguous()
-    nb = c.numel() * c.element_size()
-    if nb % 4 == 0:
-        words = c.view(torch.uint8).reshape(-1).view(torch.int32)
-        chk = int(words.sum(dtype=torch.int64).item()) ^ (int(words[::7].sum(dtype=torch.int64).item()) << 1)
-    else:
-        chk = int(c.view(torch.uint8).sum(dtype=torch.int64).item())
-    return ("inference", chk)
+    memo = _ver_memo
+    k = (t.data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype)
+    if memo is not None and k in memo:
+        return memo[k]
+    v = ("inference", _content_hash(t))
+    if memo is not None:
+        memo[k] = v
+    return v
 
 
 def staging_device() -> torch.device:
@@ -227,6 +281,10 @@ def csr_for(edge_index: torch.Tensor, n_nodes: int) -> Csr:
     (MGKN_general_darcy2d.py:79-89).  Key = storage pointer, offset, shape, strides, in-place
     version counter, node count.  The entry keeps the index storage alive so that its address
     cannot be recycled for a different graph while cached; the cache is a byte-bounded LRU."""
+    if isinstance(edge_index, Csr):          # a graph that already is a destination CSR (radius_csr, parallel.partition_rows_by_position)
+        if edge_index.n_nodes != n_nodes:
+            raise ValueError(f"the CSR was built for {edge_index.n_nodes} nodes, x has {n_nodes} rows")
+        return edge_index
     storage = edge_index.untyped_storage()
     key = (str(edge_index.device), storage.data_ptr(), edge_index.storage_offset(),
            tuple(edge_index.shape), tuple(edge_index.stride()), _ver(edge_index), n_nodes)
@@ -1151,6 +1209,32 @@ def radius_csr_raw(pos: torch.Tensor, r: float, reference_ties: bool = False, po
                                             src.data_ptr(), dst.data_ptr(), e, ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
                    "gpde_radius_csr_fill")
     return rowptr, src, dst
+
+
+def radius_in_degrees(pos: torch.Tensor, r: float, reference_ties: bool = False, pos_dst: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """int32 [n_dst]: in-degree of every destination of the radius graph - the COUNT pass of the cell-list builder alone
+    (gpde_radius_csr_count; no edge is written).  parallel.partition_rows_by_position balances its row blocks on it."""
+    lib = _lib.lib()
+    _require_cuda(pos, "pos")
+    pos = (pos.unsqueeze(1) if pos.dim() == 1 else pos).detach().to(torch.float64).contiguous()
+    pd = pos if pos_dst is None else (pos_dst.unsqueeze(1) if pos_dst.dim() == 1 else pos_dst).detach().to(torch.float64).contiguous()
+    n, nd, dim = int(pos.size(0)), int(pd.size(0)), int(pos.size(1))
+    dev = pos.device
+    deg = torch.zeros(nd, dtype=torch.int32, device=dev)
+    if n == 0 or nd == 0:
+        return deg
+    both = pos if pd is pos else torch.cat([pos, pd])
+    lo_t, hi_t = both.min(dim=0).values.cpu(), both.max(dim=0).values.cpu()
+    lo = (ctypes.c_double * dim)(*[float(v) for v in lo_t])
+    hi = (ctypes.c_double * dim)(*[float(v) for v in hi_t])
+    nbytes = int(lib.gpde_radius_csr_workspace_bytes(n, dim, float(r), lo, hi))
+    if nbytes == 0:
+        _lib.check(-1, "gpde_radius_csr_workspace_bytes")
+    ws = _alloc_ws(nbytes, dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gpde_radius_csr_count(pos.data_ptr(), n, pd.data_ptr(), nd, dim, float(r), 1 if reference_ties else 0, lo, hi,
+                                             deg.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev)), "gpde_radius_csr_count")
+    return deg
 
 
 def radius_csr(pos: torch.Tensor, r: float, reference_ties: bool = False) -> Csr:

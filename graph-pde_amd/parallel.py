@@ -133,7 +133,7 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
 class RowPartition:
     """This rank's destination-row block of one graph (make it with `partition_rows`)."""
 
-    def __init__(self, n_nodes, bounds, rank, edge_index, edge_attr, group=None):
+    def __init__(self, n_nodes, bounds, rank, edge_index, edge_attr, group=None, csr=None):
         self.n_nodes = int(n_nodes)
         self.bounds = [int(b) for b in bounds]          # world + 1 node offsets, bounds[0] = 0, bounds[-1] = N
         self.rank = int(rank)
@@ -142,6 +142,8 @@ class RowPartition:
         self.edge_index = edge_index                    # [2, E_r] global node ids, the caller's edge order
         self.edge_attr = edge_attr                      # [E_r, k0]
         self.group = group
+        self.csr = csr                                  # partition_rows_by_position: the block as a destination CSR over all N
+                                                        # nodes (ops.Csr; edge_attr rows are in its slot order) - no sort needed
 
     @property
     def n_edges(self) -> int:
@@ -158,12 +160,24 @@ def row_bounds(edge_index: torch.Tensor, n_nodes: int, world: int) -> List[int]:
     every rank computes the same list.  Ranges may be empty (more ranks than nodes with in-edges)."""
     if world < 1:
         raise ValueError("world must be >= 1")
-    e = int(edge_index.shape[1])
     if world == 1:
         return [0, n_nodes]
+    if int(edge_index.shape[1]) == 0:
+        return bounds_from_degrees(torch.zeros(n_nodes, dtype=torch.int64), world)
+    return bounds_from_degrees(torch.bincount(edge_index[1].reshape(-1).to(torch.int64), minlength=n_nodes), world)
+
+
+def bounds_from_degrees(deg: torch.Tensor, world: int) -> List[int]:
+    """`row_bounds` given the in-degree of every node ([N] integer tensor) instead of the edge list."""
+    n_nodes = int(deg.numel())
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    if world == 1:
+        return [0, n_nodes]
+    deg = deg.reshape(-1).to(torch.int64)
+    e = int(deg.sum())
     if e == 0:                                      # nothing to balance: equal node counts
         return [min(n_nodes, -(-n_nodes * r // world)) for r in range(world)] + [n_nodes]
-    deg = torch.bincount(edge_index[1].reshape(-1).to(torch.int64), minlength=n_nodes)
     cum = torch.cumsum(deg, 0)
     targets = torch.tensor([-(-e * r // world) for r in range(1, world)], dtype=cum.dtype, device=cum.device)
     cuts = (torch.searchsorted(cum, targets, right=False) + 1).clamp(max=n_nodes).tolist()
@@ -189,10 +203,63 @@ def partition_rows(edge_index: torch.Tensor, edge_attr: torch.Tensor, n_nodes: i
     bounds = row_bounds(edge_index, n_nodes, world)
     if world == 1:
         return RowPartition(n_nodes, bounds, 0, edge_index, edge_attr, group)
-    dst = edge_index[1]
-    keep = ((dst >= bounds[rank]) & (dst < bounds[rank + 1])).nonzero().reshape(-1)
-    return RowPartition(n_nodes, bounds, rank, edge_index.index_select(1, keep).contiguous(),
-                        edge_attr.index_select(0, keep).contiguous(), group)
+    # filtered in pieces of 2^24 edges: one-shot indexing of tensors above 2^26 rows is not trusted on this torch / ROCm build
+    # (synth.darcy_edge_attr found zeroed rows there), and the pieces bound the nonzero / index temporaries
+    e, step = int(edge_index.shape[1]), 1 << 24
+    ei_parts, ea_parts = [], []
+    for a0 in range(0, e, step):
+        d_ = edge_index[1, a0:a0 + step]
+        keep = ((d_ >= bounds[rank]) & (d_ < bounds[rank + 1])).nonzero().reshape(-1)
+        ei_parts.append(edge_index[:, a0:a0 + step].index_select(1, keep))
+        ea_parts.append(edge_attr[a0:a0 + step].index_select(0, keep))
+    if not ei_parts:
+        ei_parts, ea_parts = [edge_index[:, :0]], [edge_attr[:0]]
+    return RowPartition(n_nodes, bounds, rank, torch.cat(ei_parts, 1).contiguous(), torch.cat(ea_parts, 0).contiguous(), group)
+
+
+def partition_rows_by_position(pos: torch.Tensor, r: float, node_attr=None, rank: int | None = None, world: int | None = None,
+                               group=None, reference_ties: bool = False, degrees_fn=None, block_fn=None) -> RowPartition:
+    """This rank's destination-row block of the RADIUS graph of `pos` [N, dim] built from the positions alone - no rank ever
+    holds the whole edge list (the 241^2 graph: 1.5 GB of int64 indices + 2.3 GB of attributes, then nonzero / index_select
+    temporaries, per rank in `partition_rows`).  Every rank runs the COUNT pass of the cell-list builder over all nodes
+    (in-degrees only: ops.radius_in_degrees), derives the same balanced bounds from them, and runs the FILL pass for its own
+    destinations only (ops.radius_csr_raw(pos, r, pos_dst=pos[lo:hi])).  The block comes out as a destination CSR over all
+    N nodes (rows outside [lo, hi) empty, sources ascending inside a row = the single-GPU operator's summation order).
+    `node_attr`: an ops.NodeAttr (the reference's recipe edge_attr = [pos_src, pos_dst, a_src, a_dst], utilities.py:274-277):
+    the block's edge attributes are materialised from it in slot order; None leaves `edge_attr` to the caller
+    (`part.csr.edge_index` lists the block's edges).  `degrees_fn(pos, r)` / `block_fn(pos, r, pos_dst)` replace the two
+    native passes (CPU tests)."""
+    from . import ops
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world {world}")
+    pos2 = pos.unsqueeze(1) if pos.dim() == 1 else pos
+    n = int(pos2.shape[0])
+    deg = (degrees_fn or (lambda p, rr: ops.radius_in_degrees(p, rr, reference_ties)))(pos2, r)
+    bounds = bounds_from_degrees(deg.cpu(), world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    build = block_fn or (lambda p, rr, pd: ops.radius_csr_raw(p, rr, reference_ties, pos_dst=pd))
+    dev = pos2.device
+    if hi > lo:
+        rp_l, src, dst_l = build(pos2, r, pos2[lo:hi])
+    else:
+        rp_l = torch.zeros(1, dtype=torch.int32, device=dev)
+        src = torch.zeros(0, dtype=torch.int32, device=dev)
+        dst_l = src.clone()
+    e = int(src.numel())
+    rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    rowptr[:lo + 1] = 0
+    rowptr[lo:hi + 1] = rp_l.to(torch.int32)
+    rowptr[hi:] = e
+    dst = (dst_l + lo).to(torch.int32)
+    csr = ops.Csr(n, e, rowptr, src.to(torch.int32), dst, torch.arange(e, dtype=torch.int32, device=dev))
+    csr._perm_is_identity = True
+    ei = csr.edge_index
+    ea = None if node_attr is None else node_attr.materialize(ei)
+    return RowPartition(n, bounds, rank, ei, ea, group, csr=csr)
 
 
 def _gather_blocks(local: torch.Tensor, part: RowPartition) -> torch.Tensor:
@@ -239,10 +306,11 @@ def nnconv_rows(conv, x: torch.Tensor, part: RowPartition) -> torch.Tensor:
     process group) it is `conv(x, edge_index, edge_attr)`."""
     if x.shape[0] != part.n_nodes:
         raise ValueError(f"x has {x.shape[0]} rows, the partitioned graph {part.n_nodes} nodes")
+    graph = part.edge_index if part.csr is None else part.csr      # a prebuilt block CSR goes to the operator as it is
     if part.world == 1:
-        return conv(x, part.edge_index, part.edge_attr)
+        return conv(x, graph, part.edge_attr)
     if not dist.is_initialized():
         raise RuntimeError("nnconv_rows with world > 1 needs an initialised process group (parallel.init_from_env)")
     x_in = _ReplicatedInput.apply(x, part) if (torch.is_grad_enabled() and x.requires_grad) else x
-    out = conv(x_in, part.edge_index, part.edge_attr)
+    out = conv(x_in, graph, part.edge_attr)
     return _GatherRows.apply(out[part.lo:part.hi], part)

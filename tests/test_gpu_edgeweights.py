@@ -144,7 +144,8 @@ def test_module_takes_the_edge_weight_path_for_repeated_inference_calls_only(mon
 
 
 def test_aggr_max_through_the_module(monkeypatch):
-    """nn_conv.py:222-224 names 'max'; no script uses it.  Inference runs from the per-edge weights; training raises."""
+    """nn_conv.py:222-224 names 'max'; no script uses it.  Inference runs from the per-edge weights; with gradients the module
+    composes PyG's chain (gather, native message(), segment max, native update()) - checked against float64 autograd."""
     d = torch.device("cuda:0")
     hidden_cache.clear()
     torch.manual_seed(8)
@@ -153,8 +154,30 @@ def test_aggr_max_through_the_module(monkeypatch):
     with torch.no_grad():
         y = conv(x, ei, ea)
     assert rel_l2(y.cpu(), _oracle(conv, x, ei, ea, "max")) <= 2e-6
-    with pytest.raises(NotImplementedError, match="max"):
-        conv(x.clone().requires_grad_(True), ei, ea)
+    # a freshly built module in grad mode (parameters require grad): differentiable, same value, gradients of float64 autograd
+    xin = x.clone().requires_grad_(True)
+    yg = conv(xin, ei, ea)
+    assert rel_l2(yg.detach().cpu(), y.cpu()) <= 2e-6
+    g = torch.randn_like(yg)
+    (yg * g).sum().backward()
+    lin = ops.mlp_linears(conv.nn)
+    x64 = x.detach().cpu().double().requires_grad_(True)
+    W = [l.weight.detach().cpu().double().requires_grad_(True) for l in lin]
+    B = [l.bias.detach().cpu().double().requires_grad_(True) for l in lin]
+    h = ea.cpu().double()
+    for k in range(len(W)):
+        h = torch.nn.functional.linear(h, W[k], B[k])
+        if k < len(W) - 1:
+            h = torch.relu(h)
+    eic = ei.cpu()
+    m = torch.matmul(x64[eic[0]].unsqueeze(1), h.view(-1, 64, 64)).squeeze(1)
+    agg = torch.full((x.shape[0], 64), -1e9, dtype=torch.float64).scatter_reduce(0, eic[1].view(-1, 1).expand_as(m), m, "amax")
+    agg = torch.where(agg == -1e9, torch.zeros_like(agg), agg)
+    ref = agg + x64 @ conv.root.detach().cpu().double() + conv.bias.detach().cpu().double()
+    (ref * g.cpu().double()).sum().backward()
+    assert rel_l2(xin.grad.cpu(), x64.grad) <= 2e-5
+    for k, l in enumerate(lin):
+        assert rel_l2(l.weight.grad.cpu(), W[k].grad) <= 2e-5, k
     hidden_cache.clear()
 
 

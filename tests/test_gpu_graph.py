@@ -140,3 +140,48 @@ def test_operator_on_the_cell_list_csr_matches_the_edge_index_path_bit_for_bit()
     y_csr = ops.nnconv_forward_raw(x, csr, ea_csr, pm, conv.root, conv.bias, "mean")
     y_na = ops.nnconv_forward_nodeattr_raw(x, csr, gp.NodeAttr.darcy(pos, a), pm, conv.root, conv.bias, "mean")
     assert torch.equal(y_ref, y_csr) and torch.equal(y_ref, y_na)
+
+
+def test_row_blocks_built_from_positions_equal_the_whole_graph():
+    """parallel.partition_rows_by_position (SURVEY.md §8e way 2 without the whole edge list per rank): in-degree count pass
+    over all nodes -> balanced bounds -> fill pass over the rank's own destinations.  The blocks tile the whole graph's CSR
+    (rowptr / src / dst, attributes by slot) and the operator's rows on a block are the whole-graph rows."""
+    from tests.test_host_logic import DenseNet
+    import graph_pde_amd as gp
+    from graph_pde_amd import parallel
+    d = torch.device("cuda:0")
+    torch.manual_seed(7)
+    s, r = 41, 0.10
+    pos = synth.lattice_positions(s, d)
+    a = synth.darcy_coefficient(s, 2).to(d)
+    n = s * s
+    whole = ops.radius_csr(pos, r)
+    na = gp.NodeAttr.darcy(pos, a)
+    ea_whole = na.materialize(whole.edge_index)
+    deg = ops.radius_in_degrees(pos, r)
+    assert torch.equal(deg, (whole.rowptr[1:] - whole.rowptr[:-1]))
+    conv = gp.NNConv_old(64, 64, DenseNet([6, 256, 256, 4096], torch.nn.ReLU), aggr="mean").to(d)
+    x = torch.randn(n, 64, device=d)
+    with torch.no_grad():
+        y_whole = conv(x, whole, ea_whole)
+    for world in (1, 3, 8):
+        edges, rows = 0, 0
+        for rank in range(world):
+            part = parallel.partition_rows_by_position(pos, r, na, rank=rank, world=world)
+            lo, hi = part.lo, part.hi
+            e0, e1 = int(whole.rowptr[lo]), int(whole.rowptr[hi])
+            assert part.n_edges == e1 - e0 and part.csr.n_nodes == n
+            assert torch.equal(part.csr.src, whole.src[e0:e1]) and torch.equal(part.csr.dst, whole.dst[e0:e1])
+            assert torch.equal(part.csr.rowptr[lo:hi + 1], whole.rowptr[lo:hi + 1] - e0)
+            assert int(part.csr.rowptr[:lo + 1].abs().sum()) == 0 and bool((part.csr.rowptr[hi:] == e1 - e0).all())
+            assert torch.equal(part.edge_attr, ea_whole[e0:e1])
+            with torch.no_grad():
+                y = conv(x, part.csr, part.edge_attr)
+            err = float((y[lo:hi] - y_whole[lo:hi]).norm() / y_whole[lo:hi].norm())
+            assert err <= 1e-6, (world, rank, err)           # same summation order per node; the f16-split scales are per-call maxima
+            edges += part.n_edges
+            rows += hi - lo
+        assert edges == whole.n_edges and rows == n
+        if world > 1:
+            sizes = [parallel.partition_rows_by_position(pos, r, None, rank=k, world=world).n_edges for k in range(world)]
+            assert max(sizes) - min(sizes) <= 2 * int(deg.max())              # balanced on in-edges

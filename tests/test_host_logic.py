@@ -82,6 +82,42 @@ def test_module_surface_has_the_reference_methods():
         assert all(v.default is None for v in sig.values() if v.kind is inspect.Parameter.KEYWORD_ONLY), name
 
 
+def test_inference_tensor_checksum_is_position_sensitive_and_scoped():
+    """ops._content_hash / ops.ver_scope: a row permutation or a sum-preserving edit of an inference tensor moves
+    the key (the old word sum did not see either); inside one operator call the checksum is computed once per tensor."""
+    with torch.inference_mode():
+        t = torch.arange(3 * 5000, dtype=torch.float32).reshape(5000, 3)
+        k0 = ops._ver(t)
+        p = t.clone()
+        p[[10, 4000]] = p[[4000, 10]]                  # two rows swapped: same multiset of words
+        assert ops._ver(p) != k0
+        q = t.clone()
+        q[7, 0] += 1.0
+        q[9, 0] -= 1.0                                 # sum-preserving edit
+        assert ops._ver(q) != k0
+        assert ops._ver(t.clone()) == k0               # same contents elsewhere in memory: same checksum
+        idx = torch.randint(0, 100, (2, 70001))        # int64, a byte count that is not a multiple of the row size
+        assert ops._ver(idx) == ops._ver(idx.clone()) and ops._ver(idx) != ops._ver(idx.flip(1))
+        calls = {"n": 0}
+        real = ops._content_hash
+
+        def counting(x):
+            calls["n"] += 1
+            return real(x)
+        ops._content_hash = counting
+        try:
+            with ops.ver_scope():
+                a = ops._ver(t)
+                with ops.ver_scope():                  # nested calls (forward -> propagate) share the outer scope
+                    assert ops._ver(t) == a
+                assert ops._ver(t) == a
+            assert calls["n"] == 1
+            ops._ver(t), ops._ver(t)                   # outside a scope nothing is remembered
+            assert calls["n"] == 3
+        finally:
+            ops._content_hash = real
+
+
 def test_version_helper_accepts_inference_tensors():
     with torch.inference_mode():
         t = torch.arange(4)

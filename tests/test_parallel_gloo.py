@@ -171,6 +171,123 @@ def test_row_partitioned_graph_gather_and_gradients_gloo_ws2():
             assert torch.allclose(grads[k], p.grad, rtol=1e-10, atol=1e-12), (rank, k)
 
 
+# ---- the same from POSITIONS: no rank holds the whole edge list (parallel.partition_rows_by_position) ------------------
+def _pos_problem(n_pts):
+    g = torch.Generator().manual_seed(9)
+    if n_pts <= 3:
+        pos = torch.rand(n_pts, 2, generator=g, dtype=torch.float64) * 0.05          # one small cluster: world 4 -> an empty block
+    else:
+        # density varies strongly: the row blocks balanced on in-edges hold very different node counts
+        pos = torch.cat([torch.rand(n_pts // 2, 2, generator=g, dtype=torch.float64) * 0.25,
+                         torch.rand(n_pts - n_pts // 2, 2, generator=g, dtype=torch.float64)])
+    a = torch.randn(n_pts, generator=g, dtype=torch.float64)
+    a_in = torch.randn(n_pts, 5, generator=g, dtype=torch.float64)
+    y = torch.randn(n_pts, generator=g, dtype=torch.float64)
+    torch.manual_seed(12)
+    model = torch.nn.ModuleDict({"fc1": torch.nn.Linear(5, 4), "conv": _TinyConv(k0=6), "fc2": torch.nn.Linear(4, 1)}).double()
+    return pos, a, a_in, y, model
+
+
+def _cpu_degrees(pos, r):
+    d2 = ((pos[:, None, :] - pos[None, :, :]) ** 2).sum(-1)
+    return (d2 <= r * r).sum(0).to(torch.int32)                   # in-degree of every destination (self-loop included)
+
+
+def _cpu_block(pos, r, pos_dst):
+    """CPU stand-in for ops.radius_csr_raw(pos, r, pos_dst=...): rows = destinations, sources ascending inside a row."""
+    d2 = ((pos_dst[:, None, :] - pos[None, :, :]) ** 2).sum(-1)   # [n_dst, n_src]
+    nz = (d2 <= r * r).nonzero()
+    rowptr = torch.zeros(pos_dst.shape[0] + 1, dtype=torch.int32)
+    rowptr[1:] = torch.cumsum(torch.bincount(nz[:, 0], minlength=pos_dst.shape[0]), 0)
+    return rowptr, nz[:, 1].to(torch.int32), nz[:, 0].to(torch.int32)
+
+
+def _edge_attr(pos, a, ei):
+    return torch.cat([pos[ei[0]], pos[ei[1]], a[ei[0]].unsqueeze(1), a[ei[1]].unsqueeze(1)], 1)   # utilities.py:274-277
+
+
+class _TableAttr:
+    """ops.NodeAttr.darcy's `materialize` in float64 (the CPU tier has no native library calls)."""
+
+    def __init__(self, pos, a):
+        self.pos, self.a = pos, a
+
+    def materialize(self, ei):
+        return _edge_attr(self.pos, self.a, ei)
+
+
+def _pos_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from graph_pde_amd import ops, parallel
+    parallel.init_from_env("gloo")
+    res = []
+    for n_pts, r in ((60, 0.2), (3, 0.2)):
+        pos, a, a_in, y, model = _pos_problem(n_pts)
+        part = parallel.partition_rows_by_position(pos, r, _TableAttr(pos, a), degrees_fn=_cpu_degrees, block_fn=_cpu_block)
+        assert isinstance(part.csr, ops.Csr) and part.csr.n_nodes == n_pts and part.csr.n_edges == part.n_edges
+        conv = lambda h, graph, ea: model["conv"](h, graph.edge_index if isinstance(graph, ops.Csr) else graph, ea)
+        out = _rows_forward(model, a_in, lambda h: parallel.nnconv_rows(conv, h, part))
+        loss = torch.norm(out - y, 1)
+        loss.backward()
+        parallel.allreduce_gradients(model.parameters(), average=True)
+        # (numpy: pickled by value - torch tensors travel through shared-memory handles that die with this process)
+        res.append(((part.lo, part.hi, part.n_edges), part.bounds, out.detach().numpy().copy(),
+                    {k: p.grad.numpy().copy() for k, p in model.named_parameters()}))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_partition_from_positions_gloo_ws4_uneven_and_empty_blocks():
+    """Every rank builds ONLY its block (count pass over all nodes, fill pass over its own destinations), world 4: blocks of
+    very different node counts, and - 3 points on 4 ranks - an empty one; result and every gradient equal the whole-graph
+    step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 4
+    procs = [ctx.Process(target=_pos_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for case, (n_pts, r) in enumerate(((60, 0.2), (3, 0.2))):
+        pos, a, a_in, y, model = _pos_problem(n_pts)
+        rp, src, dst = _cpu_block(pos, r, pos)
+        ei = torch.stack([src.long(), dst.long()])
+        ea = _edge_attr(pos, a, ei)
+        ref = _rows_forward(model, a_in, lambda h: model["conv"](h, ei, ea))
+        torch.norm(ref - y, 1).backward()
+        blocks = [got[rk][1][case][0] for rk in range(world)]
+        bounds = got[0][1][case][1]
+        assert all(got[rk][1][case][1] == bounds for rk in range(world))              # every rank derived the same bounds
+        assert blocks[0][0] == 0 and blocks[-1][1] == n_pts and all(blocks[k][1] == blocks[k + 1][0] for k in range(world - 1))
+        assert sum(b[2] for b in blocks) == ei.shape[1]                               # every edge on exactly one rank
+        sizes = [b[1] - b[0] for b in blocks]
+        if n_pts == 3:
+            assert 0 in sizes                                                           # more ranks than nodes: an empty block
+        else:
+            assert max(sizes) >= 2 * min(sizes) and min(b[2] for b in blocks) > 0      # uneven node counts, balanced edges
+            assert max(b[2] for b in blocks) - min(b[2] for b in blocks) <= 2 * int(_cpu_degrees(pos, r).max())
+        for rk in range(world):
+            _, _, out, grads = got[rk][1][case]
+            assert torch.allclose(torch.from_numpy(out), ref.detach(), rtol=1e-12, atol=1e-12), (case, rk)
+            for k, p in model.named_parameters():
+                assert torch.allclose(torch.from_numpy(grads[k]), p.grad, rtol=1e-10, atol=1e-12), (case, rk, k)
+
+
+def test_bounds_from_degrees_with_a_hub():
+    """A node holding more than two targets' worth of in-edges leaves a block empty; the bounds stay monotone and cover N."""
+    from graph_pde_amd import parallel
+    b = parallel.bounds_from_degrees(torch.tensor([1, 1, 50, 1, 1]), 4)
+    assert b[0] == 0 and b[-1] == 5 and all(b[i] <= b[i + 1] for i in range(4)) and any(b[i] == b[i + 1] for i in range(4))
+    assert parallel.bounds_from_degrees(torch.zeros(10, dtype=torch.int64), 4) == [0, 3, 5, 8, 10]
+
+
 def test_row_bounds_and_partition_single_process():
     from graph_pde_amd import parallel
     g = torch.Generator().manual_seed(2)
