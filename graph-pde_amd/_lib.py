@@ -161,6 +161,10 @@ SIGNATURES = {
     "gpde_edge_weights_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_i32p, ctypes.c_void_p,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_size_t, ctypes.c_void_p]),
+    "gpde_nnconv_bwd_edgeweights_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64]),
+    "gpde_nnconv_bwd_edgeweights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "gpde_edge_weights_bwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, c_i32p]),
+    "gpde_edge_weights_bwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_i32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "gpde_nnconv_fwd_edgeweights_group": (ctypes.c_int, [ctypes.POINTER(GpdeWeConvDesc), ctypes.c_int, ctypes.c_void_p]),
     "gpde_radius_graph_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
                                                ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),

@@ -204,3 +204,44 @@ class NNConvDeferredFunction(torch.autograd.Function):
         gv = torch.zeros(1, dtype=torch.float32, device=x.device)        # the virtual H carries no numbers, only the dependency
         return (gx, gv, None, None, groot, gbias if ctx.has_bias else None, None, None, None,
                 *([None] * (n - 1)), gw, *([None] * (n - 1)), gb)
+
+
+class EdgeWeightsFunction(torch.autograd.Function):
+    """W_e [E, 4096] = view(nn(pseudo_e), 64, 64) flattened (nn_conv.py:274) from the hidden activations
+    (gpde_edge_weights_fwd) as an autograd node: the `depth` applications of a module share it, autograd sums their dL/dW_e and
+    the backward below runs the two 4096 x k2 products per edge ONCE per step (gpde_edge_weights_bwd)."""
+
+    @staticmethod
+    def forward(ctx, hidden, pm, w_last, b_last, token):
+        we = ops.edge_weights_raw(hidden.detach(), pm, w_last, b_last)
+        ctx.dims, ctx.token, ctx.has_b = tuple(pm.dims), token, b_last is not None
+        ctx.save_for_backward(hidden, w_last)
+        return we
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_we):
+        ctx.token.valid = False
+        hidden, w_last = ctx.saved_tensors
+        gh, gw, gb = ops.edge_weights_backward_raw(grad_we, hidden, ctx.dims, w_last, need_b=ctx.has_b)
+        return gh, None, gw, gb, None
+
+
+class WeConvFunction(torch.autograd.Function):
+    """The operator given the per-edge weights (gpde_nnconv_fwd_edgeweights_group: gather, message, add / mean, update in one
+    streaming kernel), differentiable in x, W_e, root and bias (gpde_nnconv_bwd_edgeweights)."""
+
+    @staticmethod
+    def forward(ctx, x, we, csr, root, bias, aggr):
+        out = ops.nnconv_forward_edgeweights_raw(x.detach(), csr, we.detach(), root, bias, aggr)
+        ctx.csr, ctx.aggr, ctx.has_bias = csr, aggr, bias is not None
+        ctx.save_for_backward(x, we, root)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        x, we, root = ctx.saved_tensors
+        gx, gwe, groot, gbias = ops.nnconv_backward_edgeweights_raw(x, ctx.csr, we, root, ctx.aggr, grad_out,
+                                                                    need_root=root is not None, need_bias=ctx.has_bias)
+        return gx, gwe, None, groot, gbias if ctx.has_bias else None, None

@@ -685,7 +685,197 @@ int gemm_tn_acc(const float* A, int lda, int M, const float* B, int ldb, int Nco
     return gpde_launch_reduce_splits(part, cn, splits, cn, C, accumulate, st);
 }
 
+// node-side terms of update() (nn_conv.py:277-282): dx += g root^T, droot = X^T g, dbias = colsum g
+int bwd_node_terms(const float* x, int N, const float* root, const float* grad_out, float* dx, float* grad_root, float* grad_bias,
+                   float* part, size_t part_floats, hipStream_t st) {
+    int rc;
+    if (root && dx) {
+        GpdeGemmArgs g = gemm0();
+        g.A = grad_out; g.lda = GP_W; g.B = root; g.ldb = GP_W; g.C = dx; g.ldc = GP_W;
+        g.M = N; g.N = GP_W; g.K = GP_W; g.accumulate = 1;
+        if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
+    }
+    if (grad_root)
+        if ((rc = gemm_tn_acc(x, GP_W, GP_W, grad_out, GP_W, GP_W, N, grad_root, GP_W, part, part_floats, 0, st)) != GPDE_OK) return rc;
+    if (grad_bias) {
+        int splits = 1; while (splits < 64 && N / (splits * 2) >= 64) splits *= 2;
+        hipLaunchKernelGGL(k_colsum, dim3(1, splits), dim3(256), 0, st, grad_out, N, GP_W, GP_W, splits, part, (unsigned*)nullptr);
+        if ((rc = gpde_launch_reduce_splits(part, GP_W, splits, GP_W, grad_bias, 0, st)) != GPDE_OK) return rc;
+    }
+    return GPDE_OK;
+}
+
+// ---- backward of the operator GIVEN the per-edge weights (gpde_weconv.hip's forward) --------------------------------------
+// out_i = aggr_{e -> i} x_src(e) . W_e + x_i . root + bias (nn_conv.py:275-282).  With gT_i = g_i / deg_i ('mean') or g_i:
+//   dW_e[c][o] = x_j[c] gT_i[o]          (16 KiB written per edge: what autograd forms for `weight` in nn_conv.py:274-275)
+//   dx_j[c]   += sum_o W_e[c][o] gT_i[o]
+// One workgroup per destination node, its in-edges dealt round-robin to the waves; lane = (q, o4) as in the forward (rows
+// c = 4 cc + q, outputs o4 .. o4 + 3): 16 KiB read + 16 KiB written per edge, streaming.  dx: per-edge rows for the ordered
+// reduction over the source's out-edges (k_dx_reduce), or atomics.
+struct WeBwdArgs {
+    const float* x; const float* we; const int32_t* rowptr; const int32_t* src; const float* g; int aggr;
+    float* dwe; float* dxe; float* dx;
+};
+__global__ __launch_bounds__(256) void gpde_weconv_bwd_kernel(WeBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = blockIdx.x;
+    const int q = lane >> 4, l15 = lane & 15, o4 = l15 * 4;
+    const int r0 = a.rowptr[i], r1 = a.rowptr[i + 1];
+    if (r0 == r1) return;
+    f32x4 gt = *(const f32x4*)(a.g + (size_t)i * GP_W + o4);
+    if (a.aggr == GPDE_AGGR_MEAN) {
+        const float deg = (float)(r1 - r0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gt[j] = gt[j] / deg;           // the same division k_scale_g performs
+    }
+    for (int e = r0 + wave; e < r1; e += 4) {
+        const int j_ = a.src[e];
+        const float xa = a.x[(size_t)j_ * GP_W + lane];
+        const float* w = a.we + (size_t)e * (GP_W * GP_W);
+        float* dw = a.dwe + (size_t)e * (GP_W * GP_W);
+        f32x4 v[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) v[cc] = *(const f32x4*)(w + (size_t)(4 * cc + q) * GP_W + o4);
+        float mine = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            const float xv = __int_as_float(__builtin_amdgcn_ds_bpermute((4 * cc + q) * 4, __float_as_int(xa)));
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = xv * gt[j];
+            *(f32x4*)(dw + (size_t)(4 * cc + q) * GP_W + o4) = o;
+            float p = fmaf(v[cc][3], gt[3], fmaf(v[cc][2], gt[2], fmaf(v[cc][1], gt[1], v[cc][0] * gt[0])));
+            p += __shfl_xor(p, 1); p += __shfl_xor(p, 2); p += __shfl_xor(p, 4); p += __shfl_xor(p, 8);   // the quarter's 16 lanes: all 64 outputs
+            if (l15 == cc) mine = p;                               // dx_e[c = 4 cc + q]
+        }
+        const int c = 4 * l15 + q;
+        if (a.dxe) a.dxe[(size_t)e * GP_W + c] = mine;
+        else atomicAdd(&a.dx[(size_t)j_ * GP_W + c], mine);
+    }
+}
+
 }  // namespace
+
+extern "C" size_t gpde_nnconv_bwd_edgeweights_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
+    if (n_nodes < 0 || n_edges < 0) return 0;
+    return al((size_t)(n_edges > 0 ? n_edges : 1) * GP_W * 4) + al((size_t)64 * GP_W * GP_W * 4) + 1024;
+}
+
+extern "C" int gpde_nnconv_bwd_edgeweights(const float* x, int64_t n_nodes, const float* edge_weights, int64_t n_edges,
+                                           const int32_t* rowptr, const int32_t* src, const int32_t* src_rowptr,
+                                           const int32_t* src_slots, const float* root, int aggr, const float* grad_out,
+                                           float* grad_x, float* grad_edge_weights, float* grad_root, float* grad_bias, void* ws,
+                                           size_t ws_bytes, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    if (n_nodes < 0 || n_edges < 0 || !rowptr || !grad_out || !ws || (n_nodes > 0 && (!x || !grad_x)) ||
+        (n_edges > 0 && (!edge_weights || !src || !grad_edge_weights)) || n_edges >= ((int64_t)1 << 31) / GP_W) {
+        gpde_set_error("gpde_nnconv_bwd_edgeweights: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_edgeweights: aggr %d (the gradient of 'max' is composed by the caller)", aggr); return GPDE_EUNSUPPORTED; }
+    if (ws_bytes < gpde_nnconv_bwd_edgeweights_workspace_bytes(n_nodes, n_edges)) { gpde_set_error("gpde_nnconv_bwd_edgeweights: workspace too small"); return GPDE_EWORKSPACE; }
+    if (n_nodes == 0) return GPDE_OK;
+    char* w = (char*)(((uintptr_t)ws + 255) / 256 * 256);
+    float* dxe = (float*)w;
+    float* part = (float*)(w + al((size_t)(n_edges > 0 ? n_edges : 1) * GP_W * 4));
+    const size_t part_floats = (size_t)64 * GP_W * GP_W;
+    const bool ordered = src_rowptr && src_slots;
+    GP_HIP_CHECK(hipMemsetAsync(grad_x, 0, (size_t)n_nodes * GP_W * 4, st));
+    if (n_edges > 0) {
+        WeBwdArgs a{x, edge_weights, rowptr, src, grad_out, aggr, grad_edge_weights, ordered ? dxe : nullptr, grad_x};
+        hipLaunchKernelGGL(gpde_weconv_bwd_kernel, dim3((unsigned)n_nodes), dim3(256), 0, st, a);
+        if (ordered) hipLaunchKernelGGL(k_dx_reduce, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, st, dxe, src_rowptr, src_slots, (int)n_nodes, 0, (int)n_edges, grad_x);
+        GP_LAUNCH_CHECK("gpde_weconv_bwd_kernel");
+    }
+    return bwd_node_terms(x, (int)n_nodes, root, grad_out, grad_x, grad_root, grad_bias, part, part_floats, st);
+}
+
+// ---- backward of gpde_edge_weights_fwd: W_e = view(W3 . h_e + b3, 64, 64) -------------------------------------------------
+//   dU[e][k]  = (sum_n dW_e[n] W3[n][k]) * (H[e][k] > 0)      the gradient reaching the last hidden layer's pre-activation
+//   dW3[n][k] = sum_e dW_e[n] H[e][k]            db3[n] = sum_e dW_e[n]
+// dW_e is the SUM over the applications of the module (autograd adds them): the two 4096 x k2 products per edge run once per
+// step, on the split-f16 GEMMs where the shapes allow (K2P a multiple of 128), else on the fp32 MFMA GEMM.
+namespace {
+struct WeBwdPlan { size_t off_w3p, off_w3t, off_img, off_ucol, off_rsc, off_tn, off_part, off_dw3p, total; int K2P; bool split; int ks; };
+WeBwdPlan we_bwd_plan(int64_t E, int k2) {
+    WeBwdPlan P{};
+    P.K2P = gp_round_up(k2, 128);
+    const size_t wn = (size_t)GP_W * GP_W * P.K2P;
+    P.split = gpde_gemm_f16s_supported((int)(E > 0 ? E : 1), P.K2P, GP_W * GP_W, GP_W * GP_W);
+    P.ks = 4;
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off += al(floats * 4); return o; };
+    P.off_w3p = take(wn); P.off_w3t = take(wn); P.off_img = take(wn); P.off_ucol = take(P.K2P);
+    P.off_rsc = take((size_t)2 * (E > 0 ? E : 1));
+    P.off_tn = take(P.split ? gpde_gemm_f16s_tn_ws_floats((int)(E > 0 ? E : 1), GP_W * GP_W, P.K2P, P.ks) : 1);
+    P.off_part = take((size_t)(P.split ? P.ks : 16) * wn);
+    P.off_dw3p = take(wn);
+    P.total = off + 512;
+    return P;
+}
+}  // namespace
+
+extern "C" size_t gpde_edge_weights_bwd_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims) {
+    if (!dims || n_edges < 0 || n_layers < 2 || n_layers > GPDE_MAX_LAYERS) return 0;
+    return we_bwd_plan(n_edges, dims[n_layers - 1]).total;
+}
+
+extern "C" int gpde_edge_weights_bwd(const float* grad_edge_weights, const float* hidden, int64_t n_edges, int n_layers,
+                                     const int32_t* dims, const float* w_last, float* grad_hidden, float* grad_w_last,
+                                     float* grad_b_last, void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    if (n_edges < 0 || !dims || n_layers < 2 || n_layers > GPDE_MAX_LAYERS || !w_last || !ws ||
+        (n_edges > 0 && (!grad_edge_weights || !hidden || !grad_hidden)) || n_edges >= ((int64_t)1 << 31) / GP_W) {
+        gpde_set_error("gpde_edge_weights_bwd: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    const int k2 = dims[n_layers - 1], NW3 = GP_W * GP_W, T = 256;
+    const WeBwdPlan P = we_bwd_plan(n_edges, k2);
+    if (ws_bytes < P.total) { gpde_set_error("gpde_edge_weights_bwd: workspace %zu < %zu bytes", ws_bytes, P.total); return GPDE_EWORKSPACE; }
+    char* w = (char*)(((uintptr_t)ws + 255) / 256 * 256);
+    auto F = [&](size_t off) { return (float*)(w + off); };
+    const int K2P = P.K2P, E = (int)n_edges;
+    const size_t wn = (size_t)NW3 * K2P;
+    int rc;
+    if (E == 0) {
+        if (grad_w_last) GP_HIP_CHECK(hipMemsetAsync(grad_w_last, 0, (size_t)NW3 * k2 * 4, st));
+        if (grad_b_last) GP_HIP_CHECK(hipMemsetAsync(grad_b_last, 0, (size_t)NW3 * 4, st));
+        return GPDE_OK;
+    }
+    hipLaunchKernelGGL(k_pad_mat, dim3(nblk(wn)), dim3(T), 0, st, w_last, NW3, k2, k2, NW3, K2P, F(P.off_w3p));
+    if (P.split) {
+        // dU = (dW_e . W3) (.) [H > 0]: A = dW_e rows [E][4096], B[n = k][K = (c, o)] = W3[(c, o)][k] = W3^T as a split image
+        hipLaunchKernelGGL(k_transpose, dim3(nblk(wn)), dim3(T), 0, st, F(P.off_w3p), NW3, K2P, F(P.off_w3t));
+        if ((rc = gpde_pack_split_nk(F(P.off_w3t), K2P, NW3, K2P, NW3, F(P.off_img), F(P.off_ucol), st)) != GPDE_OK) return rc;
+        GpdeGemmF16sArgs g{};
+        g.A = grad_edge_weights; g.lda = NW3; g.M = E; g.bsplit = F(P.off_img); g.ucol = F(P.off_ucol);
+        g.mask = hidden; g.ldmask = K2P; g.C = grad_hidden; g.ldc = K2P; g.K = NW3; g.N = K2P; g.ksplits = 1;
+        if ((rc = gpde_launch_gemm_f16s_nt(g, F(P.off_rsc), st)) != GPDE_OK) return rc;
+        // dW3 = dW_e^T . H (contraction over the edges)
+        if (grad_w_last) {
+            if ((rc = gpde_launch_gemm_f16s_tn(grad_edge_weights, NW3, NW3, hidden, K2P, K2P, E, P.ks, F(P.off_tn), F(P.off_part), st)) != GPDE_OK) return rc;
+            if ((rc = gpde_launch_reduce_splits(F(P.off_part), wn, P.ks, wn, F(P.off_dw3p), 0, st)) != GPDE_OK) return rc;
+        }
+    } else {
+        GpdeGemmArgs g = gemm0();
+        g.A = grad_edge_weights; g.lda = NW3; g.B = F(P.off_w3p); g.ldb = K2P; g.b_kcontig = 0;
+        g.C = grad_hidden; g.ldc = K2P; g.M = E; g.N = K2P; g.K = NW3; g.mask = hidden; g.ldmask = K2P;
+        if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
+        if (grad_w_last)
+            if ((rc = gemm_tn_acc(grad_edge_weights, NW3, NW3, hidden, K2P, K2P, E, F(P.off_dw3p), K2P, F(P.off_part), (size_t)16 * wn, 0, st)) != GPDE_OK) return rc;
+    }
+    if (grad_w_last)
+        hipLaunchKernelGGL(k_unpad_mat, dim3(nblk((size_t)NW3 * k2)), dim3(T), 0, st, F(P.off_dw3p), NW3, k2, K2P, grad_w_last);
+    if (grad_b_last) {       // db3 = column sums of dW_e (ordered split partials)
+        const int cb = (NW3 + 255) / 256;
+        int splits = 1; while (splits < 256 && cb * splits < 1024 && E / (splits * 2) >= 16) splits *= 2;
+        hipLaunchKernelGGL(k_colsum, dim3(cb, splits), dim3(T), 0, st, grad_edge_weights, E, NW3, NW3, splits, F(P.off_part), (unsigned*)nullptr);
+        if ((rc = gpde_launch_reduce_splits(F(P.off_part), NW3, splits, NW3, grad_b_last, 0, st)) != GPDE_OK) return rc;
+    }
+    GP_LAUNCH_CHECK("gpde_edge_weights_bwd kernels");
+    return GPDE_OK;
+}
 
 extern "C" size_t gpde_nnconv_bwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers,
                                                   const int32_t* dims) {
@@ -1043,19 +1233,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     GP_LAUNCH_CHECK("gpde_nnconv_bwd kernels");
 
     // ---- node-side terms of update(): dx += g root^T, droot = X^T g, dbias = colsum g ----------------------
-    if (do_conv && root && dx) {
-        GpdeGemmArgs g = gemm0();
-        g.A = grad_out; g.lda = GP_W; g.B = root; g.ldb = GP_W; g.C = dx; g.ldc = GP_W;
-        g.M = N; g.N = GP_W; g.K = GP_W; g.accumulate = 1;
-        if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
-    }
-    if (do_conv && grad_root)
-        if ((rc = gemm_tn_acc(x, GP_W, GP_W, grad_out, GP_W, GP_W, N, grad_root, GP_W, F(P.off_part), P.part_floats, 0, st)) != GPDE_OK) return rc;
-    if (do_conv && grad_bias) {
-        int splits = 1; while (splits < 64 && N / (splits * 2) >= 64) splits *= 2;
-        hipLaunchKernelGGL(k_colsum, dim3(1, splits), dim3(T), 0, st, grad_out, N, GP_W, GP_W, splits, F(P.off_part), (unsigned*)nullptr);
-        if ((rc = gpde_launch_reduce_splits(F(P.off_part), GP_W, splits, GP_W, grad_bias, 0, st)) != GPDE_OK) return rc;
-    }
+    if (do_conv && (rc = bwd_node_terms(x, N, root, grad_out, dx, grad_root, grad_bias, F(P.off_part), P.part_floats, st)) != GPDE_OK) return rc;
     // ---- un-pad the weight gradients into torch layout -------------------------------------------------------
     for (int l = 1; l < n && do_mlp; ++l) {
         if (grad_W && grad_W[l - 1])

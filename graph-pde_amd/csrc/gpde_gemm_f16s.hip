@@ -768,7 +768,8 @@ __global__ __launch_bounds__(256) void k_first_layer_pack(GpdeFirstLayerSpec f, 
 }  // namespace
 
 size_t gpde_gemm_f16s_tn_ws_floats(int rows_max, int n_out, int n_in, int ksplits) {
-    const size_t epad = (size_t)rows_max + 64 * (size_t)ksplits;
+    size_t epad = (size_t)rows_max + 64 * (size_t)ksplits;
+    if (epad < (size_t)256 * ksplits) epad = (size_t)256 * ksplits;       // the launcher pads every K split to >= 256 rows
     return epad * n_out + epad * n_in + 3 * (size_t)(n_out + n_in) + 64 +
            (epad / 1024 + 2) * (size_t)n_out + (size_t)(n_out / 64 + 1) * epad + 64;   // GpdeDuStats: column-sum partials per
                                                                                           // 1024-row strip, row maxima per column block

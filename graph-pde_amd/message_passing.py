@@ -43,7 +43,7 @@ class MessagePassing(torch.nn.Module):
         else:
             res = torch.full((n, *out.shape[1:]), -1e9, dtype=out.dtype, device=out.device)
             res = res.scatter_reduce(0, idx.view(-1, *([1] * (out.dim() - 1))).expand_as(out), out, "amax")
-            res[res == -1e9] = 0
+            res = torch.where(res == -1e9, torch.zeros_like(res), res)      # (not in place: amax saved its output for the backward)
         return self.update(res, *[kwargs[a] for a in self.__update_args__])
 
     def message(self, x_j):

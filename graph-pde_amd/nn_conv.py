@@ -22,7 +22,7 @@ import torch
 from torch.nn import Parameter
 
 from . import hidden_cache, ops
-from .autograd import NNConvDeferredFunction, NNConvFunction, NNConvHiddenFunction
+from .autograd import NNConvDeferredFunction, NNConvFunction, NNConvHiddenFunction, WeConvFunction
 from .message_passing import MessagePassing
 
 
@@ -219,6 +219,12 @@ class NNConv_old(MessagePassing):
                 if hn < csr.n_nodes:        # H of the leading nodes only: mixed forward (inference)
                     return ops.nnconv_forward_mixed_raw(x, csr, pseudo, hidden, hmax, hn, pm, root,
                                                         bias, self.aggr)
+                if not no_grad:
+                    # low in-degree / small graph (the MGKN V-cycles): the per-edge weights as a shared autograd node, the
+                    # call itself one streaming kernel forward and one backward
+                    we = hidden_cache.lookup_edge_weights_train(self, hidden, csr, pm, weights, biases)
+                    if we is not None:
+                        return WeConvFunction.apply(x, we, csr, root, bias, self.aggr)
                 return NNConvHiddenFunction.apply(x, hidden, csr, pm, weights[-1], biases[-1],
                                                   root, bias, self.aggr, hmax)
             if not no_grad:

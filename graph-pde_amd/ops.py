@@ -1004,6 +1004,64 @@ def nnconv_forward_edgeweights_raw(x, csr, edge_weights, root, bias, aggr, resid
                                                   residual=residual, relu=relu, out=out)])[0]
 
 
+def nnconv_backward_edgeweights_raw(x: torch.Tensor, csr: Csr, edge_weights: torch.Tensor, root: Optional[torch.Tensor], aggr: str,
+                                    grad_out: torch.Tensor, need_root: bool = True, need_bias: bool = True):
+    """gpde_nnconv_bwd_edgeweights: backward of the operator given the per-edge weights.  Returns (grad_x, grad_edge_weights
+    [E, 4096], grad_root or None, grad_bias or None)."""
+    lib = _lib.lib()
+    for t, nm in ((x, "x"), (edge_weights, "edge_weights"), (grad_out, "grad_out")):
+        _require_cuda(t, nm)
+    if aggr not in _AGGR:
+        raise NotImplementedError(f"aggr={aggr!r}: the gradient of the per-edge weight operator is built for 'add' and 'mean'")
+    n, e, dev = csr.n_nodes, csr.n_edges, x.device
+    x = x.detach().contiguous()
+    grad_out = grad_out.detach().contiguous().float()
+    we = edge_weights.detach()
+    if we.dtype != torch.float32 or tuple(we.shape) != (e, WIDTH * WIDTH) or not we.is_contiguous():
+        raise ValueError(f"edge_weights must be contiguous float32 [{e},{WIDTH * WIDTH}]")
+    root_c = None if root is None else root.detach().contiguous()
+    gx = torch.empty(n, WIDTH, dtype=torch.float32, device=dev)
+    gwe = torch.empty(e, WIDTH * WIDTH, dtype=torch.float32, device=dev)
+    groot = torch.empty(WIDTH, WIDTH, dtype=torch.float32, device=dev) if (need_root and root is not None) else None
+    gbias = torch.empty(WIDTH, dtype=torch.float32, device=dev) if need_bias else None
+    ws = _alloc_ws(int(lib.gpde_nnconv_bwd_edgeweights_workspace_bytes(n, e)), dev)
+    srp, ssl = csr.src_order
+    p = lambda t: None if t is None else t.data_ptr()
+    with torch.cuda.device(dev):
+        rc = lib.gpde_nnconv_bwd_edgeweights(x.data_ptr(), n, we.data_ptr(), e, csr.rowptr.data_ptr(), csr.src.data_ptr(), p(srp), p(ssl),
+                                             p(root_c), _AGGR[aggr], grad_out.data_ptr(), gx.data_ptr(), gwe.data_ptr(), p(groot), p(gbias),
+                                             ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "gpde_nnconv_bwd_edgeweights")
+    _lib.n_native_calls += 1
+    return gx, gwe, groot, gbias
+
+
+def edge_weights_backward_raw(grad_we: torch.Tensor, hidden: torch.Tensor, dims: Sequence[int], w_last: torch.Tensor,
+                              need_b: bool = True):
+    """gpde_edge_weights_bwd: (grad_hidden [E, K2P] already masked by hidden > 0, grad_w_last, grad_b_last or None) from the
+    summed gradient of the per-edge weights."""
+    lib = _lib.lib()
+    _require_cuda(grad_we, "grad_edge_weights")
+    e, dev = int(hidden.size(0)), hidden.device
+    nl = len(dims) - 1
+    dims_c = _lib.dims_array(dims)
+    grad_we = grad_we.detach().contiguous()
+    hidden = hidden.detach()
+    if tuple(grad_we.shape) != (e, WIDTH * WIDTH) or tuple(hidden.shape) != (e, hidden_width(dims)) or not hidden.is_contiguous():
+        raise ValueError("grad_edge_weights [E, 4096] and contiguous hidden [E, K2P] expected")
+    w_c = w_last.detach().contiguous()
+    gh = torch.empty_like(hidden)
+    gw = torch.empty_like(w_c)
+    gb = torch.empty(WIDTH * WIDTH, dtype=torch.float32, device=dev) if need_b else None
+    ws = _alloc_ws(int(lib.gpde_edge_weights_bwd_workspace_bytes(e, nl, dims_c)), dev)
+    with torch.cuda.device(dev):
+        rc = lib.gpde_edge_weights_bwd(grad_we.data_ptr(), hidden.data_ptr(), e, nl, dims_c, w_c.data_ptr(), gh.data_ptr(), gw.data_ptr(),
+                                       None if gb is None else gb.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "gpde_edge_weights_bwd")
+    _lib.n_native_calls += 1
+    return gh, gw, gb
+
+
 def nnconv_forward_mixed_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor, hidden: torch.Tensor,
                              hmax: Optional[torch.Tensor], hidden_nodes: int, pm: PackedMlp,
                              root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,

@@ -373,6 +373,27 @@ typedef struct GpdeWeConvDesc {
 } GpdeWeConvDesc;
 int gpde_nnconv_fwd_edgeweights_group(const GpdeWeConvDesc* descs /* HOST array */, int n_descs, void* stream);
 
+/* Training on the per-edge weights (both MGKN scripts are training scripts: MGKN_general_darcy2d.py:260-282,
+ * MGKN_orthogonal_burgers1d.py:226-242).  W_e is an autograd node shared by the `depth` applications of a module:
+ *   gpde_nnconv_bwd_edgeweights  backward of the operator given W_e: grad_x [N][64] (ordered over each source's out-edges
+ *                                when src_rowptr / src_slots are given, else fp32 atomics), grad_edge_weights [E][4096]
+ *                                = x_j (x) gT_i (what autograd forms for `weight` in nn_conv.py:274-275), grad_root,
+ *                                grad_bias (NULL to skip).  'add' / 'mean'.
+ *   gpde_edge_weights_bwd        backward of gpde_edge_weights_fwd given the SUM of grad_edge_weights over the applications:
+ *                                grad_hidden [E][K2P] = (grad_W_e . W3) (.) [hidden > 0] (the input of gpde_hidden_bwd),
+ *                                grad_w_last [4096][k2], grad_b_last [4096] - the two 4096 x k2 products per edge once per
+ *                                step instead of once per application, on the split-f16 GEMMs. */
+size_t gpde_nnconv_bwd_edgeweights_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+int gpde_nnconv_bwd_edgeweights(const float* x, int64_t n_nodes, const float* edge_weights, int64_t n_edges,
+                                const int32_t* rowptr, const int32_t* src, const int32_t* src_rowptr,
+                                const int32_t* src_slots, const float* root, int aggr, const float* grad_out,
+                                float* grad_x, float* grad_edge_weights, float* grad_root, float* grad_bias, void* ws,
+                                size_t ws_bytes, void* stream);
+size_t gpde_edge_weights_bwd_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims);
+int gpde_edge_weights_bwd(const float* grad_edge_weights, const float* hidden, int64_t n_edges, int n_layers,
+                          const int32_t* dims, const float* w_last, float* grad_hidden, float* grad_w_last,
+                          float* grad_b_last, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Edge attributes on the fly (opt-in).  The reference materialises
  * edge_attr[e] = [pos_src(2), pos_dst(2), a_src, a_dst] from node data (SquareMeshGenerator.attributes,

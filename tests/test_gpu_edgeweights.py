@@ -110,7 +110,7 @@ def test_group_rejects_dependent_calls():
         ops.nnconv_forward_edgeweights_group([dict(c1, out=out), dict(c1, x=out)])
 
 
-def test_module_takes_the_edge_weight_path_for_repeated_inference_calls_only(monkeypatch):
+def test_module_takes_the_edge_weight_path_for_repeated_calls(monkeypatch):
     d = torch.device("cuda:0")
     monkeypatch.setattr(hidden_cache, "MODE", "auto")
     monkeypatch.setattr(hidden_cache, "WE_MODE", "auto")
@@ -129,11 +129,14 @@ def test_module_takes_the_edge_weight_path_for_repeated_inference_calls_only(mon
         ops.mlp_linears(conv.nn)[-1].weight.mul_(0.5)
         y6 = conv(x, ei, ea)
     assert rel_l2(y6.cpu(), _oracle(conv, x, ei, ea, "mean")) <= 2e-6
-    # training calls never use it
+    # with gradients the module (known to repeat) builds H and W_e as autograd nodes (round 4): same value, real gradients
     b0 = hidden_cache.stats["we_builds"] + hidden_cache.stats["we_hits"]
     xg = x.clone().requires_grad_(True)
-    conv(xg, ei, ea).sum().backward()
-    assert hidden_cache.stats["we_builds"] + hidden_cache.stats["we_hits"] == b0 and xg.grad is not None
+    yg = conv(xg, ei, ea)
+    yg.sum().backward()
+    assert hidden_cache.stats["we_builds"] + hidden_cache.stats["we_hits"] == b0 + 1 and xg.grad is not None
+    assert rel_l2(yg.detach().cpu(), _oracle(conv, x, ei, ea, "mean")) <= 2e-6
+    b0 += 1
     # a dense graph (in-degree > 4, > 8192 edges) keeps the re-associated path
     ei2, ea2, x2 = _graph(300, 9000, 4, 2, d)
     with torch.no_grad():
@@ -187,8 +190,9 @@ def test_burgers_sweep_grouped_equals_fused_glue_calls(monkeypatch):
     the default module path."""
     d = torch.device("cuda:0")
     hidden_cache.clear()
+    monkeypatch.setattr(hidden_cache, "WE_MODE", "off")
     wl_0 = mgkn_workloads.orthogonal_burgers(d, s=1024, seed=2)
-    y0 = wl_0.forward()                                      # default path (edge-weight cache off)
+    y0 = wl_0.forward()                                      # the fused kernels (edge-weight cache off)
     assert hidden_cache.stats["we_builds"] == 0
     monkeypatch.setattr(hidden_cache, "WE_MODE", "auto")
     wl_f = mgkn_workloads.orthogonal_burgers(d, s=1024, seed=2, fused_glue=True)
@@ -199,4 +203,114 @@ def test_burgers_sweep_grouped_equals_fused_glue_calls(monkeypatch):
     for u, v, w in zip(a, b, y0):
         assert torch.equal(u, v)
         assert rel_l2(u.cpu(), w.cpu()) <= 2e-6
+    hidden_cache.clear()
+
+
+# ---- training on the per-edge weights (gpde_nnconv_bwd_edgeweights / gpde_edge_weights_bwd) ------------------------------
+@pytest.mark.parametrize("aggr", ["mean", "add"])
+def test_backward_given_the_edge_weights_matches_float64(aggr):
+    d = torch.device("cuda:0")
+    torch.manual_seed(11)
+    n, e = 300, 1100
+    ei, _, x = _graph(n, e, 4, 5, d)
+    we = torch.randn(e, 4096, device=d) * 0.05
+    root = torch.randn(64, 64, device=d) * 0.1
+    g = torch.randn(n, 64, device=d)
+    csr = ops.build_csr(ei, n)
+    gx, gwe, groot, gbias = ops.nnconv_backward_edgeweights_raw(x, csr, we, root, aggr, g)
+    gx2, gwe2, groot2, gbias2 = ops.nnconv_backward_edgeweights_raw(x, csr, we, root, aggr, g)
+    assert torch.equal(gx, gx2) and torch.equal(gwe, gwe2) and torch.equal(groot, groot2) and torch.equal(gbias, gbias2)
+    # float64 autograd of the same formula, edge tensors in CSR slot order
+    src, dst = csr.src.long().cpu(), csr.dst.long().cpu()
+    x64 = x.cpu().double().requires_grad_(True)
+    w64 = we.cpu().double().requires_grad_(True)
+    r64 = root.cpu().double().requires_grad_(True)
+    b64 = torch.zeros(64, dtype=torch.float64, requires_grad=True)
+    m = torch.matmul(x64[src].unsqueeze(1), w64.view(-1, 64, 64)).squeeze(1)
+    out = torch.zeros(n, 64, dtype=torch.float64).index_add(0, dst, m)
+    if aggr == "mean":
+        out = out / torch.bincount(dst, minlength=n).clamp(min=1).double().unsqueeze(1)
+    out = out + x64 @ r64 + b64
+    (out * g.cpu().double()).sum().backward()
+    assert rel_l2(gx.cpu(), x64.grad) <= 2e-6 and rel_l2(gwe.cpu(), w64.grad) <= 2e-6
+    assert rel_l2(groot.cpu(), r64.grad) <= 2e-5 and rel_l2(gbias.cpu(), b64.grad) <= 2e-5
+    # the forward it differentiates
+    y = ops.nnconv_forward_edgeweights_raw(x, csr, we, root, None, aggr)
+    assert rel_l2(y.cpu(), (out - b64).detach()) <= 2e-6
+
+
+@pytest.mark.parametrize("dims,e", [([4, 128, 256, 4096], 3000), ([4, 16, 16, 4096], 700), ([6, 64, 200, 4096], 1500)])
+def test_backward_of_the_edge_weights_matches_float64(dims, e):
+    """gpde_edge_weights_bwd: grad_hidden (masked), grad of the last Linear from the summed dL/dW_e - split-f16 GEMMs where the
+    padded width allows, fp32 MFMA otherwise."""
+    d = torch.device("cuda:0")
+    torch.manual_seed(e)
+    K2P = ops.hidden_width(dims)
+    hidden = torch.zeros(e, K2P, device=d)
+    hidden[:, :dims[-2]] = torch.relu(torch.randn(e, dims[-2], device=d))
+    gwe = torch.randn(e, 4096, device=d)
+    w3 = torch.randn(4096, dims[-2], device=d) / dims[-2] ** 0.5
+    gh, gw, gb = ops.edge_weights_backward_raw(gwe, hidden, dims, w3)
+    gh2, gw2, gb2 = ops.edge_weights_backward_raw(gwe, hidden, dims, w3)
+    assert torch.equal(gh, gh2) and torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    h64, g64, w64 = hidden[:, :dims[-2]].cpu().double(), gwe.cpu().double(), w3.cpu().double()
+    ref_h = (g64 @ w64) * (h64 > 0)
+    assert rel_l2(gh[:, :dims[-2]].cpu(), ref_h) <= 2e-5 and float(gh[:, dims[-2]:].abs().sum()) == 0.0
+    assert rel_l2(gw.cpu(), g64.t() @ h64) <= 2e-5 and rel_l2(gb.cpu(), g64.sum(0)) <= 2e-5
+
+
+def test_training_step_on_the_shared_edge_weights_matches_the_fused_path(monkeypatch):
+    """A module applied `depth` times on a low in-degree graph with gradients (the MGKN V-cycle, MGKN_orthogonal_burgers1d.py:
+    65-82, :226-242): H and W_e are autograd nodes shared by the applications; every gradient equals the fused path's and
+    float64 autograd through the oracle."""
+    from oracle.nnconv_oracle import nnconv_grads
+    d = torch.device("cuda:0")
+    torch.manual_seed(13)
+    dims, n, e, depth = [4, 128, 128, 4096], 600, 1500, 3
+    conv = gp.NNConv(64, 64, DenseNet(dims, torch.nn.ReLU), aggr="mean").to(d)
+    ei, ea, x = _graph(n, e, 4, 21, d)
+    tgt = torch.randn(n, 64, device=d)
+
+    def step():
+        conv.zero_grad(set_to_none=True)
+        xin = x.clone().requires_grad_(True)
+        h = xin
+        for _ in range(depth):
+            h = torch.relu(h + conv(h, ei, ea))
+        loss = (h - tgt).square().mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        return [xin.grad.clone()] + [p.grad.clone() for p in conv.parameters()], float(loss.detach())
+    monkeypatch.setattr(hidden_cache, "MODE", "auto")
+    monkeypatch.setattr(hidden_cache, "WE_MODE", "off")
+    hidden_cache.clear()
+    step()
+    ref, loss_ref = step()                                   # H shared (NNConvHiddenFunction), per-call fused kernels
+    monkeypatch.setattr(hidden_cache, "WE_MODE", "auto")
+    hidden_cache.clear()
+    step()
+    got, loss = step()
+    assert hidden_cache.stats["we_builds"] >= 1 and hidden_cache.stats["we_hits"] >= depth - 2
+    assert abs(loss - loss_ref) <= 1e-5 * abs(loss_ref)
+    names = ["x"] + [k for k, _ in conv.named_parameters()]
+    for name, r, g_ in zip(names, ref, got):
+        assert rel_l2(g_.cpu(), r.cpu()) <= 2e-5, (name, rel_l2(g_.cpu(), r.cpu()))
+    again, _ = step()
+    for a_, b_ in zip(got, again):
+        assert torch.equal(a_, b_)                           # bit-reproducible
+    # one application against float64 autograd through the oracle (the same W_e path: the module repeats within `step`)
+    lin = ops.mlp_linears(conv.nn)
+    conv.zero_grad(set_to_none=True)
+    xin = x.clone().requires_grad_(True)
+    gout = torch.randn(n, 64, device=d)
+    y1 = conv(xin, ei, ea)
+    y2 = conv(xin, ei, ea)                                   # second application of the same (edge_attr, weights): shared nodes
+    ((y1 + y2) * gout).sum().backward()
+    rx, rW, rb, rroot, rbias = nnconv_grads(x.cpu(), ei.cpu(), ea.cpu(), [l.weight.detach().cpu() for l in lin],
+                                            [l.bias.detach().cpu() for l in lin], conv.root.detach().cpu(), conv.bias.detach().cpu(),
+                                            "mean", 2 * gout.cpu())
+    assert rel_l2(xin.grad.cpu(), rx) <= 2e-5
+    for l, layer in enumerate(lin):
+        assert rel_l2(layer.weight.grad.cpu(), rW[l]) <= 2e-5 and rel_l2(layer.bias.grad.cpu(), rb[l]) <= 2e-5, l
+    assert rel_l2(conv.root.grad.cpu(), rroot) <= 2e-5 and rel_l2(conv.bias.grad.cpu(), rbias) <= 2e-5
     hidden_cache.clear()
