@@ -33,6 +33,11 @@ class GpdeWeConvDesc(ctypes.Structure):
                 ("aggr", ctypes.c_int32), ("relu", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+class GpdeNodeAttr(ctypes.Structure):
+    """include/gpde.h `GpdeNodeAttr`: edge attributes described by a node table (tests/test_abi.py checks the layout)."""
+    _fields_ = [("table", ctypes.c_void_p), ("stride", ctypes.c_int32), ("n_slots", ctypes.c_int32), ("sel", ctypes.c_int32 * 8)]
+
+
 # name -> (restype, argtypes); mirrors include/gpde.h one to one (tests check the two agree)
 SIGNATURES = {
     "gpde_version": (ctypes.c_int, []),
@@ -166,6 +171,12 @@ SIGNATURES = {
     "gpde_edge_weights_bwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, c_i32p]),
     "gpde_edge_weights_bwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_i32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "gpde_nnconv_fwd_edgeweights_group": (ctypes.c_int, [ctypes.POINTER(GpdeWeConvDesc), ctypes.c_int, ctypes.c_void_p]),
+    "gpde_nnconv_fwd_na": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(GpdeNodeAttr), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "gpde_hidden_fwd_na": (ctypes.c_int, [ctypes.POINTER(GpdeNodeAttr), ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_i32p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "gpde_nnconv_bwd_na": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(GpdeNodeAttr), ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "gpde_nnconv_bwd_light_na": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(GpdeNodeAttr), ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "gpde_nnconv_bwd_deferred_na": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(GpdeNodeAttr), ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "gpde_hidden_bwd_na": (ctypes.c_int, [ctypes.POINTER(GpdeNodeAttr), ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "gpde_radius_graph_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
                                                ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     "gpde_radius_graph_fill": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,

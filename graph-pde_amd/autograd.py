@@ -21,6 +21,20 @@ from torch.autograd.function import once_differentiable
 from . import ops
 
 
+def _save_attr(ctx, edge_attr):
+    """The tensor to put into save_for_backward for `edge_attr`: itself, or - for an ops.NodeAttr (attributes read from node
+    data) - its node table, the descriptor riding on ctx."""
+    if isinstance(edge_attr, ops.NodeAttr):
+        ctx.node_attr = edge_attr
+        return edge_attr.table
+    ctx.node_attr = None
+    return edge_attr
+
+
+def _saved_attr(ctx, t):
+    return t if ctx.node_attr is None else ctx.node_attr
+
+
 class NNConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, edge_index, edge_attr, root, bias, aggr, n_layers, *params):
@@ -36,7 +50,7 @@ class NNConvFunction(torch.autograd.Function):
         ctx.csr, ctx.aggr, ctx.n_layers = csr, aggr, n_layers
         ctx.has_bias = bias is not None
         ctx.attr_needs_grad = edge_attr.requires_grad
-        ctx.save_for_backward(x, edge_attr, root, *params)
+        ctx.save_for_backward(x, _save_attr(ctx, edge_attr), root, *params)
         return out
 
     @staticmethod
@@ -46,6 +60,7 @@ class NNConvFunction(torch.autograd.Function):
             raise NotImplementedError(
                 "gradient with respect to edge_attr is not built (no reference script needs it)")
         x, edge_attr, root, *params = ctx.saved_tensors
+        edge_attr = _saved_attr(ctx, edge_attr)
         n = ctx.n_layers
         weights, biases = list(params[:n]), list(params[n:])
         gx, gW, gb, groot, gbias = ops.nnconv_backward_raw(
@@ -76,7 +91,7 @@ class HiddenFunction(torch.autograd.Function):
                                                precision)
         ctx.csr, ctx.dims, ctx.n_hidden, ctx.token = csr, tuple(pm.dims), n_hidden, token
         ctx.attr_needs_grad = edge_attr.requires_grad
-        ctx.save_for_backward(edge_attr, *params)
+        ctx.save_for_backward(_save_attr(ctx, edge_attr), *params)
         return h
 
     @staticmethod
@@ -87,6 +102,7 @@ class HiddenFunction(torch.autograd.Function):
                 "gradient with respect to edge_attr is not built (no reference script needs it)")
         ctx.token.valid = False
         edge_attr, *params = ctx.saved_tensors
+        edge_attr = _saved_attr(ctx, edge_attr)
         n = ctx.n_hidden
         gW, gb = ops.hidden_backward_raw(ctx.csr, edge_attr, ctx.dims, list(params[:n]), list(params[n:]), grad_h)
         return (None, None, None, None, None, None, *gW, *gb)
@@ -138,7 +154,7 @@ class DeferredHiddenFunction(torch.autograd.Function):
     def forward(ctx, edge_attr, csr, aggr, token, n_layers, *params):
         ctx.csr, ctx.aggr, ctx.token, ctx.n_layers = csr, aggr, token, n_layers
         ctx.attr_needs_grad = edge_attr.requires_grad
-        ctx.save_for_backward(edge_attr, *params)
+        ctx.save_for_backward(_save_attr(ctx, edge_attr), *params)
         return torch.zeros(1, dtype=torch.float32, device=edge_attr.device)
 
     @staticmethod
@@ -152,6 +168,7 @@ class DeferredHiddenFunction(torch.autograd.Function):
         stash, token.stash = token.stash, []
         hp, token.hpart = token.hpart, None       # the cache builds its next partial H before this token is replaced
         edge_attr, *params = ctx.saved_tensors
+        edge_attr = _saved_attr(ctx, edge_attr)
         n = ctx.n_layers
         weights, biases = list(params[:n]), list(params[n:])
         if not stash:                   # no application took part in this backward: the hidden layers get zero
@@ -185,13 +202,14 @@ class NNConvDeferredFunction(torch.autograd.Function):
             out = ops.nnconv_forward_raw(x.detach(), csr, edge_attr.detach(), pm, root, bias, aggr, z_keep=ctx.z)
         ctx.csr, ctx.aggr, ctx.n_layers, ctx.token = csr, aggr, n_layers, token
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, edge_attr, root, *params)
+        ctx.save_for_backward(x, _save_attr(ctx, edge_attr), root, *params)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
         x, edge_attr, root, *params = ctx.saved_tensors
+        edge_attr = _saved_attr(ctx, edge_attr)
         n = ctx.n_layers
         weights, biases = list(params[:n]), list(params[n:])
         hp = ctx.token.hpart

@@ -441,6 +441,31 @@ extern "C" int gpde_nnconv_fwd_nodeattr(const float* x, int64_t n_nodes, const f
                     aggr, flags, nullptr, out, ws, ws_bytes, (hipStream_t)stream_, table_stride, sel);
 }
 
+// The training-side forward with node-table attributes (include/gpde.h GpdeNodeAttr): gpde_nnconv_fwd_nodeattr + keep-Z +
+// the partial H of gpde_nnconv_fwd_mixed in one entry point.
+extern "C" int gpde_nnconv_fwd_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, const float* hidden_part,
+                                  const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges, const int32_t* rowptr,
+                                  const int32_t* src, const int32_t* dst, int n_layers, const int32_t* dims, const void* packed,
+                                  const float* root, const float* bias, int aggr, uint32_t flags, float* z_keep, float* out,
+                                  void* ws, size_t ws_bytes, void* stream_) {
+    if (!na || !na->table || na->stride < 1 || !dims || na->n_slots != dims[0] || dims[0] < 1 || dims[0] > 7) {
+        gpde_set_error("gpde_nnconv_fwd_na: GpdeNodeAttr must describe dims[0] = 1..7 slots of a node table");
+        return GPDE_EINVAL;
+    }
+    if (n_nodes < 0 || n_edges < 0 || !packed || !rowptr || (n_nodes > 0 && (!x || !out)) || (n_edges > 0 && (!src || !dst)) ||
+        hidden_nodes < 0 || hidden_nodes > n_nodes || (hidden_nodes > 0 && !hidden_part)) {
+        gpde_set_error("gpde_nnconv_fwd_na: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    int sel[8];
+    for (int d = 0; d < 8; ++d) sel[d] = na->sel[d < dims[0] ? d : dims[0] - 1];
+    if (hidden_nodes == 0)
+        return fwd_impl(x, n_nodes, na->table, n_edges, rowptr, src, dst, nullptr, n_layers, dims, packed, root, bias, aggr, flags,
+                        nullptr, out, ws, ws_bytes, (hipStream_t)stream_, na->stride, sel, nullptr, -1, nullptr, 0, z_keep);
+    return fwd_impl(x, n_nodes, na->table, n_edges, rowptr, src, dst, nullptr, n_layers, dims, packed, root, bias, aggr, flags,
+                    hidden_part, out, ws, ws_bytes, (hipStream_t)stream_, na->stride, sel, hidden_absmax, hidden_nodes, nullptr, 0, z_keep);
+}
+
 extern "C" int gpde_nnconv_fwd_mixed(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
                                      const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges,
                                      const int32_t* rowptr, const int32_t* src, const int32_t* dst,

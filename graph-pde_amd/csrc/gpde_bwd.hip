@@ -63,6 +63,21 @@ __global__ void k_gather_attr(const float* __restrict__ attr, const int32_t* __r
     const int d = i % KP0, r = i / KP0;
     out[i] = (d < k0) ? attr[(size_t)perm[e0 + r] * k0 + d] : 0.f;
 }
+// the same from a NODE table (SURVEY.md §8 row f3 in training): slot d of the edge in CSR slot s is
+// table[(sel[d] >> 8 ? dst[s] : src[s]) * kt + (sel[d] & 255)] - no [E][k0] tensor, no slot-order copy
+struct NodeAttrSel { int kt; int sel[8]; };
+__global__ void k_gather_attr_nodes(const float* __restrict__ table, NodeAttrSel na, const int32_t* __restrict__ src,
+                                    const int32_t* __restrict__ dst, int e0, int rows, int k0, int KP0, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * KP0) return;
+    const int d = i % KP0, r = i / KP0;
+    float v = 0.f;
+    if (d < k0) {
+        const int sd = na.sel[d];
+        v = table[(size_t)((sd >> 8) ? dst[e0 + r] : src[e0 + r]) * na.kt + (sd & 255)];
+    }
+    out[i] = v;
+}
 // gT_i = g_i / max(deg,1) ('mean') or g_i ('add'); rows with no in-edge get 0 (they have no Z)
 __global__ void k_scale_g(const float* __restrict__ g, const int32_t* __restrict__ rowptr, int aggr,
                           int n0, int nn, float* __restrict__ gT) {
@@ -907,7 +922,9 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
              const float* hidden, float* grad_hidden_out, const float* grad_hidden_in, void* ws,
              size_t ws_bytes, hipStream_t st, const int32_t* src_rowptr = nullptr, const int32_t* src_slots = nullptr,
              const float* z_saved = nullptr, int n_defer = 0, const float* x_stack = nullptr, const float* g_stack = nullptr,
-             const float* hpart = nullptr, int64_t hpart_nodes = 0) {
+             const float* hpart = nullptr, int64_t hpart_nodes = 0, int kt = 0, const int32_t* sel = nullptr) {
+    // kt > 0: `edge_attr` is a NODE table [n_nodes][kt] and slot d of an edge's attribute is table[(sel[d] >> 8 ? dst : src)][sel[d] & 255]
+    // (row f3: gpde_nnconv_fwd_nodeattr's convention); perm is unused
     // hpart (BWD_LIGHT / BWD_DEFER): the last hidden activations of the in-edges of nodes [0, hpart_nodes) are GIVEN (a partial
     // H kept by the caller, CSR slots [0, rowptr[hpart_nodes])): node chunks below that bound read them instead of recomputing
     const bool do_conv = phase != BWD_MLP && phase != BWD_DEFER, do_mlp = phase != BWD_CONV && phase != BWD_LIGHT;
@@ -982,20 +999,33 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     const bool light = phase == BWD_LIGHT;
     // recompute of the hidden chain for rows [e0, e0 + rows) = in-edges of nodes [na_, nb_): layers 1 .. last
     int rc_na = 0, rc_nb = 0;
+    NodeAttrSel nas{};
+    nas.kt = kt;
+    for (int d_ = 0; d_ < 8; ++d_) nas.sel[d_] = (kt && sel) ? sel[d_ < dims[0] ? d_ : dims[0] - 1] : 0;
+    if (kt && ((recomputes && !fast_last) || !src || !dst)) {
+        gpde_set_error("gpde_nnconv_bwd: node-table attributes need the 3-Linear split-f16 form (and src / dst)");
+        return GPDE_EUNSUPPORTED;
+    }
     const float* chunk_h = nullptr;          // the current chunk's last hidden activations when they are given (hpart)
     auto recompute = [&](int e0, int rows, int last) -> int {
-        if (!light)      // (the light pass needs the last hidden layer only, which the fused kernel forms from the attributes itself)
-            hipLaunchKernelGGL(k_gather_attr, dim3(nblk((size_t)rows * P.KP[0])), dim3(T), 0, st, edge_attr, perm, e0,
-                               rows, dims[0], P.KP[0], F(P.off_H[0]));
+        if (!light) {    // (the light pass needs the last hidden layer only, which the fused kernel forms from the attributes itself)
+            if (kt) hipLaunchKernelGGL(k_gather_attr_nodes, dim3(nblk((size_t)rows * P.KP[0])), dim3(T), 0, st, edge_attr, nas, src, dst, e0,
+                                       rows, dims[0], P.KP[0], F(P.off_H[0]));
+            else hipLaunchKernelGGL(k_gather_attr, dim3(nblk((size_t)rows * P.KP[0])), dim3(T), 0, st, edge_attr, perm, e0,
+                                    rows, dims[0], P.KP[0], F(P.off_H[0]));
+        }
         if (fast_last && last == n - 1 && chunk_h) last = n - 2;
         else if (fast_last && last == n - 1) {
             const float* pk = F(P.off_pack);
             GpdeFusedArgs f{};
             f.attr = edge_attr; f.rowptr = rowptr; f.perm = perm;
+            f.src = src; f.dst = dst; f.kt = kt;
+            for (int d_ = 0; d_ < 8; ++d_) f.sel[d_] = nas.sel[d_];
             f.w1 = pk + PL.off_w1; f.w2t = pk + PL.off_w2t; f.b2 = pk + PL.off_b2;
             f.w2h = pk + PL.off_w2h; f.ucol = pk + PL.off_ucol; f.w1h = pk + PL.off_w1h; f.fcol = pk + PL.off_fcol;
             f.hout = F(P.off_H[n - 1]); f.k0 = PL.k0; f.K1P = PL.K1P; f.K2P = PL.K2P;
             f.nc0 = rc_na; f.nc1 = rc_nb; f.e_chunk0 = e0;
+            if (kt && !gpde_fused_f16v6_supported(f)) { gpde_set_error("node-table attributes: kernel MLP outside the one-wave-per-SIMD store kernel"); return GPDE_EUNSUPPORTED; }
             const int ns = PL.K2P / GP_TN;
             int groups = gpde_num_cus() / ns; if (groups < 1) groups = 1;
             const int gcap = (rows / GP_TE + GP_WAVES) / GP_WAVES; if (groups > gcap) groups = gcap;
@@ -1424,6 +1454,118 @@ extern "C" int gpde_hidden_bwd(const float* edge_attr, int64_t n_edges, const in
     return bwd_impl(BWD_MLP, nullptr, 0, edge_attr, n_edges, nullptr, nullptr, nullptr, perm, nullptr, n_layers, dims,
                     W, b, nullptr, GPDE_AGGR_ADD, nullptr, nullptr, grad_W, grad_b, nullptr, nullptr, nullptr, nullptr,
                     grad_hidden, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+
+// ---- training with the edge attributes read from a node table (include/gpde.h GpdeNodeAttr) ----------
+namespace {
+bool na_ok(const GpdeNodeAttr* na, const int32_t* dims, const char* who) {
+    if (!na || !na->table || na->stride < 1 || !dims || na->n_slots != dims[0] || dims[0] < 1 || dims[0] > 7) {
+        gpde_set_error("%s: GpdeNodeAttr must describe dims[0] = 1..7 slots of a node table", who);
+        return false;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" int gpde_nnconv_bwd_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr,
+                                  const int32_t* src, const int32_t* dst, const int32_t* rowptr_host, const int32_t* src_rowptr,
+                                  const int32_t* src_slots, int n_layers, const int32_t* dims, const float* const* W,
+                                  const float* const* b, const float* root, int aggr, const float* grad_out, const float* z_saved,
+                                  float* grad_x, float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias,
+                                  void* ws, size_t ws_bytes, void* stream_) {
+    if (!na_ok(na, dims, "gpde_nnconv_bwd_na")) return GPDE_EINVAL;
+    if (n_nodes < 0 || n_edges < 0 || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws || (n_nodes > 0 && (!x || !grad_x)) ||
+        (n_edges > 0 && (!src || !dst))) { gpde_set_error("gpde_nnconv_bwd_na: null/negative argument"); return GPDE_EINVAL; }
+    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_na: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
+    return bwd_impl(BWD_FULL, x, n_nodes, na->table, n_edges, rowptr, src, dst, nullptr, rowptr_host, n_layers, dims, W, b, root, aggr,
+                    grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream_,
+                    src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, nullptr, 0, na->stride, na->sel);
+}
+
+extern "C" int gpde_nnconv_bwd_light_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr,
+                                        const int32_t* src, const int32_t* dst, const int32_t* rowptr_host, const int32_t* src_rowptr,
+                                        const int32_t* src_slots, int n_layers, const int32_t* dims, const float* const* W,
+                                        const float* const* b, const float* root, int aggr, const float* grad_out, const float* z_saved,
+                                        const float* hidden_part, int64_t hidden_nodes, float* grad_x, float* grad_w_last,
+                                        float* grad_b_last, float* grad_root, float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
+    if (!na_ok(na, dims, "gpde_nnconv_bwd_light_na")) return GPDE_EINVAL;
+    if (n_nodes < 0 || n_edges < 0 || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws || n_layers < 2 || n_layers > GPDE_MAX_LAYERS ||
+        (n_nodes > 0 && (!x || !grad_x)) || (n_edges > 0 && (!src || !dst)) || hidden_nodes < 0 || hidden_nodes > n_nodes ||
+        (hidden_nodes > 0 && !hidden_part)) { gpde_set_error("gpde_nnconv_bwd_light_na: null/negative argument"); return GPDE_EINVAL; }
+    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_light_na: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
+    float* gW[GPDE_MAX_LAYERS] = {};
+    float* gb[GPDE_MAX_LAYERS] = {};
+    gW[n_layers - 1] = grad_w_last; gb[n_layers - 1] = grad_b_last;
+    return bwd_impl(BWD_LIGHT, x, n_nodes, na->table, n_edges, rowptr, src, dst, nullptr, rowptr_host, n_layers, dims, W, b, root, aggr,
+                    grad_out, grad_x, gW, gb, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream_,
+                    src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, hidden_nodes > 0 ? hidden_part : nullptr, hidden_nodes,
+                    na->stride, na->sel);
+}
+
+extern "C" int gpde_nnconv_bwd_deferred_na(const float* x_stack, const float* grad_out_stack, int n_defer, int64_t n_nodes,
+                                           const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
+                                           const int32_t* dst, const int32_t* rowptr_host, int n_layers, const int32_t* dims,
+                                           const float* const* W, const float* const* b, int aggr, const float* hidden_part,
+                                           int64_t hidden_nodes, float* const* grad_W, float* const* grad_b, void* ws,
+                                           size_t ws_bytes, void* stream_) {
+    if (!na_ok(na, dims, "gpde_nnconv_bwd_deferred_na")) return GPDE_EINVAL;
+    if (n_nodes < 0 || n_edges < 0 || n_defer < 1 || !W || !b || !grad_W || !grad_b || !rowptr || !rowptr_host || !ws || n_layers < 2 ||
+        n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x_stack || !grad_out_stack)) || (n_edges > 0 && (!src || !dst)) ||
+        hidden_nodes < 0 || hidden_nodes > n_nodes || (hidden_nodes > 0 && !hidden_part)) {
+        gpde_set_error("gpde_nnconv_bwd_deferred_na: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_deferred_na: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
+    return bwd_impl(BWD_DEFER, nullptr, n_nodes, na->table, n_edges, rowptr, src, dst, nullptr, rowptr_host, n_layers, dims, W, b, nullptr,
+                    aggr, nullptr, nullptr, grad_W, grad_b, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
+                    (hipStream_t)stream_, nullptr, nullptr, nullptr, n_defer, x_stack, grad_out_stack,
+                    hidden_nodes > 0 ? hidden_part : nullptr, hidden_nodes, na->stride, na->sel);
+}
+
+extern "C" int gpde_hidden_bwd_na(const GpdeNodeAttr* na, int64_t n_edges, const int32_t* src, const int32_t* dst, int n_layers,
+                                  const int32_t* dims, const float* const* W, const float* const* b, const float* grad_hidden,
+                                  float* const* grad_W, float* const* grad_b, void* ws, size_t ws_bytes, void* stream_) {
+    if (!na_ok(na, dims, "gpde_hidden_bwd_na")) return GPDE_EINVAL;
+    if (n_edges < 0 || !W || !b || !ws || !grad_W || !grad_b || (n_edges > 0 && (!src || !dst || !grad_hidden))) {
+        gpde_set_error("gpde_hidden_bwd_na: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    return bwd_impl(BWD_MLP, nullptr, 0, na->table, n_edges, nullptr, src, dst, nullptr, nullptr, n_layers, dims, W, b, nullptr,
+                    GPDE_AGGR_ADD, nullptr, nullptr, grad_W, grad_b, nullptr, nullptr, nullptr, nullptr, grad_hidden, ws, ws_bytes,
+                    (hipStream_t)stream_, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, na->stride, na->sel);
+}
+
+extern "C" int gpde_hidden_fwd_na(const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                                  int64_t n_nodes, int n_layers, const int32_t* dims, const void* packed, uint32_t flags, float* hidden,
+                                  float* hidden_absmax, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    if (hidden_absmax) GP_HIP_CHECK(hipMemsetAsync(hidden_absmax, 0, sizeof(float), st));
+    if (!na_ok(na, dims, "gpde_hidden_fwd_na")) return GPDE_EINVAL;
+    if (n_edges < 0 || n_nodes < 0 || !packed || (n_edges > 0 && (!hidden || !rowptr || !src || !dst))) {
+        gpde_set_error("gpde_hidden_fwd_na: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (n_edges == 0) return GPDE_OK;
+    GpdePackLayout L;
+    int rc = gpde_pack_layout(n_layers, dims, &L);
+    if (rc != GPDE_OK) return rc;
+    if (!(flags & GPDE_FWD_F16SPLIT) || L.mode != 1) { gpde_set_error("gpde_hidden_fwd_na: 3-Linear kernel MLPs on the split-f16 kernel only"); return GPDE_EUNSUPPORTED; }
+    const float* pk = (const float*)packed;
+    GpdeFusedArgs f{};
+    f.attr = na->table; f.rowptr = rowptr; f.src = src; f.dst = dst; f.kt = na->stride;
+    for (int d = 0; d < 8; ++d) f.sel[d] = na->sel[d < dims[0] ? d : dims[0] - 1];
+    f.w1 = pk + L.off_w1; f.w2t = pk + L.off_w2t; f.b2 = pk + L.off_b2;
+    f.w2h = pk + L.off_w2h; f.ucol = pk + L.off_ucol; f.w1h = pk + L.off_w1h; f.fcol = pk + L.off_fcol;
+    f.hout = hidden; f.hmax_out = (unsigned*)hidden_absmax; f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
+    f.nc0 = 0; f.nc1 = (int)n_nodes; f.e_chunk0 = 0;
+    const int ns = L.K2P / GP_TN;
+    int groups = gpde_num_cus() / ns; if (groups < 1) groups = 1;
+    const int64_t gcap = ((n_edges + GP_TE - 1) / GP_TE + GP_WAVES - 1) / GP_WAVES;
+    if (groups > gcap) groups = (int)gcap;
+    f.n_groups = groups;
+    if (!gpde_fused_f16v6_supported(f)) { gpde_set_error("gpde_hidden_fwd_na: kernel MLP outside the one-wave-per-SIMD store kernel (>= 8 k1 chunks)"); return GPDE_EUNSUPPORTED; }
+    return gpde_launch_fused_f16v6(f, st);
 }
 
 

@@ -492,7 +492,8 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                 }
             }
             // closing wait: the chunk's W2 pieces are retired, its side loads (issued behind them, above) stay in flight
-            if constexpr (WRITE_H && PH == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            if constexpr (WRITE_H && PH == 0 && NODEATTR) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // source + destination ids
+            else if constexpr (WRITE_H && PH == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else if constexpr (WRITE_H && PH == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if constexpr (WRITE_H) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if constexpr (PH == 0 && NODEATTR) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
@@ -689,7 +690,7 @@ extern "C" int gpde_debug_v6_timing(unsigned long long* out8, int reset) {
 // 3-Linear kernels with at least 8 k1 chunks (the side loads of a tile are spread over its first seven), attributes +
 // bias slot within one K = 8 group, split-x input (a.xs) present
 bool gpde_fused_f16v6_supported(const GpdeFusedArgs& a) {
-    return a.K1P / GP_BK >= 8 && a.k0 + 1 <= 8 && v6_lds_bytes(a.K1P) <= 160 * 1024 && (a.kt == 0 || a.hout == nullptr) &&
+    return a.K1P / GP_BK >= 8 && a.k0 + 1 <= 8 && v6_lds_bytes(a.K1P) <= 160 * 1024 &&
            (a.hout != nullptr || a.xs != nullptr);
 }
 
@@ -698,11 +699,13 @@ int gpde_launch_fused_f16v6(const GpdeFusedArgs& a, hipStream_t stream) {
     const dim3 grid(a.n_groups * ns), block(256);
     const size_t lds = v6_lds_bytes(a.K1P);
     static GpdeLdsOnce once;
-    if (int rc = once.ensure(gpde_fused_f16v6_kernel<false, false>, gpde_fused_f16v6_kernel<true, false>, gpde_fused_f16v6_kernel<false, true>)) return rc;
+    if (int rc = once.ensure(gpde_fused_f16v6_kernel<false, false>, gpde_fused_f16v6_kernel<true, false>, gpde_fused_f16v6_kernel<false, true>,
+                             gpde_fused_f16v6_kernel<true, true>)) return rc;
     if (a.hout) {
         GpdeFusedArgs b = a;
         b.blk = nullptr; b.qn = nullptr; b.qctr = nullptr;             // rows are independent: static ranges
-        hipLaunchKernelGGL((gpde_fused_f16v6_kernel<true, false>), grid, block, lds, stream, b);
+        if (a.kt) hipLaunchKernelGGL((gpde_fused_f16v6_kernel<true, true>), grid, block, lds, stream, b);     // row f3 in training
+        else hipLaunchKernelGGL((gpde_fused_f16v6_kernel<true, false>), grid, block, lds, stream, b);
     } else if (a.kt) hipLaunchKernelGGL((gpde_fused_f16v6_kernel<false, true>), grid, block, lds, stream, a);
     else hipLaunchKernelGGL((gpde_fused_f16v6_kernel<false, false>), grid, block, lds, stream, a);
     GP_LAUNCH_CHECK("gpde_fused_f16v6_kernel");

@@ -131,7 +131,13 @@ def release_all() -> bool:
     return freed
 
 
-def _key(edge_attr: torch.Tensor, csr, hidden_params: List[Optional[torch.Tensor]], precision: str):
+def _key(edge_attr, csr, hidden_params: List[Optional[torch.Tensor]], precision: str):
+    if isinstance(edge_attr, ops.NodeAttr):      # attributes described by node data: keyed on the table's memory + version + slots
+        tb = edge_attr.table
+        grad = torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in hidden_params)
+        return (str(tb.device), tb.untyped_storage().data_ptr(), tb.storage_offset(), tuple(tb.shape), tuple(tb.stride()),
+                ops._ver(tb), tuple(edge_attr.sel), id(csr),
+                tuple((0, 0) if p is None else (p.data_ptr(), ops._ver(p)) for p in hidden_params), precision, grad)
     st = edge_attr.untyped_storage()
     grad = torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in hidden_params)
     return (str(edge_attr.device), st.data_ptr(), edge_attr.storage_offset(), tuple(edge_attr.shape),
@@ -267,7 +273,10 @@ def edge_weights_qualify(csr, force: bool = False, explicit: bool = False) -> bo
         return False
     if force:
         return e * ops.EDGE_WEIGHT_BYTES <= max(WE_BUDGET_BYTES, budget_bytes(getattr(getattr(csr, "rowptr", None), "device", None)))
-    return (explicit or WE_MODE == "auto") and (e <= 4 * n or e <= WE_SMALL_EDGES) and e * ops.EDGE_WEIGHT_BYTES <= WE_BUDGET_BYTES
+    # (plain module calls: only while the hidden-activation cache it derives from is on - GPDE_HIDDEN_CACHE=off is the ONE switch
+    # for history-independent bits)
+    return (explicit or (WE_MODE == "auto" and MODE != "off")) and (e <= 4 * n or e <= WE_SMALL_EDGES) and \
+        e * ops.EDGE_WEIGHT_BYTES <= WE_BUDGET_BYTES
 
 
 def lookup_edge_weights_train(module: torch.nn.Module, hidden: torch.Tensor, csr, pm, weights, biases):

@@ -120,6 +120,12 @@ class NNConv_old(MessagePassing):
                 csr = ops.csr_for(edge_index, x.size(0))
                 pm = ops.pack_mlp([l.weight for l in lin], [l.bias for l in lin])
                 return ops.nnconv_forward_nodeattr_raw(x, csr, edge_attr, pm, self.root, self.bias, self.aggr)
+            if needs_grad and self.aggr in ("add", "mean") and x.dtype == torch.float32 and self.in_channels == ops.WIDTH and \
+                    self.out_channels == ops.WIDTH and all(l.bias is not None for l in lin) and \
+                    ops.nodeattr_train_supported([lin[0].in_features] + [l.out_features for l in lin]):
+                # training from node data (round 4): the descriptor travels the ordinary path - direct operator, shared hidden
+                # activations or the virtual-H node - and every native call reads the table (`_na` entry points)
+                return self.propagate(edge_index, x=x, pseudo=edge_attr)
             edge_attr = edge_attr.materialize(edge_index.edge_index if isinstance(edge_index, ops.Csr) else edge_index)
         pseudo = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
         return self.propagate(edge_index, x=x, pseudo=pseudo)                            # nn_conv.py:271

@@ -404,8 +404,49 @@ int gpde_edge_weights_bwd(const float* grad_edge_weights, const float* hidden, i
  * attr_sel: HOST array of dims[0] ints (endpoint << 8 | column; endpoint 0 = source j, 1 = target i).
  * Same result as gpde_nnconv_fwd on the materialised tensor (bitwise: the attribute values are the
  * same floats).  Built for 3-Linear kernel MLPs on the default GPDE_FWD_F16SPLIT kernel; anything
- * else returns GPDE_EUNSUPPORTED.  `perm` is not needed.  Forward only (training takes the
- * materialised tensor). */
+ * else returns GPDE_EUNSUPPORTED.  `perm` is not needed.
+ *
+ * Training (round 4): the `_na` entry points below are the training-side calls with the attributes described by a
+ * GpdeNodeAttr (HOST struct) instead of an [E][k0] tensor + perm - forward with keep-Z / the partial H, the store of the
+ * hidden activations, full / light / deferred backward, the hidden layers' backward - so that a training step on a graph
+ * built from positions (gpde_radius_csr_*) needs neither the [E][k0] tensor (2.3 GB on the 241^2 graph) nor its slot-order
+ * copy.  Arguments otherwise as their tensor counterparts; results are bitwise those of the materialised tensor
+ * (tests/test_gpu_nodeattr_train.py).  3-Linear kernel MLPs of >= 8 k1 chunks (the one-wave-per-SIMD kernels). */
+typedef struct GpdeNodeAttr {
+    const float* table;   /* device [n_nodes][stride] */
+    int32_t stride;
+    int32_t n_slots;      /* = dims[0], 1..7 */
+    int32_t sel[8];       /* slot d: endpoint << 8 | column (endpoint 0 = source j, 1 = target i) */
+} GpdeNodeAttr;
+int gpde_nnconv_fwd_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, const float* hidden_part,
+                       const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges, const int32_t* rowptr,
+                       const int32_t* src, const int32_t* dst, int n_layers, const int32_t* dims, const void* packed,
+                       const float* root, const float* bias, int aggr, uint32_t flags, float* z_keep, float* out, void* ws,
+                       size_t ws_bytes, void* stream);
+int gpde_hidden_fwd_na(const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                       int64_t n_nodes, int n_layers, const int32_t* dims, const void* packed, uint32_t flags, float* hidden,
+                       float* hidden_absmax, void* stream);
+int gpde_nnconv_bwd_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr,
+                       const int32_t* src, const int32_t* dst, const int32_t* rowptr_host, const int32_t* src_rowptr,
+                       const int32_t* src_slots, int n_layers, const int32_t* dims, const float* const* W, const float* const* b,
+                       const float* root, int aggr, const float* grad_out, const float* z_saved, float* grad_x,
+                       float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias, void* ws, size_t ws_bytes,
+                       void* stream);
+int gpde_nnconv_bwd_light_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr,
+                             const int32_t* src, const int32_t* dst, const int32_t* rowptr_host, const int32_t* src_rowptr,
+                             const int32_t* src_slots, int n_layers, const int32_t* dims, const float* const* W,
+                             const float* const* b, const float* root, int aggr, const float* grad_out, const float* z_saved,
+                             const float* hidden_part, int64_t hidden_nodes, float* grad_x, float* grad_w_last,
+                             float* grad_b_last, float* grad_root, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
+int gpde_nnconv_bwd_deferred_na(const float* x_stack, const float* grad_out_stack, int n_defer, int64_t n_nodes,
+                                const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
+                                const int32_t* dst, const int32_t* rowptr_host, int n_layers, const int32_t* dims,
+                                const float* const* W, const float* const* b, int aggr, const float* hidden_part,
+                                int64_t hidden_nodes, float* const* grad_W, float* const* grad_b, void* ws, size_t ws_bytes,
+                                void* stream);
+int gpde_hidden_bwd_na(const GpdeNodeAttr* na, int64_t n_edges, const int32_t* src, const int32_t* dst, int n_layers,
+                       const int32_t* dims, const float* const* W, const float* const* b, const float* grad_hidden,
+                       float* const* grad_W, float* const* grad_b, void* ws, size_t ws_bytes, void* stream);
 int gpde_nnconv_fwd_nodeattr(const float* x, int64_t n_nodes, const float* node_table,
                              int32_t table_stride, const int32_t* attr_sel, int64_t n_edges,
                              const int32_t* rowptr, const int32_t* src, const int32_t* dst,

@@ -38,7 +38,7 @@ def test_mgkn_forward_calls_match_oracle(name):
 
 
 @pytest.mark.parametrize("name", sorted(mgkn_workloads.WORKLOADS))
-def test_mgkn_gradients_of_every_distinct_call_match_float64_autograd(name):
+def test_mgkn_gradients_of_every_distinct_call_match_float64_autograd(name, monkeypatch):
     """Both MGKN scripts are TRAINING scripts (MGKN_general_darcy2d.py:260-282, MGKN_orthogonal_burgers1d.py:226-242):
     every distinct NNConv application of configs 3 / 4 at its full size - grad_x and every parameter gradient of
     gpde_nnconv_bwd against float64 autograd through the oracle (in edge chunks: the [E, 4096] float64 tensor of the
@@ -47,7 +47,7 @@ def test_mgkn_gradients_of_every_distinct_call_match_float64_autograd(name):
     d = torch.device("cuda:0")
     wl = mgkn_workloads.WORKLOADS[name](d)
     torch.manual_seed(5)
-    worst = {}
+    worst, kinked = {}, []
     for conv, x, ei, ea in wl.pairs:
         conv.zero_grad(set_to_none=True)
         xin = x.clone().requires_grad_(True)
@@ -72,20 +72,30 @@ def test_mgkn_gradients_of_every_distinct_call_match_float64_autograd(name):
             worst[k] = max(worst.get(k, 0.0), v)
             if v <= 2e-5:
                 continue
-            # ReLU-kink rows (tests/test_gpu_bwd.py): with > 10^7 hidden activations a handful lie within
-            # rounding of 0, where the fp32-level forward and the float64 oracle pick different masks; ONE flipped entry
-            # moves its unit's row of a hidden-layer gradient by ~1/sqrt(E).  Hidden-layer gradients of the big calls are
-            # therefore compared row-wise: all but <= 4 rows (units) within tolerance, the rest of the matrix within it too.
+            # ReLU-kink effect (tests/test_gpu_bwd.py): this call has 67 M hidden activations; ~50 of them lie
+            # within fp32 rounding of 0, where the fp32-level forward and the float64 oracle pick different masks.  A flipped
+            # entry of the SECOND hidden layer moves its own row of dW_2 by ~1/sqrt(E) and, through W_2, EVERY row of dW_1 /
+            # db_1 by ~1/sqrt(E k): 3e-4 on the whole matrix is that effect, not arithmetic.  Hidden-layer gradients of the big
+            # calls are therefore checked (a) against float64 at the kink level and (b) against the exact-fp32 GEMMs on the
+            # SAME masks (GPDE_BWD_GEMM_F32: what the split-f16 GEMMs replace) at rounding level.
             assert k[:2] in ("dW", "db") and int(k[2:]) < len(lin) - 1 and ei.shape[1] * lin[int(k[2:])].out_features > 1e7, \
                 (name, tuple(ei.shape), k, v)
-            layer = lin[int(k[2:])]
-            got = (layer.weight.grad if k[1] == "W" else layer.bias.grad).cpu().double().reshape(layer.out_features, -1)
-            ref = (rW if k[1] == "W" else rb)[int(k[2:])].double().reshape(layer.out_features, -1)
-            row_err = (got - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-3 * float(ref.norm()) / ref.shape[0] ** 0.5)
-            bad = row_err > 2e-5
-            assert int(bad.sum()) <= 4, (name, tuple(ei.shape), k, v, int(bad.sum()))
-            assert float((got[~bad] - ref[~bad]).norm() / ref[~bad].norm()) <= 2e-5 and float(row_err.median()) <= 5e-6, \
-                (name, tuple(ei.shape), k, v)
+            assert v <= 3e-3, (name, tuple(ei.shape), k, v)
+            kinked.append((conv, x, ei, ea, gout, k))
+    for conv, x, ei, ea, gout, k in kinked:
+        lin = ops.mlp_linears(conv.nn)
+        layer = lin[int(k[2:])]
+
+        def grad_of():
+            conv.zero_grad(set_to_none=True)
+            (conv(x.clone().requires_grad_(True), ei, ea) * gout).sum().backward()
+            torch.cuda.synchronize()
+            return (layer.weight.grad if k[1] == "W" else layer.bias.grad).detach().clone()
+        g16 = grad_of()
+        monkeypatch.setenv("GPDE_BWD_GEMM_F32", "1")
+        g32 = grad_of()
+        monkeypatch.delenv("GPDE_BWD_GEMM_F32")
+        assert rel_l2(g16.cpu(), g32.cpu()) <= 5e-6, (name, tuple(ei.shape), k, rel_l2(g16.cpu(), g32.cpu()))
     print(name, "max rel-L2 of the gradients over", len(wl.pairs), "NNConv applications:", {k: f"{v:.1e}" for k, v in worst.items()})
     before = [p.detach().clone() for m in wl.modules for p in m.parameters()]
     calls = _lib.n_native_calls

@@ -97,9 +97,19 @@ def test_kernelnn_training_loop_through_shims(shims):
     torch.save(model, buf)
     buf.seek(0)
     m2 = torch.load(buf, weights_only=False)
+    from graph_pde_amd import hidden_cache
     with torch.no_grad():
         a_, b_ = model(data[0].to(d)), m2(data[0].to(d))
-    assert torch.equal(a_, b_)
+    # `model` is known to its caches (repeating module: hidden activations / per-edge weights reused), the unpickled copy is
+    # a stranger on its first call: same value, possibly other last bits ...
+    assert float((a_ - b_).norm() / a_.norm()) <= 1e-6
+    mode0, hidden_cache.MODE = hidden_cache.MODE, "off"
+    try:                                      # ... and identical bits once the history-dependent paths are switched off
+        with torch.no_grad():
+            a_, b_ = model(data[0].to(d)), m2(data[0].to(d))
+        assert torch.equal(a_, b_)
+    finally:
+        hidden_cache.MODE = mode0
 
 
 def test_mgkn_vcycle_slice_pattern(shims):
