@@ -424,6 +424,10 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                     for (int j = 0; j < 6; ++j) {
                         const int tt = j >> 1, e = j & 1;                 // tt: 0 = hi x lo, 1 = hi x hi, 2 = lo x hi
                         const int i = nb * 6 + j;
+#ifdef GPDE_ABL_2MFMA      // ablation build ONLY (scripts/gpu/clock_evidence.sh; WRONG results): two of the three split products, to
+                           // measure how time and clock answer to a third less matrix work per edge
+                        if (tt != 2)
+#endif
                         acc[e][nb] = mfma16(__builtin_bit_cast(h8, tt == 2 ? alo[cbuf][e] : ahi[cbuf][e]),
                                             tt == 0 ? blo[nb] : bhi[nb], acc[e][nb]);
                         asm volatile("" : "+a"(acc[e][nb]));

@@ -12,8 +12,19 @@ depth = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 s, r = {"g241": (241, 0.1), "g121": (121, 0.1), "g61": (61, 0.1)}[cfg]
 dev = torch.device("cuda:0")
-ei, ea, n = synth.darcy_graph(s, r, device=dev)
-e = ei.shape[1]
+if os.environ.get("NODEATTR") == "1":
+    # row f3 in training: graph from positions (cell list -> CSR), attributes from the node table: no edge list, no [E,6] tensor
+    pos = synth.lattice_positions(s, dev)
+    a_n = synth.darcy_coefficient(s, 0).to(dev)
+    t0 = time.perf_counter()
+    ei = ops.radius_csr(pos, r)
+    ea = gp.NodeAttr.darcy(pos, a_n)
+    torch.cuda.synchronize()
+    n, e = ei.n_nodes, ei.n_edges
+    print(f"graph from positions: N={n} E={e} in {1e3 * (time.perf_counter() - t0):.1f} ms, attributes from the node table")
+else:
+    ei, ea, n = synth.darcy_graph(s, r, device=dev)
+    e = ei.shape[1]
 if cfg != "g241":
     hidden_cache.BUDGET_BYTES = 0
 res = {}

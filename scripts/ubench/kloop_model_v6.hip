@@ -43,7 +43,15 @@ void kern(long* out, const char* gsrc, float seed, int iters) {
     f32x16 d[2], acc[2][4], Z[2][4];
     for (int b = 0; b < 2; ++b)
         for (int e = 0; e < 2; ++e)
-            for (int j = 0; j < 4; ++j) { ahi[b][e][j] = 0x3c003c00u + j * 17 + lane; alo[b][e][j] = 0x14001400u + j; }
+            for (int j = 0; j < 4; ++j) {
+                // pseudo-random f16 pairs per lane / register (sign + 12 random low bits on exponent 0x30..0x3f: magnitudes 0.1 .. 2;
+                // lo parts 2^-11 of that): the power draw of an MFMA depends on the operand bits (round 4: was a near-constant)
+                unsigned r_ = (unsigned)(lane * 2654435761u) ^ (unsigned)((b * 8 + e * 4 + j + 1) * 40503u) ^ (unsigned)(blockIdx.x * 97u);
+                r_ = r_ * 1664525u + 1013904223u;
+                const unsigned h0 = 0x3000u + ((r_ >> 4) & 0x0fffu) + ((r_ >> 1) & 0x8000u), h1 = 0x3000u + ((r_ >> 18) & 0x0fffu) + ((r_ << 3) & 0x8000u);
+                ahi[b][e][j] = h0 | (h1 << 16);
+                alo[b][e][j] = (0x0400u + ((r_ >> 9) & 0x0fffu)) | ((0x0400u + ((r_ >> 13) & 0x0fffu) + ((r_ << 7) & 0x8000u)) << 16);
+            }
     for (int e = 0; e < 2; ++e)
         for (int j = 0; j < 8; ++j) { B1[e][j] = (_Float16)(seed + j * 0.1f + e); B2[e][j] = (_Float16)(seed - j * 0.1f); }
     for (int e = 0; e < 2; ++e)
@@ -135,7 +143,8 @@ void kern(long* out, const char* gsrc, float seed, int iters) {
                 for (int j = 0; j < 6; ++j) {
                     const int t = j >> 1, e = j & 1;
                     const int i = nb * 6 + j;
-                    acc[e][nb] = mfma16(__builtin_bit_cast(h8, t == 2 ? alo[cb][e] : ahi[cb][e]), t == 0 ? blo[nb] : bhi[nb], acc[e][nb]);
+                    if (!((FLAGS & 128) && t == 2))       // flag 128: two of the three split products (what less matrix work per edge would buy)
+                        acc[e][nb] = mfma16(__builtin_bit_cast(h8, t == 2 ? alo[cb][e] : ahi[cb][e]), t == 0 ? blo[nb] : bhi[nb], acc[e][nb]);
                     asm volatile("" : "+a"(acc[e][nb]));
                     // conversion pair p of the next step's operands: first part (relu, relu, hi) after MFMA 3p,
                     // second part (lo) after MFMA 3p + 1.  In step 1 the raw H1 of the next chunk was issued at
@@ -220,11 +229,13 @@ void run(long* d, const char* src, const char* what) {
     hipEventElapsedTime(&ms, a, b);
     long hcyc;
     hipMemcpy(&hcyc, d, 8, hipMemcpyDeviceToHost);
-    const int nm = 48 + ((FLAGS & 8) ? 4 : 0);
-    (void)0;
+    const int nm = ((FLAGS & 128) ? 32 : 48) + ((FLAGS & 8) ? 4 : 0);
     const double tf = 256.0 * 4 * iters * nm * 32768.0 / (ms * 1e-3) / 1e12;
-    printf("NS %d flags %2d %-46s: %6.0f cycles/chunk (ideal %d)  %7.1f TFLOP/s  %.2f ms  err=%s\n", NS, FLAGS, what,
-           (double)hcyc / iters, nm * 32, tf, ms, hipGetErrorString(hipGetLastError()));
+    // shader clock over the run: the K loop's clock64() cycles of one wave / the kernel's event time (prologue / epilogue of
+    // the kernel are < 1 % of 2048 iterations); matrix pipe occupancy = MFMA cycles issued / cycles elapsed
+    const double ghz = (double)hcyc / (ms * 1e-3) / 1e9;
+    printf("NS %d flags %3d %-46s: %6.0f cycles/chunk (MFMA %d = %4.1f %% of the cycles)  clock %.3f GHz  %7.1f TFLOP/s  %.2f ms  err=%s\n", NS, FLAGS, what,
+           (double)hcyc / iters, nm * 32, 100.0 * nm * 32 * iters / (double)hcyc, ghz, tf, ms, hipGetErrorString(hipGetLastError()));
 }
 
 int main() {
@@ -265,5 +276,7 @@ int main() {
     run<16 | 8 | 1 | 32 | 2 | 4, 4>(d, src, "FULL, 4 slots (DMA two chunks ahead)");
     run<64 | 16 | 8 | 1 | 32 | 2 | 4, 3>(d, src, "FULL, 3 slots, H1 MFMA into VGPRs (asm)");
     run<64 | 16 | 8 | 1 | 32 | 2 | 4, 4>(d, src, "FULL, 4 slots, H1 MFMA into VGPRs (asm)");
+    run<128, 3>(d, src, "32 MFMA only (2 of 3 split products)");
+    run<128 | 64 | 16 | 8 | 1 | 32 | 2 | 4, 3>(d, src, "FULL, 3 slots, asm H1, 2 of 3 split products");
     return 0;
 }
