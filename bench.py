@@ -401,6 +401,10 @@ def split_graph_mode(args, rank, world, dev, use_dist, barrier):
     torch.cuda.empty_cache()
     graph = part.edge_index if part.csr is None else part.csr
     ev = []
+    # a step is ONE NNConv forward, as in the default line (which calls the operator directly): the cross-call caches - the
+    # same x / graph / weights every step would be served from kept hidden activations - stay out of the timed region
+    from graph_pde_amd import hidden_cache
+    hidden_cache.MODE = "off"
 
     def step():
         with torch.no_grad():

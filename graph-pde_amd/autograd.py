@@ -56,18 +56,18 @@ class NNConvFunction(torch.autograd.Function):
     @staticmethod
     @once_differentiable        # the native backward is not itself differentiable: create_graph=True raises
     def backward(ctx, grad_out):
-        if ctx.attr_needs_grad:
-            raise NotImplementedError(
-                "gradient with respect to edge_attr is not built (no reference script needs it)")
         x, edge_attr, root, *params = ctx.saved_tensors
         edge_attr = _saved_attr(ctx, edge_attr)
         n = ctx.n_layers
         weights, biases = list(params[:n]), list(params[n:])
-        gx, gW, gb, groot, gbias = ops.nnconv_backward_raw(
+        res = ops.nnconv_backward_raw(
             x, ctx.csr, edge_attr, weights, biases, root, ctx.aggr, grad_out,
-            need_root=root is not None, need_bias=ctx.has_bias, z_saved=ctx.z)
+            need_root=root is not None, need_bias=ctx.has_bias, z_saved=ctx.z, need_attr=ctx.attr_needs_grad)
+        gx, gW, gb, groot, gbias = res[:5]
         ctx.z = None
-        return (gx, None, None, groot, gbias if ctx.has_bias else None, None, None, *gW, *gb)
+        # dL/d edge_attr (round 4): only this direct operator differentiates the attributes - the cached paths step aside for an
+        # edge_attr that requires a gradient (hidden_cache.lookup)
+        return (gx, None, res[5] if ctx.attr_needs_grad else None, groot, gbias if ctx.has_bias else None, None, None, *gW, *gb)
 
 
 class HiddenToken:

@@ -63,6 +63,33 @@ __global__ void k_gather_attr(const float* __restrict__ attr, const int32_t* __r
     const int d = i % KP0, r = i / KP0;
     out[i] = (d < k0) ? attr[(size_t)perm[e0 + r] * k0 + d] : 0.f;
 }
+// grad_attr[perm[e0 + r]][d] = sum_k dU1[r][k] * W1p[k][d]  (d < k0): the gradient reaching the edge attributes through the
+// first Linear of DenseNet (autograd gives `pseudo` a gradient when it requires one; no reference script asks for it).
+// One wave per edge row (a 4 KiB read of dU_1), lanes split k, eight running dots, wave reduction; every edge written once.
+__global__ __launch_bounds__(256) void k_grad_attr(const float* __restrict__ dU1, int K, const float* __restrict__ W1p, int ldw,
+                                                   const int32_t* __restrict__ perm, int e0, int rows, int k0,
+                                                   float* __restrict__ grad_attr) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = lane; k < K; k += 64) {
+        const float u = dU1[(size_t)r * K + k];
+        const f32x4 w0 = *(const f32x4*)(W1p + (size_t)k * ldw), w1 = *(const f32x4*)(W1p + (size_t)k * ldw + 4);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { acc[d] = fmaf(u, w0[d], acc[d]); acc[4 + d] = fmaf(u, w1[d], acc[4 + d]); }
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[d] += __shfl_xor(acc[d], o);
+    if (lane < k0) {
+        float v = acc[0];
+#pragma unroll
+        for (int d = 1; d < 8; ++d) v = lane == d ? acc[d] : v;
+        grad_attr[(size_t)perm[e0 + r] * k0 + lane] = v;
+    }
+}
 // the same from a NODE table (SURVEY.md §8 row f3 in training): slot d of the edge in CSR slot s is
 // table[(sel[d] >> 8 ? dst[s] : src[s]) * kt + (sel[d] & 255)] - no [E][k0] tensor, no slot-order copy
 struct NodeAttrSel { int kt; int sel[8]; };
@@ -922,7 +949,9 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
              const float* hidden, float* grad_hidden_out, const float* grad_hidden_in, void* ws,
              size_t ws_bytes, hipStream_t st, const int32_t* src_rowptr = nullptr, const int32_t* src_slots = nullptr,
              const float* z_saved = nullptr, int n_defer = 0, const float* x_stack = nullptr, const float* g_stack = nullptr,
-             const float* hpart = nullptr, int64_t hpart_nodes = 0, int kt = 0, const int32_t* sel = nullptr) {
+             const float* hpart = nullptr, int64_t hpart_nodes = 0, int kt = 0, const int32_t* sel = nullptr,
+             float* grad_attr = nullptr) {
+    // grad_attr (BWD_FULL, tensor attributes of <= 8 slots): [E][k0] in the CALLER's edge order, dL/d edge_attr
     // kt > 0: `edge_attr` is a NODE table [n_nodes][kt] and slot d of an edge's attribute is table[(sel[d] >> 8 ? dst : src)][sel[d] & 255]
     // (row f3: gpde_nnconv_fwd_nodeattr's convention); perm is unused
     // hpart (BWD_LIGHT / BWD_DEFER): the last hidden activations of the in-edges of nodes [0, hpart_nodes) are GIVEN (a partial
@@ -1055,6 +1084,11 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     };
     // MLP backward over rows [e0, e0 + rows): dU_last given (read only), activations H[0 .. n-2] in the
     // workspace, H[n-1] = Hlast
+    if (grad_attr && (phase != BWD_FULL || kt || dims[0] > 8 || P.KP[0] < 8 || !perm)) {
+        gpde_set_error("gpde_nnconv_bwd: the edge-attribute gradient is built for the full backward on an attribute tensor of <= 8 slots");
+        return GPDE_EUNSUPPORTED;
+    }
+    int mlp_e0 = 0;                          // first CSR slot of the chunk mlp_backward is working on
     auto mlp_backward = [&](const float* dUlast, int rows) -> int {
         const float* dUc = dUlast;
         float* bufs[2] = {F(P.off_dU[0]), F(P.off_dU[1])};
@@ -1067,6 +1101,9 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         for (int l = n - 1; l >= 1; --l) {
             const int Kl = P.KP[l], Kin = P.KP[l - 1];
             int rc2;
+            if (l == 1 && grad_attr)         // dU_1 is complete here: the gradient of the attributes through W_1
+                hipLaunchKernelGGL(k_grad_attr, dim3((rows + 3) / 4), dim3(T), 0, st, dUc, Kl, F(P.off_wp[1]), Kin, perm, mlp_e0, rows,
+                                   dims[0], grad_attr);
             if (l == 1 && dims[0] <= 8 && Kin >= 8 && Kin % 4 == 0 && Kl % 4 == 0 && rows >= 1024 && !getenv("GPDE_BWD_DW1_GEMM")) {
                 // dW_1 and db_1 from one pass over dU_1 (k_dw_first; attribute slots beyond k0 are zero columns of H_0)
                 const int cb = (Kl + 255) / 256;
@@ -1256,7 +1293,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 if (ordered) hipLaunchKernelGGL(k_dx_reduce, dim3((N + 3) / 4), dim3(T), 0, st, F(P.off_dxe), src_rowptr, src_slots, N, e0, e1, dx);
             }
             // MLP backward over the chunk's edges
-            if (phase == BWD_FULL) { if ((rc = mlp_backward(dUc, rows)) != GPDE_OK) return rc; }
+            if (phase == BWD_FULL) { mlp_e0 = e0; if ((rc = mlp_backward(dUc, rows)) != GPDE_OK) return rc; }
         }
         na = nb;
     }
@@ -1390,6 +1427,25 @@ extern "C" int gpde_nnconv_bwd_deferred(const float* x_stack, const float* grad_
                     aggr, nullptr, nullptr, grad_W, grad_b, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
                     (hipStream_t)stream_, nullptr, nullptr, nullptr, n_defer, x_stack, grad_out_stack,
                     hidden_nodes > 0 ? hidden_part : nullptr, hidden_nodes);
+}
+
+// gpde_nnconv_bwd_z / gpde_nnconv_bwd_ordered that also writes dL/d edge_attr ([E][k0], the caller's edge order): what autograd
+// hands `pseudo` when it requires a gradient (nn_conv.py:273-275 through DenseNet, utilities.py:223-227).
+extern "C" int gpde_nnconv_bwd_attr(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges, const int32_t* rowptr,
+                                    const int32_t* src, const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host,
+                                    const int32_t* src_rowptr, const int32_t* src_slots, int n_layers, const int32_t* dims,
+                                    const float* const* W, const float* const* b, const float* root, int aggr, const float* grad_out,
+                                    const float* z_saved, float* grad_x, float* grad_edge_attr, float* const* grad_W,
+                                    float* const* grad_b, float* grad_root, float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || !dims || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws || !grad_W || !grad_b ||
+        (n_nodes > 0 && (!x || !grad_x)) || (n_edges > 0 && (!edge_attr || !src || !dst || !perm || !grad_edge_attr))) {
+        gpde_set_error("gpde_nnconv_bwd_attr: null/negative argument");
+        return GPDE_EINVAL;
+    }
+    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_attr: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
+    return bwd_impl(BWD_FULL, x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims, W, b, root, aggr,
+                    grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream_,
+                    src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, n_edges > 0 ? grad_edge_attr : nullptr);
 }
 
 extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,

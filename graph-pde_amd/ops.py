@@ -682,9 +682,10 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
                         weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
                         root: Optional[torch.Tensor], aggr: str, grad_out: torch.Tensor,
                         need_root: bool = True, need_bias: bool = True,
-                        ws: Optional[torch.Tensor] = None, z_saved: Optional[torch.Tensor] = None):
+                        ws: Optional[torch.Tensor] = None, z_saved: Optional[torch.Tensor] = None, need_attr: bool = False):
     """One gpde_nnconv_bwd call on the current stream (`z_saved`: the keep-Z forward's buffer -> gpde_nnconv_bwd_z).
-    Returns (grad_x, [grad_W_l], [grad_b_l or None], grad_root or None, grad_bias or None)."""
+    Returns (grad_x, [grad_W_l], [grad_b_l or None], grad_root or None, grad_bias or None); with `need_attr` a sixth element,
+    dL/d edge_attr [E, k0] in the caller's edge order (gpde_nnconv_bwd_attr)."""
     lib = _lib.lib()
     for t, nm in ((x, "x"), (edge_attr, "edge_attr"), (grad_out, "grad_out")):
         _require_cuda(t, nm)
@@ -696,7 +697,11 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
     dims_c = _lib.dims_array(dims)
     x = x.detach().contiguous()
     is_na = isinstance(edge_attr, NodeAttr)
-    if not is_na:
+    if need_attr:
+        if is_na or dims[0] > 8:
+            raise NotImplementedError("the edge-attribute gradient is built for attribute tensors of <= 8 slots")
+        edge_attr, perm = edge_attr.detach().contiguous(), csr.perm      # the caller's rows: the gradient goes back by perm
+    elif not is_na:
         edge_attr, perm = attr_in_slot_order(csr, edge_attr.detach().contiguous())
     grad_out = grad_out.detach().contiguous().float()
     ws_ = [w.detach().contiguous() for w in weights]
@@ -728,6 +733,19 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
         _lib.check(rc, "gpde_nnconv_bwd_na")
         _lib.n_native_calls += 1
         return gx, gW, gb, groot, gbias
+    if need_attr:
+        ga = torch.zeros(e, dims[0], dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.gpde_nnconv_bwd_attr(x.data_ptr(), n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), csr.src.data_ptr(),
+                                          csr.dst.data_ptr(), perm.data_ptr(), rph.data_ptr(), None if srp is None else srp.data_ptr(),
+                                          None if ssl is None else ssl.data_ptr(), nl, dims_c, arr(ws_), arr(bs_),
+                                          None if root_c is None else root_c.data_ptr(), _AGGR[aggr], grad_out.data_ptr(),
+                                          None if z_saved is None else z_saved.data_ptr(), gx.data_ptr(), ga.data_ptr(), arr(gW), arr(gb),
+                                          None if groot is None else groot.data_ptr(), None if gbias is None else gbias.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "gpde_nnconv_bwd_attr")
+        _lib.n_native_calls += 1
+        return gx, gW, gb, groot, gbias, ga
     if z_saved is not None:
         with torch.cuda.device(dev):
             rc = lib.gpde_nnconv_bwd_z(x.data_ptr(), n, edge_attr.data_ptr(), None, e, csr.rowptr.data_ptr(), csr.src.data_ptr(),

@@ -194,6 +194,15 @@ int gpde_nnconv_bwd_ordered(const float* x, int64_t n_nodes, const float* edge_a
                             const float* root, int aggr, const float* grad_out, float* grad_x,
                             float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias,
                             void* ws, size_t ws_bytes, void* stream);
+/* The same (z_saved: NULL or the keep-Z forward's buffer) that also writes grad_edge_attr [E][k0] = dL/d edge_attr in the
+ * caller's edge order - what autograd hands `pseudo` when it requires a gradient (no reference script asks for it).  Attribute
+ * tensors of <= 8 slots. */
+int gpde_nnconv_bwd_attr(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges, const int32_t* rowptr,
+                         const int32_t* src, const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host,
+                         const int32_t* src_rowptr, const int32_t* src_slots, int n_layers, const int32_t* dims,
+                         const float* const* W, const float* const* b, const float* root, int aggr, const float* grad_out,
+                         const float* z_saved, float* grad_x, float* grad_edge_attr, float* const* grad_W,
+                         float* const* grad_b, float* grad_root, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
 /* src_slots = CSR slots 0..E-1 stably sorted by their source node, src_rowptr[j] = first position of source j;
  * `src` is the array gpde_csr_from_coo wrote; workspace: gpde_csr_workspace_bytes(n_edges, n_nodes). */
 int gpde_csr_source_order(const int32_t* src, int64_t n_edges, int64_t n_nodes, int32_t* src_rowptr,
@@ -350,7 +359,7 @@ int gpde_nnconv_fwd_mixed_keepz(const float* x, int64_t n_nodes, const float* ed
  * from the hidden activations of gpde_hidden_fwd ([E][4096] fp32 in CSR slot order, the last Linear's bias folded in),
  * and gpde_nnconv_fwd_edgeweights_group then runs any number of INDEPENDENT calls in one launch each doing gather,
  * message (nn_conv.py:275), aggregation (add / mean / max) and update() (nn_conv.py:277-282; + opt-in residual and
- * ReLU, the callers' `relu(x + conv(x))` glue) in a single streaming kernel.  Inference only (no backward). */
+ * ReLU, the callers' `relu(x + conv(x))` glue) in a single streaming kernel (forward; its backward pair follows below). */
 size_t gpde_edge_weights_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims);
 int gpde_edge_weights_fwd(const float* hidden /* [E][K2P], gpde_hidden_fwd */, int64_t n_edges, int n_layers,
                           const int32_t* dims, const void* packed /* gpde_mlp_pack image (k2 padded >= 256), else unused */,

@@ -220,3 +220,49 @@ def test_keep_z_forward_feeds_the_backward(cached, monkeypatch):
     monkeypatch.setattr(ops, "SAVE_Z_BYTES", 1 << 20)
     assert ops.z_buffer(ops.csr_for(ei, n), [6, 256, 256, 4096], d) is None     # over budget -> the backward aggregates itself
     hidden_cache.clear()
+
+
+def test_gradient_of_the_edge_attributes_matches_float64_autograd():
+    """dL/d edge_attr (gpde_nnconv_bwd_attr): the reference's `pseudo` is an ordinary autograd input (nn_conv.py:273-275);
+    no script differentiates it, the module does when asked.  Rows go back in the CALLER's edge order; the other gradients
+    are the bits of the call without it."""
+    import graph_pde_amd as gp
+    from tests.test_host_logic import DenseNet
+    dims, n, e = [6, 256, 256, 4096], 200, 9000
+    x, ei, ea, ws_, bs_, root, bias, gout = _case(dims, n, e, 17)
+    d = dev()
+    xs = x.double().requires_grad_(True)
+    at = ea.double().requires_grad_(True)
+    Ws = [w.double() for w in ws_]
+    Bs = [b.double() for b in bs_]
+    h = at
+    for l in range(3):
+        h = torch.nn.functional.linear(h, Ws[l], Bs[l])
+        if l < 2:
+            h = torch.relu(h)
+    m = torch.matmul(xs[ei[0]].unsqueeze(1), h.view(-1, 64, 64)).squeeze(1)
+    out = torch.zeros(n, 64, dtype=torch.float64).index_add(0, ei[1], m)
+    out = out / torch.bincount(ei[1], minlength=n).clamp(min=1).double().unsqueeze(1) + xs @ root.double() + bias.double()
+    (out * gout.double()).sum().backward()
+    csr = ops.build_csr(ei.to(d), n)
+    args = (x.to(d), csr, ea.to(d), [w.to(d) for w in ws_], [b.to(d) for b in bs_], root.to(d), "mean", gout.to(d))
+    plain = ops.nnconv_backward_raw(*args)
+    got = ops.nnconv_backward_raw(*args, need_attr=True)
+    got2 = ops.nnconv_backward_raw(*args, need_attr=True)
+    torch.cuda.synchronize()
+    assert rel_l2(got[5].cpu(), at.grad) <= TOL, rel_l2(got[5].cpu(), at.grad)
+    assert torch.equal(got[5], got2[5]) and torch.equal(got[0], plain[0])
+    for l in range(3):
+        assert torch.equal(got[1][l], plain[1][l]) and torch.equal(got[2][l], plain[2][l])
+    # through the module: an edge_attr that requires a gradient takes the direct operator and receives it
+    conv = gp.NNConv_old(64, 64, DenseNet(dims, torch.nn.ReLU), aggr="mean").to(d)
+    lin = ops.mlp_linears(conv.nn)
+    with torch.no_grad():
+        for l, layer in enumerate(lin):
+            layer.weight.copy_(ws_[l]); layer.bias.copy_(bs_[l])
+        conv.root.copy_(root); conv.bias.copy_(bias)
+    ea_d = ea.to(d).requires_grad_(True)
+    for _ in range(3):                                      # repeated calls: the caches step aside for a differentiated edge_attr
+        y = conv(x.to(d), ei.to(d), ea_d)
+    (y * gout.to(d)).sum().backward()
+    assert rel_l2(ea_d.grad.cpu(), at.grad) <= TOL
