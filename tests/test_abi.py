@@ -148,6 +148,32 @@ def test_weconv_descriptor_layout_matches_the_header():
     assert l.gpde_edge_weights_workspace_bytes(1000, 3, _lib.dims_array([6, 256, 256, 4096])) >= 8000
 
 
+def test_node_attr_descriptor_layout_matches_the_header():
+    """ctypes mirror of `GpdeNodeAttr` (include/gpde.h): pointer + 2 int32 + 8 int32 = 48 bytes; ops.NodeAttr.c_struct fills it
+    as the header says; the `_na` entry points validate on the host."""
+    import torch
+    from graph_pde_amd import ops
+    src = open(os.path.join(REPO, "include", "gpde.h")).read()
+    body = re.search(r"typedef struct GpdeNodeAttr \{(.*?)\} GpdeNodeAttr;", src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"(\w+)(?:\[\d+\])?;", body)
+    assert names == [f[0] for f in _lib.GpdeNodeAttr._fields_]
+    assert ctypes.sizeof(_lib.GpdeNodeAttr) == 48
+    na = ops.NodeAttr.darcy(torch.zeros(10, 2), torch.zeros(10))
+    c = na.c_struct()
+    assert (c.stride, c.n_slots) == (3, 6) and list(c.sel)[:6] == [0, 1, 256, 257, 2, 258] and c.table == na.table.data_ptr()
+    l = _lib.lib()
+    dims = _lib.dims_array([6, 256, 256, 4096])
+    assert l.gpde_hidden_fwd_na(None, 5, None, None, None, 5, 3, dims, None, 1, None, None, None) == -1
+    assert b"GpdeNodeAttr" in l.gpde_last_error()
+    c.n_slots = 5                                                # disagrees with dims[0]
+    assert l.gpde_nnconv_bwd_na(None, 0, ctypes.byref(c), 0, None, None, None, None, None, None, 3, dims, None, None, None, 1, None,
+                                None, None, None, None, None, None, None, 0, None) == -1
+    assert l.gpde_nnconv_bwd_deferred_supported(3, dims) == 1 and l.gpde_nnconv_bwd_deferred_supported(3, _lib.dims_array([6, 64, 128, 4096])) == 0
+    assert l.gpde_nnconv_bwd_deferred_workspace_bytes(100, 5000, 3, dims, 6) > l.gpde_nnconv_bwd_workspace_bytes(100, 5000, 3, dims)
+    assert l.gpde_gather_rows(None, 6, None, -1, None, None) == -1 and l.gpde_gather_rows(None, 6, None, 0, None, None) == 0
+
+
 def test_cell_list_queries_validate_on_the_host():
     l = _lib.lib()
     D = ctypes.c_double * 2

@@ -204,6 +204,67 @@ def test_hidden_cache_key_and_policy_bookkeeping(monkeypatch):
     torch.save(conv, buf)                                                              # nothing rides on the module
 
 
+def test_virtual_hidden_node_policy_host_logic(monkeypatch):
+    """hidden_cache.lookup_deferred, on CPU tensors - the virtual-H node holds no numbers, so the policy runs
+    without a GPU: a module seen repeating whose H is over budget gets ONE node per forward, shared by its applications until
+    its backward ran; a once-per-forward module drops out; kernel MLPs outside the deferred form, `off`, no-grad calls and a
+    differentiated edge_attr never get one."""
+    from graph_pde_amd import hidden_cache, ops
+
+    class FakeCsr:
+        n_edges, n_nodes = 3000, 50
+        rowptr_host = torch.arange(0, 3060, 60, dtype=torch.int32)
+    csr = FakeCsr()
+    conv = gp.NNConv_old(64, 64, DenseNet([6, 256, 256, 4096], torch.nn.ReLU), aggr="mean")
+    lin = ops.mlp_linears(conv.nn)
+    w, b = [l.weight for l in lin], [l.bias for l in lin]
+    pm = type("Pm", (), {"dims": (6, 256, 256, 4096)})()
+    ea = torch.randn(3000, 6)
+    assert ops.deferred_supported([6, 256, 256, 4096]) and not ops.deferred_supported([6, 64, 128, 4096])
+    assert ops.deferred_layers_padded(1) == 4 and ops.deferred_layers_padded(5) == 6 and ops.deferred_layers_padded(6) == 6
+    monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", 0)             # H never fits
+    monkeypatch.setattr(hidden_cache, "MODE", "auto")
+    monkeypatch.setattr(hidden_cache, "DEFER_MODE", "auto")
+    hidden_cache.clear()
+    assert hidden_cache.defer_possible(ea, pm, w, b, "mean") and not hidden_cache.defer_possible(ea, pm, w, b, "max")
+
+    def call():
+        assert hidden_cache.lookup(conv, ea, csr, pm, w, b, allow_partial=True) is None
+        return hidden_cache.lookup_deferred(conv, ea, csr, pm, w, b, "mean")
+    assert call() is None                                             # first sight of the key: the plain operator
+    d2, d3 = call(), call()
+    assert d2 is not None and d3[0] is d2[0] and d3[1] is d2[1]      # second and third application share one node
+    assert d2[0].requires_grad and tuple(d2[0].shape) == (1,) and d2[1].valid and d2[1].stash == []
+    assert hidden_cache.stats["deferred_builds"] == 1 and hidden_cache.stats["deferred_hits"] == 1
+    d2[1].valid = False                                               # its backward ran (DeferredHiddenFunction.backward)
+    d4 = call()
+    assert d4 is not None and d4[1] is not d2[1]                      # next forward: a fresh node from the FIRST call on
+    assert call()[1] is d4[1]
+    d4[1].valid = False
+    with torch.no_grad():
+        w[0].mul_(1.0)                                                # optimizer step; this forward applies the module once ...
+    assert call() is not None
+    hidden_cache._entries[conv].dtoken.valid = False
+    with torch.no_grad():
+        w[0].mul_(1.0)
+    assert call() is None and not hidden_cache._entries[conv].repeats  # ... so the next forward's call is a stranger again
+    # never: switched off, no gradient wanted, differentiated attributes, MLP outside the deferred form
+    hidden_cache.clear()
+    monkeypatch.setattr(hidden_cache, "DEFER_MODE", "off")
+    call(); assert call() is None
+    monkeypatch.setattr(hidden_cache, "DEFER_MODE", "auto")
+    hidden_cache.clear()
+    with torch.no_grad():
+        call(); assert call() is None
+    ea_g = ea.clone().requires_grad_(True)
+    assert not hidden_cache.defer_possible(ea_g, pm, w, b, "mean")
+    small = gp.NNConv_old(64, 64, DenseNet([6, 64, 128, 4096], torch.nn.ReLU), aggr="mean")
+    ls = ops.mlp_linears(small.nn)
+    pm_s = type("Pm", (), {"dims": (6, 64, 128, 4096)})()
+    assert not hidden_cache.defer_possible(ea, pm_s, [l.weight for l in ls], [l.bias for l in ls], "mean")
+    hidden_cache.clear()
+
+
 def test_node_attr_recipe_is_the_reference_edge_attr():
     from graph_pde_amd import synth
     """NodeAttr.darcy(pos, a).materialize(edge_index) == [pos_src, pos_dst, a_src, a_dst]
