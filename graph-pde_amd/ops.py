@@ -459,7 +459,10 @@ def z_buffer(csr: Csr, dims: Sequence[int], device) -> Optional[torch.Tensor]:
     """Zeroed [N, 64 * K2P] buffer for the keep-Z forward (gpde_nnconv_fwd_keepz), or None when it does not pay / fit:
     the forward forms Z_i = sum_e x_j (x) h_e anyway and the backward's dW_3 needs exactly that - keeping it
     (256 KiB per node at k2 = 1024: 15 GB on the 241^2 graph) saves the backward one aggregation pass over the 4 KiB-per-edge
-    hidden activations.  Graphs of low in-degree (the per-edge last layer, §3e) and buffers above GPDE_SAVE_Z_GB are skipped."""
+    hidden activations.  Graphs of low in-degree (the per-edge last layer, §3e) and buffers above GPDE_SAVE_Z_GB are skipped, and
+    (round 4) large buffers are kept only while GPDE_SAVE_Z_RESERVE_GB of the device stay free afterwards.  Precision note: with
+    a kept Z, dW_3 = sum_i gT_i (x) Z_i uses the forward's Z (split-f16 aggregation from 32768 edges on, ~2^-21 per product);
+    without it the backward re-aggregates on fp32 MFMA - both inside the gradient tolerance (tests/test_gpu_bwd.py)."""
     nbytes = csr.n_nodes * WIDTH * hidden_width(dims) * 4
     if SAVE_Z_BYTES <= 0 or nbytes > SAVE_Z_BYTES or csr.n_edges < 32 * csr.n_nodes:
         return None

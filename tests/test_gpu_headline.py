@@ -143,3 +143,22 @@ def test_headline_attributes_follow_the_recipe_on_every_edge_and_node_table_kern
     y_n = ops.nnconv_forward_nodeattr_raw(x, csr, na, pm, root, bias, "mean")
     torch.cuda.synchronize()
     assert torch.equal(y_t, y_n), rel_l2(y_n.cpu(), y_t.cpu())
+    # the slot-order copy (native gpde_gather_rows, round 4) and a row partition of the whole list (parallel.partition_rows:
+    # filtered in 2^24-edge pieces) at this size, both against the node table
+    from graph_pde_amd import parallel
+    srt, ident = ops.attr_in_slot_order(csr, ea)
+    assert srt.data_ptr() != ea.data_ptr() and torch.equal(ident, torch.arange(e, dtype=torch.int32, device=d))
+    slot_ei = csr.edge_index
+    for lo in range(0, e, 1 << 24):
+        hi = min(lo + (1 << 24), e)
+        assert torch.equal(na.materialize(slot_ei[:, lo:hi]), srt[lo:hi]), (lo, hi)
+    del slot_ei, srt
+    part = parallel.partition_rows(ei, ea, n, rank=1, world=2)
+    assert 0.49 * e <= part.n_edges <= 0.51 * e and bool((part.edge_index[1] >= part.lo).all())
+    for lo in range(0, part.n_edges, 1 << 24):
+        hi = min(lo + (1 << 24), part.n_edges)
+        assert torch.equal(na.materialize(part.edge_index[:, lo:hi]), part.edge_attr[lo:hi]), (lo, hi)
+    # the same block built from the positions alone (partition_rows_by_position) holds the same rows up to the lattice ties
+    # (float64 distances here, exact integers in synth.darcy_graph: pairs at exactly r may differ)
+    pp = parallel.partition_rows_by_position(pos, r, na, rank=1, world=2)
+    assert abs(pp.n_edges - part.n_edges) <= 2e-3 * part.n_edges and abs(pp.lo - part.lo) <= 2
