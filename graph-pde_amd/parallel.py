@@ -263,13 +263,20 @@ def partition_rows_by_position(pos: torch.Tensor, r: float, node_attr=None, rank
 
 
 def _gather_blocks(local: torch.Tensor, part: RowPartition) -> torch.Tensor:
+    """All ranks' row blocks, in rank order, as one [N, ...] tensor: ONE flat all-gather of equal-size (padded) pieces into a
+    single buffer (RCCL / gloo `all_gather_into_tensor`); the padding rows are cut out only when the blocks differ in size."""
     sizes = [part.bounds[r + 1] - part.bounds[r] for r in range(part.world)]
     mx = max(sizes)
-    pad = local.new_zeros((mx,) + tuple(local.shape[1:]))            # equal-size pieces: one plain (RCCL) all-gather
-    pad[:local.shape[0]].copy_(local)
-    bufs = [torch.empty_like(pad) for _ in range(part.world)]
-    dist.all_gather(bufs, pad, group=part.group)
-    return torch.cat([bufs[r][:sizes[r]] for r in range(part.world)], 0)
+    if local.shape[0] == mx:
+        pad = local.contiguous()
+    else:
+        pad = local.new_zeros((mx,) + tuple(local.shape[1:]))
+        pad[:local.shape[0]].copy_(local)
+    buf = local.new_empty((part.world * mx,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(buf, pad, group=part.group)
+    if min(sizes) == mx:
+        return buf
+    return torch.cat([buf[r * mx: r * mx + sizes[r]] for r in range(part.world)], 0)
 
 
 class _GatherRows(torch.autograd.Function):

@@ -37,6 +37,12 @@ def stage(src_root: str = SRC, dst: str = DST, everything: bool = False) -> int:
             if f.endswith(".py") and (everything or f in NEEDED[proj]):
                 shutil.copyfile(os.path.join(src, f), os.path.join(dst, proj, f))
                 n += 1
+    if n:
+        with open(os.path.join(dst, "STAGED_REFERENCE_FILES.txt"), "w") as fh:
+            fh.write("Byte-identical copies of files of the reference (neuraloperator/graph-pde), staged by scripts/stage_reference.py from\n"
+                     "/root/reference so that tests/test_gpu_reference_scripts.py can EXECUTE the unmodified scripts on a GPU box that has no\n"
+                     "/root/reference.  Test input only: git-ignored (never committed), never imported by graph-pde_amd/, bench.py or the\n"
+                     "oracle.  Remove with `python scripts/stage_reference.py --remove`.\n")
     return n
 
 

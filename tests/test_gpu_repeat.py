@@ -160,3 +160,75 @@ def test_backward_does_not_depend_on_workgroup_timing(which, variant, f32, monke
     monkeypatch.setenv("GPDE_DEBUG_SKEW_US", "150")
     for it in range(3):
         _assert_same(ref, _bwd(case), f"skewed run {it}")
+
+
+# ---- round 4: the depth-deferred pair and the per-edge-weight pair under the same treatment ------------------------------
+def _deferred_pair(case, L=4):
+    x, csr, ea, ws_, bs_, root, gout = case
+    g = torch.Generator(device=x.device).manual_seed(77)
+    xs = [torch.randn(x.shape, device=x.device, generator=g) * (1.0 + l) for l in range(L)]
+    gs = [torch.randn(x.shape, device=x.device, generator=g) * (0.5 ** l) for l in range(L)]
+
+    def run():
+        light = ops.nnconv_backward_light_raw(x, csr, ea, ws_, bs_, root, "mean", gout)
+        dW, db = ops.nnconv_backward_deferred_raw(xs, gs, csr, ea, ws_, bs_, "mean")
+        torch.cuda.synchronize()
+        return [t for t in light if t is not None] + list(dW) + list(db)
+    return run
+
+
+@pytest.mark.parametrize("which", ["random_256", "lattice41_1024"])
+def test_deferred_backward_is_reproducible_under_memory_pressure_and_skew(which, monkeypatch):
+    """gpde_nnconv_bwd_light + gpde_nnconv_bwd_deferred (gather GEMM on per-node images, tile list, ordered dx): 100 repeats
+    with 1 GiB fills between calls, then with odd column slices of every GEMM launch started 150 us late - the bits of the
+    first call every time."""
+    d = torch.device("cuda:0")
+    case = _bwd_case_random(d) if which == "random_256" else _bwd_case_lattice(d)
+    run = _deferred_pair(case)
+    ref = [t.clone() for t in run()]
+
+    def same(cur, what):
+        for k, (a, b) in enumerate(zip(ref, cur)):
+            if not torch.equal(a, b):
+                dif = (a != b).nonzero()
+                raise AssertionError(f"{what}: output {k}: {dif.shape[0]} of {a.numel()} entries differ, rel-L2 {float((a - b).norm() / a.norm()):.2e}")
+    for it in range(100):
+        if it % 2:
+            t = torch.randn(256 << 20, device=d) * (10.0 ** ((it % 7) - 3))
+            del t
+        else:
+            _poison(d, FILLS[(it // 2) % len(FILLS)])
+        same(run(), f"run {it}")
+    monkeypatch.setenv("GPDE_DEBUG_SKEW_US", "150")
+    for it in range(3):
+        same(run(), f"skewed run {it}")
+
+
+def test_edge_weight_backward_is_reproducible_under_memory_pressure():
+    """gpde_nnconv_bwd_edgeweights + gpde_edge_weights_bwd (streaming kernel, split GEMMs incl. the small-E transposed form):
+    100 repeats with fills between calls return the bits of the first call."""
+    d = torch.device("cuda:0")
+    torch.manual_seed(9)
+    n, e, dims = 700, 2100, [4, 256, 256, 4096]
+    ei = torch.stack([torch.randint(0, n, (e,)), torch.randint(0, n - 4, (e,))]).to(d)
+    csr = ops.build_csr(ei, n)
+    x, g = torch.randn(n, 64, device=d), torch.randn(n, 64, device=d)
+    we = torch.randn(e, 4096, device=d) * 0.03
+    root = torch.randn(64, 64, device=d) * 0.1
+    hidden = torch.relu(torch.randn(e, 256, device=d))
+    w3 = torch.randn(4096, 256, device=d) / 16
+
+    def run():
+        a = ops.nnconv_backward_edgeweights_raw(x, csr, we, root, "mean", g)
+        b = ops.edge_weights_backward_raw(a[1], hidden, dims, w3)
+        torch.cuda.synchronize()
+        return list(a) + list(b)
+    ref = [t.clone() for t in run()]
+    for it in range(100):
+        if it % 2:
+            t = torch.randn(256 << 20, device=d) * (10.0 ** ((it % 7) - 3))
+            del t
+        else:
+            _poison(d, FILLS[(it // 2) % len(FILLS)])
+        for k, (a, b) in enumerate(zip(ref, run())):
+            assert torch.equal(a, b), (it, k, float((a - b).norm() / a.norm()))
