@@ -116,13 +116,33 @@ __global__ void k_scale_g(const float* __restrict__ g, const int32_t* __restrict
     else if (aggr == GPDE_AGGR_MEAN) v = v / (float)deg;
     gT[(size_t)i * GP_W + lane] = v;
 }
-__global__ void k_nbr_sum(const float* __restrict__ x, const int32_t* __restrict__ rowptr,
-                          const int32_t* __restrict__ src, int n0, int nn, float* __restrict__ S) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+// S_i = sum over the in-edges of node i of x_src(e)  (the (sum x_j) . B3 term's operand, and db3 = S (x) gT).  One WORKGROUP per
+// node, its in-edges dealt round-robin to the four waves, eight gathered rows in flight per wave, partials combined in wave
+// order (fixed summation order: bit-reproducible).  (Rounds 1-3: one wave per node walking its ~1,650 in-edges one dependent
+// load at a time - 0.41 s of an 8 s training step on the 241^2 graph, round-4 profile.)
+__global__ __launch_bounds__(256) void k_nbr_sum(const float* __restrict__ x, const int32_t* __restrict__ rowptr,
+                                                 const int32_t* __restrict__ src, int n0, int nn, float* __restrict__ S) {
+    __shared__ float part[4][GP_W];
+    const int i = blockIdx.x, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (i >= nn) return;
+    const int r0 = rowptr[n0 + i], r1 = rowptr[n0 + i + 1];
     float s = 0.f;
-    for (int e = rowptr[n0 + i]; e < rowptr[n0 + i + 1]; ++e) s += x[(size_t)src[e] * GP_W + lane];
-    S[(size_t)i * GP_W + lane] = s;
+    int e = r0 + wave;
+    for (; e + 28 < r1; e += 32) {
+        int j[8];
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) j[q] = src[e + 4 * q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = x[(size_t)j[q] * GP_W + lane];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; e < r1; e += 4) s += x[(size_t)src[e] * GP_W + lane];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0) S[(size_t)i * GP_W + lane] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 // partial column sums: P[split][col] = sum over the split's rows of M[row][col].  A lane owns four consecutive
 // columns (16-byte loads, a wave reads 1 KiB of a row), the four waves interleave rows, four rows in flight per wave:
@@ -1252,7 +1272,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 f.n_groups = groups;
                 if ((rc = gpde_launch_zagg(f, st)) != GPDE_OK) return rc;
             }
-            hipLaunchKernelGGL(k_nbr_sum, dim3((nn + 3) / 4), dim3(T), 0, st, x, rowptr, src, na, nn, S);
+            hipLaunchKernelGGL(k_nbr_sum, dim3(nn), dim3(T), 0, st, x, rowptr, src, na, nn, S);
             // db3[c][o] += S^T gT ;  dW3[c][o][k] += gT^T Z[:, c, :]
             if ((rc = gemm_tn_acc(S, GP_W, GP_W, gT, GP_W, GP_W, nn, F(P.off_db3), GP_W, F(P.off_part), P.part_floats, 1, st)) != GPDE_OK) return rc;
             {
@@ -1260,7 +1280,16 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 g.A = gT; g.lda = GP_W; g.a_kcontig = 0; g.B = Z; g.ldb = GP_W * K2P; g.b_kcontig = 0;
                 g.C = F(P.off_dw3p); g.ldc = K2P; g.M = GP_W; g.N = K2P; g.K = nn; g.accumulate = 1;
                 g.batches = GP_W; g.strideA = 0; g.strideB = K2P; g.strideC = (size_t)GP_W * K2P;
-                if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
+                // narrow kernels (the MGKN levels: K2P = 128 / 256) give 64 - 128 workgroups that each walk all nn nodes: split
+                // the node range (ordered partial reduction: deterministic) until ~512 workgroups are busy
+                int sp = 1;
+                const int wgs = GP_W * ((K2P + 127) / 128);
+                while (sp < 16 && wgs * sp < 512 && (size_t)(sp * 2) * w3n <= P.part_floats && nn / (sp * 2) >= 128) sp *= 2;
+                if (sp > 1) {
+                    g.C = F(P.off_part); g.accumulate = 0; g.splits = sp; g.strideSplit = w3n;
+                    if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
+                    if ((rc = gpde_launch_reduce_splits(F(P.off_part), w3n, sp, w3n, F(P.off_dw3p), 1, st)) != GPDE_OK) return rc;
+                } else if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
             }
             // dZ[i][c][k] = sum_o gT[i][o] W3[c*64+o][k] ;  dS[i][c] = sum_o gT[i][o] b3[c*64+o]
             {
