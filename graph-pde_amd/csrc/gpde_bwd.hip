@@ -451,7 +451,12 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd2_kernel(EdgeBwdArgs a) {
     int* src_s = idx_all + wave * 64;
     int* dst_s = src_s + 32;
 
-    const int g0 = a.e0 + blockIdx.x * 128;                 // first slot of the group
+    // Workgroup b runs on XCD b % 8: XCD x takes the x-th CONTIGUOUS eighth of the groups, so that the groups of one
+    // destination node (3.2 on average at s=121, each reading the node's 256 KiB of dZ) follow each other on one L2 instead
+    // of fetching it into three (the grid is padded to a multiple of 8; FETCH_SIZE before: 41 GB per backward for 24 GB of H)
+    const int grp = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int g0 = a.e0 + grp * 128;                        // first slot of the group
+    if (g0 >= a.e1) return;                                 // padding workgroups (whole workgroup: before any barrier)
     const int g1 = min(g0 + 128, a.e1);
     const int t0 = g0 + wave * 32;                          // this wave's tile (may be empty)
     const int e_last = a.e1 - 1;
@@ -486,7 +491,8 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd2_kernel(EdgeBwdArgs a) {
         const int nodeA = nA0 + 2 * pass;
 #pragma unroll
         for (int nd = 0; nd < 2; ++nd) {
-            const int node = min(nodeA + nd, nB0);          // a missing second node re-reads the first
+            if (nd == 1 && nodeA + 1 > nB0) break;          // no second node in this pass: its buffer is never read (anyB is false)
+            const int node = nodeA + nd;
             const float* g = a.dZ + ((size_t)(node - a.n0) * GP_W) * a.K2P + nc + uq * 4;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -1317,7 +1323,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 const char* fe = getenv("GPDE_EDGE_BWD");          // "1" / "2": force a variant (tests, A/B)
                 const int force = fe ? atoi(fe) : 0;
                 const bool staged = force ? force == 2 : (int64_t)rows >= (int64_t)32 * nn;
-                if (staged) hipLaunchKernelGGL(gpde_edge_bwd2_kernel, dim3((rows + 127) / 128), dim3(T), lds2, st, ea);
+                if (staged) hipLaunchKernelGGL(gpde_edge_bwd2_kernel, dim3(((rows + 127) / 128 + 7) / 8 * 8), dim3(T), lds2, st, ea);
                 else hipLaunchKernelGGL(gpde_edge_bwd_kernel, dim3((rows + 127) / 128), dim3(T), lds, st, ea);
                 if (ordered) hipLaunchKernelGGL(k_dx_reduce, dim3((N + 3) / 4), dim3(T), 0, st, F(P.off_dxe), src_rowptr, src_slots, N, e0, e1, dx);
             }

@@ -251,6 +251,8 @@ struct GpdeGemmF16sArgs {
     int ksplits; size_t cstride;        // split-K (> 1): partial s at C + s * cstride; M <= 4 * 64 * n per launch group
     const float* xc_x; const int32_t* xc_src;   // contract epilogue (per-edge last layer): C = P[N/128][M][64], see the kernel
     int skew_us;                        // test hook (GPDE_DEBUG_SKEW_US): odd column slices start this many us late
+    int no_tile_prefetch;               // A/B hook (GPDE_NT_NO_PREFETCH): per-tile loads as in round 3 (no cross-tile prefetch)
+    int no_ks_xcd;                      // A/B hook (GPDE_TN_NO_KS_XCD): split-K workgroups mapped by row group, not one split per XCD
     // gather form (gpde_launch_gemm_f16s_gather; set by that launcher only): A = stack of node tables, B per destination node
     const int32_t* g_src;               // [M] source node of each row (CSR slot)
     const int32_t* g_tile;              // [g_ntiles][4]: destination node (chunk-local), first row, end row, 0

@@ -20,6 +20,7 @@
 //     < 2^-20 as in the forward.
 // Rows are independent: tiles of 64 rows are dealt round-robin to the waves, no node alignment, no aggregation.
 #include "gpde_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -60,6 +61,14 @@ __global__ void k_row_scale_kernel(const float* __restrict__ A, int M, int K, in
         isc[row] = ok ? __int_as_float((eb - 13) << 23) : 1.f;
     }
 }
+
+#ifdef GPDE_NT_TIMING      // developer probe (scripts/nt_timing.py): clock64 ticks per phase summed over waves and tiles;
+                           // [0..4] plain row tiles, [5..9] split-K (dW_2), [10..14] gather: prologue, K loop, drain, epilogue, tiles
+__device__ unsigned long long gpde_nt_tm[16];
+#define NT_MARK(acc) do { const long long tm1_ = clock64(); acc += tm1_ - tm0_; tm0_ = tm1_; } while (0)
+#else
+#define NT_MARK(acc) do { } while (0)
+#endif
 
 constexpr int A_SLOT = NW * TE * 128;      // 32 KiB: one 32-k chunk of the workgroup's 256 rows (fp32)
 
@@ -105,11 +114,22 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
     float* Cout = a.C;
     if (a.ksplits > 1) {
         const int nq = (ntile + NW - 1) / NW;
-        const int ks = group / nq;
+        int ks = group / nq;
+        tgroup = group % nq;
+        if (a.ksplits % 8 == 0 && a.n_groups == nq * a.ksplits && !a.no_ks_xcd) {
+            // One K range per XCD (workgroup b runs on XCD b % 8): the nq row quads of a K split read the same B image
+            // pieces and its ns column slices the same A rows.  With the row-group mapping above the quads of a split sat
+            // on different XCDs and every XCD fetched the split's B image for itself (rocprofv3 FETCH_SIZE of the dW_2
+            // GEMM at s=121: 13.2 GB per launch for 5.2 GB of operands, profiles/traffic_r04_bwd.json).  Which workgroup
+            // computes a (split, quad, slice) tile does not enter its arithmetic: results are bit-identical.
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = nq * ns;
+            ks = xcd + 8 * (j / per);
+            slice = (j % per) % ns;
+            tgroup = (j % per) / ns;
+        }
         if (ks >= a.ksplits) return;
         NKC = NKCT / a.ksplits;
         kc0 = ks * NKC;
-        tgroup = group % nq;
         tstride = nq;
         rounds = 1;
         Cout += (size_t)ks * a.cstride;
@@ -186,6 +206,16 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
     int slot = 0;           // B ring slot of the current chunk
     int aslot = 0;          // A ring slot of the current chunk
 
+    // Plain (non-gather) row tiles, one after the other per wave: the A chunks 0..2, the row scales and (bit masks) the
+    // mask words of the NEXT tile are requested before this tile's results are stored, so that a tile boundary costs one
+    // exposed memory round trip instead of four (A chunk 0, the scales, two batches of mask words), none of them queued
+    // behind the tile's 128 stores (vmcnt retires in order).  `pref`: this tile's A chunks 0..2 are already in the ring.
+    bool pref = false, nxt_ok = false;
+    [[maybe_unused]] float scn[2] = {1.f, 1.f}, iscn = 1.f;
+    const int drows = tstride * NW * TE;                            // rows between a wave's consecutive tiles
+#ifdef GPDE_NT_TIMING
+    long long tm_pro = 0, tm_loop = 0, tm_drain = 0, tm_epi = 0, tm0_ = clock64();
+#endif
     for (int t = 0; t < rounds; ++t) {
         int r0, rmax, rend;                                        // first row, last loadable row, end of the stored rows
         if (GATHER) {
@@ -200,18 +230,25 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
         } else {
             const int tile = (t * tstride + tgroup) * NW + wave;
             r0 = tile * TE; rmax = a.M - 1; rend = a.M;            // may lie beyond M: loads clamp, stores are masked
+            pref = nxt_ok;
+            nxt_ok = a.ksplits <= 1 && !a.no_tile_prefetch && t + 1 < rounds && (long)r0 + drows + TE <= (long)a.M;   // the next tile is a full one
         }
         // GATHER: the source nodes of the wave tile's 64 rows in ONE load (lane = row), handed round by ds_bpermute - ten
         // dependent index loads per tile otherwise
         int srcv = 0;
         if (GATHER) srcv = a.g_src[min(r0 + lane, rmax)];
         float sc[2];
+        if (!GATHER && pref) {
+            sc[0] = scn[0]; sc[1] = scn[1];
+            Es[lane] = iscn;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int row = min(r0 + 32 * e + l31, rmax);
-            const int srow = GATHER ? __shfl(srcv, 32 * e + l31) : row;
-            sc[e] = a.sc[srow];
-            if (h == 0) Es[32 * e + l31] = a.isc[srow];
+            for (int e = 0; e < 2; ++e) {
+                const int row = min(r0 + 32 * e + l31, rmax);
+                const int srow = GATHER ? __shfl(srcv, 32 * e + l31) : row;
+                sc[e] = a.sc[srow];
+                if (h == 0) Es[32 * e + l31] = a.isc[srow];
+            }
         }
         // A chunk DMA: piece j = rows 8j .. 8j+7 of the wave's tile in FULL 128-byte lines (8 lanes per row), the
         // 16-byte units of a row XOR-swizzled through the SOURCE address (unit u of row r is stored at u ^ ((r>>1)&7):
@@ -240,16 +277,18 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                     raw[e][q] = *(const f32x4*)(l + (32 * e + l31) * 128 + (((2 * q + h) ^ sw) << 4));
         };
         const int as1 = aslot + 1 == NS ? 0 : aslot + 1, as2 = as1 + 1 == NS ? 0 : as1 + 1;
-        issue_a(aslot, kc(0));
-        issue_a(as1, kc(1));
-        issue_a(as2, kc(2));
+        if (GATHER || !pref) {
+            issue_a(aslot, kc(0));
+            issue_a(as1, kc(1));
+            issue_a(as2, kc(2));
+        }
         h8 bhi[4], blo[4];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             bhi[nb] = *(const h8*)(ring + slot * TILE_B + nb * 4096 + boff[0]);
             blo[nb] = *(const h8*)(ring + slot * TILE_B + nb * 4096 + (boff[0] ^ 64));
         }
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // chunk 0 of A landed (1 and 2 may still fly)
+        if (GATHER || !pref) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // chunk 0 of A landed (1 and 2 may still fly)
         __builtin_amdgcn_sched_barrier(0);
         u4 ahi[2][2][2], alo[2][2][2];                            // [chunk parity][edge block][k16 step]
         f32x4 raw[2][4];
@@ -264,9 +303,10 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                 ahi[0][e][p >> 2][p & 3] = ph;
                 alo[0][e][p >> 2][p & 3] = pl;
             }
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // chunk 1 of A landed (converted during chunk 0)
+        if (GATHER || !pref) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // chunk 1 of A landed (converted during chunk 0)
         __builtin_amdgcn_sched_barrier(0);
         unsigned cph = 0, ct0 = 0, ct1 = 0;
+        const size_t nxt_a = (size_t)drows * a.lda;              // the same lanes' rows of the wave's next tile (floats)
 
         // one chunk; PAR = c & 1 selects the operand buffers (static: the loop is unrolled by two)
         auto chunk = [&](auto par_tag, int c) {
@@ -281,9 +321,11 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
             char* ldst = ring + slot2 * TILE_B + wave * 4096;
             const char* rb0 = ring + slot * TILE_B;
             const char* rb1 = ring + slot1 * TILE_B;
-            const size_t c3 = aofs(kc(min(c + 3, NKC - 1)));          // A(c + 3) (clamped at the tile's end: unused) -> A(c)'s slot
+            // A(c + 3) -> A(c)'s slot.  Beyond the tile's end: chunks 0..2 of the wave's NEXT tile when that is a full tile
+            // of plain rows (nxt_ok), else a clamped re-read that nobody uses
+            const size_t c3 = (!GATHER && nxt_ok && c + 3 >= NKC) ? aofs(kc(c + 3 - NKC)) + nxt_a : aofs(kc(min(c + 3, NKC - 1)));
             char* adst = awave + aslot * A_SLOT;
-            read_a(an1, raw);
+            read_a(an1, raw);      // (reading it one barrier earlier was tried in round 4: no gain, 71.0k vs 70.0k ticks per K loop)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const char* rn = (m == 0) ? rb0 : rb1;
@@ -336,12 +378,26 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
             slot = slot1;
             aslot = an1;
         };
+        NT_MARK(tm_pro);
         for (int c = 0; c < NKC; c += 2) {
             chunk(std::integral_constant<int, 0>{}, c);
             chunk(std::integral_constant<int, 1>{}, c + 1);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the clamped tail pieces: nothing may land in the ring later
+        NT_MARK(tm_loop);
+        // requested before the drain below, used after it: the mask words of this tile's rows (lane = row) and the next
+        // tile's row scales
+        [[maybe_unused]] u4 mw = {0u, 0u, 0u, 0u};
+        if constexpr (!GATHER) {
+            if (a.maskbits && !a.xc_x) mw = *(const u4*)(a.maskbits + (size_t)min(r0 + lane, rmax) * a.ldmb + slice * (GP_TN / 32));
+            if (nxt_ok) {
+                scn[0] = a.sc[r0 + drows + l31];
+                scn[1] = a.sc[r0 + drows + 32 + l31];
+                iscn = a.isc[r0 + drows + lane];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tail pieces: nothing may land in the ring later
         __builtin_amdgcn_sched_barrier(0);
+        NT_MARK(tm_drain);
 
         // ---- un-scale, mask, store --------------------------------------------------------------------------
         // The 64 mask words of an edge block are loaded as ONE batch (rows clamped, no branches) before the first
@@ -379,23 +435,43 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                 if (r0 + TE <= rend) store_rows(std::true_type{});
                 else store_rows(std::false_type{});
             }
+            NT_MARK(tm_epi);
             continue;
         }
-        const bool has_mask = a.mask != nullptr || a.maskbits != nullptr;
+        const bool has_mask = a.mask != nullptr;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
+            if constexpr (!GATHER) if (a.maskbits) {
+                // ReLU mask as bits (the first hidden layer is never materialised, GpdeFirstLayerSpec): row rr's four words sit
+                // in lane rr of `mw` (one 16-byte load per lane, above) - no load in the epilogue
+                auto store_rows_b = [&](auto full_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const int row = r0 + rr;
+                        const float ie = Es[rr];
+                        float* cp = Cout + (size_t)row * a.ldc + slice * GP_TN + l31;
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) {
+                            // keep-mask of the 64 lanes for (row, column block): lanes 0..31 hold row rr0's columns, lanes
+                            // 32..63 row rr0 + 4's - exactly the two words as one 64-bit lane mask (two v_readlane + v_cndmask)
+                            const int rr0 = 32 * e + (r & 3) + 8 * (r >> 2);
+                            const unsigned w0 = __builtin_amdgcn_readlane(mw[nb], rr0), w1 = __builtin_amdgcn_readlane(mw[nb], rr0 + 4);
+                            const bool keep = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)w1 << 32) | w0);
+                            float v = acc[e][nb][r] * (ie * ucv[nb]);
+                            acc[e][nb][r] = 0.f;
+                            v = keep ? v : 0.f;
+                            if (FULL || row < rend) cp[nb * 32] = v;
+                        }
+                    }
+                };
+                if (r0 + TE <= rend) store_rows_b(std::true_type{});
+                else store_rows_b(std::false_type{});
+                continue;
+            }
             float mk[16][4];
-            if (a.maskbits) {
-                // ReLU mask as bits (the first hidden layer is never materialised, GpdeFirstLayerSpec): one 16-byte load
-                // per row (the slice's 128 columns = 4 words, the same address in all lanes)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = min(r0 + 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h, rmax);
-                    const u4 wv = *(const u4*)(a.maskbits + (size_t)row * a.ldmb + slice * (GP_TN / 32));
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) mk[r][nb] = ((wv[nb] >> l31) & 1u) ? 1.f : 0.f;
-                }
-            } else if (has_mask) {
+            if (has_mask) {                  // (bit masks: handled above; the gather form takes a float mask only)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = min(r0 + 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h, rmax);
@@ -426,11 +502,33 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
             if (r0 + TE <= rend) store_rows(std::true_type{});
             else store_rows(std::false_type{});
         }
+        NT_MARK(tm_epi);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef GPDE_NT_TIMING
+    if (lane == 0) {
+        const int tb = GATHER ? 10 : a.ksplits > 1 ? 5 : 0;
+        atomicAdd(&gpde_nt_tm[tb + 0], (unsigned long long)tm_pro);
+        atomicAdd(&gpde_nt_tm[tb + 1], (unsigned long long)tm_loop);
+        atomicAdd(&gpde_nt_tm[tb + 2], (unsigned long long)tm_drain);
+        atomicAdd(&gpde_nt_tm[tb + 3], (unsigned long long)tm_epi);
+        atomicAdd(&gpde_nt_tm[tb + 4], (unsigned long long)rounds);
+    }
+#endif
 }
 
 }  // namespace
+
+#ifdef GPDE_NT_TIMING
+extern "C" int gpde_debug_nt_timing(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(gpde_nt_tm), 128) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gpde_nt_tm), z, 128) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 size_t gpde_gemm_f16s_workspace_floats(int M) { return (size_t)2 * (M > 0 ? M : 1); }
 
@@ -444,6 +542,8 @@ int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a_in, float* row_scale_ws, 
     GpdeGemmF16sArgs a = a_in;
     if (a.ksplits < 1) a.ksplits = 1;
     a.skew_us = gpde_debug_skew_us();
+    static const bool no_pref = getenv("GPDE_NT_NO_PREFETCH") != nullptr, no_ksx = getenv("GPDE_TN_NO_KS_XCD") != nullptr;
+    a.no_tile_prefetch = no_pref; a.no_ks_xcd = no_ksx;
     if (!gpde_gemm_f16s_supported(a.M, a.N, a.K, a.lda) || a.K % (64 * a.ksplits) != 0 || a.K / a.ksplits < 256) {
         gpde_set_error("gpde_gemm_f16s_nt: unsupported shape M=%d N=%d K=%d ksplits=%d", a.M, a.N, a.K, a.ksplits);
         return GPDE_EUNSUPPORTED;
