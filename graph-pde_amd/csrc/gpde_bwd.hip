@@ -440,7 +440,18 @@ __device__ __forceinline__ void eb2_dma16(const void* gsrc, void* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+#ifdef GPDE_EB2_TIMING     // developer probe (scripts/eb2_timing.py): clock64 ticks summed over waves: group prologue, waiting at the top of a
+                           // step (DMA + barrier), the step's products and stores, group epilogue; steps, groups
+__device__ unsigned long long gpde_eb2_tm[8];
+#define EB2_MARK(acc) do { const long long tm1_ = clock64(); acc += tm1_ - tm0_; tm0_ = tm1_; } while (0)
+#else
+#define EB2_MARK(acc) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256, 2) void gpde_edge_bwd2_kernel(EdgeBwdArgs a) {
+#ifdef GPDE_EB2_TIMING
+    long long tm_pro = 0, tm_wait = 0, tm_work = 0, tm_epi = 0, tm0_ = clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dZs = smem;                                      // [2 buf][2 node][64][32]
     float* Hs_all = smem + 2 * EB2_DZ;                      // [4 waves][2 buf][32][32]
@@ -508,21 +519,23 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd2_kernel(EdgeBwdArgs a) {
     };
 
     issue(0);
+    EB2_MARK(tm_pro);
     for (int it = 0; it < nit; ++it) {
         const int pass = it / NCH, nc = (it - pass * NCH) * EB2_NC, buf = it & 1;
         const int nodeA = nA0 + 2 * pass, nodeB = nodeA + 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        EB2_MARK(tm_wait);
         if (it + 1 < nit) issue(it + 1);
         const bool inA = nodeL == nodeA, inB = nodeL == nodeB;
         const bool anyA = __builtin_amdgcn_ballot_w64(inA) != 0, anyB = __builtin_amdgcn_ballot_w64(inB) != 0;
-        if (!anyA && !anyB) continue;
+        if (anyA || anyB) {
         const float* hb = Hs + buf * EB2_H;
         // H of lane-as-edge (A operand of product 2): units 2q' + h of row l31
         f32x4 hv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) hv[q] = *(const f32x4*)&hb[l31 * EB2_NC + (((2 * q + h) ^ (l31 & 7)) << 2)];
-        f32x16 dh;
+        f32x16 dh;                       // (two accumulators for product (1) were tried in round 4: no change - the chain is not the limit)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[r] = 0.f;
 #pragma unroll
@@ -564,6 +577,8 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd2_kernel(EdgeBwdArgs a) {
                 a.dU[(size_t)(e - a.e0) * a.K2P + nc + l31] = hval > 0.f ? dh[r] : 0.f;
             }
         }
+        }
+        EB2_MARK(tm_work);
     }
     // dx_j += dXg + dS_i : lane = channel c = l31 (+32), rows = edges
 #pragma unroll
@@ -580,7 +595,32 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd2_kernel(EdgeBwdArgs a) {
             }
         }
     }
+#ifdef GPDE_EB2_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    EB2_MARK(tm_epi);
+    if (lane == 0) {
+        atomicAdd(&gpde_eb2_tm[0], (unsigned long long)tm_pro);
+        atomicAdd(&gpde_eb2_tm[1], (unsigned long long)tm_wait);
+        atomicAdd(&gpde_eb2_tm[2], (unsigned long long)tm_work);
+        atomicAdd(&gpde_eb2_tm[3], (unsigned long long)tm_epi);
+        atomicAdd(&gpde_eb2_tm[4], (unsigned long long)nit);
+        atomicAdd(&gpde_eb2_tm[5], 1ull);
+    }
+#endif
 }
+
+#ifdef GPDE_EB2_TIMING
+}  // namespace
+extern "C" int gpde_debug_eb2_timing(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gpde_eb2_tm), 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gpde_eb2_tm), z, 64) != hipSuccess) return -1;
+    }
+    return 0;
+}
+namespace {
+#endif
 
 // Ordered mode: dx[j] += sum of the per-edge contributions of the out-edges of j that lie in this chunk's slot range
 // [e0, e1), in ascending slot order (src_slots is ascending inside a source: the chunk's part is one sub-range).
@@ -640,6 +680,7 @@ struct BwdPlan {
     // depth-deferred form (gpde_nnconv_bwd_deferred): L = n_defer layers share one pass over the hidden layers
     int L, Lp;                        // Lp = K / 64 of the gather GEMM: L rounded up to an even count >= 4 (zero layers)
     size_t off_dzstack, off_dzimg, off_nbits, off_nscale, off_tiles, off_xsc;
+    size_t off_dzun;                  // per chunk node un-scale of its split dZ image (gpde_edge_bwd3.hip)
     size_t total;
 };
 
@@ -688,7 +729,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     // (2*64*K2P + 3*64) floats
     const size_t tn_edge = P->f16s_dw2 ? (size_t)P->KP[1] + P->KP[2] : 0;
     const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0) + tn_edge + GP_W) * 4 + (P->f16s_dw2 ? P->KP[1] / 8 + (P->KP[2] / 64 + 2) * 4 + 8 : 0) + (n_defer > 0 ? 1 : 0),
-                 per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W) * 4 +
+                 per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W + 1) * 4 +
                             (n_defer > 0 ? (size_t)(P->L + P->Lp) * GP_W * P->K2P * 4 + 64 : 0);   // dZ of every deferred layer (fp32) + the node's split image + tile records
     int64_t Ec, Nc;
     // alignment of the per-chunk buffers below + the K padding of the transposed operands
@@ -722,6 +763,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     P->off_nbits = take(n_defer > 0 ? (size_t)Nc : 1);
     P->off_nscale = take(n_defer > 0 ? (size_t)2 * Nc : 1);
     P->off_tiles = take(n_defer > 0 ? (size_t)4 * (Ec / 256 + Nc + 8) : 1);
+    P->off_dzun = take((size_t)Nc);
     P->total = off + 256 + (sizing ? slack : 0);
     if (!sizing && P->total > ws_bytes) { gpde_set_error("gpde_nnconv_bwd: internal plan %zu > workspace %zu", P->total, ws_bytes); return GPDE_EWORKSPACE; }
     return GPDE_OK;
@@ -1322,8 +1364,12 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 // staged kernel where a 128-slot group rarely spans more than two destinations
                 const char* fe = getenv("GPDE_EDGE_BWD");          // "1" / "2": force a variant (tests, A/B)
                 const int force = fe ? atoi(fe) : 0;
-                const bool staged = force ? force == 2 : (int64_t)rows >= (int64_t)32 * nn;
-                if (staged) hipLaunchKernelGGL(gpde_edge_bwd2_kernel, dim3(((rows + 127) / 128 + 7) / 8 * 8), dim3(T), lds2, st, ea);
+                const bool staged = force ? force >= 2 : (int64_t)rows >= (int64_t)32 * nn;
+                if (staged && force != 2 && K2P % 32 == 0) {      // split-f16 MFMA (default); GPDE_EDGE_BWD=2: the fp32-MFMA staged kernel
+                    if ((rc = gpde_launch_dz_split(dZ, nn, K2P, F(P.off_dzun), st)) != GPDE_OK) return rc;
+                    GpdeEdgeBwd3Args e3{x, src, dst, dZ, F(P.off_dzun), dS, Hlast, dUc, dx, ordered ? F(P.off_dxe) : nullptr, e0, e1, na, K2P};
+                    if ((rc = gpde_launch_edge_bwd3(e3, st)) != GPDE_OK) return rc;
+                } else if (staged) hipLaunchKernelGGL(gpde_edge_bwd2_kernel, dim3(((rows + 127) / 128 + 7) / 8 * 8), dim3(T), lds2, st, ea);
                 else hipLaunchKernelGGL(gpde_edge_bwd_kernel, dim3((rows + 127) / 128), dim3(T), lds, st, ea);
                 if (ordered) hipLaunchKernelGGL(k_dx_reduce, dim3((N + 3) / 4), dim3(T), 0, st, F(P.off_dxe), src_rowptr, src_slots, N, e0, e1, dx);
             }

@@ -262,6 +262,22 @@ struct GpdeGemmF16sArgs {
     const float* g_unscale;             // [nodes] 2^-t of the node's image
 };
 bool gpde_gemm_f16s_supported(int M, int N, int K, int lda);
+
+// Per-edge backward through the aggregation on split-f16 MFMA (gpde_edge_bwd3.hip): dU[e][n] = (x_j . dZ_i)[n] [H > 0],
+// dx_e[c] = sum_n H[e][n] dZ_i[c][n] + dS_i[c] for the CSR slots [e0, e1) = in-edges of the chunk's nodes n0 ..
+struct GpdeEdgeBwd3Args {
+    const float* x; const int32_t* src; const int32_t* dst;
+    const float* dZ;            // split image of the chunk nodes' dZ (gpde_launch_dz_split, in place over the fp32 tensor)
+    const float* dz_unscale;    // [chunk nodes] 2^-t of each node's image
+    const float* dS;            // [chunk nodes][64]
+    const float* H;             // [e1 - e0][K2P] fp32, row 0 = slot e0
+    float* dU;                  // [e1 - e0][K2P] or nullptr (dx only)
+    float* dx;                  // [N][64] (atomics) when dxe is null
+    float* dxe;                 // [e1 - e0][64] per-edge rows (ordered reduction by k_dx_reduce)
+    int e0, e1, n0, K2P;
+};
+int gpde_launch_dz_split(float* dZ, int nn, int K2P, float* unscale, hipStream_t stream);
+int gpde_launch_edge_bwd3(const GpdeEdgeBwd3Args& a, hipStream_t stream);
 int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a, float* row_scale_ws /* 2 * M floats */, hipStream_t stream);
 // per-edge last layer of the forward for low in-degree graphs (the reference's own association, never forming [E][4096])
 size_t gpde_edge_messages_ws_floats(int64_t n_edges, int n_out);

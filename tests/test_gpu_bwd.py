@@ -55,7 +55,7 @@ def test_backward_with_split_f16_du1_matches_reference_autograd(dims, n, e, monk
     assert torch.equal(gW[2], fW[2]) and torch.equal(gW[1], fW[1])          # untouched by the change
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("variant", ["1", "2", "3"])      # per-MFMA operands / staged fp32 MFMA / staged split-f16 MFMA
 def test_all_gradients_are_bit_reproducible(variant, monkeypatch):
     """Weight gradients: ordered split partials.  grad_x: per-edge contributions summed per source node in slot order
     (gpde_nnconv_bwd_ordered + gpde_csr_source_order) instead of atomics - for both per-edge kernels, and identical

@@ -242,7 +242,7 @@ def _oracle_grads(x, ei, ea, ws_, bs_, root, bias, aggr, gout):
     ([6, 48, 4096], "mean", False, False),              # 2 Linear layers (MGKN inter-level)
     ([4, 24, 40, 56, 4096], "add", True, True),         # 4 Linear layers, Burgers attributes
 ])
-@pytest.mark.parametrize("edge_kernel", ["1", "2"])      # per-MFMA operands / staged through LDS
+@pytest.mark.parametrize("edge_kernel", ["1", "2", "3"])      # per-MFMA operands / staged through LDS (fp32 MFMA) / staged, split-f16 MFMA
 def test_backward_against_reference_autograd(dims, aggr, use_root, use_bias, edge_kernel, monkeypatch):
     """gpde_nnconv_bwd vs float64 autograd through the oracle (the reference's loss.backward())."""
     monkeypatch.setenv("GPDE_EDGE_BWD", edge_kernel)

@@ -125,7 +125,7 @@ def _assert_same(ref, cur, what):
                                  f"rel-L2 {float((a - b).norm() / a.norm()):.2e}")
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
 @pytest.mark.parametrize("which", ["random_256", "lattice41_1024"])
 def test_backward_is_reproducible_under_memory_pressure(which, variant, monkeypatch):
     """gpde_nnconv_bwd_ordered, both per-edge kernels, 200 repeats with 1 GiB fills (constants incl. NaN / -3e38, and
@@ -143,7 +143,7 @@ def test_backward_is_reproducible_under_memory_pressure(which, variant, monkeypa
         _assert_same(ref, _bwd(case), f"run {it}")
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
 @pytest.mark.parametrize("which", ["random_256", "lattice41_1024"])
 @pytest.mark.parametrize("f32", [False, True])
 def test_backward_does_not_depend_on_workgroup_timing(which, variant, f32, monkeypatch):
