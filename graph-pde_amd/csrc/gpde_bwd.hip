@@ -681,6 +681,7 @@ struct BwdPlan {
     int L, Lp;                        // Lp = K / 64 of the gather GEMM: L rounded up to an even count >= 4 (zero layers)
     size_t off_dzstack, off_dzimg, off_nbits, off_nscale, off_tiles, off_xsc;
     size_t off_dzun;                  // per chunk node un-scale of its split dZ image (gpde_edge_bwd3.hip)
+    size_t off_tcs, off_tcm;          // per 32-slot tile column sums / max bits of dU_2 [Ec / 32 + 1][KP2] (gpde_edge_bwd3.hip -> dW_2 GEMM)
     size_t total;
 };
 
@@ -728,7 +729,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     // per-chunk buffers: per edge (hsum + 2*kmax) floats (+ KP1 + KP2 for the transposed operands of dW_2), per node
     // (2*64*K2P + 3*64) floats
     const size_t tn_edge = P->f16s_dw2 ? (size_t)P->KP[1] + P->KP[2] : 0;
-    const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0) + tn_edge + GP_W) * 4 + (P->f16s_dw2 ? P->KP[1] / 8 + (P->KP[2] / 64 + 2) * 4 + 8 : 0) + (n_defer > 0 ? 1 : 0),
+    const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0) + tn_edge + GP_W) * 4 + (P->f16s_dw2 ? P->KP[1] / 8 + (P->KP[2] / 64 + 2) * 4 + 8 + P->KP[2] / 4 : 0) + (n_defer > 0 ? 1 : 0),
                  per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W + 1) * 4 +
                             (n_defer > 0 ? (size_t)(P->L + P->Lp) * GP_W * P->K2P * 4 + 64 : 0);   // dZ of every deferred layer (fp32) + the node's split image + tile records
     int64_t Ec, Nc;
@@ -764,6 +765,8 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     P->off_nscale = take(n_defer > 0 ? (size_t)2 * Nc : 1);
     P->off_tiles = take(n_defer > 0 ? (size_t)4 * (Ec / 256 + Nc + 8) : 1);
     P->off_dzun = take((size_t)Nc);
+    P->off_tcs = take(P->f16s_dw2 ? (size_t)(Ec / 32 + 1) * P->KP[2] : 1);
+    P->off_tcm = take(P->f16s_dw2 ? (size_t)(Ec / 32 + 1) * P->KP[2] : 1);
     P->total = off + 256 + (sizing ? slack : 0);
     if (!sizing && P->total > ws_bytes) { gpde_set_error("gpde_nnconv_bwd: internal plan %zu > workspace %zu", P->total, ws_bytes); return GPDE_EWORKSPACE; }
     return GPDE_OK;
@@ -1157,6 +1160,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         return GPDE_EUNSUPPORTED;
     }
     int mlp_e0 = 0;                          // first CSR slot of the chunk mlp_backward is working on
+    bool du_pre = false;                     // the per-edge kernel of this chunk wrote dU_2^T, its row scales and tile column partials
     auto mlp_backward = [&](const float* dUlast, int rows) -> int {
         const float* dUc = dUlast;
         float* bufs[2] = {F(P.off_dU[0]), F(P.off_dU[1])};
@@ -1200,7 +1204,8 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             if (tn_split) {
                 // dW_2 += dU_2^T . H_1 on the split-f16 GEMM (contraction over the edges: both operands transposed)
                 GpdeFirstLayerSpec fl{F(P.off_H[0]), P.KP[0], F(P.off_wp[1]), P.KP[0], F(P.off_bp[1]), (uint32_t*)F(P.off_maskbits)};
-                GpdeDuStats dst_{F(P.off_dbp[l]), F(P.off_rowsc), F(P.off_rowsc) + rows};
+                GpdeDuStats dst_{F(P.off_dbp[l]), F(P.off_rowsc), F(P.off_rowsc) + rows,
+                                 du_pre ? F(P.off_tcs) : nullptr, du_pre ? (const unsigned*)F(P.off_tcm) : nullptr};
                 if ((rc2 = gpde_launch_gemm_f16s_tn(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, BWD_TN_KSPLITS,
                                                     F(P.off_tnws), F(P.off_part), st, du_one_pass ? nullptr : du_bits,
                                                     skip_h1(rows) ? &fl : nullptr, du_one_pass ? &dst_ : nullptr)) != GPDE_OK) return rc2;
@@ -1365,9 +1370,19 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 const char* fe = getenv("GPDE_EDGE_BWD");          // "1" / "2": force a variant (tests, A/B)
                 const int force = fe ? atoi(fe) : 0;
                 const bool staged = force ? force >= 2 : (int64_t)rows >= (int64_t)32 * nn;
+                du_pre = false;
                 if (staged && force != 2 && K2P % 32 == 0) {      // split-f16 MFMA (default); GPDE_EDGE_BWD=2: the fp32-MFMA staged kernel
                     if ((rc = gpde_launch_dz_split(dZ, nn, K2P, F(P.off_dzun), st)) != GPDE_OK) return rc;
                     GpdeEdgeBwd3Args e3{x, src, dst, dZ, F(P.off_dzun), dS, Hlast, dUc, dx, ordered ? F(P.off_dxe) : nullptr, e0, e1, na, K2P};
+                    // full backward on the split GEMMs: the kernel also leaves what the dW_2 GEMM's pass over dU_2 would form
+                    // (mlp_backward's tn_split && du_one_pass case; GPDE_BWD_DU_TRANSPOSE_PASS=1: that pass, A/B)
+                    if (phase == BWD_FULL && n == 3 && f16s_dw2 && f16s_du1 && rows >= 8192 && !getenv("GPDE_BWD_DU_PASSES") &&
+                        !getenv("GPDE_BWD_DU_TRANSPOSE_PASS")) {
+                        e3.dUt = gpde_gemm_f16s_tn_at(F(P.off_tnws), rows, BWD_TN_KSPLITS, &e3.ldt);
+                        e3.row_sc = F(P.off_rowsc); e3.row_isc = F(P.off_rowsc) + rows;
+                        e3.csum_part = F(P.off_tcs); e3.cmax_part = (unsigned*)F(P.off_tcm);
+                        du_pre = true;
+                    }
                     if ((rc = gpde_launch_edge_bwd3(e3, st)) != GPDE_OK) return rc;
                 } else if (staged) hipLaunchKernelGGL(gpde_edge_bwd2_kernel, dim3(((rows + 127) / 128 + 7) / 8 * 8), dim3(T), lds2, st, ea);
                 else hipLaunchKernelGGL(gpde_edge_bwd_kernel, dim3((rows + 127) / 128), dim3(T), lds, st, ea);

@@ -275,6 +275,10 @@ struct GpdeEdgeBwd3Args {
     float* dx;                  // [N][64] (atomics) when dxe is null
     float* dxe;                 // [e1 - e0][64] per-edge rows (ordered reduction by k_dx_reduce)
     int e0, e1, n0, K2P;
+    // optional by-products of the dU tile (all or none; dU must be set): what gpde_launch_gemm_f16s_tn's pass over dU forms
+    float* dUt; int ldt;        // transposed copy [K2P][ldt], column e - e0 (columns >= e1 - e0 are the caller's to zero)
+    float* row_sc; float* row_isc;               // [e1 - e0] 2^(13 - E(max_n |dU[e][n]|)) and its reciprocal
+    float* csum_part; unsigned* cmax_part;       // [(e1 - e0 + 31) / 32][K2P] per 32-slot tile: column sums, column max bits
 };
 int gpde_launch_dz_split(float* dZ, int nn, int K2P, float* unscale, hipStream_t stream);
 int gpde_launch_edge_bwd3(const GpdeEdgeBwd3Args& a, hipStream_t stream);
@@ -302,7 +306,12 @@ struct GpdeFirstLayerSpec {
 struct GpdeDuStats {
     float* db_accumulate;                // [n_out] += column sums of dU (ordered: 64-row blocks ascending)
     float* row_sc; float* row_isc;       // [rows] 2^(13 - E(max_k |dU[row][k]|)) and its inverse
+    // set by a producer that has ALREADY written the transposed copy (at gpde_gemm_f16s_tn_at: [n_out][ld], columns < rows)
+    // and the row scales above (gpde_edge_bwd3.hip): its per-32-row-tile column sums / column max bits [ceil(rows / 32)][n_out]
+    const float* tile_csum; const unsigned* tile_cmax;
 };
+// where gpde_launch_gemm_f16s_tn keeps the transposed copy of dU inside `ws`, and its row length (>= rows, zero padded)
+float* gpde_gemm_f16s_tn_at(float* ws, int rows, int ksplits, int* ld);
 int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H, int ldh, int n_in, int rows,
                              int ksplits, float* ws, float* part, hipStream_t stream,
                              const unsigned* du_absmax_bits = nullptr /* [n_out] column maxima of |dU| as bit patterns */,

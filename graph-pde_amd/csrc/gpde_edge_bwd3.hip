@@ -62,6 +62,10 @@ __device__ __forceinline__ float other_half(float v) {       // the value of lan
     return __uint_as_float((threadIdx.x & 32) ? r2[0] : r2[1]);
 }
 
+template <int CTRL> __device__ __forceinline__ float dpp_shr(float v) {      // the value CTRL lanes down the 16-lane row, 0 beyond it
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
 // ---- pre-pass: per-node scale + in-place split image of dZ ------------------------------------------------------------
 // One workgroup per node: max |dZ_i| over its [64][K2P] block, s_i = 2^(13 - E(max)); then every 32-column group (128 bytes)
 // is rewritten as hi[32] | lo[32] halves of dZ * s_i.  In place: a wave owns whole 1 KiB segments (8 groups), reads a segment
@@ -186,6 +190,9 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd3_kernel(GpdeEdgeBwd3Args
 
     const int sw = l31 & 7;
     const float unL = vL ? a.dz_unscale[nodeL - a.n0] : 0.f;        // 1 / s_dZ of this lane's destination node
+    float rmax = 0.f;                                                // max |dU| of this lane's row (its half of the columns)
+    // first pass in which this wave's tile has edges (CSR order: the tile's first edge has its smallest destination)
+    const int pass_first = t0 < a.e1 ? (__builtin_amdgcn_readfirstlane(nodeL) - nA0) / 2 : 0;
     issue(0);
     for (int it = 0; it < nit; ++it) {
         const int pass = it / NCH, nc = (it - pass * NCH) * E3_NC, buf = it & 1;
@@ -289,22 +296,78 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd3_kernel(GpdeEdgeBwd3Args
                 for (int r = 0; r < 16; ++r) d1[r] = inB ? d1b[r] : d1[r];
             } else d1 = d1b;
         }
-        // dU row of this lane's edge: columns nc + 8 g + 4 h + 0..3 per group g = r >> 2
-        if (vL && (inA || inB)) {
+        // dU row of this lane's edge: columns nc + 8 g + 4 h + 0..3 per group g = r >> 2 (zeros for a lane outside this pass)
+        const bool mine = vL && (inA || inB);
+        float o[16];
+        {
             const float un = isx * unL;
-            float* du = a.dU + (size_t)(eL - a.e0) * a.K2P + nc + 4 * h;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 hm = *(const f32x4*)&hb[l31 * E3_NC + (((2 * g + h) ^ sw) << 2)];
-                f32x4 o;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float v = d1[4 * g + t] * un;
-                    o[t] = hm[t] > 0.f ? v : 0.f;
-                }
-                *(f32x4*)(du + 8 * g) = o;
+                for (int t = 0; t < 4; ++t) o[4 * g + t] = (mine && hm[t] > 0.f) ? d1[4 * g + t] * un : 0.f;
             }
         }
+        if (mine) {
+            float* du = a.dU + (size_t)(eL - a.e0) * a.K2P + nc + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *(f32x4*)(du + 8 * g) = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+        }
+        if (a.dUt) {
+            // ---- what the dW_2 GEMM and the dU_1 GEMM need from a pass over dU, formed here where the tile sits in registers
+            // (gpde_launch_gemm_f16s_tn's k_transpose_stats otherwise: 24 GB read + 24 GB written per backward at s=121) ------
+            // transposed copy: row nc + n, 32 consecutive edges per half wave = one 128-byte run
+            if (mine) {
+                float* dt = a.dUt + (size_t)(nc + 4 * h) * a.ldt + (eL - a.e0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dt[(size_t)(8 * g + t) * a.ldt] = o[4 * g + t];
+            }
+            // row maximum (this lane's 16 of the step's 32 columns; the halves are joined at the end)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rmax = fmaxf(rmax, fabsf(o[r]));
+            // column sums and maxima over the tile's 32 edges: DPP tree inside each half wave (fixed order: reproducible),
+            // totals in lanes 31 / 63 -> per-tile partials [tile][K2P], reduced in tile order by k_tile_col_reduce
+            float cs[16], cm[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sv = o[r], mv = fabsf(o[r]);
+                sv += dpp_shr<0x111>(sv); mv = fmaxf(mv, dpp_shr<0x111>(mv));      // row_shr:1, 2, 4, 8 (zero fill at the row start)
+                sv += dpp_shr<0x112>(sv); mv = fmaxf(mv, dpp_shr<0x112>(mv));
+                sv += dpp_shr<0x114>(sv); mv = fmaxf(mv, dpp_shr<0x114>(mv));
+                sv += dpp_shr<0x118>(sv); mv = fmaxf(mv, dpp_shr<0x118>(mv));
+                // lane 15 of rows 0 / 2 into every lane of rows 1 / 3: lanes 31 and 63 hold their half wave's total
+                sv += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv), 0x142, 0xa, 0xf, false));
+                mv = fmaxf(mv, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mv), 0x142, 0xa, 0xf, false)));
+                cs[r] = sv; cm[r] = mv;
+            }
+            if (l31 == 31 && t0 < a.e1) {
+                const size_t po = (size_t)((t0 - a.e0) >> 5) * a.K2P + nc + 4 * h;
+                float* ps = a.csum_part + po;
+                unsigned* pm = a.cmax_part + po;
+                const bool first = pass == pass_first;          // this wave's first pass with edges: plain stores, later passes add
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 sv4 = {cs[4 * g], cs[4 * g + 1], cs[4 * g + 2], cs[4 * g + 3]};
+                    u4 mv4 = {__float_as_uint(cm[4 * g]), __float_as_uint(cm[4 * g + 1]), __float_as_uint(cm[4 * g + 2]), __float_as_uint(cm[4 * g + 3])};
+                    if (!first) {
+                        const f32x4 ps0 = *(const f32x4*)(ps + 8 * g);
+                        const u4 pm0 = *(const u4*)(pm + 8 * g);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { sv4[t] += ps0[t]; mv4[t] = max(mv4[t], pm0[t]); }
+                    }
+                    *(f32x4*)(ps + 8 * g) = sv4;
+                    *(u4*)(pm + 8 * g) = mv4;
+                }
+            }
+        }
+    }
+    if (a.dUt && vL) {                   // row scales of dU for the dU . W^T GEMM (k_row_scales_from_parts' formula)
+        rmax = fmaxf(rmax, other_half(rmax));
+        float rs, irs;
+        pow2_scale(rmax, rs, irs);
+        if (h == 0) { a.row_sc[eL - a.e0] = rs; a.row_isc[eL - a.e0] = irs; }
     }
     // ---- dx_e[c] = D2 sum / s_dZ(node) + dS_i[c]: 16-byte pieces of the edge's row --------------------------------------
     if (vL) {

@@ -735,6 +735,23 @@ __global__ __launch_bounds__(256) void k_transpose_stats(const float* __restrict
         if (cm) atomicMax(colbits + c0 + tx, cm);
     }
 }
+// Column statistics from per-tile partials (a producer that had the dU tiles in registers, gpde_edge_bwd3.hip): a thread walks
+// one column over the 32 tiles of a 1024-row strip in tile order -> the strip's column sum (csum_part[strip][col], reduced in
+// strip order by the caller: the same two-level order as k_transpose_stats) and the column maximum (one atomicMax per strip)
+__global__ __launch_bounds__(256) void k_tile_col_reduce(const float* __restrict__ tcs, const unsigned* __restrict__ tcm, int ntile,
+                                                         int n_out, float* __restrict__ csum_part, unsigned* __restrict__ colbits) {
+    const int col = blockIdx.y * 256 + threadIdx.x, strip = blockIdx.x;
+    if (col >= n_out) return;
+    const int t1 = min((strip + 1) * (TS_STRIP / 32), ntile);
+    float sacc = 0.f;
+    unsigned cm = 0u;
+    for (int t = strip * (TS_STRIP / 32); t < t1; ++t) {
+        sacc += tcs[(size_t)t * n_out + col];
+        cm = max(cm, tcm[(size_t)t * n_out + col]);
+    }
+    csum_part[(size_t)strip * n_out + col] = sacc;
+    if (cm) atomicMax(colbits + col, cm);
+}
 __global__ void k_row_scales_from_parts(const unsigned* __restrict__ rowpart, int nparts, int ldd, int rows, float* __restrict__ sc,
                                         float* __restrict__ isc) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -875,6 +892,13 @@ size_t gpde_gemm_f16s_tn_ws_floats(int rows_max, int n_out, int n_in, int ksplit
                                                                                           // 1024-row strip, row maxima per column block
 }
 
+float* gpde_gemm_f16s_tn_at(float* ws, int rows, int ksplits, int* ld) {
+    int ksp = ((rows + 64 * ksplits - 1) / (64 * ksplits)) * 64;
+    if (ksp < 256) ksp = 256;
+    *ld = ksp * ksplits;
+    return ws;
+}
+
 // part[s][n_out][n_in] (s < ksplits, stride n_out * n_in) = partial sums of dU^T . H over the K splits
 int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H, int ldh, int n_in, int rows,
                              int ksplits, float* ws, float* part, hipStream_t stream, const unsigned* du_absmax_bits,
@@ -905,7 +929,15 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
     int splits = 1;
     while (splits < 256 && rows / (splits * 2) >= 64) splits *= 2;
     // column maxima of dU: given by the caller when another pass over dU has already collected them (k_colsum)
-    if (st_) {
+    if (st_ && st_->tile_csum) {
+        // the producer of dU wrote the transposed copy and the row scales itself: zero the K padding, fold its tile partials
+        if (epad > rows) GP_HIP_CHECK(hipMemset2DAsync(At + rows, (size_t)epad * 4, 0, (size_t)(epad - rows) * 4, (size_t)n_out, stream));
+        const int ntile = (rows + 31) / 32;
+        hipLaunchKernelGGL(k_tile_col_reduce, dim3(nstrip, (n_out + 255) / 256), dim3(256), 0, stream, st_->tile_csum, st_->tile_cmax, ntile,
+                           n_out, csum_part, bits);
+        if (int rc = gpde_launch_reduce_splits(csum_part, (size_t)n_out, nstrip, (size_t)n_out, st_->db_accumulate, 1, stream)) return rc;
+        hipLaunchKernelGGL(k_scales_from_max, dim3((n_out + 255) / 256), dim3(256), 0, stream, bits, n_out, sca, isca);
+    } else if (st_) {
         // ONE pass over dU: transposed copy, column sums (-> bias gradient), column maxima (-> scales of the A rows here),
         // row maxima (-> row scales of the dU . W^T GEMM that follows)
         hipLaunchKernelGGL(k_transpose_stats, dim3(nstrip, n_out / 64), dim3(256), 0, stream, dU, rows, ldu, At, epad, n_out,
