@@ -78,6 +78,7 @@ SIGNATURES = {
     "gpde_nnconv_fwd_kernel": (ctypes.c_char_p, [ctypes.c_int64, ctypes.c_int, c_i32p, ctypes.c_uint32]),
     "gpde_nnconv_bwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64,
                                                           ctypes.c_int, c_i32p]),
+    "gpde_nnconv_bwd_workspace_bytes_one_chunk": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, c_i32p]),
     "gpde_csr_source_order": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "gpde_nnconv_bwd_ordered": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,

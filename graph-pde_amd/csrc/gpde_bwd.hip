@@ -683,6 +683,7 @@ struct BwdPlan {
     size_t off_dzun;                  // per chunk node un-scale of its split dZ image (gpde_edge_bwd3.hip)
     size_t off_tcs, off_tcm;          // per 32-slot tile column sums / max bits of dU_2 [Ec / 32 + 1][KP2] (gpde_edge_bwd3.hip -> dW_2 GEMM)
     size_t total;
+    size_t one_chunk;                 // workspace bytes with which everything is one chunk
 };
 
 int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws_bytes, bool sizing,
@@ -735,6 +736,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     int64_t Ec, Nc;
     // alignment of the per-chunk buffers below + the K padding of the transposed operands
     const size_t slack = 64 * 256 + (P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats(0, P->KP[2], P->KP[1], BWD_TN_KSPLITS) * 4 : 0);
+    P->one_chunk = fixed + (size_t)(E > 0 ? E : 1) * per_edge + (size_t)(N > 0 ? N : 1) * per_node + slack + (1 << 20);
     if (sizing) {
         Ec = (int64_t)(((size_t)(P->f16s_dw2 ? 18 : 12) << 30) / per_edge); Nc = (int64_t)(((size_t)8 << 30) / per_node);
     } else if (ws_bytes >= fixed + (size_t)(E > 0 ? E : 1) * per_edge + (size_t)(N > 0 ? N : 1) * per_node + slack) {
@@ -742,7 +744,11 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     } else {
         if (ws_bytes < fixed + (1 << 20)) { gpde_set_error("gpde_nnconv_bwd: workspace %zu bytes too small (%zu fixed)", ws_bytes, fixed); return GPDE_EWORKSPACE; }
         const size_t avail = ws_bytes - fixed - slack;
-        Ec = (int64_t)(avail * 6 / 10 / per_edge); Nc = (int64_t)(avail * 4 / 10 / per_node);
+        // nodes first (at most 40 %); what they leave - all of it when every node fits - goes to the edges
+        Nc = (int64_t)(avail * 4 / 10 / per_node);
+        if (Nc > N) Nc = N;
+        if (Nc < 1) Nc = 1;
+        Ec = (int64_t)((avail - (size_t)Nc * per_node) / per_edge);
     }
     if (Ec > E) Ec = E;
     if (Nc > N) Nc = N;
@@ -1415,6 +1421,13 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
 }
 
 }  // namespace
+
+extern "C" size_t gpde_nnconv_bwd_workspace_bytes_one_chunk(int64_t n_nodes, int64_t n_edges, int n_layers, const int32_t* dims) {
+    BwdPlan P;
+    if (!dims || n_nodes < 0 || n_edges < 0) return 0;
+    if (make_bwd_plan(n_nodes, n_edges, n_layers, dims, 0, true, &P) != GPDE_OK) return 0;
+    return P.one_chunk > P.total ? P.one_chunk : P.total;
+}
 
 extern "C" int gpde_nnconv_bwd_ordered(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
                                        const int32_t* rowptr, const int32_t* src, const int32_t* dst,

@@ -183,6 +183,17 @@ __global__ void gpde_reduce_splits_kernel(const float* __restrict__ P, size_t n,
     C[i] = s;
 }
 
+// first level for very many partials: P[g * G][i] = sum of the G partials of group g (in place: a thread reads its own element
+// of every partial of the group, then overwrites the group's first)
+__global__ void gpde_reduce_groups_kernel(float* __restrict__ P, size_t n, int splits, size_t stride, int G) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k0 = blockIdx.y * G, k1 = min(k0 + G, splits);
+    float s = 0.f;
+    for (int k = k0; k < k1; ++k) s += P[(size_t)k * stride + i];
+    P[(size_t)k0 * stride + i] = s;
+}
+
 }  // namespace
 
 int gpde_debug_skew_us() {
@@ -217,6 +228,15 @@ int gpde_launch_gemm(const GpdeGemmArgs& g_in, hipStream_t stream) {
 
 int gpde_launch_reduce_splits(const float* P, size_t n, int splits, size_t stride, float* C,
                               int accumulate, hipStream_t stream) {
+    // one thread per output walks the partials in order.  Few outputs and thousands of partials (column sums per 1024-row
+    // strip of a 3 M-row chunk: 1024 threads x 2900 serial loads = 2.1 ms) go through groups of 64 first - still a fixed order
+    if (splits > 256 && n <= (1u << 20)) {
+        const int G = 64, groups = (splits + G - 1) / G;
+        hipLaunchKernelGGL(gpde_reduce_groups_kernel, dim3((unsigned)((n + 255) / 256), groups), dim3(256), 0, stream,
+                           const_cast<float*>(P), n, splits, stride, G);
+        splits = groups;
+        stride *= G;
+    }
     hipLaunchKernelGGL(gpde_reduce_splits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P,
                        n, splits, stride, C, accumulate);
     GP_LAUNCH_CHECK("gpde_reduce_splits_kernel");

@@ -736,16 +736,18 @@ __global__ __launch_bounds__(256) void k_transpose_stats(const float* __restrict
     }
 }
 // Column statistics from per-tile partials (a producer that had the dU tiles in registers, gpde_edge_bwd3.hip): a thread walks
-// one column over the 32 tiles of a 1024-row strip in tile order -> the strip's column sum (csum_part[strip][col], reduced in
-// strip order by the caller: the same two-level order as k_transpose_stats) and the column maximum (one atomicMax per strip)
+// one column over the tiles of a strip (at most 64 strips: the second level is one thread per column walking the strips) in
+// tile order -> the strip's column sum (csum_part[strip][col], reduced in strip order by the caller) and the column maximum
+// (one atomicMax per strip)
 __global__ __launch_bounds__(256) void k_tile_col_reduce(const float* __restrict__ tcs, const unsigned* __restrict__ tcm, int ntile,
-                                                         int n_out, float* __restrict__ csum_part, unsigned* __restrict__ colbits) {
+                                                         int tiles_per_strip, int n_out, float* __restrict__ csum_part,
+                                                         unsigned* __restrict__ colbits) {
     const int col = blockIdx.y * 256 + threadIdx.x, strip = blockIdx.x;
     if (col >= n_out) return;
-    const int t1 = min((strip + 1) * (TS_STRIP / 32), ntile);
+    const int t1 = min((strip + 1) * tiles_per_strip, ntile);
     float sacc = 0.f;
     unsigned cm = 0u;
-    for (int t = strip * (TS_STRIP / 32); t < t1; ++t) {
+    for (int t = strip * tiles_per_strip; t < t1; ++t) {
         sacc += tcs[(size_t)t * n_out + col];
         cm = max(cm, tcm[(size_t)t * n_out + col]);
     }
@@ -839,12 +841,18 @@ __global__ __launch_bounds__(256) void k_first_layer_pack(GpdeFirstLayerSpec f, 
     for (int d = 0; d < 8; ++d) wd[d] = f.Wp[(size_t)col * f.ldw + d];
     const int sw = (n >> 1) & 7;
     _Float16* row = img + n * 64;
-    for (int kcn = blockIdx.x * FLP_TILES; kcn < min((int)(blockIdx.x + 1) * FLP_TILES, nkct); ++kcn) {
-        {
-            const int e = kcn * 32 + (threadIdx.x >> 3), d = threadIdx.x & 7;
-            h0s[threadIdx.x >> 3][d] = e < rows ? f.H0[(size_t)e * f.ld0 + d] : 0.f;
-        }
+    // the attributes of the NEXT tile are requested before this tile's arithmetic (a workgroup's tiles used to run load ->
+    // barrier -> compute -> barrier -> store -> barrier back to back: 9.1 ms per backward at s=121 for 24 GB of image)
+    auto load_h0 = [&](int kc) {
+        const int e = kc * 32 + (threadIdx.x >> 3), d = threadIdx.x & 7;
+        return e < rows ? f.H0[(size_t)e * f.ld0 + d] : 0.f;
+    };
+    const int kc_end = min((int)(blockIdx.x + 1) * FLP_TILES, nkct);
+    float h0n = blockIdx.x * FLP_TILES < kc_end ? load_h0(blockIdx.x * FLP_TILES) : 0.f;
+    for (int kcn = blockIdx.x * FLP_TILES; kcn < kc_end; ++kcn) {
+        h0s[threadIdx.x >> 3][threadIdx.x & 7] = h0n;
         __syncthreads();
+        if (kcn + 1 < kc_end) h0n = load_h0(kcn + 1);
         const int e0 = kcn * 32 + 16 * m;
         float w[16];
 #pragma unroll
@@ -933,9 +941,10 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
         // the producer of dU wrote the transposed copy and the row scales itself: zero the K padding, fold its tile partials
         if (epad > rows) GP_HIP_CHECK(hipMemset2DAsync(At + rows, (size_t)epad * 4, 0, (size_t)(epad - rows) * 4, (size_t)n_out, stream));
         const int ntile = (rows + 31) / 32;
-        hipLaunchKernelGGL(k_tile_col_reduce, dim3(nstrip, (n_out + 255) / 256), dim3(256), 0, stream, st_->tile_csum, st_->tile_cmax, ntile,
-                           n_out, csum_part, bits);
-        if (int rc = gpde_launch_reduce_splits(csum_part, (size_t)n_out, nstrip, (size_t)n_out, st_->db_accumulate, 1, stream)) return rc;
+        const int ns2 = nstrip < 64 ? nstrip : 64, tps = (ntile + ns2 - 1) / ns2;
+        hipLaunchKernelGGL(k_tile_col_reduce, dim3(ns2, (n_out + 255) / 256), dim3(256), 0, stream, st_->tile_csum, st_->tile_cmax, ntile,
+                           tps, n_out, csum_part, bits);
+        if (int rc = gpde_launch_reduce_splits(csum_part, (size_t)n_out, ns2, (size_t)n_out, st_->db_accumulate, 1, stream)) return rc;
         hipLaunchKernelGGL(k_scales_from_max, dim3((n_out + 255) / 256), dim3(256), 0, stream, bits, n_out, sca, isca);
     } else if (st_) {
         // ONE pass over dU: transposed copy, column sums (-> bias gradient), column maxima (-> scales of the A rows here),

@@ -432,6 +432,23 @@ SAVE_Z_BYTES = int(float(os.environ.get("GPDE_SAVE_Z_GB", "16")) * (1 << 30))   
 SAVE_Z_RESERVE_BYTES = int(float(os.environ.get("GPDE_SAVE_Z_RESERVE_GB", "48")) * (1 << 30))   # device memory left free by a kept Z
 
 
+BWD_WS_FRACTION = float(os.environ.get("GPDE_BWD_WS_FRACTION", "0.6"))      # of the free device memory a full backward's workspace may take
+
+
+def bwd_workspace_bytes(lib, n: int, e: int, nl: int, dims_c, dev) -> int:
+    """Workspace of a full backward (gpde_nnconv_bwd*): the library's default (~26 GB at k = 1024: node-aligned chunks of
+    ~640 k edges), raised towards its one-chunk size while that stays below GPDE_BWD_WS_FRACTION of what the device has free -
+    fewer chunks = fewer launches, GEMM tile rounds and split-K reductions (s=121: 10 chunks 152 ms, one chunk 147 ms)."""
+    nbytes = int(lib.gpde_nnconv_bwd_workspace_bytes(n, e, nl, dims_c))
+    if nbytes == 0:
+        _lib.check(-2, "gpde_nnconv_bwd_workspace_bytes")
+    if BWD_WS_FRACTION > 0:
+        one = int(lib.gpde_nnconv_bwd_workspace_bytes_one_chunk(n, e, nl, dims_c))
+        free, _ = device_free_bytes(dev)
+        nbytes = max(nbytes, min(one, int(BWD_WS_FRACTION * free)))
+    return nbytes
+
+
 def device_free_bytes(dev):
     """(bytes an allocation can still get, device total): what the driver reports free PLUS what torch's caching allocator
     holds in freed blocks (it returns them to the driver when a large request needs the room) - after a training step the
@@ -718,10 +735,7 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
     P = ctypes.c_void_p
     arr = lambda ts: (P * nl)(*[None if t is None else t.data_ptr() for t in ts])
     if ws is None:
-        nbytes = int(lib.gpde_nnconv_bwd_workspace_bytes(n, e, nl, dims_c))
-        if nbytes == 0:
-            _lib.check(-2, "gpde_nnconv_bwd_workspace_bytes")
-        ws = _alloc_ws(nbytes, dev)
+        ws = _alloc_ws(bwd_workspace_bytes(lib, n, e, nl, dims_c, dev), dev)
     rph = csr.rowptr_host
     srp, ssl = csr.src_order
     if is_na:
@@ -1307,10 +1321,7 @@ def hidden_backward_raw(csr: Csr, edge_attr: torch.Tensor, dims: Sequence[int],
     bs_ = [None if b is None else b.detach().contiguous() for b in biases] + [None]
     gW = [torch.empty_like(w) for w in ws_[:-1]] + [None]
     gb = [None if b is None else torch.empty_like(b) for b in bs_[:-1]] + [None]
-    nbytes = int(lib.gpde_nnconv_bwd_workspace_bytes(0, e, nl, dims_c))
-    if nbytes == 0:
-        _lib.check(-2, "gpde_nnconv_bwd_workspace_bytes")
-    ws = _alloc_ws(nbytes, dev)
+    ws = _alloc_ws(bwd_workspace_bytes(lib, 0, e, nl, dims_c, dev), dev)
     if is_na:
         na = edge_attr.c_struct()
         with torch.cuda.device(dev):

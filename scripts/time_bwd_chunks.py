@@ -1,7 +1,7 @@
 """Does the single-call backward gain from edge chunks small enough for their 4 KiB-per-edge intermediates to stay in the
 256 MB Infinity Cache between producer and consumer kernels?  (Its PMC record, profiles/traffic_r04_bwd.json, shows 416 GB of
 L2-side traffic per backward at s=121.)  Times gpde_nnconv_bwd with workspaces of different sizes = different chunkings.
-usage: time_bwd_chunks.py [g121]"""
+usage: [FRACS=6,4,2,1] time_bwd_chunks.py [g121]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,7 +22,8 @@ x, g = torch.randn(n, 64, device=dev), torch.randn(n, 64, device=dev)
 dims_c = _lib.dims_array([6, 1024, 1024, 4096])
 full = int(_lib.lib().gpde_nnconv_bwd_workspace_bytes(n, e, 3, dims_c))
 ref = None
-for frac in (1.0, 0.5, 0.25, 0.12, 0.06, 0.03, 0.015):
+fracs = [float(v) for v in os.environ.get("FRACS", "1,0.5,0.25,0.12,0.06,0.03,0.015").split(",")]      # multiples of the default workspace
+for frac in fracs:
     nbytes = max(int(full * frac), 600 << 20)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     ts = []
