@@ -662,7 +662,15 @@ __global__ __launch_bounds__(256) void k_dx_reduce(const float* __restrict__ dxe
 size_t al(size_t v) { return (v + 255) / 256 * 256; }
 unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
-constexpr int BWD_TN_KSPLITS = 8;      // K splits of the dW_2 GEMM: 4 row quads x 8 splits x 8 slices = 256 workgroups
+// K splits of the dW_2 GEMM (contraction over the chunk's edges): 4 row quads x 8 splits x 8 slices = 256 workgroups up to
+// 786 k edges, then 8 more per 786 k so that no fp32 accumulator runs over more than ~100 k edges: with the whole s=121
+// graph as ONE chunk (5.9 M edges) 8 splits left 741 k-term chains and dW_2 3e-5 away from the 10-chunk result.
+int tn_ksplits(int64_t rows) {
+    int64_t g = (rows + 786431) / 786432;
+    if (g < 1) g = 1;
+    if (g > 16) g = 16;
+    return (int)(8 * g);
+}
 struct BwdPlan {
     int n_layers, nh;                 // nh = hidden layers = n_layers - 1
     int KP[GPDE_MAX_LAYERS + 1];      // padded widths: KP[0] = pad32(k0), KP[l] = pad128(k_l), l < n_layers
@@ -708,7 +716,8 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     const size_t w3 = (size_t)GP_W * GP_W * P->K2P;
     P->off_w3p = take(w3); P->off_dw3p = take(w3);
     P->off_b3 = take(GP_W * GP_W); P->off_db3 = take(GP_W * GP_W);
-    const int max_splits = 16;
+    const int ks_max = tn_ksplits(E);
+    const int max_splits = ks_max > 16 ? ks_max : 16;
     P->part_floats = (size_t)max_splits * (wmax > 4096 ? wmax : 4096);
     P->off_part = take(P->part_floats);
     // packed MLP image for the fused f16-split recompute of the last hidden layer (3-Linear kernels)
@@ -735,7 +744,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
                             (n_defer > 0 ? (size_t)(P->L + P->Lp) * GP_W * P->K2P * 4 + 64 : 0);   // dZ of every deferred layer (fp32) + the node's split image + tile records
     int64_t Ec, Nc;
     // alignment of the per-chunk buffers below + the K padding of the transposed operands
-    const size_t slack = 64 * 256 + (P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats(0, P->KP[2], P->KP[1], BWD_TN_KSPLITS) * 4 : 0);
+    const size_t slack = 64 * 256 + (P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats(0, P->KP[2], P->KP[1], ks_max) * 4 : 0);
     P->one_chunk = fixed + (size_t)(E > 0 ? E : 1) * per_edge + (size_t)(N > 0 ? N : 1) * per_node + slack + (1 << 20);
     if (sizing) {
         Ec = (int64_t)(((size_t)(P->f16s_dw2 ? 18 : 12) << 30) / per_edge); Nc = (int64_t)(((size_t)8 << 30) / per_node);
@@ -762,7 +771,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     P->off_gT = take((size_t)Nc * GP_W); P->off_S = take((size_t)Nc * GP_W); P->off_dS = take((size_t)Nc * GP_W);
     P->off_rowsc = take(P->f16s_du1 ? (size_t)2 * Ec : 1);
     P->off_dxe = take((size_t)Ec * GP_W);
-    P->off_tnws = take(P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats((int)Ec, P->KP[2], P->KP[1], BWD_TN_KSPLITS) : 1);
+    P->off_tnws = take(P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats((int)Ec, P->KP[2], P->KP[1], tn_ksplits(Ec)) : 1);
     P->off_dubits = take((size_t)(kmax > 0 ? kmax : 1));
     P->off_maskbits = take(P->f16s_dw2 ? (size_t)Ec * (P->KP[1] / 32) : 1);
     P->off_dzstack = take(n_defer > 0 ? (size_t)P->L * Nc * GP_W * P->K2P : 1);
@@ -1212,10 +1221,10 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 GpdeFirstLayerSpec fl{F(P.off_H[0]), P.KP[0], F(P.off_wp[1]), P.KP[0], F(P.off_bp[1]), (uint32_t*)F(P.off_maskbits)};
                 GpdeDuStats dst_{F(P.off_dbp[l]), F(P.off_rowsc), F(P.off_rowsc) + rows,
                                  du_pre ? F(P.off_tcs) : nullptr, du_pre ? (const unsigned*)F(P.off_tcm) : nullptr};
-                if ((rc2 = gpde_launch_gemm_f16s_tn(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, BWD_TN_KSPLITS,
+                if ((rc2 = gpde_launch_gemm_f16s_tn(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, tn_ksplits(rows),
                                                     F(P.off_tnws), F(P.off_part), st, du_one_pass ? nullptr : du_bits,
                                                     skip_h1(rows) ? &fl : nullptr, du_one_pass ? &dst_ : nullptr)) != GPDE_OK) return rc2;
-                if ((rc2 = gpde_launch_reduce_splits(F(P.off_part), (size_t)Kl * Kin, BWD_TN_KSPLITS, (size_t)Kl * Kin,
+                if ((rc2 = gpde_launch_reduce_splits(F(P.off_part), (size_t)Kl * Kin, tn_ksplits(rows), (size_t)Kl * Kin,
                                                      F(P.off_dwp[l]), 1, st)) != GPDE_OK) return rc2;
             } else if ((rc2 = gemm_tn_acc(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, F(P.off_dwp[l]), Kin,
                                           F(P.off_part), P.part_floats, 1, st)) != GPDE_OK) return rc2;
@@ -1384,7 +1393,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                     // (mlp_backward's tn_split && du_one_pass case; GPDE_BWD_DU_TRANSPOSE_PASS=1: that pass, A/B)
                     if (phase == BWD_FULL && n == 3 && f16s_dw2 && f16s_du1 && rows >= 8192 && !getenv("GPDE_BWD_DU_PASSES") &&
                         !getenv("GPDE_BWD_DU_TRANSPOSE_PASS")) {
-                        e3.dUt = gpde_gemm_f16s_tn_at(F(P.off_tnws), rows, BWD_TN_KSPLITS, &e3.ldt);
+                        e3.dUt = gpde_gemm_f16s_tn_at(F(P.off_tnws), rows, tn_ksplits(rows), &e3.ldt);
                         e3.row_sc = F(P.off_rowsc); e3.row_isc = F(P.off_rowsc) + rows;
                         e3.csum_part = F(P.off_tcs); e3.cmax_part = (unsigned*)F(P.off_tcm);
                         du_pre = true;

@@ -266,3 +266,41 @@ def test_gradient_of_the_edge_attributes_matches_float64_autograd():
         y = conv(x.to(d), ei.to(d), ea_d)
     (y * gout.to(d)).sum().backward()
     assert rel_l2(ea_d.grad.cpu(), at.grad) <= TOL
+
+
+def test_one_chunk_backward_agrees_with_the_default_chunking_at_s121():
+    """The module's backward takes a workspace of up to one chunk when the device has the room (ops.bwd_workspace_bytes):
+    on the s=121 graph (5.9 M edges) that is ONE 5.9 M-row chunk instead of ten of ~640 k.  The dW_2 GEMM then contracts over
+    all of them: its K split count follows the chunk (tn_ksplits, gpde_bwd.hip) so that no fp32 accumulator runs over more than
+    ~100 k edges - with 8 splits the two chunkings sat 3e-5 apart in dW_2.  grad_x is the same bits in both."""
+    from graph_pde_amd import _lib, synth
+    d = dev()
+    torch.manual_seed(3)
+    ei, ea, n = synth.darcy_graph(121, 0.1, device=d, seed=0)
+    e = int(ei.shape[1])
+    dims = [6, 1024, 1024, 4096]
+    mlp = torch.nn.Sequential(torch.nn.Linear(6, 1024), torch.nn.ReLU(), torch.nn.Linear(1024, 1024), torch.nn.ReLU(),
+                              torch.nn.Linear(1024, 4096)).to(d)
+    lin = ops.mlp_linears(mlp)
+    ws_, bs_ = [l.weight.detach() for l in lin], [l.bias.detach() for l in lin]
+    root = torch.randn(64, 64, device=d) / 8
+    x, g = torch.randn(n, 64, device=d), torch.randn(n, 64, device=d)
+    csr = ops.csr_for(ei, n)
+    dims_c = _lib.dims_array(dims)
+    lib = _lib.lib()
+    small = int(lib.gpde_nnconv_bwd_workspace_bytes(n, e, 3, dims_c))
+    one = int(lib.gpde_nnconv_bwd_workspace_bytes_one_chunk(n, e, 3, dims_c))
+    assert one > 4 * small
+    free, _ = ops.device_free_bytes(d)
+    if one + (8 << 30) > free:
+        pytest.skip("device has no room for the one-chunk workspace")
+    outs = []
+    for nbytes in (small, one):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
+        outs.append(ops.nnconv_backward_raw(x, csr, ea, ws_, bs_, root, "mean", g, ws=ws))
+        del ws
+    a, b = outs
+    assert torch.equal(a[0], b[0])                                   # grad_x: per-edge rows, one owner per element
+    for l in range(3):
+        assert rel_l2(a[1][l].cpu(), b[1][l].cpu()) <= 1.5e-5, (f"dW{l + 1}", rel_l2(a[1][l].cpu(), b[1][l].cpu()))
+        assert rel_l2(a[2][l].cpu(), b[2][l].cpu()) <= 1.5e-5, (f"db{l + 1}", rel_l2(a[2][l].cpu(), b[2][l].cpu()))
