@@ -854,11 +854,12 @@ def main():
             tb_med = sorted(tb[1:])[1]
             eb_ = int(eib.shape[1])
             # executed MFMA work of one backward per edge (3-Linear kernel, split-f16 GEMMs): recompute of H_2 on the forward's
-            # kernel (3 x hidden + H1 regeneration), dU_1 and dW_2 (3 x hidden each) on the f16 pipe; the per-edge kernel's two
-            # 64 x k2 products on the fp32 pipe (Z comes from the forward: keep-Z)
+            # kernel (3 x hidden + H1 regeneration), dU_1 and dW_2 (3 x hidden each) and - round 4, gpde_edge_bwd3.hip - the
+            # per-edge kernel's two 64 x k2 products (3 MFMAs per product as well) on the f16 pipe; what is left on the fp32
+            # pipe is per NODE (dZ = gT . W3, dW_3 = gT^T . Z: 2 x 2 x 64 x 64 x k2 per node; Z comes from the forward: keep-Z)
             kwp = (kw + 127) // 128 * 128
-            f16_bwd = 3 * (3 * 2 * kwp * kwp) + 2 * 2 * 16 * kwp * (kwp // 128)
-            f32_bwd = 2 * (2 * 64 * kwp)
+            f16_bwd = 3 * (3 * 2 * kwp * kwp) + 2 * 2 * 16 * kwp * (kwp // 128) + 2 * (3 * 2 * 64 * kwp)
+            f32_bwd = 2 * (2 * 64 * 64 * kwp) * nb_ / max(int(eib.shape[1]), 1)
             bwd_rate = eb_ / tb_med / 1e12
             trec = None
             tfile = os.path.join(REPO, "profiles", "traffic_r04_bwd.json")
@@ -871,7 +872,7 @@ def main():
             backward = {"graph": "g121 (N=%d, E=%d)" % (nb_, eb_), "ms": round(1e3 * tb_med, 2),
                         "M_edges_per_s": round(eb_ / tb_med / 1e6, 2),
                         "roofline": {
-                            "bound": "mfma", "pipe": "f16 MFMA (2-term split operands) for the three k1 x k2 products, fp32 MFMA for the per-edge 64 x k2 products",
+                            "bound": "mfma", "pipe": "f16 MFMA (2-term split operands) for the three k1 x k2 products and the per-edge 64 x k2 products; fp32 MFMA for the per-node dZ / dW_3 products",
                             "executed_flop_per_edge": {"f16_mfma": f16_bwd, "fp32_mfma": f32_bwd},
                             "achieved": round(f16_bwd * bwd_rate, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(f16_bwd * bwd_rate / PEAK_F16_MFMA_TFLOPS, 4),
@@ -886,8 +887,9 @@ def main():
                             "traffic_by_kernel": None if trec is None else trec.get("kernels")},
                         "grads_finite": bool(torch.isfinite(xb.grad).all()) and
                         all(bool(torch.isfinite(p_.grad).all()) for p_ in conv.parameters()),
-                        "arithmetic": "dU_1 and dW_2 GEMMs on the 2-term f16 split (gpde_gemm_f16s_nt_kernel), "
-                                      "recompute of H_2 on the forward's kernel, remaining products fp32 MFMA",
+                        "arithmetic": "dU_1 and dW_2 GEMMs (gpde_gemm_f16s_nt_kernel) and the per-edge products (gpde_edge_bwd3_kernel) on the "
+                                      "2-term f16 split, recompute of H_2 on the forward's kernel, per-node products fp32 MFMA",
+                        "workspace_GiB": round(ops.bwd_workspace_bytes(_lib.lib(), nb_, eb_, 3, _lib.dims_array([6, kw, kw, 4096]), dev) / 2**30, 1),
                         "note": "median of 3 timed backward passes after one warm-up; parity of every gradient "
                                 "against float64 autograd: tests/test_gpu_bwd.py, tests/test_gpu_parity.py"}
             log(f"[bench] backward g121: {backward['ms']} ms, {backward['M_edges_per_s']} M-edges/s")
