@@ -437,15 +437,19 @@ BWD_WS_FRACTION = float(os.environ.get("GPDE_BWD_WS_FRACTION", "0.6"))      # of
 
 def bwd_workspace_bytes(lib, n: int, e: int, nl: int, dims_c, dev) -> int:
     """Workspace of a full backward (gpde_nnconv_bwd*): the library's default (~26 GB at k = 1024: node-aligned chunks of
-    ~640 k edges), raised towards its one-chunk size while that stays below GPDE_BWD_WS_FRACTION of what the device has free -
-    fewer chunks = fewer launches, GEMM tile rounds and split-K reductions (s=121: 10 chunks 152 ms, one chunk 147 ms)."""
+    ~640 k edges), or its one-chunk size when that is below GPDE_BWD_WS_FRACTION of what the device has free - one chunk =
+    fewer launches, GEMM tile rounds and split-K reductions (s=121, 5.9 M edges: 139.4 -> 135.5 ms).  All or nothing: sizes
+    in between were tried (G241: one NNConv backward 2.57 -> 2.11 s with 0.6 of the free memory) and dropped - in a training
+    run on a graph whose hidden activations take most of the device an odd-sized 40 GB block fragments torch's cache until
+    the 27 GB workspace of the next application no longer fits (scripts/time_deferred.py g241: OOM in step 1)."""
     nbytes = int(lib.gpde_nnconv_bwd_workspace_bytes(n, e, nl, dims_c))
     if nbytes == 0:
         _lib.check(-2, "gpde_nnconv_bwd_workspace_bytes")
     if BWD_WS_FRACTION > 0:
         one = int(lib.gpde_nnconv_bwd_workspace_bytes_one_chunk(n, e, nl, dims_c))
         free, _ = device_free_bytes(dev)
-        nbytes = max(nbytes, min(one, int(BWD_WS_FRACTION * free)))
+        if nbytes < one <= int(BWD_WS_FRACTION * free):
+            nbytes = one
     return nbytes
 
 

@@ -177,7 +177,8 @@ size_t gpde_nnconv_bwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_l
 /* The workspace with which the backward runs ALL edges and nodes as ONE chunk (the call above caps its answer at ~26 GB and
  * the backward then walks node-aligned chunks of ~640 k edges at k = 1024).  Any size in between is accepted and gives
  * proportionally fewer chunks; fewer chunks are faster (s=121, 5.9 M edges: 152 ms with 10 chunks, 147 ms with one) - a
- * caller with memory to spare may pass up to this many bytes (ops.py: GPDE_BWD_WS_FRACTION of the free device memory). */
+ * caller with memory to spare may pass up to this many bytes (ops.py: when it is below GPDE_BWD_WS_FRACTION of the free device
+ * memory). */
 size_t gpde_nnconv_bwd_workspace_bytes_one_chunk(int64_t n_nodes, int64_t n_edges, int n_layers,
                                                  const int32_t* dims);
 int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
