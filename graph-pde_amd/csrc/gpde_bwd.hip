@@ -1435,6 +1435,7 @@ extern "C" size_t gpde_nnconv_bwd_workspace_bytes_one_chunk(int64_t n_nodes, int
     BwdPlan P;
     if (!dims || n_nodes < 0 || n_edges < 0) return 0;
     if (make_bwd_plan(n_nodes, n_edges, n_layers, dims, 0, true, &P) != GPDE_OK) return 0;
+    if (P.Ec >= n_edges && P.Nc >= n_nodes) return P.total;          // the default size already runs everything as one chunk
     return P.one_chunk > P.total ? P.one_chunk : P.total;
 }
 

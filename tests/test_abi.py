@@ -171,6 +171,9 @@ def test_node_attr_descriptor_layout_matches_the_header():
                                 None, None, None, None, None, None, None, 0, None) == -1
     assert l.gpde_nnconv_bwd_deferred_supported(3, dims) == 1 and l.gpde_nnconv_bwd_deferred_supported(3, _lib.dims_array([6, 64, 128, 4096])) == 0
     assert l.gpde_nnconv_bwd_deferred_workspace_bytes(100, 5000, 3, dims, 6) > l.gpde_nnconv_bwd_workspace_bytes(100, 5000, 3, dims)
+    # the one-chunk size: never below the default, and for a graph far beyond the default's chunk far above it
+    assert l.gpde_nnconv_bwd_workspace_bytes_one_chunk(100, 5000, 3, dims) >= l.gpde_nnconv_bwd_workspace_bytes(100, 5000, 3, dims)
+    assert l.gpde_nnconv_bwd_workspace_bytes_one_chunk(14641, 5931137, 3, dims) > 4 * l.gpde_nnconv_bwd_workspace_bytes(14641, 5931137, 3, dims)
     assert l.gpde_gather_rows(None, 6, None, -1, None, None) == -1 and l.gpde_gather_rows(None, 6, None, 0, None, None) == 0
 
 

@@ -519,3 +519,30 @@ def test_workspace_allocation_drops_the_caches_once_when_the_device_is_full(monk
     with pytest.raises(torch.OutOfMemoryError):
         ops._alloc_ws(100, "cpu")
     hidden_cache.clear()
+
+
+def test_backward_workspace_is_one_chunk_or_the_default_never_in_between(monkeypatch):
+    """ops.bwd_workspace_bytes: the library's default size, or its one-chunk size when that is below GPDE_BWD_WS_FRACTION of
+    the free device memory - partial growth fragmented torch's cache in G241 training."""
+    from graph_pde_amd import _lib, ops
+    lib = _lib.lib()
+    dims_c = _lib.dims_array([6, 1024, 1024, 4096])
+    n, e = 14641, 5931137                                            # the s=121 graph
+    small = int(lib.gpde_nnconv_bwd_workspace_bytes(n, e, 3, dims_c))
+    one = int(lib.gpde_nnconv_bwd_workspace_bytes_one_chunk(n, e, 3, dims_c))
+    assert one > 4 * small
+    monkeypatch.setattr(ops, "BWD_WS_FRACTION", 0.6)
+    monkeypatch.setattr(ops, "device_free_bytes", lambda dev: (int(one / 0.6) + (1 << 20), 288 << 30))      # just enough
+    assert ops.bwd_workspace_bytes(lib, n, e, 3, dims_c, None) == one
+    monkeypatch.setattr(ops, "device_free_bytes", lambda dev: (int(one / 0.6) - (1 << 30), 288 << 30))      # 1 GB short
+    assert ops.bwd_workspace_bytes(lib, n, e, 3, dims_c, None) == small
+    monkeypatch.setattr(ops, "device_free_bytes", lambda dev: (288 << 30, 288 << 30))
+    monkeypatch.setattr(ops, "BWD_WS_FRACTION", 0.0)                                                       # switched off
+    assert ops.bwd_workspace_bytes(lib, n, e, 3, dims_c, None) == small
+    monkeypatch.setattr(ops, "BWD_WS_FRACTION", 0.6)
+    # a small graph: the default already is one chunk
+    assert ops.bwd_workspace_bytes(lib, 200, 9000, 3, _lib.dims_array([6, 256, 256, 4096]), None) == \
+        int(lib.gpde_nnconv_bwd_workspace_bytes(200, 9000, 3, _lib.dims_array([6, 256, 256, 4096])))
+    # the headline graph: one chunk (2.4 TB) never fits - default
+    g_small = int(lib.gpde_nnconv_bwd_workspace_bytes(58081, 95539625, 3, dims_c))
+    assert ops.bwd_workspace_bytes(lib, 58081, 95539625, 3, dims_c, None) == g_small
