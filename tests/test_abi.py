@@ -173,7 +173,8 @@ def test_node_attr_descriptor_layout_matches_the_header():
     assert l.gpde_nnconv_bwd_deferred_workspace_bytes(100, 5000, 3, dims, 6) > l.gpde_nnconv_bwd_workspace_bytes(100, 5000, 3, dims)
     # the one-chunk size: never below the default, and for a graph far beyond the default's chunk far above it
     assert l.gpde_nnconv_bwd_workspace_bytes_one_chunk(100, 5000, 3, dims) >= l.gpde_nnconv_bwd_workspace_bytes(100, 5000, 3, dims)
-    assert l.gpde_nnconv_bwd_workspace_bytes_one_chunk(14641, 5931137, 3, dims) > 4 * l.gpde_nnconv_bwd_workspace_bytes(14641, 5931137, 3, dims)
+    d1k = _lib.dims_array([6, 1024, 1024, 4096])
+    assert l.gpde_nnconv_bwd_workspace_bytes_one_chunk(14641, 5931137, 3, d1k) > 4 * l.gpde_nnconv_bwd_workspace_bytes(14641, 5931137, 3, d1k)
     assert l.gpde_gather_rows(None, 6, None, -1, None, None) == -1 and l.gpde_gather_rows(None, 6, None, 0, None, None) == 0
 
 
