@@ -19,7 +19,13 @@
 // added to the running dx accumulators), dZ per destination node (pre-pass k_dz_split: the node's [64][K2P] block becomes,
 // in place, per 32-column group 32 hi halves | 32 lo halves - the same 128 bytes, so the DMA geometry is the fp32 kernel's).
 // A 128-slot group spanning two destination nodes runs both nodes' products on all lanes and selects per lane (P1) /
-// zeroes the other node's lanes of B (P2).
+// zeroes the other node's lanes of B (P2); groups spanning more than two run the step loop once per node pair.
+//
+// By-products (full backward only, GpdeEdgeBwd3Args::dUt): with the dU tile in registers in the transposed orientation the kernel
+// also writes dU^T (what the dW_2 = dU_2^T . H_1 GEMM contracts over), each row's power-of-two scale (for the dU_1 = dU_2 . W_2
+// GEMM's A operand) and per-tile column sums / maxima (db_2, the dW_2 GEMM's row scales) - gpde_launch_gemm_f16s_tn then skips
+// its own 48 GB pass over dU_2 (k_transpose_stats).  Measured at s=121: 25 ms of fp32-MFMA kernel + 12 ms of
+// transposing pass -> 17 ms; the kernel is HBM-bound (reads H, writes dU twice: 12 KiB per edge at k2 = 1024, 4.3 TB/s).
 #include "gpde_common.h"
 #include <cstdlib>
 
