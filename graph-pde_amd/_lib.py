@@ -14,6 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPDE_LIB", os.path.join(_PKG, "libgpde.so"))   # GPDE_LIB: experiments
 
 GPDE_OK = 0
+GPDE_VERSION, GPDE_VERSION_ABLATION, GPDE_VERSION_INSTRUMENTED = 100, 0x10000, 0x20000
 GPDE_AGGR_ADD, GPDE_AGGR_MEAN, GPDE_AGGR_MAX = 0, 1, 2
 GPDE_WECONV_MAX_GROUP = 16
 GPDE_FWD_DEFAULT, GPDE_FWD_F16SPLIT = 0, 1
@@ -42,6 +43,7 @@ class GpdeNodeAttr(ctypes.Structure):
 SIGNATURES = {
     "gpde_version": (ctypes.c_int, []),
     "gpde_last_error": (ctypes.c_char_p, []),
+    "gpde_reload_switches": (ctypes.c_int, []),
     "gpde_csr_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64]),
     "gpde_csr_from_coo": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                          ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
@@ -241,8 +243,19 @@ def lib() -> ctypes.CDLL:
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(l, name)          # AttributeError if a declared symbol is missing
                     fn.restype, fn.argtypes = res, args
+                ver = int(l.gpde_version())
+                if ver & GPDE_VERSION_ABLATION and os.environ.get("GPDE_ALLOW_ABLATION") != "1":
+                    raise GpdeError(
+                        f"{LIB_PATH} is an ABLATION build (gpde_version() = {ver:#x}: arithmetic compiled out, results are "
+                        "wrong; timing experiments only) - refused.  GPDE_ALLOW_ABLATION=1 loads it for such an experiment")
                 _lib = l
     return _lib
+
+
+def reload_switches() -> None:
+    """Re-read the library's GPDE_* developer switches from the environment (they are read once per process otherwise)."""
+    if _lib is not None:
+        _lib.gpde_reload_switches()
 
 
 def check(rc: int, what: str) -> None:

@@ -135,14 +135,28 @@ class NNConvHiddenFunction(torch.autograd.Function):
 class DeferredToken:
     """Shared by the virtual-H node and the applications hanging on it: the (input, output gradient) pairs the light
     backward passes leave for the deferred pass, and the validity flag of the cached virtual H (as HiddenToken)."""
-    __slots__ = ("valid", "stash", "hpart")
+    __slots__ = ("valid", "stash", "hpart", "serial")
 
     def __init__(self):
         self.valid = True
-        self.stash = []
+        # application serial -> (x, grad_out), in the order the light passes ran.  Keyed, not appended: an application whose
+        # backward runs twice before the deferred pass (torch.autograd.grad(out, x, retain_graph=True), then loss.backward())
+        # contributes its LAST output gradient once; and `drop_stale` empties it when a new forward finds pairs a finished
+        # backward left behind (a pass abandoned by an exception, or one that asked for input gradients only - the virtual
+        # node's backward, the only consumer, never ran: ADVICE r4)
+        self.stash = {}
+        self.serial = 0
         self.hpart = None       # (H rows of the in-edges of nodes [0, hn), max |H| scalar, hn): the cache's partial H, or None.
                                 # Read at call time and droppable at any moment (hidden_cache.release_all): without it
                                 # everything is recomputed - same mathematics
+
+    def drop_stale(self) -> int:
+        """Called at FORWARD time (hidden_cache.lookup_deferred, NNConvDeferredFunction.forward): pairs on the stash now belong
+        to a backward pass whose deferred step never ran.  Returns how many were dropped."""
+        n = len(self.stash)
+        if n:
+            self.stash = {}
+        return n
 
 
 class DeferredHiddenFunction(torch.autograd.Function):
@@ -165,7 +179,7 @@ class DeferredHiddenFunction(torch.autograd.Function):
                 "gradient with respect to edge_attr is not built (no reference script needs it)")
         token = ctx.token
         token.valid = False
-        stash, token.stash = token.stash, []
+        stash, token.stash = list(token.stash.values()), {}
         hp, token.hpart = token.hpart, None       # the cache builds its next partial H before this token is replaced
         edge_attr, *params = ctx.saved_tensors
         edge_attr = _saved_attr(ctx, edge_attr)
@@ -201,6 +215,10 @@ class NNConvDeferredFunction(torch.autograd.Function):
         else:
             out = ops.nnconv_forward_raw(x.detach(), csr, edge_attr.detach(), pm, root, bias, aggr, z_keep=ctx.z)
         ctx.csr, ctx.aggr, ctx.n_layers, ctx.token = csr, aggr, n_layers, token
+        if token.valid:
+            token.drop_stale()
+        token.serial += 1
+        ctx.serial = token.serial
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, _save_attr(ctx, edge_attr), root, *params)
         return out
@@ -218,7 +236,7 @@ class NNConvDeferredFunction(torch.autograd.Function):
             need_root=root is not None, need_bias=ctx.has_bias, z_saved=ctx.z,
             hidden_part=None if hp is None else hp[0], hidden_nodes=0 if hp is None else hp[2])
         ctx.z = None
-        ctx.token.stash.append((x, grad_out.detach().contiguous()))
+        ctx.token.stash[ctx.serial] = (x, grad_out.detach().contiguous())
         gv = torch.zeros(1, dtype=torch.float32, device=x.device)        # the virtual H carries no numbers, only the dependency
         return (gx, gv, None, None, groot, gbias if ctx.has_bias else None, None, None, None,
                 *([None] * (n - 1)), gw, *([None] * (n - 1)), gb)

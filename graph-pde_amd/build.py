@@ -17,15 +17,19 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(REPO, "include")
-_SUFFIX = os.environ.get("GPDE_BUILD_SUFFIX", "")          # ablation builds: libgpde<suffix>.so
-LIB = os.path.join(PKG, f"libgpde{_SUFFIX}.so")
-OBJDIR = os.path.join(PKG, "build" + _SUFFIX)
+# Developer builds (ablations: -DGPDE_ABL_*, clock probes: -DGPDE_*_TIMING) carry a suffix and live OUTSIDE the package, under the
+# git-ignored scripts/ubench/ - the package directory holds the one production library only
+_SUFFIX = os.environ.get("GPDE_BUILD_SUFFIX", "")
+DEVDIR = os.path.join(REPO, "scripts", "ubench", "lib")
+LIB = os.path.join(DEVDIR, f"libgpde{_SUFFIX}.so") if _SUFFIX else os.path.join(PKG, "libgpde.so")
+OBJDIR = os.path.join(DEVDIR, "build" + _SUFFIX) if _SUFFIX else os.path.join(PKG, "build")
 
 SOURCES = ["gpde_api.hip", "gpde_csr.hip", "gpde_pack.hip", "gpde_fused.hip", "gpde_fused_f16v3.hip", "gpde_fused_f16v6.hip",
            "gpde_zagg.hip", "gpde_prep.hip", "gpde_gemm3.hip", "gpde_gemm.hip", "gpde_gemm_f16s.hip", "gpde_bwd.hip", "gpde_edge_bwd3.hip", "gpde_graph.hip", "gpde_weconv.hip", "gpde_cellgraph.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function",
+         "-fvisibility=hidden"]        # only the GPDE_API entry points of include/gpde.h are dynamic symbols
 
 
 def _deps():

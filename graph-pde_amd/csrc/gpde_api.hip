@@ -4,6 +4,7 @@
 #include "gpde_common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -15,7 +16,51 @@ void gpde_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int gpde_version(void) { return GPDE_VERSION; }
+namespace {
+GpdeSwitches load_switches() {
+    auto on = [](const char* n) { return getenv(n) != nullptr; };
+    auto num = [](const char* n) { const char* e = getenv(n); return e ? atoi(e) : 0; };
+    GpdeSwitches s{};
+    s.bwd_gemm_f32 = on("GPDE_BWD_GEMM_F32");
+    s.bwd_dw2_f32 = on("GPDE_BWD_DW2_F32");
+    s.bwd_recompute_f32 = on("GPDE_BWD_RECOMPUTE_F32");
+    s.bwd_h1_materialize = on("GPDE_BWD_H1_MATERIALIZE");
+    s.bwd_h1_gemm = on("GPDE_BWD_H1_GEMM");
+    s.bwd_dw1_gemm = on("GPDE_BWD_DW1_GEMM");
+    s.bwd_du_passes = on("GPDE_BWD_DU_PASSES");
+    s.bwd_du_transpose_pass = on("GPDE_BWD_DU_TRANSPOSE_PASS");
+    s.bwd_two_pass = on("GPDE_BWD_TWO_PASS");
+    s.store_v3 = on("GPDE_STORE_V3");
+    s.nt_no_prefetch = on("GPDE_NT_NO_PREFETCH");
+    s.tn_no_ks_xcd = on("GPDE_TN_NO_KS_XCD");
+    s.edge_bwd = num("GPDE_EDGE_BWD");
+    const int v = num("GPDE_DEBUG_SKEW_US");
+    s.debug_skew_us = v > 0 ? (v < 100000 ? v : 100000) : 0;
+    return s;
+}
+GpdeSwitches& switches_storage() {
+    static GpdeSwitches s = load_switches();        // first native call of the process (thread-safe static initialisation)
+    return s;
+}
+}  // namespace
+
+const GpdeSwitches& gpde_switches() { return switches_storage(); }
+
+extern "C" int gpde_reload_switches(void) {
+    switches_storage() = load_switches();
+    return GPDE_OK;
+}
+
+// An ablation build (-DGPDE_ABL_*: part of the arithmetic removed, WRONG results, timing only) or an instrumented build
+// (-DGPDE_*_TIMING: clock64 probes) says so in its version word; graph-pde_amd/_lib.py refuses the former unless asked.
+#if defined(GPDE_ABL_2MFMA) || defined(GPDE_ABL_NOSTAGE) || defined(GPDE_ABL_NOBARRIER) || defined(GPDE_ABL_NOGEMM2) || defined(GPDE_ABL_NOWAIT)
+#define GPDE_BUILD_FLAGS_ GPDE_VERSION_ABLATION
+#elif defined(GPDE_V6_TIMING) || defined(GPDE_NT_TIMING) || defined(GPDE_EB2_TIMING) || defined(GPDE_V3_TIMING)
+#define GPDE_BUILD_FLAGS_ GPDE_VERSION_INSTRUMENTED
+#else
+#define GPDE_BUILD_FLAGS_ 0
+#endif
+extern "C" int gpde_version(void) { return GPDE_VERSION | GPDE_BUILD_FLAGS_; }
 extern "C" const char* gpde_last_error(void) { return g_err; }
 
 namespace {

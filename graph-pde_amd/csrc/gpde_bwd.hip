@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd2_kernel(EdgeBwdArgs a) {
 
 #ifdef GPDE_EB2_TIMING
 }  // namespace
-extern "C" int gpde_debug_eb2_timing(unsigned long long* out8, int reset) {
+extern "C" GPDE_API int gpde_debug_eb2_timing(unsigned long long* out8, int reset) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gpde_eb2_tm), 64) != hipSuccess) return -1;
     if (reset) {
         unsigned long long z[8] = {};
@@ -1043,6 +1043,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     // hpart (BWD_LIGHT / BWD_DEFER): the last hidden activations of the in-edges of nodes [0, hpart_nodes) are GIVEN (a partial
     // H kept by the caller, CSR slots [0, rowptr[hpart_nodes])): node chunks below that bound read them instead of recomputing
     const bool do_conv = phase != BWD_MLP && phase != BWD_DEFER, do_mlp = phase != BWD_CONV && phase != BWD_LIGHT;
+    const GpdeSwitches& SW = gpde_switches();       // developer / A-B switches, read once per process (gpde_common.h)
     BwdPlan P;
     int rc = make_bwd_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P, phase == BWD_DEFER ? n_defer : 0);
     if (rc != GPDE_OK) return rc;
@@ -1062,8 +1063,8 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         GP_HIP_CHECK(hipMemsetAsync(F(P.off_dwp[l]), 0, wn * 4, st));
         GP_HIP_CHECK(hipMemsetAsync(F(P.off_dbp[l]), 0, (size_t)P.KP[l] * 4, st));
     }
-    const bool f16s_du1 = do_mlp && P.f16s_du1 && !getenv("GPDE_BWD_GEMM_F32");
-    const bool f16s_dw2 = f16s_du1 && P.f16s_dw2 && !getenv("GPDE_BWD_DW2_F32");
+    const bool f16s_du1 = do_mlp && P.f16s_du1 && !SW.bwd_gemm_f32;
+    const bool f16s_dw2 = f16s_du1 && P.f16s_dw2 && !SW.bwd_dw2_f32;
     if (f16s_du1) {
         // B operand of dU_1 = dU_2 . W_2: rows = k1 (output), contraction = k2  ->  W_2^T, split + swizzled like the forward's W2
         const size_t wn = (size_t)P.KP[2] * P.KP[1];
@@ -1091,7 +1092,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     GpdePackLayout PL;
     bool fast_last = false;
     const bool recomputes = phase == BWD_FULL || phase == BWD_LIGHT || phase == BWD_DEFER;
-    if (recomputes && P.pack_bytes && rowptr && (phase != BWD_FULL || !getenv("GPDE_BWD_RECOMPUTE_F32")) &&
+    if (recomputes && P.pack_bytes && rowptr && (phase != BWD_FULL || !SW.bwd_recompute_f32) &&
         gpde_pack_layout(n, dims, &PL) == GPDE_OK && PL.mode == 1) {
         GpdeFusedArgs probe{};
         probe.k0 = PL.k0; probe.K1P = PL.K1P; probe.K2P = PL.K2P;
@@ -1103,8 +1104,8 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     // 3-Linear kernels on the split-f16 GEMMs: the first hidden layer H_1 is never written.  Its only consumers in the
     // backward are dW_2 = dU_2^T . H_1 (operand image generated straight from the 8 attribute slots, k_first_layer_pack)
     // and the ReLU mask of dU_1 (128 bytes of bits per edge instead of 4 KiB).  GPDE_BWD_H1_MATERIALIZE=1: the tensor (A/B).
-    const bool h1_on_the_fly = n == 3 && f16s_du1 && f16s_dw2 && dims[0] <= 8 && P.KP[0] >= 8 && !getenv("GPDE_BWD_H1_MATERIALIZE") &&
-                               !getenv("GPDE_BWD_H1_GEMM");
+    const bool h1_on_the_fly = n == 3 && f16s_du1 && f16s_dw2 && dims[0] <= 8 && P.KP[0] >= 8 && !SW.bwd_h1_materialize &&
+                               !SW.bwd_h1_gemm;
     auto skip_h1 = [&](int rows) { return h1_on_the_fly && rows >= 8192; };
     if ((phase == BWD_LIGHT && !fast_last) || (phase == BWD_DEFER && !(fast_last && f16s_du1 && f16s_dw2 && n == 3))) {
         gpde_set_error("gpde_nnconv_bwd_%s: kernel MLP outside the depth-deferred form (3 Linear layers of widths that are multiples of 128, "
@@ -1152,7 +1153,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         if (light) return GPDE_OK;
         for (int l = 1; l <= last; ++l) {
             if (l == 1 && last == 1 && skip_h1(rows)) continue;
-            if (l == 1 && dims[0] <= 8 && P.KP[0] >= 8 && P.KP[1] % 4 == 0 && rows >= 1024 && !getenv("GPDE_BWD_H1_GEMM")) {
+            if (l == 1 && dims[0] <= 8 && P.KP[0] >= 8 && P.KP[1] % 4 == 0 && rows >= 1024 && !SW.bwd_h1_gemm) {
                 const int cb = (P.KP[1] + 255) / 256;
                 int rb = rows / 64; if (rb > 4096 / cb) rb = 4096 / cb; if (rb < 1) rb = 1;
                 hipLaunchKernelGGL(k_first_layer, dim3(cb, rb), dim3(T), 0, st, F(P.off_H[0]), P.KP[0], F(P.off_wp[1]), P.KP[0],
@@ -1191,7 +1192,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             if (l == 1 && grad_attr)         // dU_1 is complete here: the gradient of the attributes through W_1
                 hipLaunchKernelGGL(k_grad_attr, dim3((rows + 3) / 4), dim3(T), 0, st, dUc, Kl, F(P.off_wp[1]), Kin, perm, mlp_e0, rows,
                                    dims[0], grad_attr);
-            if (l == 1 && dims[0] <= 8 && Kin >= 8 && Kin % 4 == 0 && Kl % 4 == 0 && rows >= 1024 && !getenv("GPDE_BWD_DW1_GEMM")) {
+            if (l == 1 && dims[0] <= 8 && Kin >= 8 && Kin % 4 == 0 && Kl % 4 == 0 && rows >= 1024 && !SW.bwd_dw1_gemm) {
                 // dW_1 and db_1 from one pass over dU_1 (k_dw_first; attribute slots beyond k0 are zero columns of H_0)
                 const int cb = (Kl + 255) / 256;
                 int splits = 1; while (splits < 256 && cb * splits < 1024 && rows / (splits * 2) >= 64) splits *= 2;
@@ -1206,7 +1207,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             const bool tn_split = l == 2 && f16s_dw2 && rows >= 8192;
             // one pass over dU_2 for its transposed copy, db_2, and the row scales of the dU_1 GEMM (GPDE_BWD_DU_PASSES=1:
             // the separate k_colsum / k_row_scale_kernel passes of round 2, A/B)
-            const bool du_one_pass = tn_split && f16s_du1 && !getenv("GPDE_BWD_DU_PASSES");
+            const bool du_one_pass = tn_split && f16s_du1 && !SW.bwd_du_passes;
             unsigned* du_bits = tn_split ? (unsigned*)F(P.off_dubits) : nullptr;
             if (!du_one_pass) {   // db_l = column sums of dU_l; the same pass collects the column maxima the split dW_2 GEMM scales with
                 const int cb = (Kl + 255) / 256;
@@ -1382,8 +1383,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 if (int rc_ = once.ensure(gpde_edge_bwd_kernel, gpde_edge_bwd2_kernel)) return rc_;
                 if (!dx) { gpde_set_error("gpde_nnconv_bwd: grad_x must be provided"); return GPDE_EINVAL; }
                 // staged kernel where a 128-slot group rarely spans more than two destinations
-                const char* fe = getenv("GPDE_EDGE_BWD");          // "1" / "2": force a variant (tests, A/B)
-                const int force = fe ? atoi(fe) : 0;
+                const int force = SW.edge_bwd;                     // GPDE_EDGE_BWD = 1 / 2 / 3: force a variant (tests, A/B)
                 const bool staged = force ? force >= 2 : (int64_t)rows >= (int64_t)32 * nn;
                 du_pre = false;
                 if (staged && force != 2 && K2P % 32 == 0) {      // split-f16 MFMA (default); GPDE_EDGE_BWD=2: the fp32-MFMA staged kernel
@@ -1391,8 +1391,8 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                     GpdeEdgeBwd3Args e3{x, src, dst, dZ, F(P.off_dzun), dS, Hlast, dUc, dx, ordered ? F(P.off_dxe) : nullptr, e0, e1, na, K2P};
                     // full backward on the split GEMMs: the kernel also leaves what the dW_2 GEMM's pass over dU_2 would form
                     // (mlp_backward's tn_split && du_one_pass case; GPDE_BWD_DU_TRANSPOSE_PASS=1: that pass, A/B)
-                    if (phase == BWD_FULL && n == 3 && f16s_dw2 && f16s_du1 && rows >= 8192 && !getenv("GPDE_BWD_DU_PASSES") &&
-                        !getenv("GPDE_BWD_DU_TRANSPOSE_PASS")) {
+                    if (phase == BWD_FULL && n == 3 && f16s_dw2 && f16s_du1 && rows >= 8192 && !SW.bwd_du_passes &&
+                        !SW.bwd_du_transpose_pass) {
                         e3.dUt = gpde_gemm_f16s_tn_at(F(P.off_tnws), rows, tn_ksplits(rows), &e3.ldt);
                         e3.row_sc = F(P.off_rowsc); e3.row_isc = F(P.off_rowsc) + rows;
                         e3.csum_part = F(P.off_tcs); e3.cmax_part = (unsigned*)F(P.off_tcm);

@@ -64,6 +64,27 @@ int gpde_pack_layout(int n_layers, const int32_t* dims, GpdePackLayout* L);
 
 void gpde_set_error(const char* fmt, ...);
 
+// Developer / A-B switches (GPDE_* environment variables consumed by native code).  They are read ONCE - on the first native
+// call of the process - and never inside a launch path; gpde_reload_switches() (include/gpde.h) re-reads them (the test
+// suite's monkeypatch fixture calls it, tests/conftest.py).
+struct GpdeSwitches {
+    bool bwd_gemm_f32;           // GPDE_BWD_GEMM_F32: dU_1 / dW_2 on the fp32-MFMA GEMMs
+    bool bwd_dw2_f32;            // GPDE_BWD_DW2_F32
+    bool bwd_recompute_f32;      // GPDE_BWD_RECOMPUTE_F32: H recomputed by fp32 GEMMs in the full backward
+    bool bwd_h1_materialize;     // GPDE_BWD_H1_MATERIALIZE: round-2 plan (H_1 written)
+    bool bwd_h1_gemm;            // GPDE_BWD_H1_GEMM
+    bool bwd_dw1_gemm;           // GPDE_BWD_DW1_GEMM
+    bool bwd_du_passes;          // GPDE_BWD_DU_PASSES: separate bias / maxima / transpose passes over dU_2
+    bool bwd_du_transpose_pass;  // GPDE_BWD_DU_TRANSPOSE_PASS: k_transpose_stats instead of the per-edge kernel's by-products
+    bool bwd_two_pass;           // GPDE_BWD_TWO_PASS: recompute-store + gpde_edge_bwd3 instead of the one-pass kernel (round 5)
+    bool store_v3;               // GPDE_STORE_V3: hidden-activation store on the 8-wave kernel
+    bool nt_no_prefetch;         // GPDE_NT_NO_PREFETCH
+    bool tn_no_ks_xcd;           // GPDE_TN_NO_KS_XCD
+    int edge_bwd;                // GPDE_EDGE_BWD = 1 | 2 | 3: force a per-edge backward kernel (0: by in-degree)
+    int debug_skew_us;           // GPDE_DEBUG_SKEW_US: odd column slices of the GEMMs start late (race tests)
+};
+const GpdeSwitches& gpde_switches();
+
 #define GP_HIP_CHECK(expr)                                                              \
     do {                                                                                \
         hipError_t _e = (expr);                                                         \

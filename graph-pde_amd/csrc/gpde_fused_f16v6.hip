@@ -681,7 +681,7 @@ size_t v6_lds_bytes(int K1P) {
 }  // namespace
 
 #ifdef GPDE_V6_TIMING
-extern "C" int gpde_debug_v6_timing(unsigned long long* out8, int reset) {
+extern "C" GPDE_API int gpde_debug_v6_timing(unsigned long long* out8, int reset) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gpde_v6_tm), 64) != hipSuccess) return -1;
     if (reset) {
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -725,7 +725,7 @@ bool gpde_fused_store_supported(GpdeFusedArgs probe) {
 
 int gpde_launch_fused_store(const GpdeFusedArgs& f, hipStream_t stream) {
     if (!f.hout) { gpde_set_error("gpde_launch_fused_store: hout is null"); return GPDE_EINVAL; }
-    static const bool force_v3 = getenv("GPDE_STORE_V3") != nullptr;
+    const bool force_v3 = gpde_switches().store_v3;
     if (!force_v3 && gpde_fused_f16v6_supported(f)) return gpde_launch_fused_f16v6(f, stream);
     if (gpde_fused_f16v3_supported(f)) return gpde_launch_fused_f16v3(f, stream);
     gpde_set_error("fused store kernel: unsupported kernel MLP (K1P = %d, k0 = %d)", f.K1P, f.k0);

@@ -196,11 +196,7 @@ __global__ void gpde_reduce_groups_kernel(float* __restrict__ P, size_t n, int s
 
 }  // namespace
 
-int gpde_debug_skew_us() {
-    const char* e = getenv("GPDE_DEBUG_SKEW_US");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? (v < 100000 ? v : 100000) : 0;
-}
+int gpde_debug_skew_us() { return gpde_switches().debug_skew_us; }
 
 int gpde_launch_gemm(const GpdeGemmArgs& g_in, hipStream_t stream) {
     GpdeGemmArgs g = g_in;

@@ -520,7 +520,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
 }  // namespace
 
 #ifdef GPDE_NT_TIMING
-extern "C" int gpde_debug_nt_timing(unsigned long long* out16, int reset) {
+extern "C" GPDE_API int gpde_debug_nt_timing(unsigned long long* out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(gpde_nt_tm), 128) != hipSuccess) return -1;
     if (reset) {
         unsigned long long z[16] = {};
@@ -542,8 +542,7 @@ int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a_in, float* row_scale_ws, 
     GpdeGemmF16sArgs a = a_in;
     if (a.ksplits < 1) a.ksplits = 1;
     a.skew_us = gpde_debug_skew_us();
-    static const bool no_pref = getenv("GPDE_NT_NO_PREFETCH") != nullptr, no_ksx = getenv("GPDE_TN_NO_KS_XCD") != nullptr;
-    a.no_tile_prefetch = no_pref; a.no_ks_xcd = no_ksx;
+    a.no_tile_prefetch = gpde_switches().nt_no_prefetch; a.no_ks_xcd = gpde_switches().tn_no_ks_xcd;
     if (!gpde_gemm_f16s_supported(a.M, a.N, a.K, a.lda) || a.K % (64 * a.ksplits) != 0 || a.K / a.ksplits < 256) {
         gpde_set_error("gpde_gemm_f16s_nt: unsupported shape M=%d N=%d K=%d ksplits=%d", a.M, a.N, a.K, a.ksplits);
         return GPDE_EUNSUPPORTED;

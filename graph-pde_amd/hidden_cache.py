@@ -244,6 +244,8 @@ def lookup_deferred(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, w
     if ent.dtoken is not None and ent.dkey == key and ent.dtoken.valid:
         ent.dcount += 1
         ent.dtoken.hpart = hpart
+        if ent.dtoken.drop_stale():      # a backward over this (still valid) node ended without its deferred pass
+            stats["deferred_stale_dropped"] = stats.get("deferred_stale_dropped", 0) + 1
         stats["deferred_hits"] = stats.get("deferred_hits", 0) + 1
         return ent.dvirtual, ent.dtoken
     if ent.dtoken is not None and ent.dcount <= 1:

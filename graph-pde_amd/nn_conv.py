@@ -115,6 +115,12 @@ class NNConv_old(MessagePassing):
             # the default f16-split kernel; anything else takes the tensor the reference would build.
             lin = ops.mlp_linears(self.nn)
             needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+            if torch.is_grad_enabled() and edge_attr.table.requires_grad:
+                # a node table that wants a gradient (learned positions / coefficients): the `_na` kernels do not differentiate
+                # the table, the materialised tensor does (differentiable gather -> gpde_nnconv_bwd_attr) - ADVICE r4
+                edge_attr = edge_attr.materialize(edge_index.edge_index if isinstance(edge_index, ops.Csr) else edge_index)
+                pseudo = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
+                return self.propagate(edge_index, x=x, pseudo=pseudo)
             if not needs_grad and self.aggr != "max" and len(lin) == 3 and ops.DEFAULT_PRECISION == "f16split" and \
                     self.in_channels == ops.WIDTH and self.out_channels == ops.WIDTH:
                 csr = ops.csr_for(edge_index, x.size(0))

@@ -462,6 +462,25 @@ def device_free_bytes(dev):
     return free + max(0, cached), total
 
 
+def alloc_bwd_ws(lib, n: int, e: int, nl: int, dims_c, dev) -> torch.Tensor:
+    """Workspace of a full backward.  The one-chunk size (`bwd_workspace_bytes`) is an optimisation worth ~3 %: its estimate of
+    the free memory is racy (other ranks / processes on the device, torch's cached blocks), so when that allocation fails the
+    library's default plan (~26 GB) is taken instead - BEFORE any cache is dropped; only the default size goes through
+    `_alloc_ws`'s release-and-retry (a run that fitted with the default plan must keep fitting)."""
+    nbytes = bwd_workspace_bytes(lib, n, e, nl, dims_c, dev)
+    default = int(lib.gpde_nnconv_bwd_workspace_bytes(n, e, nl, dims_c))
+    if nbytes > default:
+        try:
+            return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        except torch.OutOfMemoryError:
+            global n_bwd_ws_fallbacks
+            n_bwd_ws_fallbacks += 1
+    return _alloc_ws(default, dev)
+
+
+n_bwd_ws_fallbacks = 0      # times the one-chunk workspace did not fit and the default plan ran (tests / diagnostics)
+
+
 def _alloc_ws(nbytes: int, dev) -> torch.Tensor:
     """Workspace of a native call.  The hidden-activation / per-edge-weight caches may hold most of the device (their
     budget follows the HBM size: hidden_cache.budget_bytes) - they are recomputable, a workspace is not optional: when the
@@ -739,7 +758,7 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
     P = ctypes.c_void_p
     arr = lambda ts: (P * nl)(*[None if t is None else t.data_ptr() for t in ts])
     if ws is None:
-        ws = _alloc_ws(bwd_workspace_bytes(lib, n, e, nl, dims_c, dev), dev)
+        ws = alloc_bwd_ws(lib, n, e, nl, dims_c, dev)
     rph = csr.rowptr_host
     srp, ssl = csr.src_order
     if is_na:
@@ -1325,7 +1344,7 @@ def hidden_backward_raw(csr: Csr, edge_attr: torch.Tensor, dims: Sequence[int],
     bs_ = [None if b is None else b.detach().contiguous() for b in biases] + [None]
     gW = [torch.empty_like(w) for w in ws_[:-1]] + [None]
     gb = [None if b is None else torch.empty_like(b) for b in bs_[:-1]] + [None]
-    ws = _alloc_ws(bwd_workspace_bytes(lib, 0, e, nl, dims_c, dev), dev)
+    ws = alloc_bwd_ws(lib, 0, e, nl, dims_c, dev)
     if is_na:
         na = edge_attr.c_struct()
         with torch.cuda.device(dev):

@@ -28,6 +28,15 @@ extern "C" {
 #endif
 
 #define GPDE_VERSION 100 /* 0.1.0 */
+/* gpde_version() of a developer build carries one of these on top of GPDE_VERSION: an ABLATION build has part of the arithmetic
+ * compiled out (timing experiments; its results are WRONG and a binding must refuse it), an INSTRUMENTED build carries
+ * clock probes (results correct). */
+#define GPDE_VERSION_ABLATION 0x10000
+#define GPDE_VERSION_INSTRUMENTED 0x20000
+
+/* libgpde.so is built with -fvisibility=hidden: the entry points declared here are its ONLY dynamic symbols (internal
+ * launchers and kernels stay out of the dynamic symbol table; tests/test_abi.py diffs `nm -D` against this header). */
+#define GPDE_API __attribute__((visibility("default")))
 
 enum {
     GPDE_OK = 0,
@@ -62,8 +71,12 @@ enum {
 #define GPDE_MAX_LAYERS 8
 #define GPDE_WIDTH 64 /* node-feature width (in_channels == out_channels) the kernels are built for */
 
-int gpde_version(void);
-const char* gpde_last_error(void);
+GPDE_API int gpde_version(void);
+GPDE_API const char* gpde_last_error(void);
+/* The library's developer / A-B switches (GPDE_BWD_*, GPDE_EDGE_BWD, GPDE_DEBUG_SKEW_US, ...: INTEGRATION.md) are environment
+ * variables read ONCE, at the first native call of the process - no launch path calls getenv().  This re-reads them (test
+ * suites and A/B scripts that flip a switch inside one process). */
+GPDE_API int gpde_reload_switches(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Destination-sorted CSR of a COO edge list.
@@ -79,15 +92,15 @@ const char* gpde_last_error(void);
  *   n_bad      : int32 device word, receives the number of edges with an endpoint outside [0,N)
  *                (those edges are dropped from the CSR; the reference would raise IndexError)
  */
-size_t gpde_csr_workspace_bytes(int64_t n_edges, int64_t n_nodes);
-int gpde_csr_from_coo(const int64_t* edge_index, int64_t stride_row, int64_t stride_col,
+GPDE_API size_t gpde_csr_workspace_bytes(int64_t n_edges, int64_t n_nodes);
+GPDE_API int gpde_csr_from_coo(const int64_t* edge_index, int64_t stride_row, int64_t stride_col,
                       int64_t n_edges, int64_t n_nodes, int32_t* rowptr, int32_t* src,
                       int32_t* dst, int32_t* perm, int32_t* n_bad, void* ws, size_t ws_bytes,
                       void* stream);
 /* out[s][0..k) = rows[perm[s]][0..k) for the n CSR slots: a per-edge tensor (edge_attr [E][k0], the `pseudo` of
  * nn_conv.py:271) laid out by CSR slot, once per (graph, tensor), so that the fused kernels stream it instead of chasing
  * perm (8 column slices x one cache line per edge otherwise).  Same values: results are bit-identical. */
-int gpde_gather_rows(const float* rows, int k, const int32_t* perm, int64_t n, float* out, void* stream);
+GPDE_API int gpde_gather_rows(const float* rows, int k, const int32_t* perm, int64_t n, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Kernel-MLP weights, repacked once per parameter update into MFMA-tile order.
@@ -100,8 +113,8 @@ int gpde_gather_rows(const float* rows, int k, const int32_t* perm, int64_t n, f
  *                (b[l] may be NULL = no bias)
  *   packed        : device buffer of gpde_mlp_pack_bytes() bytes
  */
-size_t gpde_mlp_pack_bytes(int n_layers, const int32_t* dims);
-int gpde_mlp_pack(int n_layers, const int32_t* dims, const float* const* W,
+GPDE_API size_t gpde_mlp_pack_bytes(int n_layers, const int32_t* dims);
+GPDE_API int gpde_mlp_pack(int n_layers, const int32_t* dims, const float* const* W,
                   const float* const* b, void* packed, size_t packed_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -119,9 +132,9 @@ int gpde_mlp_pack(int n_layers, const int32_t* dims, const float* const* W,
  *   ws: gpde_nnconv_fwd_workspace_bytes() is the recommended size; any size that holds one
  *   64-node tile works (more workspace = more destination nodes per launch), else GPDE_EWORKSPACE.
  */
-size_t gpde_nnconv_fwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers,
+GPDE_API size_t gpde_nnconv_fwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers,
                                        const int32_t* dims);
-int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
+GPDE_API int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
                     const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                     const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
                     const float* root, const float* bias, int aggr, uint32_t flags, float* out,
@@ -133,12 +146,12 @@ int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edge_attr, int
  *                                            relu_out != 0: act = max(., 0), else identity
  * - `F.relu(x + conv(x, ...))` of the MGKN V-cycles (MGKN_general_darcy2d.py:79-80,89-90;
  * MGKN_orthogonal_burgers1d.py:74-82) and `F.relu(conv(...))` of KernelNN.forward (UAI1_full_resolution.py:30). */
-int gpde_nnconv_fwd_act(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
+GPDE_API int gpde_nnconv_fwd_act(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
                         const int32_t* rowptr, const int32_t* src, const int32_t* dst, const int32_t* perm,
                         int n_layers, const int32_t* dims, const void* packed, const float* root,
                         const float* bias, int aggr, uint32_t flags, const float* residual, int relu_out,
                         float* out, void* ws, size_t ws_bytes, void* stream);
-int gpde_nnconv_fwd_hidden_act(const float* x, int64_t n_nodes, const float* hidden, const float* hidden_absmax,
+GPDE_API int gpde_nnconv_fwd_hidden_act(const float* x, int64_t n_nodes, const float* hidden, const float* hidden_absmax,
                                int64_t n_edges, const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                                int n_layers, const int32_t* dims, const void* packed, const float* root,
                                const float* bias, int aggr, const float* residual, int relu_out, float* out,
@@ -148,7 +161,7 @@ int gpde_nnconv_fwd_hidden_act(const float* x, int64_t n_nodes, const float* hid
  * device work): number of destination-node chunks, nodes per chunk, workgroups of the fused
  * kernel per chunk, and which fused variant runs (0: one hidden layer, 1: two hidden layers with
  * the first generated on the fly, 2: hidden activations precomputed by dense front layers). */
-int gpde_nnconv_fwd_plan(int64_t n_nodes, int64_t n_edges, int n_layers, const int32_t* dims,
+GPDE_API int gpde_nnconv_fwd_plan(int64_t n_nodes, int64_t n_edges, int n_layers, const int32_t* dims,
                          size_t ws_bytes, int32_t* n_chunks, int64_t* nodes_per_chunk,
                          int32_t* fused_workgroups, int32_t* mode);
 
@@ -160,7 +173,7 @@ int gpde_nnconv_fwd_plan(int64_t n_nodes, int64_t n_edges, int n_layers, const i
  * It names the kernel of the RE-ASSOCIATED path; a low in-degree graph (mean in-degree <= 4, >= 4096 edges, k2 >= 256,
  * one node chunk: DESIGN.md §3e) runs the store variant of the same kernel family plus gpde_gemm_f16s_nt_kernel instead -
  * whether it does depends on the node count and the workspace, which this query does not see. */
-const char* gpde_nnconv_fwd_kernel(int64_t n_edges, int n_layers, const int32_t* dims, uint32_t flags);
+GPDE_API const char* gpde_nnconv_fwd_kernel(int64_t n_edges, int n_layers, const int32_t* dims, uint32_t flags);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward of the fused NNConv (what autograd computes through nn_conv.py:267-282,
@@ -172,16 +185,16 @@ const char* gpde_nnconv_fwd_kernel(int64_t n_edges, int n_layers, const int32_t*
  * (the edge chunks are planned on the host).  Hidden activations are recomputed per node-aligned
  * chunk of edges; nothing from the forward needs to be saved.  Edge-attribute gradients are not
  * produced (the reference never asks for them).  fp32 MFMA throughout. */
-size_t gpde_nnconv_bwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers,
+GPDE_API size_t gpde_nnconv_bwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers,
                                        const int32_t* dims);
 /* The workspace with which the backward runs ALL edges and nodes as ONE chunk (the call above caps its answer at ~26 GB and
  * the backward then walks node-aligned chunks of ~640 k edges at k = 1024).  Any size in between is accepted and gives
  * proportionally fewer chunks; fewer chunks are faster (s=121, 5.9 M edges: 152 ms with 10 chunks, 147 ms with one) - a
  * caller with memory to spare may pass up to this many bytes (ops.py: when it is below GPDE_BWD_WS_FRACTION of the free device
  * memory). */
-size_t gpde_nnconv_bwd_workspace_bytes_one_chunk(int64_t n_nodes, int64_t n_edges, int n_layers,
+GPDE_API size_t gpde_nnconv_bwd_workspace_bytes_one_chunk(int64_t n_nodes, int64_t n_edges, int n_layers,
                                                  const int32_t* dims);
-int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
+GPDE_API int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
                     const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                     const int32_t* perm, const int32_t* rowptr_host, int n_layers,
                     const int32_t* dims, const float* const* W, const float* const* b,
@@ -193,7 +206,7 @@ int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int
  * given the CSR slots regrouped by source node (gpde_csr_source_order below: src_rowptr [N+1], src_slots [E]) the
  * per-edge contributions are written out and summed per source in ascending slot order by one owner per element.
  * src_rowptr == NULL or src_slots == NULL selects the atomic path.  Weight gradients are ordered either way. */
-int gpde_nnconv_bwd_ordered(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
+GPDE_API int gpde_nnconv_bwd_ordered(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
                             const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                             const int32_t* perm, const int32_t* rowptr_host, const int32_t* src_rowptr,
                             const int32_t* src_slots, int n_layers,
@@ -204,7 +217,7 @@ int gpde_nnconv_bwd_ordered(const float* x, int64_t n_nodes, const float* edge_a
 /* The same (z_saved: NULL or the keep-Z forward's buffer) that also writes grad_edge_attr [E][k0] = dL/d edge_attr in the
  * caller's edge order - what autograd hands `pseudo` when it requires a gradient (no reference script asks for it).  Attribute
  * tensors of <= 8 slots. */
-int gpde_nnconv_bwd_attr(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges, const int32_t* rowptr,
+GPDE_API int gpde_nnconv_bwd_attr(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges, const int32_t* rowptr,
                          const int32_t* src, const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host,
                          const int32_t* src_rowptr, const int32_t* src_slots, int n_layers, const int32_t* dims,
                          const float* const* W, const float* const* b, const float* root, int aggr, const float* grad_out,
@@ -212,7 +225,7 @@ int gpde_nnconv_bwd_attr(const float* x, int64_t n_nodes, const float* edge_attr
                          float* const* grad_b, float* grad_root, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
 /* src_slots = CSR slots 0..E-1 stably sorted by their source node, src_rowptr[j] = first position of source j;
  * `src` is the array gpde_csr_from_coo wrote; workspace: gpde_csr_workspace_bytes(n_edges, n_nodes). */
-int gpde_csr_source_order(const int32_t* src, int64_t n_edges, int64_t n_nodes, int32_t* src_rowptr,
+GPDE_API int gpde_csr_source_order(const int32_t* src, int64_t n_edges, int64_t n_nodes, int32_t* src_rowptr,
                           int32_t* src_slots, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -246,12 +259,12 @@ int gpde_csr_source_order(const int32_t* src, int64_t n_edges, int64_t n_nodes, 
  * path computed H (the general path leaves 0: the value is then NOT a maximum and must not be
  * passed on).  Given back to gpde_nnconv_fwd_hidden it lets the aggregation run on split-f16 MFMA
  * from 32768 edges on; NULL: fp32 MFMA. */
-size_t gpde_hidden_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims);
-int gpde_hidden_fwd(const float* edge_attr, int64_t n_edges, const int32_t* rowptr, int64_t n_nodes,
+GPDE_API size_t gpde_hidden_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims);
+GPDE_API int gpde_hidden_fwd(const float* edge_attr, int64_t n_edges, const int32_t* rowptr, int64_t n_nodes,
                     const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
                     const float* const* W, const float* const* b, uint32_t flags, float* hidden,
                     float* hidden_absmax, void* ws, size_t ws_bytes, void* stream);
-int gpde_nnconv_fwd_hidden(const float* x, int64_t n_nodes, const float* hidden,
+GPDE_API int gpde_nnconv_fwd_hidden(const float* x, int64_t n_nodes, const float* hidden,
                            const float* hidden_absmax, int64_t n_edges,
                            const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                            int n_layers, const int32_t* dims, const void* packed, const float* root,
@@ -262,13 +275,13 @@ int gpde_nnconv_fwd_hidden(const float* x, int64_t n_nodes, const float* hidden,
  * [0, rowptr[hidden_nodes]); build it with gpde_hidden_fwd(..., n_edges = rowptr[hidden_nodes],
  * n_nodes = hidden_nodes)); those nodes aggregate from it, all others run the fused kernel on
  * edge_attr.  Same result as gpde_nnconv_fwd.  3-Linear kernel MLPs; forward only. */
-int gpde_nnconv_fwd_mixed(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
+GPDE_API int gpde_nnconv_fwd_mixed(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
                           const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges,
                           const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                           const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
                           const float* root, const float* bias, int aggr, uint32_t flags, float* out,
                           void* ws, size_t ws_bytes, void* stream);
-int gpde_nnconv_bwd_hidden(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
+GPDE_API int gpde_nnconv_bwd_hidden(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
                            const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                            const int32_t* rowptr_host, int n_layers, const int32_t* dims,
                            const float* w_last, const float* b_last, const float* root, int aggr,
@@ -276,7 +289,7 @@ int gpde_nnconv_bwd_hidden(const float* x, int64_t n_nodes, const float* hidden,
                            float* grad_w_last, float* grad_b_last, float* grad_root, float* grad_bias,
                            void* ws, size_t ws_bytes, void* stream);
 /* bit-reproducible grad_x, as gpde_nnconv_bwd_ordered */
-int gpde_nnconv_bwd_hidden_ordered(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
+GPDE_API int gpde_nnconv_bwd_hidden_ordered(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
                                    const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                                    const int32_t* rowptr_host, const int32_t* src_rowptr,
                                    const int32_t* src_slots, int n_layers, const int32_t* dims,
@@ -284,7 +297,7 @@ int gpde_nnconv_bwd_hidden_ordered(const float* x, int64_t n_nodes, const float*
                                    const float* grad_out, float* grad_x, float* grad_hidden,
                                    float* grad_w_last, float* grad_b_last, float* grad_root, float* grad_bias,
                                    void* ws, size_t ws_bytes, void* stream);
-int gpde_hidden_bwd(const float* edge_attr, int64_t n_edges, const int32_t* perm, int n_layers,
+GPDE_API int gpde_hidden_bwd(const float* edge_attr, int64_t n_edges, const int32_t* perm, int n_layers,
                     const int32_t* dims, const float* const* W, const float* const* b,
                     const float* grad_hidden, float* const* grad_W, float* const* grad_b, void* ws,
                     size_t ws_bytes, void* stream);
@@ -297,12 +310,12 @@ int gpde_hidden_bwd(const float* edge_attr, int64_t n_edges, const int32_t* perm
  * width padded to 128; ZERO-INITIALISED by the caller: nodes without in-edges are not written); the per-edge last layer of
  * low in-degree graphs is not taken.  gpde_nnconv_bwd_z = gpde_nnconv_bwd_ordered / gpde_nnconv_bwd_hidden_ordered with
  * that Z (W / b: all n_layers entries for the full form; only the last for the hidden form). */
-int gpde_nnconv_fwd_keepz(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
+GPDE_API int gpde_nnconv_fwd_keepz(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
                           const float* hidden_absmax, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
                           const int32_t* dst, const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
                           const float* root, const float* bias, int aggr, uint32_t flags, float* z_keep, float* out,
                           void* ws, size_t ws_bytes, void* stream);
-int gpde_nnconv_bwd_z(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden, int64_t n_edges,
+GPDE_API int gpde_nnconv_bwd_z(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden, int64_t n_edges,
                       const int32_t* rowptr, const int32_t* src, const int32_t* dst, const int32_t* perm,
                       const int32_t* rowptr_host, const int32_t* src_rowptr, const int32_t* src_slots, int n_layers,
                       const int32_t* dims, const float* const* W, const float* const* b, const float* root, int aggr,
@@ -333,24 +346,24 @@ int gpde_nnconv_bwd_z(const float* x, int64_t n_nodes, const float* edge_attr, c
  * at most 7 attributes: the split-f16 path); others return GPDE_EUNSUPPORTED - use gpde_nnconv_bwd per application.
  * Results: grad_x etc. of the light pass are the bits of gpde_nnconv_bwd_ordered; the hidden layers' gradients equal the
  * sum of the per-application ones up to fp32 / split-f16 summation order (tests/test_gpu_deferred.py: <= 2e-5). */
-int gpde_nnconv_bwd_deferred_supported(int n_layers, const int32_t* dims);
-size_t gpde_nnconv_bwd_deferred_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers, const int32_t* dims,
+GPDE_API int gpde_nnconv_bwd_deferred_supported(int n_layers, const int32_t* dims);
+GPDE_API size_t gpde_nnconv_bwd_deferred_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers, const int32_t* dims,
                                                 int n_defer);
-int gpde_nnconv_bwd_light(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges, const int32_t* rowptr,
+GPDE_API int gpde_nnconv_bwd_light(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges, const int32_t* rowptr,
                           const int32_t* src, const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host,
                           const int32_t* src_rowptr, const int32_t* src_slots, int n_layers, const int32_t* dims,
                           const float* const* W, const float* const* b, const float* root, int aggr, const float* grad_out,
                           const float* z_saved, const float* hidden_part, int64_t hidden_nodes, float* grad_x,
                           float* grad_w_last, float* grad_b_last, float* grad_root,
                           float* grad_bias, void* ws, size_t ws_bytes, void* stream);
-int gpde_nnconv_bwd_deferred(const float* x_stack, const float* grad_out_stack, int n_defer, int64_t n_nodes,
+GPDE_API int gpde_nnconv_bwd_deferred(const float* x_stack, const float* grad_out_stack, int n_defer, int64_t n_nodes,
                              const float* edge_attr, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
                              const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host, int n_layers,
                              const int32_t* dims, const float* const* W, const float* const* b, int aggr,
                              const float* hidden_part, int64_t hidden_nodes,
                              float* const* grad_W, float* const* grad_b, void* ws, size_t ws_bytes, void* stream);
 /* The mixed forward (gpde_nnconv_fwd_mixed) that also leaves Z_i for the backward (z_keep as in gpde_nnconv_fwd_keepz; NULL: none). */
-int gpde_nnconv_fwd_mixed_keepz(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
+GPDE_API int gpde_nnconv_fwd_mixed_keepz(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
                                 const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges,
                                 const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                                 const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
@@ -367,8 +380,8 @@ int gpde_nnconv_fwd_mixed_keepz(const float* x, int64_t n_nodes, const float* ed
  * and gpde_nnconv_fwd_edgeweights_group then runs any number of INDEPENDENT calls in one launch each doing gather,
  * message (nn_conv.py:275), aggregation (add / mean / max) and update() (nn_conv.py:277-282; + opt-in residual and
  * ReLU, the callers' `relu(x + conv(x))` glue) in a single streaming kernel (forward; its backward pair follows below). */
-size_t gpde_edge_weights_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims);
-int gpde_edge_weights_fwd(const float* hidden /* [E][K2P], gpde_hidden_fwd */, int64_t n_edges, int n_layers,
+GPDE_API size_t gpde_edge_weights_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims);
+GPDE_API int gpde_edge_weights_fwd(const float* hidden /* [E][K2P], gpde_hidden_fwd */, int64_t n_edges, int n_layers,
                           const int32_t* dims, const void* packed /* gpde_mlp_pack image (k2 padded >= 256), else unused */,
                           const float* w_last /* [4096][k2] */, const float* b_last /* [4096] or NULL */,
                           float* edge_weights /* [E][4096] */, void* ws, size_t ws_bytes, void* stream);
@@ -387,7 +400,7 @@ typedef struct GpdeWeConvDesc {
     int32_t relu;              /* 1: ReLU on the result */
     int32_t reserved;
 } GpdeWeConvDesc;
-int gpde_nnconv_fwd_edgeweights_group(const GpdeWeConvDesc* descs /* HOST array */, int n_descs, void* stream);
+GPDE_API int gpde_nnconv_fwd_edgeweights_group(const GpdeWeConvDesc* descs /* HOST array */, int n_descs, void* stream);
 
 /* Training on the per-edge weights (both MGKN scripts are training scripts: MGKN_general_darcy2d.py:260-282,
  * MGKN_orthogonal_burgers1d.py:226-242).  W_e is an autograd node shared by the `depth` applications of a module:
@@ -399,14 +412,14 @@ int gpde_nnconv_fwd_edgeweights_group(const GpdeWeConvDesc* descs /* HOST array 
  *                                grad_hidden [E][K2P] = (grad_W_e . W3) (.) [hidden > 0] (the input of gpde_hidden_bwd),
  *                                grad_w_last [4096][k2], grad_b_last [4096] - the two 4096 x k2 products per edge once per
  *                                step instead of once per application, on the split-f16 GEMMs. */
-size_t gpde_nnconv_bwd_edgeweights_workspace_bytes(int64_t n_nodes, int64_t n_edges);
-int gpde_nnconv_bwd_edgeweights(const float* x, int64_t n_nodes, const float* edge_weights, int64_t n_edges,
+GPDE_API size_t gpde_nnconv_bwd_edgeweights_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+GPDE_API int gpde_nnconv_bwd_edgeweights(const float* x, int64_t n_nodes, const float* edge_weights, int64_t n_edges,
                                 const int32_t* rowptr, const int32_t* src, const int32_t* src_rowptr,
                                 const int32_t* src_slots, const float* root, int aggr, const float* grad_out,
                                 float* grad_x, float* grad_edge_weights, float* grad_root, float* grad_bias, void* ws,
                                 size_t ws_bytes, void* stream);
-size_t gpde_edge_weights_bwd_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims);
-int gpde_edge_weights_bwd(const float* grad_edge_weights, const float* hidden, int64_t n_edges, int n_layers,
+GPDE_API size_t gpde_edge_weights_bwd_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims);
+GPDE_API int gpde_edge_weights_bwd(const float* grad_edge_weights, const float* hidden, int64_t n_edges, int n_layers,
                           const int32_t* dims, const float* w_last, float* grad_hidden, float* grad_w_last,
                           float* grad_b_last, void* ws, size_t ws_bytes, void* stream);
 
@@ -434,36 +447,36 @@ typedef struct GpdeNodeAttr {
     int32_t n_slots;      /* = dims[0], 1..7 */
     int32_t sel[8];       /* slot d: endpoint << 8 | column (endpoint 0 = source j, 1 = target i) */
 } GpdeNodeAttr;
-int gpde_nnconv_fwd_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, const float* hidden_part,
+GPDE_API int gpde_nnconv_fwd_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, const float* hidden_part,
                        const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges, const int32_t* rowptr,
                        const int32_t* src, const int32_t* dst, int n_layers, const int32_t* dims, const void* packed,
                        const float* root, const float* bias, int aggr, uint32_t flags, float* z_keep, float* out, void* ws,
                        size_t ws_bytes, void* stream);
-int gpde_hidden_fwd_na(const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+GPDE_API int gpde_hidden_fwd_na(const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                        int64_t n_nodes, int n_layers, const int32_t* dims, const void* packed, uint32_t flags, float* hidden,
                        float* hidden_absmax, void* stream);
-int gpde_nnconv_bwd_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr,
+GPDE_API int gpde_nnconv_bwd_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr,
                        const int32_t* src, const int32_t* dst, const int32_t* rowptr_host, const int32_t* src_rowptr,
                        const int32_t* src_slots, int n_layers, const int32_t* dims, const float* const* W, const float* const* b,
                        const float* root, int aggr, const float* grad_out, const float* z_saved, float* grad_x,
                        float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias, void* ws, size_t ws_bytes,
                        void* stream);
-int gpde_nnconv_bwd_light_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr,
+GPDE_API int gpde_nnconv_bwd_light_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr,
                              const int32_t* src, const int32_t* dst, const int32_t* rowptr_host, const int32_t* src_rowptr,
                              const int32_t* src_slots, int n_layers, const int32_t* dims, const float* const* W,
                              const float* const* b, const float* root, int aggr, const float* grad_out, const float* z_saved,
                              const float* hidden_part, int64_t hidden_nodes, float* grad_x, float* grad_w_last,
                              float* grad_b_last, float* grad_root, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
-int gpde_nnconv_bwd_deferred_na(const float* x_stack, const float* grad_out_stack, int n_defer, int64_t n_nodes,
+GPDE_API int gpde_nnconv_bwd_deferred_na(const float* x_stack, const float* grad_out_stack, int n_defer, int64_t n_nodes,
                                 const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
                                 const int32_t* dst, const int32_t* rowptr_host, int n_layers, const int32_t* dims,
                                 const float* const* W, const float* const* b, int aggr, const float* hidden_part,
                                 int64_t hidden_nodes, float* const* grad_W, float* const* grad_b, void* ws, size_t ws_bytes,
                                 void* stream);
-int gpde_hidden_bwd_na(const GpdeNodeAttr* na, int64_t n_edges, const int32_t* src, const int32_t* dst, int n_layers,
+GPDE_API int gpde_hidden_bwd_na(const GpdeNodeAttr* na, int64_t n_edges, const int32_t* src, const int32_t* dst, int n_layers,
                        const int32_t* dims, const float* const* W, const float* const* b, const float* grad_hidden,
                        float* const* grad_W, float* const* grad_b, void* ws, size_t ws_bytes, void* stream);
-int gpde_nnconv_fwd_nodeattr(const float* x, int64_t n_nodes, const float* node_table,
+GPDE_API int gpde_nnconv_fwd_nodeattr(const float* x, int64_t n_nodes, const float* node_table,
                              int32_t table_stride, const int32_t* attr_sel, int64_t n_edges,
                              const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                              int n_layers, const int32_t* dims, const void* packed, const float* root,
@@ -477,9 +490,9 @@ int gpde_nnconv_fwd_nodeattr(const float* x, int64_t n_nodes, const float* node_
  * exclusive prefix sum `offsets` [n+1] (int64) and allocates edge_index int64 [2][E], E =
  * offsets[n]; pass 2 fills it: edge (j -> i) iff |pos_j - pos_i|^2 <= r^2 (float64, exact sum of
  * squares), self-loops included, sorted by source then target — the reference's order. */
-int gpde_radius_graph_count(const double* pos, int64_t n, int dim, double r, int32_t* deg,
+GPDE_API int gpde_radius_graph_count(const double* pos, int64_t n, int dim, double r, int32_t* deg,
                             void* stream);
-int gpde_radius_graph_fill(const double* pos, int64_t n, int dim, double r, const int64_t* offsets,
+GPDE_API int gpde_radius_graph_fill(const double* pos, int64_t n, int dim, double r, const int64_t* offsets,
                            int64_t* edge_index, int64_t n_edges, void* stream);
 
 /* The same between TWO point sets - edges (j in pos_src -> i in pos_dst), row-major np.where order - which is what
@@ -490,9 +503,9 @@ int gpde_radius_graph_fill(const double* pos, int64_t n, int dim, double r, cons
  * exactly distance r are kept or dropped as in the reference (its default s = 61, r = 0.10 graph: 376,471 edges).
  * pos_dst == pos_src with n_dst == n_src means ONE point set: self-loops, diagonal forced to distance 0. */
 enum { GPDE_RADIUS_REFERENCE_TIES = 1 };
-int gpde_radius_graph2_count(const double* pos_src, int64_t n_src, const double* pos_dst, int64_t n_dst, int dim,
+GPDE_API int gpde_radius_graph2_count(const double* pos_src, int64_t n_src, const double* pos_dst, int64_t n_dst, int dim,
                              double r, uint32_t flags, int32_t* deg, void* stream);
-int gpde_radius_graph2_fill(const double* pos_src, int64_t n_src, const double* pos_dst, int64_t n_dst, int dim,
+GPDE_API int gpde_radius_graph2_fill(const double* pos_src, int64_t n_src, const double* pos_dst, int64_t n_dst, int dim,
                             double r, uint32_t flags, const int64_t* offsets, int64_t* edge_index, int64_t n_edges,
                             void* stream);
 
@@ -504,11 +517,11 @@ int gpde_radius_graph2_fill(const double* pos_src, int64_t n_src, const double* 
  * row in ascending source order - exactly what gpde_csr_from_coo makes of the reference's source-major edge list
  * (rows longer than 4096 edges keep cell order).  lo / hi: HOST arrays [dim], a bounding box of both point sets.
  * Edge attributes for such a graph are addressed by CSR slot (perm = identity). */
-size_t gpde_radius_csr_workspace_bytes(int64_t n_src, int dim, double r, const double* lo, const double* hi);
-int gpde_radius_csr_count(const double* pos_src, int64_t n_src, const double* pos_dst, int64_t n_dst, int dim, double r,
+GPDE_API size_t gpde_radius_csr_workspace_bytes(int64_t n_src, int dim, double r, const double* lo, const double* hi);
+GPDE_API int gpde_radius_csr_count(const double* pos_src, int64_t n_src, const double* pos_dst, int64_t n_dst, int dim, double r,
                           uint32_t flags, const double* lo, const double* hi, int32_t* deg, void* ws, size_t ws_bytes,
                           void* stream);
-int gpde_radius_csr_fill(const double* pos_src, int64_t n_src, const double* pos_dst, int64_t n_dst, int dim, double r,
+GPDE_API int gpde_radius_csr_fill(const double* pos_src, int64_t n_src, const double* pos_dst, int64_t n_dst, int dim, double r,
                          uint32_t flags, const double* lo, const double* hi, const int32_t* rowptr, int32_t* src,
                          int32_t* dst, int64_t n_edges, void* ws, size_t ws_bytes, void* stream);
 
@@ -517,8 +530,8 @@ int gpde_radius_csr_fill(const double* pos_src, int64_t n_src, const double* pos
  * gpde_profile_begin() arms it; gpde_profile_end() disarms it, SYNCHRONISES on the recorded
  * events and returns the summed duration (ms) and launch count of the fused edge kernel and the
  * summed duration of the node-side kernels (gemm3 + epilogue).  Not for production calls. */
-int gpde_profile_begin(void);
-int gpde_profile_end(double* fused_ms, int32_t* fused_launches, double* other_ms);
+GPDE_API int gpde_profile_begin(void);
+GPDE_API int gpde_profile_end(double* fused_ms, int32_t* fused_launches, double* other_ms);
 /* The same, split by kernel kind: ms_by_kind / launches_by_kind are arrays of GPDE_PROF_KINDS entries. */
 enum {
     GPDE_PROF_FUSED = 0,     /* fused edge kernel (gpde_nnconv_fwd_kernel names it) or gpde_zagg_kernel */
@@ -528,7 +541,7 @@ enum {
     GPDE_PROF_OTHER = 4,
     GPDE_PROF_KINDS = 5
 };
-int gpde_profile_end_kinds(double* ms_by_kind, int32_t* launches_by_kind);
+GPDE_API int gpde_profile_end_kinds(double* ms_by_kind, int32_t* launches_by_kind);
 
 #ifdef __cplusplus
 }

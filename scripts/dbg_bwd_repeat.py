@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tests.test_gpu_bwd import _case, _native
+from graph_pde_amd import _lib
 names = ["dx", "dW1", "dW2", "dW3", "db1", "db2", "db3", "droot", "dbias"]
 def flat(o):
     return [o[0]] + list(o[1]) + list(o[2]) + [o[3], o[4]]
@@ -11,6 +12,7 @@ for dims, n, e in (([6, 256, 256, 4096], 200, 9000), ([6, 1024, 1024, 4096], 300
     x, ei, ea, ws_, bs_, root, bias, gout = _case(dims, n, e, 5)
     for variant in ("1", "2"):
         os.environ["GPDE_EDGE_BWD"] = variant
+        _lib.reload_switches()         # the library reads its switches once per process
         ref = flat(_native(x, ei, ea, ws_, bs_, root, gout))
         nbad = 0
         for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):

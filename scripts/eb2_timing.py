@@ -1,6 +1,6 @@
 """Phase timing of the staged per-edge backward kernel inside one NNConv backward (needs a build with -DGPDE_EB2_TIMING):
     GPDE_BUILD_SUFFIX=_TE python graph-pde_amd/build.py -DGPDE_EB2_TIMING
-    GPDE_LIB=$PWD/graph-pde_amd/libgpde_TE.so GPDE_HIDDEN_CACHE=off python scripts/eb2_timing.py g121
+    GPDE_LIB=$PWD/scripts/ubench/lib/libgpde_TE.so GPDE_HIDDEN_CACHE=off python scripts/eb2_timing.py g121
 clock64 ticks per wave and step (32 edges x 32 hidden columns: 64 fp32 MFMAs = 4096 matrix-pipe cycles) spent waiting at the
 top of the step (DMA of the step's dZ / H tiles + the workgroup barrier) and in the step's products and stores."""
 import ctypes

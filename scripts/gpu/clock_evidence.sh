@@ -14,7 +14,7 @@ cd $R
 timeout 120 scripts/ubench/kloop_model_v6 > $O/kloop_model_v6.txt 2>&1; echo "ubench rc=$?"
 B="python $R/bench.py --no-cpu-baseline --no-reuse-probe --no-mgkn --no-alt --no-backward-probe"
 for v in base abl2; do
-  if [ $v = abl2 ]; then export GPDE_LIB=$R/graph-pde_amd/libgpde_abl2.so; else unset GPDE_LIB; fi
+  if [ $v = abl2 ]; then export GPDE_LIB=$R/scripts/ubench/lib/libgpde_abl2.so; export GPDE_ALLOW_ABLATION=1; else unset GPDE_LIB GPDE_ALLOW_ABLATION; fi
   timeout 200 $B --steps 5 --warmup 2 2>/dev/null | tail -1 > $O/bench_$v.json; echo "bench $v rc=$?"
   timeout 300 rocprofv3 --output-format csv --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $O/pmc_$v -o run -- $B --steps 2 --warmup 1 > $O/pmc_$v.log 2>&1; echo "pmc $v rc=$?"
 done

@@ -1,6 +1,6 @@
 """Phase timing of the split-f16 GEMM kernel inside one NNConv backward (needs a build with -DGPDE_NT_TIMING):
     GPDE_BUILD_SUFFIX=_TN python graph-pde_amd/build.py -DGPDE_NT_TIMING
-    GPDE_LIB=$PWD/graph-pde_amd/libgpde_TN.so GPDE_HIDDEN_CACHE=off python scripts/nt_timing.py g121
+    GPDE_LIB=$PWD/scripts/ubench/lib/libgpde_TN.so GPDE_HIDDEN_CACHE=off python scripts/nt_timing.py g121
 clock64 ticks per wave-tile round (64 rows x 128 columns x K) in the tile prologue (scales, A chunks 0..2, first conversions),
 the K loop, the drain of the tail loads and the epilogue (un-scale, mask, stores) - for the plain row tiles (dU_1 = dU_2 . W_2,
 K = k2), the split-K form (dW_2 = dU_2^T . H_1, K = edges / 8) and the gather form (depth-deferred dU_2)."""

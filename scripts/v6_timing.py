@@ -1,6 +1,6 @@
 """Phase timing of the v6 forward kernel (needs a build with -DGPDE_V6_TIMING):
     GPDE_BUILD_SUFFIX=_T6 python graph-pde_amd/build.py -DGPDE_V6_TIMING
-    GPDE_LIB=$PWD/graph-pde_amd/libgpde_T6.so python scripts/v6_timing.py g241
+    GPDE_LIB=$PWD/scripts/ubench/lib/libgpde_T6.so python scripts/v6_timing.py g241
 clock64 ticks per wave-tile (64 edges x 128 columns) spent in the tile prologue (attributes, H1 of chunk 0),
 the K loop (32 chunks at k1 = 1024: 1664 MFMA-cycles each) and the un-scale + aggregation phase."""
 import ctypes

@@ -39,3 +39,27 @@ def load_golden(name):
 @pytest.fixture(params=GOLDEN_CASES)
 def golden(request):
     return load_golden(request.param)
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """pytest's monkeypatch, plus: libgpde.so reads its GPDE_* developer switches ONCE per process (no getenv() in launch
+    paths), so a test that flips one through setenv / delenv has the library re-read them - and once more when the
+    environment is restored."""
+    from graph_pde_amd import _lib
+    touched = []
+
+    def wrap(fn):
+        def inner(name, *a, **k):
+            r = fn(name, *a, **k)
+            if str(name).startswith("GPDE_"):
+                touched.append(name)
+                _lib.reload_switches()
+            return r
+        return inner
+    monkeypatch.setenv = wrap(monkeypatch.setenv)
+    monkeypatch.delenv = wrap(monkeypatch.delenv)
+    yield monkeypatch
+    monkeypatch.undo()
+    if touched:
+        _lib.reload_switches()

@@ -18,10 +18,90 @@ def _declared_functions():
     return sorted(set(re.findall(r"\b(gpde_[a-z0-9_]+)\s*\(", src)))
 
 
+def _prototypes():
+    """{name: (return C type, [argument C types])} parsed from include/gpde.h - the binding is checked against THIS, not against
+    a hand-kept list (the ABI grew faster than hand lists)."""
+    src = open(os.path.join(REPO, "include", "gpde.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"GPDE_API\s+([\w \*]+?)\s*\b(gpde_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
+        types = []
+        if args not in ("", "void"):
+            for a in args.split(","):
+                a = a.strip()
+                t = re.sub(r"\b\w+$", "", a).strip() if not a.endswith("*") else a       # drop the parameter name
+                types.append(t.replace(" *", "*"))
+        out[name] = (ret.replace(" *", "*"), types)
+    return out
+
+
+_SCALARS = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint32_t": ctypes.c_uint32,
+            "size_t": ctypes.c_size_t, "double": ctypes.c_double}
+
+
+def _is_pointer_ctype(t):
+    return t in (ctypes.c_void_p, ctypes.c_char_p) or isinstance(t, type) and issubclass(t, ctypes._Pointer)
+
+
 def test_header_and_binding_agree():
     declared = _declared_functions()
     assert declared, "no functions parsed from include/gpde.h"
     assert sorted(_lib.SIGNATURES) == declared
+    assert sorted(_prototypes()) == declared, "a declaration without GPDE_API (it would not be exported: -fvisibility=hidden)"
+
+
+def test_every_binding_signature_is_the_header_prototype():
+    """Argument COUNT, scalar argument types (int / int32_t / int64_t / uint32_t / size_t / double: exact ctypes type) and
+    pointer-ness of every argument and of the return value, for every entry point, generated from the header."""
+    protos = _prototypes()
+    for name, (res, args) in _lib.SIGNATURES.items():
+        ret, ctypes_ = protos[name]
+        assert len(args) == len(ctypes_), f"{name}: binding has {len(args)} arguments, header {len(ctypes_)}"
+        if ret.endswith("*"):
+            assert _is_pointer_ctype(res), (name, ret, res)
+        else:
+            assert res is _SCALARS[ret], (name, ret, res)
+        for i, (ct, bt) in enumerate(zip(ctypes_, args)):
+            if ct.endswith("*"):
+                assert _is_pointer_ctype(bt), f"{name} argument {i}: header {ct}, binding {bt}"
+            else:
+                base = ct.replace("const ", "")
+                assert base in _SCALARS, f"{name} argument {i}: unparsed C type {ct!r}"
+                assert bt is _SCALARS[base], f"{name} argument {i}: header {ct}, binding {bt}"
+
+
+def test_dynamic_symbols_are_exactly_the_header(tmp_path):
+    """libgpde.so is built with -fvisibility=hidden: `nm -D` shows the GPDE_API entry points and nothing else of ours - no mangled
+    internal launcher (round 4 exported 36 of them), no kernel stub."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    ours = sorted(s for s in syms if not s.startswith("__hip_cuid_"))        # (hipcc's per-translation-unit id words)
+    assert ours == _declared_functions(), sorted(set(ours) ^ set(_declared_functions()))
+
+
+def test_ablation_builds_are_refused(monkeypatch):
+    """A library whose gpde_version() carries GPDE_VERSION_ABLATION (arithmetic compiled out: wrong results) is not loaded unless
+    the experiment says GPDE_ALLOW_ABLATION=1; the package directory holds the production library only."""
+    src = open(os.path.join(REPO, "include", "gpde.h")).read()
+    assert int(re.search(r"#define GPDE_VERSION_ABLATION (0x[0-9a-f]+)", src).group(1), 16) == _lib.GPDE_VERSION_ABLATION
+    assert int(re.search(r"#define GPDE_VERSION_INSTRUMENTED (0x[0-9a-f]+)", src).group(1), 16) == _lib.GPDE_VERSION_INSTRUMENTED
+    pkg = os.path.dirname(_lib.__file__)
+    assert [f for f in os.listdir(pkg) if f.endswith(".so")] == ["libgpde.so"], "developer builds belong under scripts/ubench/lib/"
+
+    class Fake:
+        def __getattr__(self, name):
+            f = lambda *a: _lib.GPDE_VERSION | _lib.GPDE_VERSION_ABLATION
+            return f
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(ctypes, "CDLL", lambda path: Fake())
+    monkeypatch.delenv("GPDE_ALLOW_ABLATION", raising=False)
+    with pytest.raises(_lib.GpdeError, match="ABLATION"):
+        _lib.lib()
+    monkeypatch.setenv("GPDE_ALLOW_ABLATION", "1")
+    assert _lib.lib() is not None
+    monkeypatch.setattr(_lib, "_lib", None)
 
 
 def test_library_exports_every_declared_symbol():

@@ -234,12 +234,14 @@ def test_virtual_hidden_node_policy_host_logic(monkeypatch):
     assert call() is None                                             # first sight of the key: the plain operator
     d2, d3 = call(), call()
     assert d2 is not None and d3[0] is d2[0] and d3[1] is d2[1]      # second and third application share one node
-    assert d2[0].requires_grad and tuple(d2[0].shape) == (1,) and d2[1].valid and d2[1].stash == []
+    assert d2[0].requires_grad and tuple(d2[0].shape) == (1,) and d2[1].valid and len(d2[1].stash) == 0
     assert hidden_cache.stats["deferred_builds"] == 1 and hidden_cache.stats["deferred_hits"] == 1
     d2[1].valid = False                                               # its backward ran (DeferredHiddenFunction.backward)
     d4 = call()
     assert d4 is not None and d4[1] is not d2[1]                      # next forward: a fresh node from the FIRST call on
     assert call()[1] is d4[1]
+    d4[1].stash[1] = ("x", "g")                                       # a backward that ended without its deferred pass
+    assert call()[1] is d4[1] and len(d4[1].stash) == 0 and hidden_cache.stats["deferred_stale_dropped"] == 1
     d4[1].valid = False
     with torch.no_grad():
         w[0].mul_(1.0)                                                # optimizer step; this forward applies the module once ...
