@@ -167,6 +167,55 @@ def nnconv_grads(x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Ten
             None if bb is None else zero(bb))
 
 
+def nnconv_grads_shared(xs: Sequence[torch.Tensor], edge_index: torch.Tensor, edge_attr: torch.Tensor,
+                        weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
+                        root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,
+                        grad_outs: Sequence[torch.Tensor], chunk_edges: int = 16384):
+    """`KernelNN.forward` applies ONE conv `depth` times with the same edge_attr and weights
+    (/root/reference/graph-neural-operator/UAI1_full_resolution.py:29-30) and `loss.backward()` (:266) sums the parameter
+    gradients over the applications.  This is float64 autograd of  loss = sum_l sum(conv(x_l) * g_l)  with the applications'
+    inputs x_l given (independent leaves): the kernel MLP (nn_conv.py:274, utilities.py:223-227) is evaluated once per edge
+    chunk and shared by the `depth` messages, exactly the sharing the reference's graph has.  Equal to the sum of
+    `nnconv_grads` over the applications (tests/test_oracle_golden.py), at 1/depth of the cost.
+    Returns ([grad_x_l], [grad_W], [grad_b], grad_root or None, grad_bias or None)."""
+    if aggr not in ("add", "mean"):
+        raise ValueError(aggr)
+    n = xs[0].shape[0]
+    xl = [x.double().requires_grad_(True) for x in xs]
+    Ws = [w.double().requires_grad_(True) for w in weights]
+    Bs = [None if b is None else b.double().requires_grad_(True) for b in biases]
+    r = None if root is None else root.double().requires_grad_(True)
+    bb = None if bias is None else bias.double().requires_grad_(True)
+    src, dst = edge_index[0], edge_index[1]
+    e = int(src.numel())
+    gT = [g.double() for g in grad_outs]
+    if aggr == "mean":
+        cnt = torch.bincount(dst, minlength=n).clamp(min=1).double().unsqueeze(1)
+        gT = [g / cnt for g in gT]
+    for lo in range(0, e, max(1, chunk_edges)):
+        sl = slice(lo, lo + chunk_edges)
+        h = densenet_forward(edge_attr[sl].double(), Ws, Bs)
+        we = h.view(-1, xl[0].shape[1], h.shape[1] // xl[0].shape[1])                       # nn_conv.py:274
+        loss = 0.0
+        for x, g in zip(xl, gT):
+            m = torch.matmul(x[src[sl]].unsqueeze(1), we).squeeze(1)                       # nn_conv.py:275
+            loss = loss + (m * g[dst[sl]]).sum()
+        loss.backward()
+    if r is not None or bb is not None:
+        loss = 0.0
+        for x, g in zip(xl, grad_outs):
+            node = torch.zeros(n, g.shape[1], dtype=torch.float64)
+            if r is not None:
+                node = node + x @ r                                                        # nn_conv.py:277-282
+            if bb is not None:
+                node = node + bb
+            loss = loss + (node * g.double()).sum()
+        loss.backward()
+    zero = lambda t: torch.zeros_like(t) if t.grad is None else t.grad
+    return ([zero(x) for x in xl], [zero(w) for w in Ws], [None if b is None else zero(b) for b in Bs],
+            None if r is None else zero(r), None if bb is None else zero(bb))
+
+
 def rel_l2(y: torch.Tensor, y_ref: torch.Tensor) -> float:
     """Relative L2 over the whole output, the `LpLoss.rel` formula for one sample
     (/root/reference/graph-neural-operator/utilities.py:184-196)."""

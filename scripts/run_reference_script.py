@@ -136,9 +136,26 @@ def install_torch_drift_compat():
     torch.Tensor.__getitem__ = getitem
 
 
-def run(script: str, overrides: dict, workdir: str | None = None, n_samples: int | None = None) -> dict:
+def run(script: str, overrides: dict, workdir: str | None = None, n_samples: int | None = None, seed: int | None = 0,
+        composite: bool = False) -> dict:
+    """`seed`: torch / numpy / random are seeded before the script starts (the scripts seed nothing themselves), so two runs see
+    the same initial weights, sample order and random sub-graphs.  `composite`: the modules' forward is replaced by the
+    stock-torch-ops composite of tests/helpers/composite_nnconv.py - the OTHER arm of the script-level parity test."""
     script = find_script(script)
     install_torch_drift_compat()
+    import torch
+    torch.set_printoptions(precision=8)            # the scripts print CPU tensors (`tensor(0.0597)`): enough digits to compare runs
+    if seed is not None:
+        import random
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        random.seed(seed)
+    if composite:
+        if REPO not in sys.path:
+            sys.path.insert(0, REPO)
+        import graph_pde_amd  # noqa: F401
+        from tests.helpers import composite_nnconv
+        run.composite_counter = composite_nnconv.install()
     if n_samples is None:
         n_samples = max([int(v) for k, v in overrides.items() if k in ("ntrain", "ntest")] + [2])
     own_tmp = None
@@ -185,15 +202,20 @@ def main():
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE")
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--samples", type=int, default=None, help="samples in the synthetic .mat files")
+    ap.add_argument("--seed", type=int, default=0, help="torch / numpy / random seed set before the script starts")
+    ap.add_argument("--composite", action="store_true",
+                    help="test harness: run the script on the stock-torch-ops composite of the operator instead of libgpde.so")
     args = ap.parse_args()
     overrides = {}
     for kv in args.set:
         k, v = kv.split("=", 1)
         overrides[k] = ast.literal_eval(v)
-    ns = run(args.script, overrides, args.workdir, args.samples)
+    ns = run(args.script, overrides, args.workdir, args.samples, args.seed, args.composite)
     print(f"[run_reference_script] {os.path.basename(args.script)} finished; overrides {overrides}")
     from graph_pde_amd import _lib
     print(f"[run_reference_script] native libgpde.so calls: {_lib.n_native_calls}")
+    if args.composite:
+        print(f"[run_reference_script] composite forward calls: {run.composite_counter['calls']}")
     return ns
 
 

@@ -9,7 +9,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 GOLDEN = os.path.join(REPO, "tests", "golden")
-GOLDEN_CASES = ["ckpt_g16", "ragged_add", "mlp2_mean_noroot", "burgers_k4", "mlp5_g16"]
+GOLDEN_CASES = ["ckpt_g16", "ragged_add", "mlp2_mean_noroot", "burgers_k4", "mlp5_g16", "ckpt_torus_m100"]
 
 
 def pytest_configure(config):

@@ -105,17 +105,18 @@ def _load(name, path):
     return mod
 
 
-def _checkpoint_conv(ref_nn_conv, ref_util):
-    """conv1 of the shipped trained model (k0=6, DenseNet[6,64,128,4096], aggr='mean')."""
+def _checkpoint_conv(ref_nn_conv, ref_util, name="grain_new_r64_s64testm100", k0=6):
+    """conv1 of a shipped trained model (DenseNet[k0,64,128,4096], aggr='mean'): grain_new_r64_s64testm100 (k0=6) or
+    grain_torus_r64_radius0.4testm100 (k0=5: [dx, dy, distance, a_src, a_dst] on the torus, utilities.py:795-801)."""
     main = sys.modules["__main__"]
 
     class KernelNN(torch.nn.Module):        # placeholder for the pickled `__main__.KernelNN`
         pass
     main.KernelNN = KernelNN
-    model = torch.load(os.path.join(REF, "model", "grain_new_r64_s64testm100"),
+    model = torch.load(os.path.join(REF, "model", name),
                        weights_only=False, map_location="cpu")
     sd = {k: v for k, v in model.state_dict().items() if k.startswith("conv1.")}
-    conv = ref_nn_conv.NNConv_old(64, 64, ref_util.DenseNet([6, 64, 128, 4096], torch.nn.ReLU),
+    conv = ref_nn_conv.NNConv_old(64, 64, ref_util.DenseNet([k0, 64, 128, 4096], torch.nn.ReLU),
                                   aggr="mean")
     conv.load_state_dict({k[len("conv1."):]: v for k, v in sd.items()})
     return conv
@@ -201,6 +202,27 @@ def case_mesh_ties(ref_util):
 
 
 
+def case_ckpt_torus(ref_nn_conv, ref_util):
+    # 10. the SECOND shipped checkpoint, grain_torus_r64_radius0.4testm100 (k0 = 5), on a graph and attributes built by the
+    #     reference's own TorusGridSplitter.sample() (utilities.py:644-808: periodic distances over five shifted copies of the
+    #     grid, edge_attr = [X_difference, Y_difference, distance, a_src, a_dst]): 16 x 16 grid, sub-sampling r = 2, m = 100
+    #     nodes, radius 0.4 as in the checkpoint's name.  Outputs AND gradients of the reference's module.
+    import contextlib, io
+    res = 16
+    g = np.linspace(0, 1, res)
+    grid = torch.tensor(np.vstack([xx.ravel() for xx in np.meshgrid(g, g)]).T, dtype=torch.float)
+    torch.manual_seed(10)
+    sp = ref_util.TorusGridSplitter(grid, res, r=2, m=100, radius=0.4, edge_features=1)
+    theta, Y = torch.randn(res * res, 4), torch.randn(res * res)
+    with contextlib.redirect_stdout(io.StringIO()):
+        data = sp.sample(theta, Y)
+    conv = _checkpoint_conv(ref_nn_conv, ref_util, "grain_torus_r64_radius0.4testm100", 5)
+    ei, ea = data.edge_index, data.edge_attr
+    x = torch.randn(data.x.shape[0], 64, generator=torch.Generator().manual_seed(10))
+    _save("ckpt_torus_m100", conv, x, ei, ea, *_run(conv, x, ei, ea))
+    _save_grads("ckpt_torus_m100", conv, x, ei, ea, 30)
+
+
 def main():
     _install_stubs()
     ref_util = _load("utilities", os.path.join(REF, "utilities.py"))
@@ -208,6 +230,9 @@ def main():
         case_mesh_ties(ref_util)
         return
     ref_nn_conv = _load("nn_conv", os.path.join(REF, "nn_conv.py"))
+    if len(sys.argv) > 1 and sys.argv[1] == "torus":     # only the second checkpoint's fixture
+        case_ckpt_torus(ref_nn_conv, ref_util)
+        return
     sys.path.insert(0, os.path.join(REPO, "graph-pde_amd"))
     import synth
 
@@ -337,6 +362,7 @@ def main():
     print(f"mgkn_graphs_s20: inner {e_in.shape[1]} / down {e_dn.shape[1]} edges -> {os.path.getsize(path)} B")
 
     case_mesh_ties(ref_util)
+    case_ckpt_torus(ref_nn_conv, ref_util)
 
 
 if __name__ == "__main__":

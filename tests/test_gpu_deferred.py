@@ -249,3 +249,41 @@ def test_unsupported_kernels_keep_the_plain_backward(monkeypatch):
     for _ in range(2):
         _grads(net, x.to(d), ei.to(d), ea.to(d), torch.zeros(64, 64, device=d))
     assert hidden_cache.stats.get("deferred_builds", 0) == 0
+
+
+def test_abandoned_or_input_only_backward_leaves_nothing_for_the_next_deferred_pass(monkeypatch):
+    """a backward that never reaches the virtual-H node - `torch.autograd.grad(out, x)` (input gradients only), or a
+    pass abandoned by an exception - used to leave its (x, grad_out) pairs on the shared token; with unchanged parameters the
+    next forward re-used the token and the next deferred pass added the stale applications to the hidden-layer gradients."""
+    dims, n, deg, depth = [6, 256, 256, 4096], 96, 110, 3
+    x, ei, ea, *_ = _dense_case(dims, n, deg, 41)
+    d = dev()
+    torch.manual_seed(0)
+    net = _Net(dims, depth).to(d)
+    x, ei, ea = x.to(d), ei.to(d), ea.to(d)
+    tgt = torch.randn(n, 64, device=d)
+    monkeypatch.setattr(hidden_cache, "MODE", "auto")
+    monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", 0)             # H never fits: the virtual-H node
+    hidden_cache.clear()
+    _grads(net, x, ei, ea, tgt)                                      # the module is seen repeating
+    ref, _ = _grads(net, x, ei, ea, tgt)                             # steady state: every application on the virtual H
+    # (a) input gradients only: the light passes run, the deferred pass does not
+    xin = x.clone().requires_grad_(True)
+    out = net(xin, ei, ea)
+    gx_only, = torch.autograd.grad(((out - tgt) ** 2).mean(), xin)
+    tok = hidden_cache._entries[net.conv1].dtoken
+    assert tok is not None and tok.valid and len(tok.stash) == depth
+    assert rel_l2(gx_only.cpu(), ref[0].cpu()) <= 1e-6
+    got, _ = _grads(net, x, ei, ea, tgt)                             # same parameters: same key, same token
+    assert hidden_cache.stats.get("deferred_stale_dropped", 0) >= 1
+    for name, r, g in zip(["x"] + [k for k, _ in net.named_parameters()], ref, got):
+        assert torch.equal(r, g), name
+    # (b) the same application differentiated twice before the deferred pass (retain_graph): it counts once
+    net.zero_grad(set_to_none=True)
+    xin = x.clone().requires_grad_(True)
+    loss = ((net(xin, ei, ea) - tgt) ** 2).mean()
+    torch.autograd.grad(loss, xin, retain_graph=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    for name, r, g in zip(["x"] + [k for k, _ in net.named_parameters()], ref, [xin.grad] + [p.grad for p in net.parameters()]):
+        assert rel_l2(g.cpu(), r.cpu()) <= 1e-6, (name, rel_l2(g.cpu(), r.cpu()))

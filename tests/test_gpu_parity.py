@@ -276,7 +276,7 @@ def test_backward_against_reference_autograd(dims, aggr, use_root, use_bias, edg
         assert rel_l2(gbias.cpu(), rbias) <= tol
 
 
-@pytest.mark.parametrize("name", ["ragged_add", "mlp2_mean_noroot", "burgers_k4"])
+@pytest.mark.parametrize("name", ["ragged_add", "mlp2_mean_noroot", "burgers_k4", "ckpt_torus_m100"])
 def test_backward_against_reference_module_gradients(name):
     """gpde_nnconv_bwd against tests/golden/<name>_grad.npz: float64 autograd through the reference's OWN
     NNConv_old / DenseNet classes (make_golden.py) on the golden inputs."""

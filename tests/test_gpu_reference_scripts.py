@@ -5,7 +5,12 @@ The scripts are not part of this repository.  They are looked up under /root/ref
 or oracle/_ref (staged for a GPU-box run by scripts/stage_reference.py, git-ignored); when neither is
 present the tests skip - the logs of the staged runs are committed under profiles/.  Only module-level
 hyper-parameters are overridden (ntrain / ntest / epochs), through a line tracer, not by editing the file:
-scripts/run_reference_script.py."""
+scripts/run_reference_script.py.
+
+Round 5: NUMBERS, not just "ran and finite".  Every script runs twice from the same seed - on libgpde.so and on the
+stock-torch-ops composite of the operator (tests/helpers/composite_nnconv.py, installed by the runner's --composite: the
+reference's own op chain under torch autograd) - and the losses / errors the script prints over two epochs (training steps
+through Adam included) must agree to 1e-4 relative."""
 import math
 import os
 import subprocess
@@ -30,12 +35,27 @@ def _have(name):
         sys.path.pop(0)
 
 
-def _run(name, sets, timeout=1500):
-    cmd = [sys.executable, RUNNER, name] + [a for kv in sets for a in ("--set", kv)]
-    r = subprocess.run(cmd, cwd="/tmp", capture_output=True, text=True, timeout=timeout)
+def _run(name, sets, timeout=1500, composite=False):
+    cmd = [sys.executable, RUNNER, name] + [a for kv in sets for a in ("--set", kv)] + (["--composite"] if composite else [])
+    # history-independent bits for the comparison (README: the ONE switch); the default policy is exercised by the other tests
+    env = dict(os.environ, GPDE_HIDDEN_CACHE=os.environ.get("GPDE_TEST_SCRIPT_CACHE", "auto"))
+    r = subprocess.run(cmd, cwd="/tmp", capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
-    assert "native libgpde.so calls: 0" not in r.stdout       # the HIP operator really ran
+    if composite:
+        assert "native libgpde.so calls: 0" in r.stdout and "composite forward calls: 0" not in r.stdout, r.stdout[-600:]
+    else:
+        assert "native libgpde.so calls: 0" not in r.stdout       # the HIP operator really ran
     return r.stdout
+
+
+REL = 1e-4        # the numbers an unmodified script prints, native operator vs stock-torch composite
+
+
+def _agree(tag, native, composite):
+    assert len(native) == len(composite) and native, (tag, native, composite)
+    for k, (a, b) in enumerate(zip(native, composite)):
+        assert math.isfinite(a) and math.isfinite(b) and abs(a - b) <= REL * abs(b), (tag, k, a, b, native, composite)
+    print(tag, "native", native, "composite", composite)
 
 
 def _floats_after(line, key):
@@ -47,20 +67,59 @@ def _floats_after(line, key):
 def test_uai1_full_resolution_runs_unchanged():
     """GKN Darcy: trains at s=61 on cuda, then `model.cpu()` and evaluates at 16 / 31 / 61 on CPU tensors
     (UAI1_full_resolution.py:287-303) - the CPU-tensor staging path."""
-    out = _run("UAI1_full_resolution.py", ["ntrain=2", "ntest=2", "epochs=1"])
-    last = [l for l in out.splitlines() if "test16:" in l][-1]
-    for key in ("train_mse:", "test16:", "test31:", "test61:"):
-        assert math.isfinite(_floats_after(last, key)), last
+    sets = ["ntrain=2", "ntest=2", "epochs=2"]
+
+    def numbers(out):
+        lines = out.splitlines()
+        last = [l for l in lines if "test16:" in l][-1]
+        return [_floats_after(l, "train_mse:") for l in lines if "train_mse:" in l and "test16:" not in l] + \
+            [_floats_after(last, key) for key in ("train_mse:", "test16:", "test31:", "test61:")]
+    native = numbers(_run("UAI1_full_resolution.py", sets))
+    assert len(native) == 2 + 4
+    _agree("UAI1_full_resolution.py: train_mse per epoch, final train_mse / test16 / test31 / test61", native,
+           numbers(_run("UAI1_full_resolution.py", sets, composite=True)))
 
 
 @pytest.mark.skipif(not _have("MGKN_general_darcy2d.py"), reason="reference scripts not staged on this box")
 def test_mgkn_general_darcy2d_runs_unchanged():
-    out = _run("MGKN_general_darcy2d.py", ["ntrain=2", "ntest=1", "epochs=1"])
-    lines = [l for l in out.splitlines() if l.startswith("test i =")]
-    assert lines and all(math.isfinite(float(v)) for v in lines[-1].split()[3:5]), out[-2000:]
+    sets = ["ntrain=2", "ntest=1", "epochs=2"]
+
+    def numbers(out):
+        vals = []
+        for l in out.splitlines():
+            t = l.split()
+            if l.startswith("test i ="):
+                vals += [float(t[4]), float(t[5])]                                  # l2 of the sample, running mean
+            elif len(t) == 4 and t[0].isdigit() and "[" not in l:
+                vals += [float(t[2]), float(t[3])]                                  # epoch: train mse, train l2 (t[1] = seconds)
+            elif len(t) == 3 and t[0].isdigit() and "[" not in l and "." in t[1]:
+                vals.append(float(t[2]))                                            # test epoch: test l2
+        return vals
+    native = numbers(_run("MGKN_general_darcy2d.py", sets))
+    assert len(native) >= 2 * 2 + 2 + 1, native
+    _agree("MGKN_general_darcy2d.py: per-epoch train mse / l2, test l2", native,
+           numbers(_run("MGKN_general_darcy2d.py", sets, composite=True)))
 
 
 @pytest.mark.skipif(not _have("MGKN_orthogonal_burgers1d.py"), reason="reference scripts not staged on this box")
 def test_mgkn_orthogonal_burgers1d_runs_unchanged():
-    out = _run("MGKN_orthogonal_burgers1d.py", ["ntrain=2", "ntest=1", "epochs=1"])
-    assert "nan" not in out.lower().split("native libgpde.so")[0][-600:], out[-2000:]
+    sets = ["ntrain=2", "ntest=1", "epochs=2"]
+
+    def numbers(out):
+        vals = []
+        for l in out.split("[run_reference_script]")[0].splitlines():
+            t = l.split()
+            try:
+                if len(t) == 4 and t[0].isdigit():
+                    vals += [float(t[2]), float(t[3])]                              # epoch: train mse, train l2
+                elif len(t) == 2 and t[0].isdigit():
+                    vals.append(float(t[1]))                                        # test sample: loss
+                elif len(t) == 3 and t[0].isdigit() and "." in t[1]:
+                    vals.append(float(t[2]))                                        # final: test l2
+            except ValueError:
+                pass
+        return vals
+    native = numbers(_run("MGKN_orthogonal_burgers1d.py", sets))
+    assert len(native) >= 2 * 2 + 1 + 1, native
+    _agree("MGKN_orthogonal_burgers1d.py: per-epoch train mse / l2, test losses", native,
+           numbers(_run("MGKN_orthogonal_burgers1d.py", sets, composite=True)))

@@ -121,7 +121,7 @@ def test_mgkn_graph_fixture_pins_the_sampled_multilevel_family():
         assert np.array_equal(ea.numpy(), g["edge_attr_up"][lo:hi]), l
 
 
-GRAD_CASES = ["ragged_add", "mlp2_mean_noroot", "burgers_k4"]
+GRAD_CASES = ["ragged_add", "mlp2_mean_noroot", "burgers_k4", "ckpt_torus_m100"]
 
 
 def load_golden_grads(name):
@@ -176,6 +176,41 @@ def test_oracle_gradients_in_edge_chunks_equal_the_whole(name):
         assert rel_l2(groot, r["groot"]) <= tol
     if gbias is not None:
         assert rel_l2(gbias, r["gbias"]) <= tol
+
+
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_oracle_shared_application_gradients_equal_the_sum_over_applications(name):
+    """nnconv_grads_shared (one conv applied `depth` times, UAI1_full_resolution.py:29-30: the checker of the depth-deferred
+    backward at sizes where `depth` separate float64 passes would take minutes): with ONE application it is the pinned
+    gradient; with three it is the sum of three pinned-operator gradients."""
+    from oracle.nnconv_oracle import nnconv_grads, nnconv_grads_shared
+    from tests.conftest import load_golden
+    g, r = load_golden(name), load_golden_grads(name)
+    e = g["edge_index"].shape[1]
+    args = (g["edge_index"], g["edge_attr"], g["weights"], g["biases"], g["root"], g["bias"], g["aggr"])
+    gxs, gW, gb, groot, gbias = nnconv_grads_shared([g["x"]], *args, [r["gout"]], chunk_edges=max(1, e // 3))
+    tol = 1e-12
+    assert rel_l2(gxs[0], r["gx"]) <= tol
+    for l in range(len(gW)):
+        assert rel_l2(gW[l], r["gW"][l]) <= tol and rel_l2(gb[l], r["gb"][l]) <= tol, l
+    torch.manual_seed(3)
+    xs = [g["x"], torch.randn_like(g["x"]) * 0.5, torch.randn_like(g["x"]) * 2.0]
+    gs = [r["gout"], torch.randn_like(r["gout"]), torch.randn_like(r["gout"]) * 0.25]
+    gxs, gW, gb, groot, gbias = nnconv_grads_shared(xs, *args, gs, chunk_edges=max(1, e // 2))
+    sW = [torch.zeros_like(w, dtype=torch.float64) for w in g["weights"]]
+    sb = [torch.zeros_like(b, dtype=torch.float64) for b in g["biases"]]
+    sroot = None if g["root"] is None else torch.zeros_like(g["root"], dtype=torch.float64)
+    for i, (x, go) in enumerate(zip(xs, gs)):
+        ox, oW, ob, oroot, obias = nnconv_grads(x, *args, go)
+        assert rel_l2(gxs[i], ox) <= tol
+        for l in range(len(sW)):
+            sW[l] += oW[l]; sb[l] += ob[l]
+        if sroot is not None:
+            sroot += oroot
+    for l in range(len(sW)):
+        assert rel_l2(gW[l], sW[l]) <= tol and rel_l2(gb[l], sb[l]) <= tol, l
+    if sroot is not None:
+        assert rel_l2(groot, sroot) <= tol
 
 
 def _lattice(s):

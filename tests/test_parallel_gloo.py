@@ -312,3 +312,73 @@ def test_row_bounds_and_partition_single_process():
     part = parallel.partition_rows(ei, ea, n, rank=0, world=1)
     x = torch.randn(n, 4, generator=g)
     assert parallel.nnconv_rows(lambda x_, ei_, ea_: x_ * 2.0, x, part).equal(x * 2.0)
+
+
+# ---- BASELINE config 5's bookkeeping: 256 samples over 8 ranks, 32 accumulated per rank, ONE all-reduce ---------------
+def _accum_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from graph_pde_amd import parallel
+    parallel.init_from_env("gloo")
+    n_samples = 256
+    mine = list(parallel.shard_range(n_samples, rank, world))
+    torch.manual_seed(7 + rank)                            # deliberately different init per rank
+    model = _TinyConv().double()
+    extra = torch.nn.Linear(4, 4).double()                 # a layer NO sample touches: its gradient stays None on every rank
+    parallel.broadcast_parameters(model, src=0)
+    params = list(model.parameters()) + list(extra.parameters())
+
+    def sample(i):                                         # sample i: its own small graph, attributes, input and target
+        g = torch.Generator().manual_seed(1000 + i)
+        n, e = 6 + i % 5, 20 + i % 7
+        ei = torch.stack([torch.randint(0, n, (e,), generator=g), torch.randint(0, n, (e,), generator=g)])
+        return (torch.randn(n, 4, generator=g, dtype=torch.float64), ei, torch.randn(e, 3, generator=g, dtype=torch.float64),
+                torch.randn(n, 4, generator=g, dtype=torch.float64))
+    for p in params:
+        p.grad = None
+    for i in mine:                                         # gradient accumulation over the rank's 32 samples
+        x, ei, ea, y = sample(i)
+        (((model(x, ei, ea) - y) ** 2).mean() / len(mine)).backward()
+    calls = {"n": 0}
+    real = dist.all_reduce
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    dist.all_reduce = counted
+    n_red = parallel.allreduce_gradients(params, average=True)          # ONE flat all-reduce: mean over ranks of per-rank means
+    dist.all_reduce = real
+    got = [None if p.grad is None else p.grad.clone() for p in params]
+    ref = _TinyConv().double()
+    ref.load_state_dict(model.state_dict())
+    loss = sum(((ref(*sample(i)[:3]) - sample(i)[3]) ** 2).mean() for i in range(n_samples)) / n_samples
+    loss.backward()
+    err = max(float((g_ - p.grad).abs().max()) for g_, p in zip(got, ref.parameters()))
+    q.put((rank, len(mine), calls["n"], n_red, err, [g_ is None for g_ in got[-2:]]))
+    dist.destroy_process_group()
+
+
+def test_batch_of_256_over_8_ranks_accumulates_32_each_and_allreduces_once_gloo_ws8():
+    """GKN Darcy 241^2, batch = 256 samples sharded over 8 GPUs (BASELINE config 5; UAI1_full_resolution.py:54 trains with
+    batch_size 1, the sharded batch is the data-parallel form): every rank accumulates the gradients of its 32 samples, one
+    flat all-reduce averages them - the result is the gradient of the mean loss over all 256 samples under rank 0's weights,
+    a parameter no sample touched keeps grad = None on every rank (Adam with weight decay must not see a zero there)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 8
+    procs = [ctx.Process(target=_accum_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    n_par = sum(p.numel() for p in _TinyConv().parameters()) + 4 * 4 + 4
+    for rank, n_mine, n_calls, n_red, err, none_flags in res:
+        assert n_mine == 32 and n_calls == 1 and n_red == n_par, (rank, n_mine, n_calls, n_red)
+        assert err < 1e-12, (rank, err)
+        assert none_flags == [True, True], (rank, none_flags)
