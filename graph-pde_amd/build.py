@@ -25,7 +25,7 @@ LIB = os.path.join(DEVDIR, f"libgpde{_SUFFIX}.so") if _SUFFIX else os.path.join(
 OBJDIR = os.path.join(DEVDIR, "build" + _SUFFIX) if _SUFFIX else os.path.join(PKG, "build")
 
 SOURCES = ["gpde_api.hip", "gpde_csr.hip", "gpde_pack.hip", "gpde_fused.hip", "gpde_fused_f16v3.hip", "gpde_fused_f16v6.hip",
-           "gpde_zagg.hip", "gpde_prep.hip", "gpde_gemm3.hip", "gpde_gemm.hip", "gpde_gemm_f16s.hip", "gpde_bwd.hip", "gpde_edge_bwd3.hip", "gpde_graph.hip", "gpde_weconv.hip", "gpde_cellgraph.hip"]
+           "gpde_zagg.hip", "gpde_prep.hip", "gpde_gemm3.hip", "gpde_gemm.hip", "gpde_gemm_f16s.hip", "gpde_bwd.hip", "gpde_edge_bwd3.hip", "gpde_bwd_onepass.hip", "gpde_graph.hip", "gpde_weconv.hip", "gpde_cellgraph.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
          "-Wall", "-Wno-unused-function",

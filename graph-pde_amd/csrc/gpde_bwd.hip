@@ -625,9 +625,11 @@ namespace {
 // Ordered mode: dx[j] += sum of the per-edge contributions of the out-edges of j that lie in this chunk's slot range
 // [e0, e1), in ascending slot order (src_slots is ascending inside a source: the chunk's part is one sub-range).
 // One wave per source node, lane = channel: a single owner per dx element, no atomics -> bit-reproducible.
+// `nparts` > 1 (the one-pass kernel): dxe holds nparts partial rows per edge, part s at dxe + s * part_stride; an edge's
+// contribution is their sum in ascending s (fixed order).
 __global__ __launch_bounds__(256) void k_dx_reduce(const float* __restrict__ dxe, const int32_t* __restrict__ srp,
                                                    const int32_t* __restrict__ ssl, int n_nodes, int e0, int e1,
-                                                   float* __restrict__ dx) {
+                                                   float* __restrict__ dx, int nparts, size_t part_stride) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= n_nodes) return;
@@ -646,15 +648,30 @@ __global__ __launch_bounds__(256) void k_dx_reduce(const float* __restrict__ dxe
 #pragma unroll
         for (int q = 0; q < 8; ++q) sl[q] = ssl[p + q];
         if (sl[7] >= e1) break;
+        if (nparts == 1) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = dxe[(size_t)(sl[q] - e0) * GP_W + lane];
+            for (int q = 0; q < 8; ++q) v[q] = dxe[(size_t)(sl[q] - e0) * GP_W + lane];
+        } else {
+            // an edge's value = its partial rows summed in part order (8 edges x nparts loads in flight)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = dxe[(size_t)(sl[q] - e0) * GP_W + lane];
+            for (int s_ = 1; s_ < nparts; ++s_) {
+                float w[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) w[q] = dxe[(size_t)s_ * part_stride + (size_t)(sl[q] - e0) * GP_W + lane];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += w[q];
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc += v[q];
     }
     for (; p < end; ++p) {
         const int sl = ssl[p];
         if (sl >= e1) break;
-        acc += dxe[(size_t)(sl - e0) * GP_W + lane];
+        float v = dxe[(size_t)(sl - e0) * GP_W + lane];
+        for (int s_ = 1; s_ < nparts; ++s_) v += dxe[(size_t)s_ * part_stride + (size_t)(sl - e0) * GP_W + lane];
+        acc += v;
     }
     dx[(size_t)j * GP_W + lane] = acc;
 }
@@ -690,6 +707,7 @@ struct BwdPlan {
     size_t off_dzstack, off_dzimg, off_nbits, off_nscale, off_tiles, off_xsc;
     size_t off_dzun;                  // per chunk node un-scale of its split dZ image (gpde_edge_bwd3.hip)
     size_t off_tcs, off_tcm;          // per 32-slot tile column sums / max bits of dU_2 [Ec / 32 + 1][KP2] (gpde_edge_bwd3.hip -> dW_2 GEMM)
+    size_t off_scal;                  // [2] words: bits of max_e B_e for the one-pass kernel's global H scale (gpde_launch_attr_bound)
     size_t total;
     size_t one_chunk;                 // workspace bytes with which everything is one chunk
 };
@@ -735,6 +753,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     P->L = n_defer; P->Lp = n_defer > 0 ? (n_defer + 1) / 2 * 2 : 0;
     if (n_defer > 0 && P->Lp < 4) P->Lp = 4;
     P->off_xsc = take(n_defer > 0 ? (size_t)2 * (N > 0 ? N : 1) : 1);      // per source node row scales of the layer-input stack
+    P->off_scal = take(4);
     const size_t fixed = off;
     // per-chunk buffers: per edge (hsum + 2*kmax) floats (+ KP1 + KP2 for the transposed operands of dW_2), per node
     // (2*64*K2P + 3*64) floats
@@ -913,7 +932,7 @@ extern "C" int gpde_nnconv_bwd_edgeweights(const float* x, int64_t n_nodes, cons
     if (n_edges > 0) {
         WeBwdArgs a{x, edge_weights, rowptr, src, grad_out, aggr, grad_edge_weights, ordered ? dxe : nullptr, grad_x};
         hipLaunchKernelGGL(gpde_weconv_bwd_kernel, dim3((unsigned)n_nodes), dim3(256), 0, st, a);
-        if (ordered) hipLaunchKernelGGL(k_dx_reduce, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, st, dxe, src_rowptr, src_slots, (int)n_nodes, 0, (int)n_edges, grad_x);
+        if (ordered) hipLaunchKernelGGL(k_dx_reduce, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, st, dxe, src_rowptr, src_slots, (int)n_nodes, 0, (int)n_edges, grad_x, 1, (size_t)0);
         GP_LAUNCH_CHECK("gpde_weconv_bwd_kernel");
     }
     return bwd_node_terms(x, (int)n_nodes, root, grad_out, grad_x, grad_root, grad_bias, part, part_floats, st);
@@ -1122,7 +1141,21 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         gpde_set_error("gpde_nnconv_bwd: node-table attributes need the 3-Linear split-f16 form (and src / dst)");
         return GPDE_EUNSUPPORTED;
     }
+    // ---- the one-pass kernel (round 5, gpde_fused_f16v6_kernel<2>): K loop of the recompute + both per-edge products, H_2 neither
+    // written nor read.  Needs: the fused store kernel's shape, Z kept by the forward (dW_3 wants Z, and Z from H_2 is what this
+    // path no longer has), the source-ordered slots (its dx comes out as per-slice partial rows for k_dx_reduce), and - in the
+    // full backward - the split GEMMs that take the by-products.  GPDE_BWD_TWO_PASS=1 / GPDE_EDGE_BWD=1|2|3: the two-pass forms.
+    bool onepass_ok = false;
+    if ((phase == BWD_FULL || light) && fast_last && n == 3 && !SW.bwd_two_pass && (SW.edge_bwd == 0 || SW.edge_bwd == 4) && z_saved &&
+        src_rowptr && src_slots && src && dst && K2P % GP_TN == 0 && K2P / GP_TN <= GP_W && n_edges > 0) {
+        GpdeFusedArgs probe{};
+        probe.k0 = PL.k0; probe.K1P = PL.K1P; probe.K2P = PL.K2P; probe.xs = (const unsigned*)x;
+        onepass_ok = gpde_fused_f16v6_supported(probe);
+        if (onepass_ok && (rc = gpde_launch_attr_bound(edge_attr, n_edges, PL.k0, F(P.off_pack) + PL.off_w1 + (size_t)PL.K1P * 8,
+                                                       (unsigned*)F(P.off_scal), st, kt, kt ? nas.sel : nullptr, src, dst)) != GPDE_OK) return rc;
+    }
     const float* chunk_h = nullptr;          // the current chunk's last hidden activations when they are given (hpart)
+    bool skip_store = false;                 // the chunk runs the one-pass kernel: the last hidden layer is not written
     auto recompute = [&](int e0, int rows, int last) -> int {
         if (!light) {    // (the light pass needs the last hidden layer only, which the fused kernel forms from the attributes itself)
             if (kt) hipLaunchKernelGGL(k_gather_attr_nodes, dim3(nblk((size_t)rows * P.KP[0])), dim3(T), 0, st, edge_attr, nas, src, dst, e0,
@@ -1131,6 +1164,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                                     rows, dims[0], P.KP[0], F(P.off_H[0]));
         }
         if (fast_last && last == n - 1 && chunk_h) last = n - 2;
+        else if (fast_last && last == n - 1 && skip_store) last = n - 2;
         else if (fast_last && last == n - 1) {
             const float* pk = F(P.off_pack);
             GpdeFusedArgs f{};
@@ -1323,8 +1357,14 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         }
         hipLaunchKernelGGL(k_scale_g, dim3((nn + 3) / 4), dim3(T), 0, st, grad_out, rowptr, aggr, na, nn, gT);
         if (rows > 0) {
+            // the chunk's per-edge part on the one-pass kernel: in-degree >= 32 (a 64-slot tile rarely spans more than two
+            // destinations), H not given, and - full backward - enough rows for the split GEMMs that take its by-products
+            const bool use1 = onepass_ok && !chunk_h && (int64_t)rows >= (int64_t)32 * nn &&
+                              (light || (f16s_dw2 && f16s_du1 && rows >= 8192 && !SW.bwd_du_passes && !SW.bwd_du_transpose_pass));
             // hidden activations of the chunk's edges: recomputed, or rows of the given cache
+            skip_store = use1;
             if (phase == BWD_FULL || light) { rc_na = na; rc_nb = nb; if ((rc = recompute(e0, rows, n - 1)) != GPDE_OK) return rc; }
+            skip_store = false;
             const float* Hlast = chunk_h ? chunk_h : (phase == BWD_FULL || light) ? F(P.off_H[n - 1]) : hidden + (size_t)e0 * K2P;
             // Z of the chunk's nodes: kept by the forward (gpde_nnconv_fwd_keepz), else re-aggregated from the recomputed /
             // given activations
@@ -1374,7 +1414,40 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             }
             // per-edge backward through the aggregation -> dU_{n-1}, dx_j
             float* dUc = phase == BWD_FULL ? F(P.off_dU[0]) : light ? nullptr : grad_hidden_out + (size_t)e0 * K2P;   // light: dx only
-            {
+            if (use1) {
+                // dZ_i as the two split images (img2 in place, img1 into the Z buffer - Z itself is the forward's: z_saved), then
+                // ONE kernel: K loop + dU_2 (+ transposed copy, row maxima, tile column statistics) + per-slice partial dx rows
+                du_pre = false;
+                if (!dx) { gpde_set_error("gpde_nnconv_bwd: grad_x must be provided"); return GPDE_EINVAL; }
+                if ((rc = gpde_launch_dz_images(dZ, nn, K2P, F(P.off_Z), F(P.off_dzun), st)) != GPDE_OK) return rc;
+                const float* pk = F(P.off_pack);
+                GpdeFusedArgs f{};
+                f.attr = edge_attr; f.rowptr = rowptr; f.perm = perm; f.src = src; f.dst = dst; f.kt = kt;
+                for (int d_ = 0; d_ < 8; ++d_) f.sel[d_] = nas.sel[d_];
+                f.w1 = pk + PL.off_w1; f.w2t = pk + PL.off_w2t; f.b2 = pk + PL.off_b2;
+                f.w2h = pk + PL.off_w2h; f.ucol = pk + PL.off_ucol; f.w1h = pk + PL.off_w1h; f.fcol = pk + PL.off_fcol;
+                f.k0 = PL.k0; f.K1P = PL.K1P; f.K2P = PL.K2P; f.nc0 = na; f.nc1 = nb; f.e_chunk0 = e0;
+                f.xs = (const unsigned*)x; f.scal = (const unsigned*)F(P.off_scal);
+                f.bw_img1 = F(P.off_Z); f.bw_img2 = dZ; f.bw_unscale = F(P.off_dzun); f.bw_dS = dS;
+                f.bw_dxp = F(P.off_H[n - 1]); f.bw_rows = rows;
+                const int ns = K2P / GP_TN;
+                if (dUc) {
+                    f.bw_dU = dUc;
+                    f.bw_dUt = gpde_gemm_f16s_tn_at(F(P.off_tnws), rows, tn_ksplits(rows), &f.bw_ldt);
+                    f.bw_rowmax = F(P.off_dxe);            // [ns][rows] (the per-edge dx rows of the two-pass form are not used)
+                    f.bw_csum = F(P.off_tcs); f.bw_cmax = (unsigned*)F(P.off_tcm);
+                }
+                int groups = gpde_num_cus() / ns; if (groups < 1) groups = 1;
+                const int gcap = (rows / 64 + GP_WAVES) / GP_WAVES; if (groups > gcap) groups = gcap;
+                f.n_groups = groups;
+                if ((rc = gpde_launch_fused_bwd(f, st)) != GPDE_OK) return rc;
+                if (dUc) {
+                    if ((rc = gpde_launch_row_scales_from_slices(F(P.off_dxe), ns, rows, F(P.off_rowsc), F(P.off_rowsc) + rows, st)) != GPDE_OK) return rc;
+                    du_pre = true;
+                }
+                hipLaunchKernelGGL(k_dx_reduce, dim3((N + 3) / 4), dim3(T), 0, st, F(P.off_H[n - 1]), src_rowptr, src_slots, N, e0, e1, dx, ns,
+                                   (size_t)rows * GP_W);
+            } else {
                 const bool ordered = src_rowptr && src_slots;
                 EdgeBwdArgs ea{x, rowptr, src, dst, dZ, dS, Hlast, dUc, dx, e0, e1, na, K2P, ordered ? F(P.off_dxe) : nullptr};
                 const size_t lds = (size_t)4 * (32 * EB_XS + 32 * EB_HS) * 4;
@@ -1401,7 +1474,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                     if ((rc = gpde_launch_edge_bwd3(e3, st)) != GPDE_OK) return rc;
                 } else if (staged) hipLaunchKernelGGL(gpde_edge_bwd2_kernel, dim3(((rows + 127) / 128 + 7) / 8 * 8), dim3(T), lds2, st, ea);
                 else hipLaunchKernelGGL(gpde_edge_bwd_kernel, dim3((rows + 127) / 128), dim3(T), lds, st, ea);
-                if (ordered) hipLaunchKernelGGL(k_dx_reduce, dim3((N + 3) / 4), dim3(T), 0, st, F(P.off_dxe), src_rowptr, src_slots, N, e0, e1, dx);
+                if (ordered) hipLaunchKernelGGL(k_dx_reduce, dim3((N + 3) / 4), dim3(T), 0, st, F(P.off_dxe), src_rowptr, src_slots, N, e0, e1, dx, 1, (size_t)0);
             }
             // MLP backward over the chunk's edges
             if (phase == BWD_FULL) { mlp_e0 = e0; if ((rc = mlp_backward(dUc, rows)) != GPDE_OK) return rc; }

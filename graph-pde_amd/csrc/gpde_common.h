@@ -159,6 +159,21 @@ struct GpdeFusedArgs {
     int nc0, nc1;          // destination-node chunk
     int e_chunk0;          // rowptr[nc0] (mode 2: first row of hbuf)
     int n_groups;          // edge groups (workgroups per slice)
+    // ---- the backward's one-pass mode (gpde_fused_f16v6_kernel<2>, gpde_launch_fused_bwd; round 5): the K loop of the store
+    // variant with H_2^T left in the accumulators (lane = edge) and the two per-edge products of the backward through the
+    // aggregation taken from there - H_2 is neither written nor read.  `xs` carries the fp32 x rows here ([N][64] floats),
+    // `scal[1]` the bits of max_e B_e (gpde_launch_attr_bound).  Rows = CSR slots [e_chunk0, rowptr[nc1]) of the chunk.
+    const void* bw_img1;   // [chunk node][K2P n][hi 64 c halves | lo 64 c halves]: dZ_i^T split image (gpde_launch_dz_images)
+    const void* bw_img2;   // [chunk node][64 c][K2P/32 groups][hi 32 halves | lo 32 halves], in place over the fp32 dZ, halves
+                           // ordered for the accumulator's row order (gpde_dz_img2_col)
+    const float* bw_unscale;   // [chunk nodes] 2^-t of the node's images
+    const float* bw_dS;        // [chunk nodes][64]
+    float* bw_dU;          // [rows][K2P] dU_2 rows, or nullptr: dx only (the light pass of the depth-deferred backward)
+    float* bw_dUt; int bw_ldt; // with bw_dU: transposed copy [K2P][ldt] (gpde_gemm_f16s_tn_at)
+    float* bw_rowmax;      // with bw_dU: [K2P/128][rows] max_n |dU[e][n]| over the slice's columns
+    float* bw_csum; unsigned* bw_cmax;   // with bw_dU: [ceil(rows/32)][K2P] per-32-slot tile column sums / column max bits
+    float* bw_dxp;         // [K2P/128][rows][64] per-slice partial rows of dx_e (slice 0 carries dS_i); summed by k_dx_reduce
+    int bw_rows;
 };
 int gpde_launch_fused(int mode, bool f16split, const GpdeFusedArgs& a, hipStream_t stream);
 // pre-passes of the f16-split aggregation (gpde_prep.hip): scal[0..1], xs [n_nodes][64]
@@ -191,6 +206,17 @@ int gpde_launch_fused_store(const GpdeFusedArgs& a, hipStream_t stream);
 // one wave per SIMD, 64 x 128 wave tile, 512 registers (gpde_fused_f16v6.hip): the default from 32768 edges on
 bool gpde_fused_f16v6_supported(const GpdeFusedArgs& a);
 int gpde_launch_fused_f16v6(const GpdeFusedArgs& a, hipStream_t stream);
+// the backward's one-pass mode of the same kernel (bw_* fields above) and its operand pre-passes
+int gpde_launch_fused_bwd(const GpdeFusedArgs& a, hipStream_t stream);
+// scal[1] = bits of max_e B_e (the per-edge first-layer bound of DESIGN.md §3c) alone; scal[0] is zeroed
+int gpde_launch_attr_bound(const float* attr, int64_t n_edges, int k0, const float* wmax8, unsigned* scal, hipStream_t stream,
+                           int kt = 0, const int* sel = nullptr, const int32_t* src = nullptr, const int32_t* dst = nullptr);
+// per chunk node: scale from max |dZ_i|, img1 (out) and img2 (in place over dZ) of GpdeFusedArgs::bw_img1 / bw_img2
+int gpde_launch_dz_images(float* dZ, int nn, int K2P, void* img1, float* unscale, hipStream_t stream);
+// row_sc / row_isc [rows] = 2^(13 - E(m)), 2^(E(m) - 13) with m = max over the `nparts` slices of rowmax[s][row]
+int gpde_launch_row_scales_from_slices(const float* rowmax, int nparts, int rows, float* row_sc, float* row_isc, hipStream_t stream);
+// column of a 32-column group stored at half position p of bw_img2's planes: the accumulator row order of the 32x32x16 MFMA
+__host__ __device__ static inline int gpde_dz_img2_col(int p) { return 16 * (p >> 4) + (p & 3) + 8 * ((p & 7) >> 2) + 4 * ((p >> 3) & 1); }
 
 struct GpdeGemm3Args {
     const float* zbuf;     // [nn][64*K2P]

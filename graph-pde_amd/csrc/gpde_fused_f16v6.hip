@@ -25,6 +25,7 @@
 //     issued during chunk c (4 pieces per wave, one address + immediate offsets), retired by the
 //     s_waitcnt vmcnt(0) + s_barrier that ends chunk c; fragments are read half a chunk ahead, in place.
 #include "gpde_common.h"
+#include "gpde_split.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -67,15 +68,36 @@ constexpr int NW = 4;                      // waves per workgroup
 // (j -> i) is table[(sel[d] >> 8 ? i : j) * kt + (sel[d] & 255)], read from the node table (a.attr) with the tile's
 // source / destination ids (the reference builds the [E, 6] tensor from node data, utilities.py:274-277).  No `perm`,
 // no per-edge attribute traffic: the table (N x kt floats) lives in L2.
-template <bool WRITE_H, bool NODEATTR = false>
+//
+// MODE 2, the backward's ONE-PASS kernel (round 5; backward of NNConv_old.message + the scatter, nn_conv.py:273-275, reached from
+// loss.backward(), UAI1_full_resolution.py:266).  The store variant wrote H_2 (4 KiB per edge) for gpde_edge_bwd3_kernel to read
+// back; here the K loop runs with the MFMA operands SWAPPED (A = W2 fragment, B = H1 operand), so the accumulators hold H_2^T -
+// lane = edge, registers = hidden columns, gpde_edge_bwd3_kernel's orientation - and the two per-edge products are formed from
+// them in place:
+//   P1  dU[e][n]  = (sum_c x_e[c] dZ_i[c][n]) [H_2[e][n] > 0]    A = dZ_i^T image (lane = n, K = c), B = x_e (lane = e): the result
+//                                                               has the accumulators' layout, the ReLU mask is `y > 0` in place
+//   P2  dx_e[c]   =  sum_n H_2[e][n] dZ_i[c][n]                  A = dZ_i image (lane = c, K = n in the accumulator's row order),
+//                                                               B = the accumulator registers themselves (split in the lane)
+// plus what gpde_edge_bwd3_kernel left for the next GEMMs (transposed dU, row maxima, per-tile column sums / maxima).  Every
+// per-edge quantity (validity, destination node, scales, mask) is per lane; a tile spanning several destination nodes runs one
+// pass per node with the other nodes' lanes masked.  The workgroup owns a 128-column slice, so dx_e comes out as K2P / 128
+// partial rows (2 KiB per edge instead of the 8 KiB H_2 round trip), summed per source node by k_dx_reduce.  Wave tiles are
+// 64-slot aligned and dealt round-robin over the waves of a slice (no node alignment needed: nothing is accumulated across
+// edges), so that the waves of an XCD work on neighbouring tiles and a node's two 32 KiB image slices are fetched once.
+// The dZ_i fragments are staged per 32-column block through the wave's 16 KiB x stage by LDS-DMA, after the x_j rows (DMA'd
+// during the K loop as in the forward) have been converted into registers.
+template <int MODE, bool NODEATTR = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
+    constexpr bool WRITE_H = MODE == 1;       // store variant
+    constexpr bool BWD = MODE == 2;           // backward one-pass
     extern __shared__ __attribute__((aligned(16))) char smem[];     // ONE LDS object (cdna guide, glds trap a)
     char* ring = smem;                                               // [3][16 KiB]
     char* w1s = smem + NS * TILE_B;                                  // [K1P][hi 16 B | lo 16 B]
     unsigned* Xs_all = (unsigned*)(w1s + (size_t)a.K1P * 32);        // [4 waves][64 rows][64 words]
     float* Es_all = (float*)(Xs_all + NW * TE * GP_W);               // [4][64]
     int* red = (int*)(Es_all + NW * TE);                             // [2][4]
+    [[maybe_unused]] float* cst = (float*)(red + 16);                // BWD: [128] ucol * sh, [128] b2 * sh of this column slice
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -91,6 +113,17 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
     const int NKC = a.K1P / GP_BK;
 
     for (int i = tid; i < a.K1P * 2; i += 256) ((f32x4*)w1s)[i] = ((const f32x4*)a.w1h)[i];
+    [[maybe_unused]] float bw_ish = 1.f;        // BWD: 1 / (global power-of-two scale of the hidden activations)
+    if constexpr (BWD) {
+        // h <= max|b2| + max_k ||W2_k||_1 * max_e B_e (the forward's a-priori bound): ONE power of two for all H
+        const float hb = a.fcol[8] + a.fcol[9] * __uint_as_float(a.scal[1]);
+        const float sh = gpde_pow2_to_2p13(hb);
+        bw_ish = 1.f / sh;
+        if (tid < GP_TN) {
+            cst[tid] = a.ucol[(blockIdx.x % (a.K2P / GP_TN)) * GP_TN + tid] * sh;             // exact: sh is a power of two
+            cst[GP_TN + tid] = a.b2[(blockIdx.x % (a.K2P / GP_TN)) * GP_TN + tid] * sh;
+        }
+    }
 
     // ---- work assignment ---------------------------------------------------------------------------------
     // Queue mode (a.blk != nullptr, the default): the chunk's edges are cut into node-aligned BLOCKS of ~4096 edges
@@ -118,8 +151,14 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
             if (bb > ba) return true;
         }
     };
+    // BWD: 64-slot aligned tiles dealt round-robin over the waves of the slice (tile k of wave w = w + k * waves)
+    [[maybe_unused]] const int bw_stride = TE * a.n_groups * NW;
     if (queue) {
         have = draw_block(blk_a, blk_b);
+    } else if constexpr (BWD) {
+        blk_a = e_lo + TE * (group * NW + wave);
+        blk_b = min(blk_a + TE, e_hi);
+        have = blk_a < e_hi;
     } else {
         const long tot = (long)e_hi - e_lo;
         const int nranges = a.n_groups * NW;
@@ -146,9 +185,11 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
     };
 
     // constants of the un-scaling: h <= max|b2| + max_k ||W2_k||_1 * max_e B_e (pack-time constants in fcol[8..9])
-    float b2v[4], ucv[4];
+    float b2v[4] = {0.f, 0.f, 0.f, 0.f}, ucv[4] = {0.f, 0.f, 0.f, 0.f};
     float z_unscale = 1.f;
-    if constexpr (WRITE_H) {
+    if constexpr (BWD) {
+        // (per-register constants: read from `cst` in the epilogue)
+    } else if constexpr (WRITE_H) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             b2v[nb] = a.b2[slice * GP_TN + nb * 32 + l31];
@@ -181,6 +222,7 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
     int perm_n = 0;
     [[maybe_unused]] int dst_n = 0;     // NODEATTR: perm_n holds the SOURCE node of the next tile's edge, dst_n its destination
     int src_l = 0;                      // source node of edge (tile start + lane), for the x_j row DMA
+    [[maybe_unused]] int dst_e = 0;     // BWD: destination node of edge (tile start + lane)
     float attr_n[8];
     auto load_perm = [&](int e0n) {
         if constexpr (NODEATTR) {
@@ -206,7 +248,10 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
     int xsidx[4];
     auto x_addr1 = [&](int i0, int i) { xsidx[i] = __builtin_amdgcn_ds_bpermute((4 * (i0 + i) + (lane >> 4)) * 4, src_l); };
     auto x_issue1 = [&](int i0, int i) {
-        GPDE_GLDS(a.xs + (size_t)xsidx[i] * GP_W + (lane & 15) * 4, Xs + (i0 + i) * 4 * GP_W, 0);
+        int unit = lane & 15;
+        // BWD: the rows are read back one row per lane (256 B apart): unit p of row r is stored at position p ^ (r & 15)
+        if constexpr (BWD) unit ^= (4 * (i0 + i) + (lane >> 4)) & 15;
+        GPDE_GLDS(a.xs + (size_t)xsidx[i] * GP_W + unit * 4, Xs + (i0 + i) * 4 * GP_W, 0);
     };
 
     // ---- conversions and H1 generation (asm: see the header) ----------------------------------------------
@@ -252,7 +297,16 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[e][nb][r] = 0.f; Z[e][nb][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { acc[e][nb][r] = 0.f; if constexpr (!BWD) Z[e][nb][r] = 0.f; }
+    [[maybe_unused]] f32x16 D2[2][2];       // BWD: dx accumulators [channel block][edge block] (Z is not used there)
+    if constexpr (BWD) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) D2[cb][b][r] = 0.f;
+    }
     int cur = -1;
     [[maybe_unused]] float hmax_run = 0.f;      // WRITE_H: running maximum of the stored activations (>= 0)
 
@@ -299,6 +353,9 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
         int na_ = 0, nb_ = 0;
         bool have_n = have && !last_in_blk;
         if (last_in_blk && queue) have_n = draw_block(na_, nb_);      // drawn ONE tile ahead: no block is held in reserve
+        if constexpr (BWD) {
+            if (last_in_blk) { na_ = blk_a + bw_stride; nb_ = min(na_ + TE, e_hi); have_n = na_ < e_hi; }
+        }
         const int e0n = !have ? e_hi : (last_in_blk ? (have_n ? na_ : e_hi) : e0 + TE);
         if (t > 0) {
             // all four waves out of tiles -> done.  Flags of this round were written before the barrier; the other
@@ -428,6 +485,10 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                            // measure how time and clock answer to a third less matrix work per edge
                         if (tt != 2)
 #endif
+                        if constexpr (BWD)       // operands swapped: the accumulator holds the TRANSPOSED tile (rows = columns n, lane = edge)
+                            acc[e][nb] = mfma16(tt == 0 ? blo[nb] : bhi[nb],
+                                                __builtin_bit_cast(h8, tt == 2 ? alo[cbuf][e] : ahi[cbuf][e]), acc[e][nb]);
+                        else
                         acc[e][nb] = mfma16(__builtin_bit_cast(h8, tt == 2 ? alo[cbuf][e] : ahi[cbuf][e]),
                                             tt == 0 ? blo[nb] : bhi[nb], acc[e][nb]);
                         asm volatile("" : "+a"(acc[e][nb]));
@@ -459,7 +520,13 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                         // the last MFMA they cost ~570 cycles in each of the six peeled chunks, the matrix pipe idling
                         // while ~60 address / load instructions went out).  The x_j row addresses (ds_bpermute of the
                         // source ids loaded two chunks earlier) go into the gaps of step 0.
-                        if constexpr (!WRITE_H && PH == 0) {
+                        if constexpr (BWD && PH == 0) {
+                            if (m == 1) {
+                                if (i == 2) load_perm(e0n);
+                                if (i == 5) src_l = a.src[min(e0 + lane, e_clamp)];
+                                if (i == 8) dst_e = a.dst[min(e0 + lane, e_clamp)];
+                            }
+                        } else if constexpr (MODE == 0 && PH == 0) {
                             if (m == 1) {
                                 if (i == 2) load_perm(e0n);
                                 if (i == 5) src_l = a.src[min(e0 + lane, e_clamp)];
@@ -496,7 +563,9 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                 }
             }
             // closing wait: the chunk's W2 pieces are retired, its side loads (issued behind them, above) stay in flight
-            if constexpr (WRITE_H && PH == 0 && NODEATTR) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // source + destination ids
+            if constexpr (BWD && PH == 0 && NODEATTR) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // next tile's src + dst ids, this tile's
+            else if constexpr (BWD && PH == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                // next tile's edge ids, this tile's src + dst
+            else if constexpr (WRITE_H && PH == 0 && NODEATTR) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // source + destination ids
             else if constexpr (WRITE_H && PH == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else if constexpr (WRITE_H && PH == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if constexpr (WRITE_H) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -522,7 +591,288 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
 
 
         TM_MARK(tm_loop);
-        if constexpr (WRITE_H) {
+        if constexpr (BWD) {
+          if (have) {       // (wave-uniform; a wave without a tile only keeps the workgroup's barriers company)
+            char* S1 = (char*)Xs;                  // dZ_i^T fragments of one 32-column block: [32 n][hi 128 B | lo 128 B], units swizzled by row
+            char* S2 = (char*)Xs + 8192;           // dZ_i fragments: [64 c][hi 64 B | lo 64 B], units swizzled by row
+            const int erow0 = e0 - a.e_chunk0;     // chunk-local row of the tile's first slot (a multiple of 64)
+            const bool with_du = a.bw_dU != nullptr;
+            // ---- per-lane data of the two 32-edge blocks: lane (l31, h) <-> edge e0 + 32 b + l31 in both halves ----
+            int nodeL[2];
+            bool vL[2];
+            float unL[2], isx[2], ie[2];
+            u4 xhi[2][4], xlo[2][4];               // P1's B operand: step s <-> channels 16 s + 8 h + 0..7, scaled by the row's 2^t
+            {
+                const auto nd2 = __builtin_amdgcn_permlane32_swap((unsigned)dst_e, (unsigned)dst_e, false, false);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    vL[b] = (e0 + 32 * b + l31) < eb;
+                    nodeL[b] = vL[b] ? (int)nd2[b] : -1;
+                    unL[b] = vL[b] ? a.bw_unscale[nodeL[b] - a.nc0] : 0.f;
+                    ie[b] = Es[32 * b + l31];
+                    const int row = 32 * b + l31;
+                    const char* xrow = (const char*)Xs + row * 256;
+                    f32x4 xr[4][2];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) xr[s][u] = *(const f32x4*)(xrow + (((4 * s + 2 * h + u) ^ (row & 15)) << 4));
+                    float m = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int t2 = 0; t2 < 4; ++t2) m = fmaxf(m, fabsf(xr[s][u][t2]));
+                    m = fmaxf(m, gp_other_half(m));
+                    float sx;
+                    gp_pow2_scale(m, sx, isx[b]);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            unsigned p0, q0, p1, q1;
+                            gp_split2(xr[s][u][0], xr[s][u][1], sx, p0, q0);
+                            gp_split2(xr[s][u][2], xr[s][u][3], sx, p1, q1);
+                            xhi[b][s][2 * u] = p0; xhi[b][s][2 * u + 1] = p1;
+                            xlo[b][s][2 * u] = q0; xlo[b][s][2 * u + 1] = q1;
+                        }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the x stage has been read: it becomes S1 | S2
+            __builtin_amdgcn_sched_barrier(0);
+            // destination range of the tile (CSR order: ascending with the lane)
+            const int nFirst = __builtin_amdgcn_readfirstlane(nodeL[0]);
+            const int lastIdx = __builtin_amdgcn_readfirstlane(eb - e0 - 1);
+            const int nLast = lastIdx < 32 ? __builtin_amdgcn_readlane(nodeL[0], lastIdx) : __builtin_amdgcn_readlane(nodeL[1], lastIdx - 32);
+            // Fragment DMA of one 32-column block: 8 pieces of 1 KiB into `buf` (8 KiB).  dZ^T rows (P1): row r = 4 i + (lane >> 4),
+            // position p = lane & 15 holds unit p ^ (r & 15); dZ rows (P2): row c = 8 i + (lane >> 3), position p = lane & 7 holds
+            // unit p ^ (c & 7).  Each product walks the node's four blocks with the two halves of the stage as a double buffer.
+            // Addresses = a SCALAR base rebuilt at every issue (opaque to the optimiser: per-lane 64-bit addresses of all 64 pieces
+            // would be hoisted out of the node loop and spilled) + one of a few 32-bit lane offsets.
+            unsigned s1_off[4];        // piece i uses s1_off[i & 3]: (4 i + (lane >> 4)) & 15 = 4 (i & 3) + (lane >> 4)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s1_off[i] = (unsigned)((lane >> 4) * 256 + (((lane & 15) ^ (4 * i + (lane >> 4))) << 4));
+            const unsigned s2_off = (unsigned)((lane >> 3) * a.K2P * 4 + (((lane & 7) ^ (lane >> 3)) << 4));
+            auto issue_S1 = [&](const char* g1, int nb, char* buf) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    unsigned long long gb = (unsigned long long)g1 + (size_t)(nb * 32 + 4 * i) * 256;
+                    asm volatile("" : "+s"(gb));
+                    GPDE_GLDS((const char*)gb + s1_off[i & 3], buf + i * 1024, 0);
+                }
+            };
+            auto issue_S2 = [&](const char* g2, int nb, char* buf) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    unsigned long long gb = (unsigned long long)g2 + ((size_t)(8 * i) * a.K2P + nb * 32) * 4;
+                    asm volatile("" : "+s"(gb));
+                    GPDE_GLDS((const char*)gb + s2_off, buf + i * 1024, 0);
+                }
+            };
+            // y = sh * (pre-activation of the H_2^T block [32 n][64 e] of column block nb); y > 0 is the ReLU mask
+            auto y_block = [&](auto nb_tag, float (&y)[2][16]) {
+                constexpr int nb = decltype(nb_tag)::value;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 uc4 = *(const f32x4*)&cst[nb * 32 + 8 * g + 4 * h];
+                    const f32x4 b24 = *(const f32x4*)&cst[GP_TN + nb * 32 + 8 * g + 4 * h];
+#pragma unroll
+                    for (int t2 = 0; t2 < 4; ++t2)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) y[b][4 * g + t2] = fmaf(acc[b][nb][4 * g + t2], ie[b] * uc4[t2], b24[t2]);
+                }
+            };
+            float rmax[2] = {0.f, 0.f};            // max |dU| of this lane's rows (its half of the slice's columns)
+            bool seen[2] = {false, false};         // block b's tile partials have been written by an earlier node pass
+            const int sw7 = l31 & 7, sw15 = l31 & 15;
+            for (int node = nFirst; node <= nLast; ++node) {
+                const bool inN[2] = {nodeL[0] == node, nodeL[1] == node};
+                const bool anyb[2] = {__builtin_amdgcn_ballot_w64(inN[0]) != 0, __builtin_amdgcn_ballot_w64(inN[1]) != 0};
+                if (!anyb[0] && !anyb[1]) continue;
+                const char* g1 = (const char*)a.bw_img1 + ((size_t)(node - a.nc0) * a.K2P + slice * GP_TN) * 256;
+                const char* g2 = (const char*)a.bw_img2 + ((size_t)(node - a.nc0) * GP_W * a.K2P + slice * GP_TN) * 4;
+                // ================= P1 and the dU outputs =================================================================
+                if (with_du) {
+                    issue_S1(g1, 0, S1);
+                    auto p1_block = [&](auto nb_tag) {
+                        constexpr int nb = decltype(nb_tag)::value;
+                        char* buf = (nb & 1) ? S2 : S1;
+                        float y[2][16];
+                        y_block(nb_tag, y);
+                        // block nb's fragments have landed: the first block waits here, the others were waited for between the
+                        // previous block's output arithmetic and its stores (so that no wait covers a block's own stores)
+                        if (nb == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (nb + 1 < 4) issue_S1(g1, nb + 1, (nb & 1) ? S1 : S2);      // (the other half: read one block ago)
+                        __builtin_amdgcn_sched_barrier(0);
+                        // ---- D1[n][e] = sum_c dZ[c][n] x_e[c] ----
+                        f32x16 d1[2];
+                        const char* r1 = buf + l31 * 256;
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) d1[b][r] = 0.f;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const h8 Ah = *(const h8*)(r1 + (((2 * s + h) ^ sw15) << 4));
+                            const h8 Al = *(const h8*)(r1 + (((8 + 2 * s + h) ^ sw15) << 4));
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) {
+                                if (!anyb[b]) continue;
+                                const h8 Bh = __builtin_bit_cast(h8, xhi[b][s]), Bl = __builtin_bit_cast(h8, xlo[b][s]);
+                                d1[b] = mfma16(Ah, Bh, d1[b]);
+                                d1[b] = mfma16(Ah, Bl, d1[b]);
+                                d1[b] = mfma16(Al, Bh, d1[b]);
+                            }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the fragments have been read
+                        __builtin_amdgcn_sched_barrier(0);
+                        // ---- dU of the block: rows, transposed copy, row maxima, per-tile column sums / maxima ----
+                        const int nc = slice * GP_TN + nb * 32;
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            float o[16], cs[16], cm[16];
+                            if (anyb[b]) {
+                                const float un = isx[b] * unL[b];
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    o[r] = (inN[b] && y[b][r] > 0.f) ? d1[b][r] * un : 0.f;
+                                    rmax[b] = fmaxf(rmax[b], fabsf(o[r]));
+                                }
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) gp_half_wave_sum_max(o[r], cs[r], cm[r]);
+                            }
+                            // the next block's fragments (issued before this block's MFMAs) have landed; the stores follow the wait
+                            if (b == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (!anyb[b]) continue;
+                            const int er = erow0 + 32 * b + l31;
+                            if (inN[b]) {
+                                float* du = a.bw_dU + (size_t)er * a.K2P + nc + 4 * h;
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) *(f32x4*)(du + 8 * g) = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+                                // transposed copy: row nc + 8 g + 4 h + t, column er: scalar row base + one 32-bit lane offset
+                                const unsigned dt_off = (unsigned)(4 * h * a.bw_ldt + er) * 4u;
+#pragma unroll
+                                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                    for (int t2 = 0; t2 < 4; ++t2) {
+                                        unsigned long long tb = (unsigned long long)a.bw_dUt + (size_t)(nc + 8 * g + t2) * a.bw_ldt * 4;
+                                        asm volatile("" : "+s"(tb));
+                                        *(float*)((char*)tb + dt_off) = o[4 * g + t2];
+                                    }
+                            }
+                            if (l31 == 31) {
+                                const size_t po = (size_t)((erow0 >> 5) + b) * a.K2P + nc + 4 * h;
+                                float* ps = a.bw_csum + po;
+                                unsigned* pm = a.bw_cmax + po;
+                                const bool first = !seen[b];
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    f32x4 sv4 = {cs[4 * g], cs[4 * g + 1], cs[4 * g + 2], cs[4 * g + 3]};
+                                    u4 mv4 = {__float_as_uint(cm[4 * g]), __float_as_uint(cm[4 * g + 1]), __float_as_uint(cm[4 * g + 2]), __float_as_uint(cm[4 * g + 3])};
+                                    if (!first) {
+                                        const f32x4 ps0 = *(const f32x4*)(ps + 8 * g);
+                                        const u4 pm0 = *(const u4*)(pm + 8 * g);
+#pragma unroll
+                                        for (int t2 = 0; t2 < 4; ++t2) { sv4[t2] += ps0[t2]; mv4[t2] = max(mv4[t2], pm0[t2]); }
+                                    }
+                                    *(f32x4*)(ps + 8 * g) = sv4;
+                                    *(u4*)(pm + 8 * g) = mv4;
+                                }
+                            }
+                        }
+                    };
+                    p1_block(std::integral_constant<int, 0>{});
+                    p1_block(std::integral_constant<int, 1>{});
+                    p1_block(std::integral_constant<int, 2>{});
+                    p1_block(std::integral_constant<int, 3>{});
+                }
+                // ================= P2: D2[c][e] += sum_n dZ[c][n] H[e][n] ====================================================
+                // B = the lane's own accumulator rows (split in the lane, zero outside this node), A = the node's dZ rows
+                issue_S2(g2, 0, S1);
+                auto p2_block = [&](auto nb_tag) {
+                    constexpr int nb = decltype(nb_tag)::value;
+                    const char* buf = (nb & 1) ? S2 : S1;
+                    float y[2][16];
+                    y_block(nb_tag, y);
+                    u4 yh[2][2], yl[2][2];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int jp = 0; jp < 8; ++jp) {
+                            unsigned ph, pl;
+                            conv_pair(y[b][2 * jp], y[b][2 * jp + 1], ph, pl);       // relu, rtz16 hi, rn16 lo
+                            yh[b][jp >> 2][jp & 3] = inN[b] ? ph : 0u;
+                            yl[b][jp >> 2][jp & 3] = inN[b] ? pl : 0u;
+                        }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // block nb's fragments (issued a block ago) have landed
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (nb + 1 < 4) issue_S2(g2, nb + 1, (nb & 1) ? S1 : S2);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb) {
+                            const char* row = buf + (cb * 32 + l31) * 128;
+                            const h8 Ah = *(const h8*)(row + (((2 * q + h) ^ sw7) << 4));
+                            const h8 Al = *(const h8*)(row + (((4 + 2 * q + h) ^ sw7) << 4));
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) {
+                                if (!anyb[b]) continue;
+                                const h8 Bh = __builtin_bit_cast(h8, yh[b][q]), Bl = __builtin_bit_cast(h8, yl[b][q]);
+                                D2[cb][b] = mfma16(Ah, Bh, D2[cb][b]);
+                                D2[cb][b] = mfma16(Ah, Bl, D2[cb][b]);
+                                D2[cb][b] = mfma16(Al, Bh, D2[cb][b]);
+                                asm volatile("" : "+a"(D2[cb][b]));
+                            }
+                        }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the fragments have been read
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                p2_block(std::integral_constant<int, 0>{});
+                p2_block(std::integral_constant<int, 1>{});
+                p2_block(std::integral_constant<int, 2>{});
+                p2_block(std::integral_constant<int, 3>{});
+                seen[0] = seen[0] || anyb[0];
+                seen[1] = seen[1] || anyb[1];
+            }
+            // ---- row maxima over the slice's columns; the edge's partial dx row (slice 0 adds dS_i) ---------------------------
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float rm = fmaxf(rmax[b], gp_other_half(rmax[b]));
+                const int er = erow0 + 32 * b + l31;
+                if (with_du && vL[b] && h == 0) a.bw_rowmax[(size_t)slice * a.bw_rows + er] = rm;
+                if (vL[b]) {
+                    const float un = bw_ish * unL[b];
+                    float* dxr = a.bw_dxp + ((size_t)slice * a.bw_rows + er) * GP_W + 4 * h;
+                    const float* ds = a.bw_dS + (size_t)(nodeL[b] - a.nc0) * GP_W + 4 * h;
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int c0 = 32 * cb + 8 * g;
+                            f32x4 o4;
+#pragma unroll
+                            for (int t2 = 0; t2 < 4; ++t2) o4[t2] = D2[cb][b][4 * g + t2] * un;
+                            if (slice == 0) {
+                                const f32x4 dv = *(const f32x4*)(ds + c0);
+#pragma unroll
+                                for (int t2 = 0; t2 < 4; ++t2) o4[t2] += dv[t2];
+                            }
+                            *(f32x4*)(dxr + c0) = o4;
+                        }
+                }
+            }
+          }
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+              for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) { acc[b][nb][r] = 0.f; if (nb < 2) D2[b][nb][r] = 0.f; }
+        } else if constexpr (WRITE_H) {
             // ---- un-scale + bias + ReLU, store the tile's hidden activations (128-byte runs along the columns) ----
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
@@ -639,7 +989,7 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                 if (e_seg < s_end) node = a.dst[e_seg];
             }
         }
-        if constexpr (!WRITE_H)
+        if constexpr (MODE == 0)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -661,7 +1011,9 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
             for (int o = 32; o > 0; o >>= 1) hmax_run = fmaxf(hmax_run, __shfl_xor(hmax_run, o));
             if (lane == 0 && hmax_run > 0.f) atomicMax(a.hmax_out, __float_as_uint(hmax_run));
         }
-    } else if (cur >= 0) flush(cur);
+    } else if constexpr (MODE == 0) {
+        if (cur >= 0) flush(cur);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef GPDE_V6_TIMING
     if (lane == 0) {
@@ -675,7 +1027,8 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
 }
 
 size_t v6_lds_bytes(int K1P) {
-    return (size_t)NS * TILE_B + (size_t)K1P * 32 + (size_t)NW * TE * GP_W * 4 + (size_t)NW * TE * 4 + 64;
+    return (size_t)NS * TILE_B + (size_t)K1P * 32 + (size_t)NW * TE * GP_W * 4 + (size_t)NW * TE * 4 + 64 +
+           2 * GP_TN * 4;       // (+ the backward mode's per-slice constants)
 }
 
 }  // namespace
@@ -703,16 +1056,38 @@ int gpde_launch_fused_f16v6(const GpdeFusedArgs& a, hipStream_t stream) {
     const dim3 grid(a.n_groups * ns), block(256);
     const size_t lds = v6_lds_bytes(a.K1P);
     static GpdeLdsOnce once;
-    if (int rc = once.ensure(gpde_fused_f16v6_kernel<false, false>, gpde_fused_f16v6_kernel<true, false>, gpde_fused_f16v6_kernel<false, true>,
-                             gpde_fused_f16v6_kernel<true, true>)) return rc;
+    if (int rc = once.ensure(gpde_fused_f16v6_kernel<0, false>, gpde_fused_f16v6_kernel<1, false>, gpde_fused_f16v6_kernel<0, true>,
+                             gpde_fused_f16v6_kernel<1, true>)) return rc;
     if (a.hout) {
         GpdeFusedArgs b = a;
         b.blk = nullptr; b.qn = nullptr; b.qctr = nullptr;             // rows are independent: static ranges
-        if (a.kt) hipLaunchKernelGGL((gpde_fused_f16v6_kernel<true, true>), grid, block, lds, stream, b);     // row f3 in training
-        else hipLaunchKernelGGL((gpde_fused_f16v6_kernel<true, false>), grid, block, lds, stream, b);
-    } else if (a.kt) hipLaunchKernelGGL((gpde_fused_f16v6_kernel<false, true>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((gpde_fused_f16v6_kernel<false, false>), grid, block, lds, stream, a);
+        if (a.kt) hipLaunchKernelGGL((gpde_fused_f16v6_kernel<1, true>), grid, block, lds, stream, b);     // row f3 in training
+        else hipLaunchKernelGGL((gpde_fused_f16v6_kernel<1, false>), grid, block, lds, stream, b);
+    } else if (a.kt) hipLaunchKernelGGL((gpde_fused_f16v6_kernel<0, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((gpde_fused_f16v6_kernel<0, false>), grid, block, lds, stream, a);
     GP_LAUNCH_CHECK("gpde_fused_f16v6_kernel");
+    return GPDE_OK;
+}
+
+// The backward's one-pass mode (MODE 2): grid = edge groups x column slices like the other modes; tiles are dealt round-robin
+int gpde_launch_fused_bwd(const GpdeFusedArgs& a, hipStream_t stream) {
+    if (!a.xs || !a.scal || !a.bw_img2 || !a.bw_unscale || !a.bw_dS || !a.bw_dxp || !a.src || !a.dst || a.hout || a.blk ||
+        (a.bw_dU && (!a.bw_img1 || !a.bw_dUt || !a.bw_rowmax || !a.bw_csum || !a.bw_cmax)) || a.bw_rows <= 0 || a.n_groups < 1) {
+        gpde_set_error("gpde_launch_fused_bwd: incomplete arguments");
+        return GPDE_EINVAL;
+    }
+    if (!gpde_fused_f16v6_supported(a) || a.K2P % GP_TN != 0) {
+        gpde_set_error("gpde_launch_fused_bwd: kernel MLP outside the one-wave-per-SIMD kernel (K1P = %d, K2P = %d, k0 = %d)", a.K1P, a.K2P, a.k0);
+        return GPDE_EUNSUPPORTED;
+    }
+    const int ns = a.K2P / GP_TN;
+    const dim3 grid(a.n_groups * ns), block(256);
+    const size_t lds = v6_lds_bytes(a.K1P);
+    static GpdeLdsOnce once;
+    if (int rc = once.ensure(gpde_fused_f16v6_kernel<2, false>, gpde_fused_f16v6_kernel<2, true>)) return rc;
+    if (a.kt) hipLaunchKernelGGL((gpde_fused_f16v6_kernel<2, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((gpde_fused_f16v6_kernel<2, false>), grid, block, lds, stream, a);
+    GP_LAUNCH_CHECK("gpde_fused_f16v6_kernel<2>");
     return GPDE_OK;
 }
 

@@ -105,6 +105,22 @@ int gpde_launch_block_bounds(const int32_t* rowptr, int nc0, int nc1, int nblk_m
     return GPDE_OK;
 }
 
+int gpde_launch_attr_bound(const float* attr, int64_t n_edges, int k0, const float* wmax8, unsigned* scal, hipStream_t stream,
+                           int kt, const int* sel, const int32_t* src, const int32_t* dst) {
+    GP_HIP_CHECK(hipMemsetAsync(scal, 0, 8, stream));
+    if (n_edges <= 0) return GPDE_OK;
+    const unsigned ge = (unsigned)((n_edges + 1023) / 1024 < 2048 ? (n_edges + 1023) / 1024 : 2048);
+    if (kt) {
+        SelArr sa;
+        for (int d = 0; d < 8; ++d) sa.v[d] = sel[d];
+        hipLaunchKernelGGL(k_attr_bound_nodes, dim3(ge ? ge : 1), dim3(256), 0, stream, attr, kt, sa, src, dst, n_edges, k0, wmax8, scal);
+    } else {
+        hipLaunchKernelGGL(k_attr_bound, dim3(ge ? ge : 1), dim3(256), 0, stream, attr, n_edges, k0, wmax8, scal);
+    }
+    GP_LAUNCH_CHECK("k_attr_bound");
+    return GPDE_OK;
+}
+
 int gpde_launch_g2_prep(const float* x, int64_t n_nodes, const float* attr, int64_t n_edges, int k0,
                         const float* wmax8, unsigned* scal, unsigned* xs, hipStream_t stream, int kt,
                         const int* sel, const int32_t* src, const int32_t* dst) {

@@ -19,6 +19,11 @@ from tests.helpers.kinks import edges_off_the_kink
 
 pytestmark = pytest.mark.gpu
 TOL_FWD, TOL_BWD = 1e-6, 2e-5
+# Random graphs include ill-conditioned outputs: without root weight and bias the result is a mean of hundreds of messages of
+# random sign, which cancel to a few percent of their size - 1e-7 per message is then 1e-6 .. 1e-5 of what is left (the first two
+# drawn examples), in the reference's own fp32 arithmetic exactly as on the device.  The forward bar is therefore
+# max(1e-6, 4 x the distance of the fp32 ORACLE from float64 on the same inputs): "as close to float64 as the reference's own
+# arithmetic", never looser than north_star's 1e-5 where the problem is well conditioned.
 
 
 @st.composite
@@ -71,6 +76,7 @@ def test_random_graphs_forward_and_gradients_vs_float64(c):
     root = None if conv.root is None else conv.root.detach().clone()
     bias = None if conv.bias is None else conv.bias.detach().clone()
     ref = nnconv_forward(x, ei, ea, W, B, root, bias, aggr=c["aggr"], dtype=torch.float64)
+    e32 = rel_l2(nnconv_forward(x, ei, ea, W, B, root, bias, aggr=c["aggr"], dtype=torch.float32), ref)
     rx, rW, rb, rroot, rbias = nnconv_grads(x, ei, ea, W, B, root, bias, c["aggr"], gout, chunk_edges=4096)
 
     conv = conv.to(d)
@@ -87,7 +93,7 @@ def test_random_graphs_forward_and_gradients_vs_float64(c):
     (out * gout.to(d)).sum().backward()
     torch.cuda.synchronize()
     err = rel_l2(out.detach().cpu(), ref)
-    assert err <= TOL_FWD, ("forward", c, err)
+    assert err <= max(TOL_FWD, 4 * e32), ("forward", c, err, "fp32 oracle vs float64:", e32)
     lin = ops.mlp_linears(conv.nn)
     errs = {"dx": rel_l2(xin.grad.cpu(), rx)}
     for l, layer in enumerate(lin):
