@@ -29,7 +29,7 @@ GpdeSwitches load_switches() {
     s.bwd_dw1_gemm = on("GPDE_BWD_DW1_GEMM");
     s.bwd_du_passes = on("GPDE_BWD_DU_PASSES");
     s.bwd_du_transpose_pass = on("GPDE_BWD_DU_TRANSPOSE_PASS");
-    s.bwd_two_pass = on("GPDE_BWD_TWO_PASS");
+    s.bwd_one_pass = on("GPDE_BWD_ONE_PASS");
     s.store_v3 = on("GPDE_STORE_V3");
     s.nt_no_prefetch = on("GPDE_NT_NO_PREFETCH");
     s.tn_no_ks_xcd = on("GPDE_TN_NO_KS_XCD");
@@ -53,7 +53,7 @@ extern "C" int gpde_reload_switches(void) {
 
 // An ablation build (-DGPDE_ABL_*: part of the arithmetic removed, WRONG results, timing only) or an instrumented build
 // (-DGPDE_*_TIMING: clock64 probes) says so in its version word; graph-pde_amd/_lib.py refuses the former unless asked.
-#if defined(GPDE_ABL_2MFMA) || defined(GPDE_ABL_NOSTAGE) || defined(GPDE_ABL_NOBARRIER) || defined(GPDE_ABL_NOGEMM2) || defined(GPDE_ABL_NOWAIT)
+#if defined(GPDE_ABL_2MFMA) || defined(GPDE_ABL_NOSTAGE) || defined(GPDE_ABL_NOBARRIER) || defined(GPDE_ABL_NOGEMM2) || defined(GPDE_ABL_NOWAIT) || defined(GPDE_BWABL)
 #define GPDE_BUILD_FLAGS_ GPDE_VERSION_ABLATION
 #elif defined(GPDE_V6_TIMING) || defined(GPDE_NT_TIMING) || defined(GPDE_EB2_TIMING) || defined(GPDE_V3_TIMING)
 #define GPDE_BUILD_FLAGS_ GPDE_VERSION_INSTRUMENTED

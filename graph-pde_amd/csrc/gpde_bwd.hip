@@ -1144,9 +1144,12 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     // ---- the one-pass kernel (round 5, gpde_fused_f16v6_kernel<2>): K loop of the recompute + both per-edge products, H_2 neither
     // written nor read.  Needs: the fused store kernel's shape, Z kept by the forward (dW_3 wants Z, and Z from H_2 is what this
     // path no longer has), the source-ordered slots (its dx comes out as per-slice partial rows for k_dx_reduce), and - in the
-    // full backward - the split GEMMs that take the by-products.  GPDE_BWD_TWO_PASS=1 / GPDE_EDGE_BWD=1|2|3: the two-pass forms.
+    // full backward - the split GEMMs that take the by-products.  OPT-IN (GPDE_BWD_ONE_PASS=1 or GPDE_EDGE_BWD=4): measured at
+    // s=121 the kernel takes 52.6 ms where recompute-store + gpde_edge_bwd3_kernel take 32.1 + 17.5 - a one-wave-per-SIMD kernel
+    // cannot hide the products' conversions, cross-lane column statistics and 12 KiB per edge of stores under anything
+    // (ablations: profiles/r05_onepass_ablation.txt).
     bool onepass_ok = false;
-    if ((phase == BWD_FULL || light) && fast_last && n == 3 && !SW.bwd_two_pass && (SW.edge_bwd == 0 || SW.edge_bwd == 4) && z_saved &&
+    if ((phase == BWD_FULL || light) && fast_last && n == 3 && (SW.bwd_one_pass || SW.edge_bwd == 4) && (SW.edge_bwd == 0 || SW.edge_bwd == 4) && z_saved &&
         src_rowptr && src_slots && src && dst && K2P % GP_TN == 0 && K2P / GP_TN <= GP_W && n_edges > 0) {
         GpdeFusedArgs probe{};
         probe.k0 = PL.k0; probe.K1P = PL.K1P; probe.K2P = PL.K2P; probe.xs = (const unsigned*)x;
@@ -1359,8 +1362,8 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         if (rows > 0) {
             // the chunk's per-edge part on the one-pass kernel: in-degree >= 32 (a 64-slot tile rarely spans more than two
             // destinations), H not given, and - full backward - enough rows for the split GEMMs that take its by-products
-            const bool use1 = onepass_ok && !chunk_h && (int64_t)rows >= (int64_t)32 * nn &&
-                              (light || (f16s_dw2 && f16s_du1 && rows >= 8192 && !SW.bwd_du_passes && !SW.bwd_du_transpose_pass));
+            const bool use1 = onepass_ok && !chunk_h && (int64_t)rows >= (int64_t)32 * nn;
+            const bool use1_by = use1 && !light && f16s_dw2 && f16s_du1 && rows >= 8192 && !SW.bwd_du_passes && !SW.bwd_du_transpose_pass;
             // hidden activations of the chunk's edges: recomputed, or rows of the given cache
             skip_store = use1;
             if (phase == BWD_FULL || light) { rc_na = na; rc_nb = nb; if ((rc = recompute(e0, rows, n - 1)) != GPDE_OK) return rc; }
@@ -1431,8 +1434,8 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 f.bw_img1 = F(P.off_Z); f.bw_img2 = dZ; f.bw_unscale = F(P.off_dzun); f.bw_dS = dS;
                 f.bw_dxp = F(P.off_H[n - 1]); f.bw_rows = rows;
                 const int ns = K2P / GP_TN;
-                if (dUc) {
-                    f.bw_dU = dUc;
+                if (dUc) f.bw_dU = dUc;
+                if (use1_by) {
                     f.bw_dUt = gpde_gemm_f16s_tn_at(F(P.off_tnws), rows, tn_ksplits(rows), &f.bw_ldt);
                     f.bw_rowmax = F(P.off_dxe);            // [ns][rows] (the per-edge dx rows of the two-pass form are not used)
                     f.bw_csum = F(P.off_tcs); f.bw_cmax = (unsigned*)F(P.off_tcm);
@@ -1441,7 +1444,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 const int gcap = (rows / 64 + GP_WAVES) / GP_WAVES; if (groups > gcap) groups = gcap;
                 f.n_groups = groups;
                 if ((rc = gpde_launch_fused_bwd(f, st)) != GPDE_OK) return rc;
-                if (dUc) {
+                if (use1_by) {
                     if ((rc = gpde_launch_row_scales_from_slices(F(P.off_dxe), ns, rows, F(P.off_rowsc), F(P.off_rowsc) + rows, st)) != GPDE_OK) return rc;
                     du_pre = true;
                 }

@@ -76,7 +76,8 @@ struct GpdeSwitches {
     bool bwd_dw1_gemm;           // GPDE_BWD_DW1_GEMM
     bool bwd_du_passes;          // GPDE_BWD_DU_PASSES: separate bias / maxima / transpose passes over dU_2
     bool bwd_du_transpose_pass;  // GPDE_BWD_DU_TRANSPOSE_PASS: k_transpose_stats instead of the per-edge kernel's by-products
-    bool bwd_two_pass;           // GPDE_BWD_TWO_PASS: recompute-store + gpde_edge_bwd3 instead of the one-pass kernel (round 5)
+    bool bwd_one_pass;           // GPDE_BWD_ONE_PASS: the one-pass kernel (gpde_fused_f16v6_kernel<2>, round 5; measured slower than
+                                 // recompute-store + gpde_edge_bwd3: opt-in) where its conditions hold; also GPDE_EDGE_BWD=4
     bool store_v3;               // GPDE_STORE_V3: hidden-activation store on the 8-wave kernel
     bool nt_no_prefetch;         // GPDE_NT_NO_PREFETCH
     bool tn_no_ks_xcd;           // GPDE_TN_NO_KS_XCD
@@ -169,9 +170,9 @@ struct GpdeFusedArgs {
     const float* bw_unscale;   // [chunk nodes] 2^-t of the node's images
     const float* bw_dS;        // [chunk nodes][64]
     float* bw_dU;          // [rows][K2P] dU_2 rows, or nullptr: dx only (the light pass of the depth-deferred backward)
-    float* bw_dUt; int bw_ldt; // with bw_dU: transposed copy [K2P][ldt] (gpde_gemm_f16s_tn_at)
-    float* bw_rowmax;      // with bw_dU: [K2P/128][rows] max_n |dU[e][n]| over the slice's columns
-    float* bw_csum; unsigned* bw_cmax;   // with bw_dU: [ceil(rows/32)][K2P] per-32-slot tile column sums / column max bits
+    float* bw_dUt; int bw_ldt; // optional with bw_dU (all four by-products or none): transposed copy [K2P][ldt] (gpde_gemm_f16s_tn_at)
+    float* bw_rowmax;      // with bw_dUt: [K2P/128][rows] max_n |dU[e][n]| over the slice's columns
+    float* bw_csum; unsigned* bw_cmax;   // with bw_dUt: [ceil(rows/32)][K2P] per-32-slot tile column sums / column max bits
     float* bw_dxp;         // [K2P/128][rows][64] per-slice partial rows of dx_e (slice 0 carries dS_i); summed by k_dx_reduce
     int bw_rows;
 };

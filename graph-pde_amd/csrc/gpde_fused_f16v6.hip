@@ -597,6 +597,7 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
             char* S2 = (char*)Xs + 8192;           // dZ_i fragments: [64 c][hi 64 B | lo 64 B], units swizzled by row
             const int erow0 = e0 - a.e_chunk0;     // chunk-local row of the tile's first slot (a multiple of 64)
             const bool with_du = a.bw_dU != nullptr;
+            const bool with_by = a.bw_dUt != nullptr;          // the by-products for the split GEMMs (else: dU rows only)
             // ---- per-lane data of the two 32-edge blocks: lane (l31, h) <-> edge e0 + 32 b + l31 in both halves ----
             int nodeL[2];
             bool vL[2];
@@ -693,7 +694,11 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                 const char* g1 = (const char*)a.bw_img1 + ((size_t)(node - a.nc0) * a.K2P + slice * GP_TN) * 256;
                 const char* g2 = (const char*)a.bw_img2 + ((size_t)(node - a.nc0) * GP_W * a.K2P + slice * GP_TN) * 4;
                 // ================= P1 and the dU outputs =================================================================
+#ifdef GPDE_BWABL
+                if (with_du && !(GPDE_BWABL & 8)) {
+#else
                 if (with_du) {
+#endif
                     issue_S1(g1, 0, S1);
                     auto p1_block = [&](auto nb_tag) {
                         constexpr int nb = decltype(nb_tag)::value;
@@ -740,8 +745,13 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                                     o[r] = (inN[b] && y[b][r] > 0.f) ? d1[b][r] * un : 0.f;
                                     rmax[b] = fmaxf(rmax[b], fabsf(o[r]));
                                 }
+#ifdef GPDE_BWABL
+                                if (!(GPDE_BWABL & 1))
+#endif
+                                if (with_by) {
 #pragma unroll
-                                for (int r = 0; r < 16; ++r) gp_half_wave_sum_max(o[r], cs[r], cm[r]);
+                                    for (int r = 0; r < 16; ++r) gp_half_wave_sum_max(o[r], cs[r], cm[r]);
+                                }
                             }
                             // the next block's fragments (issued before this block's MFMAs) have landed; the stores follow the wait
                             if (b == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -750,10 +760,17 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                             const int er = erow0 + 32 * b + l31;
                             if (inN[b]) {
                                 float* du = a.bw_dU + (size_t)er * a.K2P + nc + 4 * h;
+#ifdef GPDE_BWABL
+                                if (!(GPDE_BWABL & 4))
+#endif
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) *(f32x4*)(du + 8 * g) = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
                                 // transposed copy: row nc + 8 g + 4 h + t, column er: scalar row base + one 32-bit lane offset
                                 const unsigned dt_off = (unsigned)(4 * h * a.bw_ldt + er) * 4u;
+#ifdef GPDE_BWABL
+                                if (!(GPDE_BWABL & 2))
+#endif
+                                if (with_by)
 #pragma unroll
                                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -763,7 +780,10 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                                         *(float*)((char*)tb + dt_off) = o[4 * g + t2];
                                     }
                             }
-                            if (l31 == 31) {
+#ifdef GPDE_BWABL
+                            if (!(GPDE_BWABL & 1))
+#endif
+                            if (with_by && l31 == 31) {
                                 const size_t po = (size_t)((erow0 >> 5) + b) * a.K2P + nc + 4 * h;
                                 float* ps = a.bw_csum + po;
                                 unsigned* pm = a.bw_cmax + po;
@@ -791,6 +811,9 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                 }
                 // ================= P2: D2[c][e] += sum_n dZ[c][n] H[e][n] ====================================================
                 // B = the lane's own accumulator rows (split in the lane, zero outside this node), A = the node's dZ rows
+#ifdef GPDE_BWABL
+                if (!(GPDE_BWABL & 16)) {
+#endif
                 issue_S2(g2, 0, S1);
                 auto p2_block = [&](auto nb_tag) {
                     constexpr int nb = decltype(nb_tag)::value;
@@ -835,6 +858,9 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
                 p2_block(std::integral_constant<int, 1>{});
                 p2_block(std::integral_constant<int, 2>{});
                 p2_block(std::integral_constant<int, 3>{});
+#ifdef GPDE_BWABL
+                }
+#endif
                 seen[0] = seen[0] || anyb[0];
                 seen[1] = seen[1] || anyb[1];
             }
@@ -843,7 +869,7 @@ void gpde_fused_f16v6_kernel(GpdeFusedArgs a) {
             for (int b = 0; b < 2; ++b) {
                 const float rm = fmaxf(rmax[b], gp_other_half(rmax[b]));
                 const int er = erow0 + 32 * b + l31;
-                if (with_du && vL[b] && h == 0) a.bw_rowmax[(size_t)slice * a.bw_rows + er] = rm;
+                if (with_by && vL[b] && h == 0) a.bw_rowmax[(size_t)slice * a.bw_rows + er] = rm;
                 if (vL[b]) {
                     const float un = bw_ish * unL[b];
                     float* dxr = a.bw_dxp + ((size_t)slice * a.bw_rows + er) * GP_W + 4 * h;
@@ -1072,7 +1098,7 @@ int gpde_launch_fused_f16v6(const GpdeFusedArgs& a, hipStream_t stream) {
 // The backward's one-pass mode (MODE 2): grid = edge groups x column slices like the other modes; tiles are dealt round-robin
 int gpde_launch_fused_bwd(const GpdeFusedArgs& a, hipStream_t stream) {
     if (!a.xs || !a.scal || !a.bw_img2 || !a.bw_unscale || !a.bw_dS || !a.bw_dxp || !a.src || !a.dst || a.hout || a.blk ||
-        (a.bw_dU && (!a.bw_img1 || !a.bw_dUt || !a.bw_rowmax || !a.bw_csum || !a.bw_cmax)) || a.bw_rows <= 0 || a.n_groups < 1) {
+        (a.bw_dU && !a.bw_img1) || (a.bw_dUt && (!a.bw_dU || !a.bw_rowmax || !a.bw_csum || !a.bw_cmax)) || a.bw_rows <= 0 || a.n_groups < 1) {
         gpde_set_error("gpde_launch_fused_bwd: incomplete arguments");
         return GPDE_EINVAL;
     }

@@ -3,10 +3,12 @@
 `loss.backward()` (/root/reference/graph-neural-operator/UAI1_full_resolution.py:266) through `NNConv_old.message`
 (nn_conv.py:273-275) needs, per edge, dU_2 = (x_j . dZ_i) [H_2 > 0] and dx_e = H_2 . dZ_i.  Rounds 2-4 recomputed H_2 into
 memory (4 KiB per edge) and read it back in a second kernel; the one-pass kernel runs the recompute's K loop with the operands
-swapped, so that H_2^T sits in the accumulators with the lane as the edge, and takes both products from there.  It is the default
-whenever the forward kept Z (the module's training path on graphs of in-degree >= 32).  Checked here, through the C ABI:
+swapped, so that H_2^T sits in the accumulators with the lane as the edge, and takes both products from there.  It is correct and
+complete - and measured SLOWER than the two kernels it replaces (52.6 ms against 32.1 + 17.5 ms at s=121: a one-wave-per-SIMD kernel
+hides none of the epilogue's conversions, cross-lane statistics and stores; DESIGN.md §6b, profiles/r05_onepass_ablation.txt), so it
+is OPT-IN (GPDE_BWD_ONE_PASS=1; needs the forward's kept Z).  Checked here, through the C ABI:
   * every gradient of the full backward against float64 autograd through the oracle and against the two-pass form
-    (GPDE_BWD_TWO_PASS=1: recompute-store + gpde_edge_bwd3_kernel) - ragged last tile, destinations with 1 .. 2000 in-edges
+    (the default: recompute-store + gpde_edge_bwd3_kernel) - ragged last tile, destinations with 1 .. 2000 in-edges
     (tiles spanning several nodes), nodes without in-edges, several node / edge chunks, `add` and `mean`;
   * the light pass (dx only) against the full backward's bits for everything it returns;
   * bit-reproducibility run to run, under a different chunking (grad_x), and under workgroup skew;
@@ -76,12 +78,11 @@ def test_one_pass_backward_matches_float64_and_the_two_pass_form(dims, n, e, agg
     rx, rW, rb, rroot, rbias = nnconv_grads(x, ei, ea, W, B, root, bias, aggr, gout, chunk_edges=4096)
     ref = dict([("dx", rx)] + [(f"dW{l + 1}", w) for l, w in enumerate(rW)] + [(f"db{l + 1}", b) for l, b in enumerate(rb)] +
                [("droot", rroot), ("dbias", rbias)])
-    monkeypatch.delenv("GPDE_BWD_TWO_PASS", raising=False)
+    monkeypatch.setenv("GPDE_BWD_ONE_PASS", "1")
     one = _flat(_run(*case, aggr=aggr))
     again = _flat(_run(*case, aggr=aggr))
-    monkeypatch.setenv("GPDE_BWD_TWO_PASS", "1")
+    monkeypatch.delenv("GPDE_BWD_ONE_PASS")
     two = _flat(_run(*case, aggr=aggr))
-    monkeypatch.delenv("GPDE_BWD_TWO_PASS")
     assert not torch.equal(one[0][1], two[0][1]), "the switch changed nothing: did the one-pass kernel run?"
     errs = {}
     for (k, a), (_, a2), (_, t) in zip(one, again, two):
@@ -97,7 +98,7 @@ def test_one_pass_backward_matches_float64_and_the_two_pass_form(dims, n, e, agg
 def test_one_pass_light_pass_and_chunking(monkeypatch):
     dims, n, e = [6, 256, 256, 4096], 300, 40000
     case = _case(dims, n, e, 5)
-    monkeypatch.delenv("GPDE_BWD_TWO_PASS", raising=False)
+    monkeypatch.setenv("GPDE_BWD_ONE_PASS", "1")
     fx, fW, fb, froot, fbias = _run(*case)
     lx, lw, lb, lroot, lbias = _run(*case, light=True)
     assert torch.equal(lx, fx) and torch.equal(lw, fW[-1]) and torch.equal(lb, fb[-1])
@@ -115,9 +116,10 @@ def test_one_pass_light_pass_and_chunking(monkeypatch):
     assert torch.equal(sx, fx) and all(torch.equal(a, b) for a, b in zip(sW, fW)) and all(torch.equal(a, b) for a, b in zip(sb, fb))
 
 
-def test_one_pass_backward_with_node_table_attributes_is_bitwise_the_tensor_path():
+def test_one_pass_backward_with_node_table_attributes_is_bitwise_the_tensor_path(monkeypatch):
     """Row f3 in training: the attributes come from node data inside the kernel (`GpdeNodeAttr`): same floats, same bits."""
     from graph_pde_amd import synth
+    monkeypatch.setenv("GPDE_BWD_ONE_PASS", "1")
     d = torch.device("cuda:0")
     s = 41
     ei, ea, n = synth.darcy_graph(s, 0.10)
