@@ -1,0 +1,85 @@
+"""Record a model function's native calls once into a HIP graph and replay it (opt-in).
+
+The MGKN V-cycles issue 52 / 65 NNConv calls per forward on graphs of a few hundred to a few ten-thousand edges
+(/root/reference/multipole-graph-neural-operator/MGKN_orthogonal_burgers1d.py:65-82, MGKN_general_darcy2d.py:76-90): the
+GPU work of such a forward is ~1-2 ms while the host needs longer than that to ISSUE the calls (Python dispatch, cache
+look-ups, ctypes, kernel launches).  Shapes, graphs and pointers are the same for every call of one sample, so the whole
+sequence can be recorded once (`hipStreamBeginCapture` through `torch.cuda.CUDAGraph`) and replayed with one launch:
+
+    fwd = gp.capture(lambda x: model(x, edge_index, edge_attr), x_example)      # warm-up calls, then ONE recorded call
+    y = fwd(x)                                                                   # copies x into the static input, replays
+
+What is recorded is exactly what the uncaptured call launches - the same kernels of libgpde.so with the same arguments - so
+the result is bit-identical to calling the function directly.  Everything the host decides (CSR look-ups, weight packing,
+the cache policies of hidden_cache.py) is decided during the warm-up / recording call and frozen:
+  * tensors passed as arguments are copied into static buffers at every call; everything else the function reads (weights,
+    edge_index, edge_attr) is read from where it lay at recording time - in-place updates of those tensors (an optimizer
+    step) are seen, NEW tensors are not: re-capture then;
+  * the outputs live in the graph's memory pool and are overwritten by the next replay (`copy_outputs=True` returns clones);
+  * for a training step (`loss.backward()` and `optimizer.step()` inside `fn`) the optimizer must be capturable
+    (`torch.optim.Adam(..., capturable=True)`) and gradients must be zeroed with `set_to_none=False` semantics handled by the
+    caller's function; see tests/test_gpu_capture.py.
+Not a tracing compiler: nothing is transformed, fused or re-ordered.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable
+
+import torch
+
+
+def _map_tensors(obj: Any, f: Callable[[torch.Tensor], Any]) -> Any:
+    if isinstance(obj, torch.Tensor):
+        return f(obj)
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_map_tensors(o, f) for o in obj)
+    if isinstance(obj, dict):
+        return {k: _map_tensors(v, f) for k, v in obj.items()}
+    return obj
+
+
+class Captured:
+    """A recorded call of `fn(*args)`; calling it replays the HIP graph (see the module docstring)."""
+
+    def __init__(self, fn: Callable, args: tuple, warmup: int = 3, copy_outputs: bool = False):
+        devs = {a.device for a in args if isinstance(a, torch.Tensor)}
+        if any(d.type != "cuda" for d in devs):
+            raise ValueError("capture() records a HIP graph: tensor arguments must live on the GPU")
+        self._static_in = [a.clone() if isinstance(a, torch.Tensor) else a for a in args]
+        self._copy_outputs = copy_outputs
+        dev = next(iter(devs)) if devs else torch.device("cuda", torch.cuda.current_device())
+        # warm-up on a side stream (torch's capture protocol): builds the CSRs, packs the weights, lets the cache policies see
+        # the module repeat - host-side state that the recording call must find settled
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                fn(*self._static_in)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        # "relaxed": the host side of a native call may query free memory (workspace / cache budgets) - not a stream operation
+        with torch.cuda.graph(self.graph, capture_error_mode="relaxed"):
+            self._static_out = fn(*self._static_in)
+        torch.cuda.synchronize(dev)
+        self.replays = 0
+
+    def __call__(self, *args):
+        if len(args) != len(self._static_in):
+            raise TypeError(f"captured with {len(self._static_in)} arguments, called with {len(args)}")
+        for s, a in zip(self._static_in, args):
+            if isinstance(s, torch.Tensor):
+                if not isinstance(a, torch.Tensor) or a.shape != s.shape or a.dtype != s.dtype:
+                    raise ValueError("a captured call replays fixed shapes: argument of other shape / dtype - capture again")
+                if a.data_ptr() != s.data_ptr():
+                    s.copy_(a)
+            elif a != s:
+                raise ValueError("non-tensor arguments are frozen at capture time")
+        self.graph.replay()
+        self.replays += 1
+        return _map_tensors(self._static_out, lambda t: t.clone()) if self._copy_outputs else self._static_out
+
+
+def capture(fn: Callable, *example_args, warmup: int = 3, copy_outputs: bool = False) -> Captured:
+    """Record `fn(*example_args)` into a HIP graph after `warmup` ordinary calls; returns the replaying callable."""
+    return Captured(fn, example_args, warmup=warmup, copy_outputs=copy_outputs)
