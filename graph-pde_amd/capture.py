@@ -16,9 +16,10 @@ the cache policies of hidden_cache.py) is decided during the warm-up / recording
     edge_index, edge_attr) is read from where it lay at recording time - in-place updates of those tensors (an optimizer
     step) are seen, NEW tensors are not: re-capture then;
   * the outputs live in the graph's memory pool and are overwritten by the next replay (`copy_outputs=True` returns clones);
-  * for a training step (`loss.backward()` and `optimizer.step()` inside `fn`) the optimizer must be capturable
-    (`torch.optim.Adam(..., capturable=True)`) and gradients must be zeroed with `set_to_none=False` semantics handled by the
-    caller's function; see tests/test_gpu_capture.py.
+  * a whole training step can be recorded too (`zero_grad(set_to_none=True)`, forward, `loss.backward()`, `optimizer.step()`
+    inside `fn`): the optimizer must be capturable (`torch.optim.Adam(..., capturable=True)`: its step count lives on the
+    device) and `capture(..., updates_parameters=True)` must be said, because the recorded step rewrites the weights behind
+    Python's back (tests/test_gpu_capture.py).
 Not a tracing compiler: nothing is transformed, fused or re-ordered.
 """
 from __future__ import annotations
@@ -41,12 +42,13 @@ def _map_tensors(obj: Any, f: Callable[[torch.Tensor], Any]) -> Any:
 class Captured:
     """A recorded call of `fn(*args)`; calling it replays the HIP graph (see the module docstring)."""
 
-    def __init__(self, fn: Callable, args: tuple, warmup: int = 3, copy_outputs: bool = False):
+    def __init__(self, fn: Callable, args: tuple, warmup: int = 3, copy_outputs: bool = False, updates_parameters: bool = False):
         devs = {a.device for a in args if isinstance(a, torch.Tensor)}
         if any(d.type != "cuda" for d in devs):
             raise ValueError("capture() records a HIP graph: tensor arguments must live on the GPU")
         self._static_in = [a.clone() if isinstance(a, torch.Tensor) else a for a in args]
         self._copy_outputs = copy_outputs
+        self._updates_parameters = updates_parameters
         dev = next(iter(devs)) if devs else torch.device("cuda", torch.cuda.current_device())
         # warm-up on a side stream (torch's capture protocol): builds the CSRs, packs the weights, lets the cache policies see
         # the module repeat - host-side state that the recording call must find settled
@@ -77,9 +79,18 @@ class Captured:
                 raise ValueError("non-tensor arguments are frozen at capture time")
         self.graph.replay()
         self.replays += 1
+        if self._updates_parameters:
+            # the recorded optimizer step rewrote the weights without Python seeing it: the host-side caches key on tensor
+            # version counters, which a replay does not move - drop them, or a later DIRECT call would reuse the packed image
+            # / hidden activations of the weights as they were at recording time
+            from . import hidden_cache, ops
+            ops.clear_param_caches()
+            hidden_cache.clear()
         return _map_tensors(self._static_out, lambda t: t.clone()) if self._copy_outputs else self._static_out
 
 
-def capture(fn: Callable, *example_args, warmup: int = 3, copy_outputs: bool = False) -> Captured:
-    """Record `fn(*example_args)` into a HIP graph after `warmup` ordinary calls; returns the replaying callable."""
-    return Captured(fn, example_args, warmup=warmup, copy_outputs=copy_outputs)
+def capture(fn: Callable, *example_args, warmup: int = 3, copy_outputs: bool = False, updates_parameters: bool = False) -> Captured:
+    """Record `fn(*example_args)` into a HIP graph after `warmup` ordinary calls; returns the replaying callable.
+    `updates_parameters`: `fn` contains an optimizer step (the weights change inside the graph): every replay then drops the
+    host-side weight / activation caches (see Captured.__call__)."""
+    return Captured(fn, example_args, warmup=warmup, copy_outputs=copy_outputs, updates_parameters=updates_parameters)

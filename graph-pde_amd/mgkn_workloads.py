@@ -51,7 +51,8 @@ class Workload:
 
 
 def orthogonal_burgers(device, s: int = 8192, depth: int = 4, ker_width: int = 1024, seed: int = 0,
-                       fused_glue: bool = False, grouped: bool = False) -> Workload:
+                       fused_glue: bool = False, grouped: bool = False, capturable: bool = False) -> Workload:
+    """`capturable`: Adam keeps its step count on the device, so that `train_step` can be recorded by `gp.capture`."""
     torch.manual_seed(seed)
     graphs = [(ei.to(device), ea.to(device), n) for ei, ea, n in synth.burgers_multipole_graphs(s, seed=seed)]
     nlev = len(graphs)                              # level + 1 graphs: nearest neighbours + one per level
@@ -79,7 +80,7 @@ def orthogonal_burgers(device, s: int = 8192, depth: int = 4, ker_width: int = 1
         with torch.no_grad():
             return sweep_all()
 
-    opt = torch.optim.Adam([p for c in convs for p in c.parameters()], lr=1e-3, weight_decay=5e-4)   # :209-211
+    opt = torch.optim.Adam([p for c in convs for p in c.parameters()], lr=1e-3, weight_decay=5e-4, capturable=capturable)   # :209-211
 
     def train_step():
         opt.zero_grad(set_to_none=True)
@@ -95,7 +96,7 @@ def orthogonal_burgers(device, s: int = 8192, depth: int = 4, ker_width: int = 1
 
 
 def general_darcy(device, s: int = 421, depth: int = 5, ker_width: int = 256, seed: int = 0,
-                  fused_glue: bool = False) -> Workload:
+                  fused_glue: bool = False, capturable: bool = False) -> Workload:
     torch.manual_seed(seed)
     m = [2400, 1600, 400, 100, 25]
     r_inner = [0.5 / 8 * 1.41, 0.5 / 8, 0.5 / 4, 0.5 / 2, 0.5]
@@ -145,7 +146,8 @@ def general_darcy(device, s: int = 421, depth: int = 5, ker_width: int = 256, se
         with torch.no_grad():
             return sweep_all()
 
-    opt = torch.optim.Adam([p for c in inner + down + up for p in c.parameters()], lr=1e-3, weight_decay=5e-4)   # :240-242
+    opt = torch.optim.Adam([p for c in inner + down + up for p in c.parameters()], lr=1e-3, weight_decay=5e-4,
+                           capturable=capturable)   # :240-242
 
     def train_step():
         opt.zero_grad(set_to_none=True)

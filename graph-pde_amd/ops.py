@@ -300,6 +300,13 @@ def csr_for(edge_index: torch.Tensor, n_nodes: int) -> Csr:
     return csr
 
 
+def clear_param_caches():
+    """Drop the packed-weight cache only (capture.py: a recorded optimizer step rewrote the weights without moving their
+    version counters; the graphs - CSR cache - are untouched)."""
+    _pack_cache.clear()
+    _pack_by_ptr.clear()
+
+
 def clear_caches():
     """Drop the CSR / packed-weight / staging caches.  REQUIRED after writing a parameter or an index tensor
     through `.data` (`p.data.add_(..)`, `p.data.clamp_()`, `dist.broadcast(p.data)`): such writes do not bump

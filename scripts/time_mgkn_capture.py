@@ -22,3 +22,16 @@ for name in sorted(mgkn_workloads.WORKLOADS):
     rep = timeit(cap)
     same = all(torch.equal(a, b) for a, b in zip(cap(), wl.forward()))
     print(f"{name}: {wl.calls} calls per forward: direct {direct:.3f} ms, captured {rep:.3f} ms, bit-identical {same}")
+for name in sorted(mgkn_workloads.WORKLOADS):
+    hidden_cache.clear()
+    wl = mgkn_workloads.WORKLOADS[name](d, capturable=True)
+    for _ in range(4):
+        wl.train_step()
+    torch.cuda.synchronize()
+    direct = timeit(wl.train_step, 8)
+    try:
+        cap = gp.capture(wl.train_step, updates_parameters=True)
+        rep = timeit(cap, 8)
+        print(f"{name}: optimisation step: direct {direct:.2f} ms, captured {rep:.2f} ms")
+    except Exception as ex:       # noqa: BLE001
+        print(f"{name}: optimisation step: direct {direct:.2f} ms, capture failed: {type(ex).__name__}: {str(ex)[:300]}")

@@ -33,9 +33,9 @@ def test_captured_mgkn_forward_is_bitwise_the_direct_calls(name):
         for m in wl.modules:
             for p in m.parameters():
                 p.mul_(1.01)
-    hidden_cache.clear()
-    ref2 = [t.clone() for t in wl.forward()]
-    cap2 = gp.capture(wl.forward)                          # (the caches were rebuilt: a new recording)
+    for _ in range(3):
+        ref2 = [t.clone() for t in wl.forward()]           # (the caches rebuild for the new weight versions and settle again)
+    cap2 = gp.capture(wl.forward)                          # new cached tensors: a new recording
     assert all(torch.equal(a, b) for a, b in zip(cap2(), ref2))
     assert not torch.equal(ref2[0], ref[0])
 
@@ -62,3 +62,37 @@ def test_captured_call_takes_new_inputs_and_checks_shapes():
         cap(torch.randn(n + 1, 64, device=d))
     with pytest.raises(ValueError):
         gp.capture(model, x0.cpu())
+
+
+@pytest.mark.parametrize("name", sorted(mgkn_workloads.WORKLOADS))
+def test_captured_training_step_follows_the_direct_steps(name):
+    """A whole optimisation step (forward with autograd, loss, native backward of every call, Adam with its step count on the
+    device) recorded once: four replays leave the weights where four direct steps of a twin model leave them (same kernels, same
+    order: bit for bit), and a DIRECT forward afterwards sees the updated weights (the replay drops the host-side caches)."""
+    d = torch.device("cuda:0")
+    hidden_cache.clear()
+    wl_a = mgkn_workloads.WORKLOADS[name](d, capturable=True)
+    wl_b = mgkn_workloads.WORKLOADS[name](d, capturable=True)
+    for ma, mb in zip(wl_a.modules, wl_b.modules):
+        mb.load_state_dict(ma.state_dict())
+    warm = 3
+    cap = gp.capture(wl_a.train_step, warmup=warm, updates_parameters=True)          # warm-up steps + the recorded one = 4 steps
+    for _ in range(warm + 1):
+        wl_b.train_step()
+    torch.cuda.synchronize()
+    for pa, pb in zip([p for m in wl_a.modules for p in m.parameters()], [p for m in wl_b.modules for p in m.parameters()]):
+        assert torch.equal(pa, pb)
+    calls = _lib.n_native_calls
+    for _ in range(4):
+        loss = cap()
+    torch.cuda.synchronize()
+    assert _lib.n_native_calls == calls and torch.isfinite(loss)
+    for _ in range(4):
+        wl_b.train_step()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for pa, pb in zip([p for m in wl_a.modules for p in m.parameters()], [p for m in wl_b.modules for p in m.parameters()]):
+        worst = max(worst, float((pa - pb).abs().max() / pb.abs().max().clamp_min(1e-30)))
+    assert worst <= 1e-6, worst            # (the twin's direct steps go through cache policies that re-settle: same arithmetic class)
+    ya, yb = wl_a.forward(), wl_b.forward()
+    assert all(float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) for a, b in zip(ya, yb))
