@@ -61,7 +61,10 @@ class Captured:
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         # "relaxed": the host side of a native call may query free memory (workspace / cache budgets) - not a stream operation
-        with torch.cuda.graph(self.graph, capture_error_mode="relaxed"):
+        # (recorded on the warm-up's stream: autograd's AccumulateGrad nodes - created by the warm-up steps, one per parameter,
+        # alive across iterations - run on the stream they were created on; on another stream the gradient accumulation of a
+        # recorded training step is an unjoined fork of the capture)
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="relaxed"):
             self._static_out = fn(*self._static_in)
         torch.cuda.synchronize(dev)
         self.replays = 0

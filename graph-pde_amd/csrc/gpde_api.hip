@@ -17,6 +17,49 @@ void gpde_set_error(const char* fmt, ...) {
 }
 
 namespace {
+__global__ void k_zero_words(unsigned* __restrict__ p, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0u;
+}
+__global__ void k_zero_vec4(uint4* __restrict__ p, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = uint4{0u, 0u, 0u, 0u};
+}
+__global__ void k_zero2d_words(unsigned* __restrict__ p, size_t pitch_words, size_t width_words, size_t rows) {
+    const size_t n = width_words * rows, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[(i / width_words) * pitch_words + i % width_words] = 0u;
+}
+__global__ void k_copy_words(unsigned* __restrict__ d, const unsigned* __restrict__ s_, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = s_[i];
+}
+unsigned fill_blocks(size_t items) {
+    size_t b = (items + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+}  // namespace
+
+hipError_t gpde_zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    if (bytes % 4 != 0 || ((uintptr_t)p & 3)) return hipErrorInvalidValue;
+    if (bytes % 16 == 0 && ((uintptr_t)p & 15) == 0) hipLaunchKernelGGL(k_zero_vec4, dim3(fill_blocks(bytes / 16)), dim3(256), 0, st, (uint4*)p, bytes / 16);
+    else hipLaunchKernelGGL(k_zero_words, dim3(fill_blocks(bytes / 4)), dim3(256), 0, st, (unsigned*)p, bytes / 4);
+    return hipGetLastError();
+}
+hipError_t gpde_zero2d_async(void* p, size_t pitch_bytes, size_t width_bytes, size_t rows, hipStream_t st) {
+    if (width_bytes == 0 || rows == 0) return hipSuccess;
+    if (pitch_bytes % 4 != 0 || width_bytes % 4 != 0 || ((uintptr_t)p & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_zero2d_words, dim3(fill_blocks(width_bytes / 4 * rows)), dim3(256), 0, st, (unsigned*)p, pitch_bytes / 4, width_bytes / 4, rows);
+    return hipGetLastError();
+}
+hipError_t gpde_copy_async(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    if (bytes % 4 != 0 || ((uintptr_t)dst & 3) || ((uintptr_t)src & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_copy_words, dim3(fill_blocks(bytes / 4)), dim3(256), 0, st, (unsigned*)dst, (const unsigned*)src, bytes / 4);
+    return hipGetLastError();
+}
+
+namespace {
 GpdeSwitches load_switches() {
     auto on = [](const char* n) { return getenv(n) != nullptr; };
     auto num = [](const char* n) { const char* e = getenv(n); return e ? atoi(e) : 0; };

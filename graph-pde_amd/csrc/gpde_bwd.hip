@@ -928,7 +928,7 @@ extern "C" int gpde_nnconv_bwd_edgeweights(const float* x, int64_t n_nodes, cons
     float* part = (float*)(w + al((size_t)(n_edges > 0 ? n_edges : 1) * GP_W * 4));
     const size_t part_floats = (size_t)64 * GP_W * GP_W;
     const bool ordered = src_rowptr && src_slots;
-    GP_HIP_CHECK(hipMemsetAsync(grad_x, 0, (size_t)n_nodes * GP_W * 4, st));
+    GP_HIP_CHECK(gpde_zero_async(grad_x, (size_t)n_nodes * GP_W * 4, st));
     if (n_edges > 0) {
         WeBwdArgs a{x, edge_weights, rowptr, src, grad_out, aggr, grad_edge_weights, ordered ? dxe : nullptr, grad_x};
         hipLaunchKernelGGL(gpde_weconv_bwd_kernel, dim3((unsigned)n_nodes), dim3(256), 0, st, a);
@@ -986,8 +986,8 @@ extern "C" int gpde_edge_weights_bwd(const float* grad_edge_weights, const float
     const size_t wn = (size_t)NW3 * K2P;
     int rc;
     if (E == 0) {
-        if (grad_w_last) GP_HIP_CHECK(hipMemsetAsync(grad_w_last, 0, (size_t)NW3 * k2 * 4, st));
-        if (grad_b_last) GP_HIP_CHECK(hipMemsetAsync(grad_b_last, 0, (size_t)NW3 * 4, st));
+        if (grad_w_last) GP_HIP_CHECK(gpde_zero_async(grad_w_last, (size_t)NW3 * k2 * 4, st));
+        if (grad_b_last) GP_HIP_CHECK(gpde_zero_async(grad_b_last, (size_t)NW3 * 4, st));
         return GPDE_OK;
     }
     hipLaunchKernelGGL(k_pad_mat, dim3(nblk(wn)), dim3(T), 0, st, w_last, NW3, k2, k2, NW3, K2P, F(P.off_w3p));
@@ -1078,9 +1078,9 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         hipLaunchKernelGGL(k_pad_mat, dim3(nblk(wn)), dim3(T), 0, st, W[l - 1], dims[l], dims[l - 1], dims[l - 1],
                            P.KP[l], P.KP[l - 1], F(P.off_wp[l]));
         if (b[l - 1]) hipLaunchKernelGGL(k_pad_mat, dim3(nblk(P.KP[l])), dim3(T), 0, st, b[l - 1], 1, dims[l], dims[l], 1, P.KP[l], F(P.off_bp[l]));
-        else GP_HIP_CHECK(hipMemsetAsync(F(P.off_bp[l]), 0, (size_t)P.KP[l] * 4, st));
-        GP_HIP_CHECK(hipMemsetAsync(F(P.off_dwp[l]), 0, wn * 4, st));
-        GP_HIP_CHECK(hipMemsetAsync(F(P.off_dbp[l]), 0, (size_t)P.KP[l] * 4, st));
+        else GP_HIP_CHECK(gpde_zero_async(F(P.off_bp[l]), (size_t)P.KP[l] * 4, st));
+        GP_HIP_CHECK(gpde_zero_async(F(P.off_dwp[l]), wn * 4, st));
+        GP_HIP_CHECK(gpde_zero_async(F(P.off_dbp[l]), (size_t)P.KP[l] * 4, st));
     }
     const bool f16s_du1 = do_mlp && P.f16s_du1 && !SW.bwd_gemm_f32;
     const bool f16s_dw2 = f16s_du1 && P.f16s_dw2 && !SW.bwd_dw2_f32;
@@ -1097,11 +1097,11 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     if (do_conv) {
         hipLaunchKernelGGL(k_pad_mat, dim3(nblk(w3n)), dim3(T), 0, st, W[n - 1], GP_W * GP_W, dims[n - 1], dims[n - 1],
                            GP_W * GP_W, K2P, F(P.off_w3p));
-        if (b[n - 1]) GP_HIP_CHECK(hipMemcpyAsync(F(P.off_b3), b[n - 1], GP_W * GP_W * 4, hipMemcpyDeviceToDevice, st));
-        else GP_HIP_CHECK(hipMemsetAsync(F(P.off_b3), 0, GP_W * GP_W * 4, st));
-        GP_HIP_CHECK(hipMemsetAsync(F(P.off_dw3p), 0, w3n * 4, st));
-        GP_HIP_CHECK(hipMemsetAsync(F(P.off_db3), 0, GP_W * GP_W * 4, st));
-        if (grad_x) GP_HIP_CHECK(hipMemsetAsync(grad_x, 0, (size_t)N * GP_W * 4, st));
+        if (b[n - 1]) GP_HIP_CHECK(gpde_copy_async(F(P.off_b3), b[n - 1], GP_W * GP_W * 4, st));
+        else GP_HIP_CHECK(gpde_zero_async(F(P.off_b3), GP_W * GP_W * 4, st));
+        GP_HIP_CHECK(gpde_zero_async(F(P.off_dw3p), w3n * 4, st));
+        GP_HIP_CHECK(gpde_zero_async(F(P.off_db3), GP_W * GP_W * 4, st));
+        if (grad_x) GP_HIP_CHECK(gpde_zero_async(grad_x, (size_t)N * GP_W * 4, st));
     }
     float* dx = grad_x;
 
@@ -1250,7 +1250,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 const int cb = (Kl + 255) / 256;
                 int splits = 1; while (splits < 512 && cb * splits < 2048 && rows / (splits * 2) >= 64) splits *= 2;
                 while (splits > 1 && (size_t)splits * Kl > P.part_floats) splits /= 2;
-                if (du_bits) GP_HIP_CHECK(hipMemsetAsync(du_bits, 0, (size_t)Kl * 4, st));
+                if (du_bits) GP_HIP_CHECK(gpde_zero_async(du_bits, (size_t)Kl * 4, st));
                 hipLaunchKernelGGL(k_colsum, dim3(cb, splits), dim3(T), 0, st, dUc, rows, Kl, Kl, splits, F(P.off_part), du_bits);
                 if ((rc2 = gpde_launch_reduce_splits(F(P.off_part), Kl, splits, Kl, F(P.off_dbp[l]), 1, st)) != GPDE_OK) return rc2;
             }
@@ -1372,7 +1372,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             // Z of the chunk's nodes: kept by the forward (gpde_nnconv_fwd_keepz), else re-aggregated from the recomputed /
             // given activations
             if (z_saved) Z = const_cast<float*>(z_saved) + (size_t)na * GP_W * K2P;      // read only below
-            else GP_HIP_CHECK(hipMemsetAsync(Z, 0, (size_t)nn * GP_W * K2P * 4, st));
+            else GP_HIP_CHECK(gpde_zero_async(Z, (size_t)nn * GP_W * K2P * 4, st));
             if (!z_saved) {
                 GpdeFusedArgs f{};
                 f.x = x; f.attr = edge_attr; f.rowptr = rowptr; f.src = src; f.dst = dst; f.perm = perm;
@@ -1494,13 +1494,13 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             hipLaunchKernelGGL(k_unpad_mat, dim3(nblk((size_t)dims[l] * dims[l - 1])), dim3(T), 0, st, F(P.off_dwp[l]),
                                dims[l], dims[l - 1], P.KP[l - 1], grad_W[l - 1]);
         if (grad_b && grad_b[l - 1])
-            GP_HIP_CHECK(hipMemcpyAsync(grad_b[l - 1], F(P.off_dbp[l]), (size_t)dims[l] * 4, hipMemcpyDeviceToDevice, st));
+            GP_HIP_CHECK(gpde_copy_async(grad_b[l - 1], F(P.off_dbp[l]), (size_t)dims[l] * 4, st));
     }
     if (do_conv && grad_W && grad_W[n - 1])
         hipLaunchKernelGGL(k_unpad_mat, dim3(nblk((size_t)GP_W * GP_W * dims[n - 1])), dim3(T), 0, st, F(P.off_dw3p),
                            GP_W * GP_W, dims[n - 1], K2P, grad_W[n - 1]);
     if (do_conv && grad_b && grad_b[n - 1])
-        GP_HIP_CHECK(hipMemcpyAsync(grad_b[n - 1], F(P.off_db3), GP_W * GP_W * 4, hipMemcpyDeviceToDevice, st));
+        GP_HIP_CHECK(gpde_copy_async(grad_b[n - 1], F(P.off_db3), GP_W * GP_W * 4, st));
     GP_LAUNCH_CHECK("gpde_nnconv_bwd epilogue kernels");
     return GPDE_OK;
 }
@@ -1791,7 +1791,7 @@ extern "C" int gpde_hidden_fwd_na(const GpdeNodeAttr* na, int64_t n_edges, const
                                   int64_t n_nodes, int n_layers, const int32_t* dims, const void* packed, uint32_t flags, float* hidden,
                                   float* hidden_absmax, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    if (hidden_absmax) GP_HIP_CHECK(hipMemsetAsync(hidden_absmax, 0, sizeof(float), st));
+    if (hidden_absmax) GP_HIP_CHECK(gpde_zero_async(hidden_absmax, sizeof(float), st));
     if (!na_ok(na, dims, "gpde_hidden_fwd_na")) return GPDE_EINVAL;
     if (n_edges < 0 || n_nodes < 0 || !packed || (n_edges > 0 && (!hidden || !rowptr || !src || !dst))) {
         gpde_set_error("gpde_hidden_fwd_na: null/negative argument");
@@ -1840,7 +1840,7 @@ extern "C" int gpde_hidden_fwd(const float* edge_attr, int64_t n_edges, const in
     hipStream_t st = (hipStream_t)stream_;
     // hidden_absmax (nullable, one float): max |H|, recorded by the fused path only (0 = not recorded);
     // it lets gpde_nnconv_fwd_hidden run the aggregation on split-f16 MFMA
-    if (hidden_absmax) GP_HIP_CHECK(hipMemsetAsync(hidden_absmax, 0, sizeof(float), st));
+    if (hidden_absmax) GP_HIP_CHECK(gpde_zero_async(hidden_absmax, sizeof(float), st));
     if (n_edges < 0 || n_nodes < 0 || !dims || (n_edges > 0 && (!edge_attr || !perm || !hidden || !rowptr))) {
         gpde_set_error("gpde_hidden_fwd: null/negative argument");
         return GPDE_EINVAL;
@@ -1878,7 +1878,7 @@ extern "C" int gpde_hidden_fwd(const float* edge_attr, int64_t n_edges, const in
         hipLaunchKernelGGL(k_pad_mat, dim3(nblk(wn)), dim3(T), 0, st, W[l - 1], dims[l], dims[l - 1], dims[l - 1],
                            P.KP[l], P.KP[l - 1], F(P.off_wp[l]));
         if (b[l - 1]) hipLaunchKernelGGL(k_pad_mat, dim3(nblk(P.KP[l])), dim3(T), 0, st, b[l - 1], 1, dims[l], dims[l], 1, P.KP[l], F(P.off_bp[l]));
-        else GP_HIP_CHECK(hipMemsetAsync(F(P.off_bp[l]), 0, (size_t)P.KP[l] * 4, st));
+        else GP_HIP_CHECK(gpde_zero_async(F(P.off_bp[l]), (size_t)P.KP[l] * 4, st));
     }
     for (int64_t e0 = 0; e0 < n_edges; e0 += P.Ec) {
         const int rows = (int)((n_edges - e0) < P.Ec ? (n_edges - e0) : P.Ec);

@@ -64,6 +64,14 @@ int gpde_pack_layout(int n_layers, const int32_t* dims, GpdePackLayout* L);
 
 void gpde_set_error(const char* fmt, ...);
 
+// Zero-fill / device-to-device copy as KERNELS of this library (gpde_api.hip), instead of hipMemsetAsync / hipMemcpyAsync:
+// on ROCm 7.0 a hipMemsetAsync of >= 256 bytes recorded into a HIP graph replays correctly ONCE and writes garbage from the
+// second replay on (scripts/dbg_memset_graph.py; found through gp.capture of a training step, round 5) - and nothing here
+// should be the reason a caller cannot record the operator.  Byte counts must be multiples of 4 (every buffer here is).
+hipError_t gpde_zero_async(void* p, size_t bytes, hipStream_t st);
+hipError_t gpde_zero2d_async(void* p, size_t pitch_bytes, size_t width_bytes, size_t rows, hipStream_t st);
+hipError_t gpde_copy_async(void* dst, const void* src, size_t bytes, hipStream_t st);
+
 // Developer / A-B switches (GPDE_* environment variables consumed by native code).  They are read ONCE - on the first native
 // call of the process - and never inside a launch path; gpde_reload_switches() (include/gpde.h) re-reads them (the test
 // suite's monkeypatch fixture calls it, tests/conftest.py).

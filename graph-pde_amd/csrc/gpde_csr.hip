@@ -91,7 +91,7 @@ extern "C" int gpde_csr_from_coo(const int64_t* edge_index, int64_t stride_row, 
                        gpde_csr_workspace_bytes(n_edges, n_nodes));
         return GPDE_EWORKSPACE;
     }
-    GP_HIP_CHECK(hipMemsetAsync(n_bad, 0, sizeof(int32_t), stream));
+    GP_HIP_CHECK(gpde_zero_async(n_bad, sizeof(int32_t), stream));
     const int T = 256;
     const int E = (int)n_edges, N = (int)n_nodes;
     if (E > 0) {

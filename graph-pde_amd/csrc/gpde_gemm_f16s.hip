@@ -932,13 +932,13 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
     const int nstrip = (epad + TS_STRIP - 1) / TS_STRIP;
     float* csum_part = (float*)(bits + n_out + n_in) + 16;    // [nstrip][n_out]   (GpdeDuStats)
     unsigned* rowpart = (unsigned*)(csum_part + (size_t)nstrip * n_out);        // [n_out / 64][epad]
-    GP_HIP_CHECK(hipMemsetAsync(bits, 0, (size_t)(n_out + n_in) * 4, stream));
+    GP_HIP_CHECK(gpde_zero_async(bits, (size_t)(n_out + n_in) * 4, stream));
     int splits = 1;
     while (splits < 256 && rows / (splits * 2) >= 64) splits *= 2;
     // column maxima of dU: given by the caller when another pass over dU has already collected them (k_colsum)
     if (st_ && st_->tile_csum) {
         // the producer of dU wrote the transposed copy and the row scales itself: zero the K padding, fold its tile partials
-        if (epad > rows) GP_HIP_CHECK(hipMemset2DAsync(At + rows, (size_t)epad * 4, 0, (size_t)(epad - rows) * 4, (size_t)n_out, stream));
+        if (epad > rows) GP_HIP_CHECK(gpde_zero2d_async(At + rows, (size_t)epad * 4, (size_t)(epad - rows) * 4, (size_t)n_out, stream));
         const int ntile = (rows + 31) / 32;
         const int ns2 = nstrip < 64 ? nstrip : 64, tps = (ntile + ns2 - 1) / ns2;
         hipLaunchKernelGGL(k_tile_col_reduce, dim3(ns2, (n_out + 255) / 256), dim3(256), 0, stream, st_->tile_csum, st_->tile_cmax, ntile,
@@ -955,7 +955,7 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
                            st_->row_sc, st_->row_isc);
         hipLaunchKernelGGL(k_scales_from_max, dim3((n_out + 255) / 256), dim3(256), 0, stream, bits, n_out, sca, isca);
     } else {
-        if (du_absmax_bits) GP_HIP_CHECK(hipMemcpyAsync(bits, du_absmax_bits, (size_t)n_out * 4, hipMemcpyDeviceToDevice, stream));
+        if (du_absmax_bits) GP_HIP_CHECK(gpde_copy_async(bits, du_absmax_bits, (size_t)n_out * 4, stream));
         else hipLaunchKernelGGL(k_colabsmax, dim3((n_out + 255) / 256, splits), dim3(256), 0, stream, dU, rows, n_out, ldu, splits, bits);
         hipLaunchKernelGGL(k_scales_from_max, dim3((n_out + 255) / 256), dim3(256), 0, stream, bits, n_out, sca, isca);
         hipLaunchKernelGGL(k_transpose_pad, dim3(epad / 64, n_out / 64), dim3(256), 0, stream, dU, rows, ldu, At, epad);
@@ -1106,7 +1106,7 @@ int gpde_launch_dz_image(const float* dZ, size_t dz_layer_stride, int L, int Lp,
                          float* unscale, void* img, hipStream_t stream) {
     if (nn <= 0) return GPDE_OK;
     if (K2P % 128 != 0 || L < 1 || Lp < L || Lp % 2 != 0) { gpde_set_error("gpde_launch_dz_image: bad shape L=%d Lp=%d K2P=%d", L, Lp, K2P); return GPDE_EINVAL; }
-    GP_HIP_CHECK(hipMemsetAsync(bits, 0, (size_t)nn * 4, stream));
+    GP_HIP_CHECK(gpde_zero_async(bits, (size_t)nn * 4, stream));
     for (int l = 0; l < L; ++l)
         hipLaunchKernelGGL(k_node_absmax, dim3(nn), dim3(256), 0, stream, dZ + (size_t)l * dz_layer_stride, GP_W * K2P, bits);
     hipLaunchKernelGGL(k_scales_from_max, dim3((nn + 255) / 256), dim3(256), 0, stream, bits, nn, scale, unscale);

@@ -107,7 +107,7 @@ int gpde_launch_block_bounds(const int32_t* rowptr, int nc0, int nc1, int nblk_m
 
 int gpde_launch_attr_bound(const float* attr, int64_t n_edges, int k0, const float* wmax8, unsigned* scal, hipStream_t stream,
                            int kt, const int* sel, const int32_t* src, const int32_t* dst) {
-    GP_HIP_CHECK(hipMemsetAsync(scal, 0, 8, stream));
+    GP_HIP_CHECK(gpde_zero_async(scal, 8, stream));
     if (n_edges <= 0) return GPDE_OK;
     const unsigned ge = (unsigned)((n_edges + 1023) / 1024 < 2048 ? (n_edges + 1023) / 1024 : 2048);
     if (kt) {
@@ -124,7 +124,7 @@ int gpde_launch_attr_bound(const float* attr, int64_t n_edges, int k0, const flo
 int gpde_launch_g2_prep(const float* x, int64_t n_nodes, const float* attr, int64_t n_edges, int k0,
                         const float* wmax8, unsigned* scal, unsigned* xs, hipStream_t stream, int kt,
                         const int* sel, const int32_t* src, const int32_t* dst) {
-    GP_HIP_CHECK(hipMemsetAsync(scal, 0, 8, stream));
+    GP_HIP_CHECK(gpde_zero_async(scal, 8, stream));
     const size_t n = (size_t)n_nodes * GP_W;
     const unsigned gx = (unsigned)((n + 1023) / 1024 < 1024 ? (n + 1023) / 1024 : 1024);
     const unsigned ge = (unsigned)((n_edges + 1023) / 1024 < 2048 ? (n_edges + 1023) / 1024 : 2048);

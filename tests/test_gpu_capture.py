@@ -76,8 +76,8 @@ def test_captured_training_step_follows_the_direct_steps(name):
     for ma, mb in zip(wl_a.modules, wl_b.modules):
         mb.load_state_dict(ma.state_dict())
     warm = 3
-    cap = gp.capture(wl_a.train_step, warmup=warm, updates_parameters=True)          # warm-up steps + the recorded one = 4 steps
-    for _ in range(warm + 1):
+    cap = gp.capture(wl_a.train_step, warmup=warm, updates_parameters=True)          # (recording executes nothing: 3 steps so far)
+    for _ in range(warm):
         wl_b.train_step()
     torch.cuda.synchronize()
     for pa, pb in zip([p for m in wl_a.modules for p in m.parameters()], [p for m in wl_b.modules for p in m.parameters()]):
