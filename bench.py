@@ -254,6 +254,17 @@ def mgkn_probe(dev, steps=10):
                 worst_we = max(worst_we, rel_l2(y.cpu(), ref))
         finally:
             hc_.WE_MODE = we0
+        # the UNMODIFIED call sequence recorded once into a HIP graph and replayed (gp.capture, opt-in): same kernels, same bits
+        import graph_pde_amd as gp_
+        hc_.clear()
+        wl_c = build(dev)
+        for _ in range(3):
+            y_direct = [t_.clone() for t_ in wl_c.forward()]
+        ms_direct_c = median_ms(wl_c.forward, steps, warmup=1)
+        cap_ = gp_.capture(wl_c.forward)
+        ms_cap = median_ms(cap_, steps, warmup=2)
+        cap_same = all(torch.equal(a_, b_) for a_, b_ in zip(cap_(), wl_c.forward()))
+        del cap_
         # one optimisation step of the NNConv stack (forward with autograd + native backward of every call + Adam): the
         # scripts' inner loop (MGKN_general_darcy2d.py:260-282, MGKN_orthogonal_burgers1d.py:226-242), default policy
         # (hidden-activation cache `auto`: every module's H is built once per step and its MLP backward runs once)
@@ -271,10 +282,32 @@ def mgkn_probe(dev, steps=10):
         train_ms = 1e3 * statistics.median(tts)
         train_stats = dict(hc_.stats)
         hc_.clear()
+        # ... and the whole step recorded (Adam with its step count on the device)
+        train_cap_ms = None
+        try:
+            wl_tc = build(dev, capturable=True)
+            cap_t = gp_.capture(wl_tc.train_step, updates_parameters=True)
+            tts = []
+            for _ in range(6):
+                tq = time.perf_counter()
+                loss_c = cap_t()
+                torch.cuda.synchronize()
+                tts.append(time.perf_counter() - tq)
+            if bool(torch.isfinite(loss_c)):
+                train_cap_ms = round(1e3 * statistics.median(tts[1:]), 3)
+            del cap_t, wl_tc
+        except Exception as ex:       # noqa: BLE001
+            log(f"[bench] {name}: captured training step failed: {type(ex).__name__}: {str(ex)[:200]}")
+        hc_.clear()
         out[name] = {
             "workload": wl.description, "nnconv_calls": wl.calls, "edge_applications": wl.edge_applications,
             "ms_per_forward": round(ms, 3),
+            "ms_per_forward_captured": round(ms_cap, 3),
+            "captured": {"what": "the same unmodified module calls recorded once into a HIP graph and replayed (graph_pde_amd.capture, "
+                                 "opt-in): no host issue per call", "bit_identical_to_direct_calls": bool(cap_same),
+                         "ms_direct_same_run": round(ms_direct_c, 3)},
             "train_step_ms": round(train_ms, 3),
+            "train_step_captured_ms": train_cap_ms,
             "train_step": {"ms": round(train_ms, 3), "loss_finite": bool(torch.isfinite(loss_t)),
                            "M_edge_applications_per_s": round(wl.edge_applications / train_ms / 1e3, 2),
                            "hidden_cache": {k: train_stats.get(k) for k in ("hits", "builds", "direct")},

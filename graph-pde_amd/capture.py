@@ -50,6 +50,14 @@ class Captured:
         self._copy_outputs = copy_outputs
         self._updates_parameters = updates_parameters
         dev = next(iter(devs)) if devs else torch.device("cuda", torch.cuda.current_device())
+        # The caches keep tensors WITH their autograd history (a shared H node, W_e): as long as such a graph lives, the
+        # parameters' AccumulateGrad nodes live - bound to the stream of the step that created them, usually the default stream of
+        # earlier direct calls.  Recorded that way the gradient accumulation is an unjoined fork onto the legacy stream
+        # (hipStreamEndCapture crashed on it).  Drop them: the warm-up below rebuilds everything on the recording stream.
+        from . import hidden_cache
+        hidden_cache.clear()
+        import gc
+        gc.collect()
         # warm-up on a side stream (torch's capture protocol): builds the CSRs, packs the weights, lets the cache policies see
         # the module repeat - host-side state that the recording call must find settled
         side = torch.cuda.Stream(device=dev)
