@@ -142,7 +142,7 @@ def measure_traffic(args, kernel):
         return None, "rocprofv3 not on PATH"
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--config", args.config,
              "--kernel-width", str(args.kernel_width), "--no-cpu-baseline", "--no-reuse-probe", "--no-mgkn", "--no-alt",
-             "--no-backward-probe"] + (["--precision", args.precision] if args.precision else [])
+             "--no-backward-probe", "--no-measure-traffic"] + (["--precision", args.precision] if args.precision else [])
     got = {}
     tmp = tempfile.mkdtemp(prefix="gpde_traffic_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
@@ -513,7 +513,9 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the exact-fp32 leg")
     ap.add_argument("--measure-traffic", action="store_true",
                     help="re-derive roofline.traffic in THIS run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a one-step "
-                         "child run of this script (needs rocprofv3 on the box; adds ~2 minutes)")
+                         "child run of this script.  Since round 5 this is the DEFAULT for the headline configuration on one GPU "
+                         "when rocprofv3 is on the box (adds ~1-2 minutes); --no-measure-traffic keeps the committed record")
+    ap.add_argument("--no-measure-traffic", action="store_true", help="roofline.traffic from the committed profiles/traffic_r*.json")
     ap.add_argument("--precision", default=None, choices=["f32", "f16split", "f16split_8wave", "f16split_static", "f16split_agg16", "f16split_agg32", "f16split_noedge"],
                     help="arithmetic of the hidden layer (default: graph_pde_amd.ops.DEFAULT_PRECISION)")
     ap.add_argument("--train", action="store_true", help="training-step mode (see the module docstring)")
@@ -652,6 +654,11 @@ def main():
     n_param = sum(p.numel() for p in conv.parameters())
     alg_bytes_per_launch = (40.0 * e + 512.0 * n + 4.0 * n_param) * edges_per_launch / e   # SURVEY §8(d) x units per launch
     rec, src = traffic_record(args.config, kw, kernel)
+    import shutil as _sh
+    under_profiler = any(k_.startswith(("ROCPROF", "ROCP_")) for k_ in os.environ)        # (this run is itself a rocprofv3 child)
+    if not args.measure_traffic and not args.no_measure_traffic and world == 1 and args.config == "g241" and _sh.which("rocprofv3") and \
+            not under_profiler:
+        args.measure_traffic = True
     if args.measure_traffic and world == 1:
         del ws
         torch.cuda.empty_cache()                      # the child run needs the device's memory
@@ -925,7 +932,27 @@ def main():
                         "workspace_GiB": round(ops.bwd_workspace_bytes(_lib.lib(), nb_, eb_, 3, _lib.dims_array([6, kw, kw, 4096]), dev) / 2**30, 1),
                         "note": "median of 3 timed backward passes after one warm-up; parity of every gradient "
                                 "against float64 autograd: tests/test_gpu_bwd.py, tests/test_gpu_parity.py"}
-            log(f"[bench] backward g121: {backward['ms']} ms, {backward['M_edges_per_s']} M-edges/s")
+            # the same backward under the library's DEFAULT workspace plan (~26 GB, ten edge chunks) instead of the one-chunk
+            # workspace ops.bwd_workspace_bytes takes when 0.6 of the free memory allows (workspace_GiB above)
+            try:
+                frac0 = ops.BWD_WS_FRACTION
+                ops.BWD_WS_FRACTION = 0.0
+                td = []
+                for it in range(3):
+                    conv.zero_grad(set_to_none=True)
+                    xb.grad = None
+                    yb = conv(xb, eib, eab)
+                    lossb = yb.square().mean()
+                    torch.cuda.synchronize()
+                    tq = time.perf_counter()
+                    lossb.backward()
+                    torch.cuda.synchronize()
+                    td.append(time.perf_counter() - tq)
+                backward["default_workspace_ms"] = round(1e3 * sorted(td[1:])[0], 2)
+                backward["default_workspace_GiB"] = round(ops.bwd_workspace_bytes(_lib.lib(), nb_, eb_, 3, _lib.dims_array([6, kw, kw, 4096]), dev) / 2**30, 1)
+            finally:
+                ops.BWD_WS_FRACTION = frac0
+            log(f"[bench] backward g121: {backward['ms']} ms, {backward['M_edges_per_s']} M-edges/s; default workspace {backward.get('default_workspace_ms')} ms")
             del eib, eab, xb, yb, lossb
             # ---- the same at the headline size, and BASELINE config 5's per-GPU unit of work: one training step of the
             #      depth-6 GKN on ONE 241^2 sample (UAI1_full_resolution.py:258-273: forward, L1 loss, backward, Adam).
@@ -991,7 +1018,40 @@ def main():
                             "state: all six applications on the shared virtual-H node), `first_step_s` includes the cold start; "
                             "round 3 ran every application's own full backward: 18.98 s"}
                 log(f"[bench] g241 depth-6 train step: first {t_steps[0]:.2f} s, steady {t_step:.2f} s")
-                del hcur, loss_t, opt
+                # ---- the same step over three DISTINCT samples, as an epoch sees them (UAI1_full_resolution.py:258-273: every batch
+                # is another sample): a NEW edge_index tensor (the loader's) and new edge attributes per step, so that the dst-CSR
+                # build, the slot-order gather of the attributes and the re-keying of every cache are INSIDE the step time
+                del hcur, loss_t
+                try:
+                    t_dist = []
+                    pos = synth.lattice_positions(s, dev)
+                    for it in range(3):
+                        a_s = synth.darcy_coefficient(s, seed=100 + it).to(dev)
+                        ea_s = synth.darcy_edge_attr(ei, pos, a_s)             # this sample's [E, 6] attributes
+                        ei_s = ei.clone()                                       # a fresh index tensor, as a DataLoader hands over
+                        a_in_s = torch.randn(n, 6, device=dev)
+                        torch.cuda.synchronize()
+                        tq = time.perf_counter()
+                        opt.zero_grad(set_to_none=True)
+                        hcur = fc1(a_in_s)
+                        for _ in range(depth):
+                            hcur = torch.relu(conv(hcur, ei_s, ea_s))
+                        loss_s = torch.norm(fc2(hcur).view(-1) - y_t, 1)
+                        loss_s.backward()
+                        opt.step()
+                        torch.cuda.synchronize()
+                        t_dist.append(time.perf_counter() - tq)
+                        del hcur, ei_s, ea_s
+                    backward["g241_depth6_train_step"]["distinct_samples"] = {
+                        "steps_s": [round(t_, 2) for t_ in t_dist], "s": round(statistics.median(t_dist), 2),
+                        "loss_finite": bool(torch.isfinite(loss_s)),
+                        "note": "three steps on three different samples (new edge_index tensor and new edge_attr each): graph / attribute "
+                                "preparation and cache re-keying inside the time"}
+                    log(f"[bench] g241 depth-6 train step, distinct samples: {[round(t_, 2) for t_ in t_dist]} s")
+                    del loss_s
+                except Exception as ex:       # noqa: BLE001
+                    backward["g241_depth6_train_step"]["distinct_samples"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
+                del opt
         finally:
             hidden_cache.MODE = mode0
             hidden_cache.clear()
@@ -1006,6 +1066,21 @@ def main():
         "precision": precision, "data": "synthetic",
         "median_step_ms": round(med, 3), "value_at_median": round(world * e / med / 1e3, 3),
         "rccl_ranks": world if use_dist else 0,
+        # the other legs' headline figures, up front (the full objects follow `cpu_baseline`; a reader of a truncated line still
+        # sees these)
+        "summary": {
+            "graph_prep_ms": None if graph_prep is None else {"csr_build": graph_prep.get("csr_build_ms"), "attr_reorder": graph_prep.get("attr_reorder_ms")},
+            "mgkn_ms_per_forward": None if not mgkn else {k_: {"unmodified_calls": v_.get("ms_per_forward"), "captured": v_.get("ms_per_forward_captured"),
+                                                             "grouped": v_.get("ms_per_forward_grouped")} for k_, v_ in mgkn.items()},
+            "mgkn_train_step_ms": None if not mgkn else {k_: {"direct": v_.get("train_step_ms"), "captured": v_.get("train_step_captured_ms")} for k_, v_ in mgkn.items()},
+            "backward_g121": None if not backward else {"ms": backward.get("ms"), "M_edges_per_s": backward.get("M_edges_per_s"),
+                                                        "default_workspace_ms": backward.get("default_workspace_ms"),
+                                                        "frac_f16_peak": backward.get("roofline", {}).get("frac")},
+            "g241_depth6_train_step_s": None if not backward or "g241_depth6_train_step" not in backward else
+            {"same_sample": backward["g241_depth6_train_step"].get("s"),
+             "distinct_samples": backward["g241_depth6_train_step"].get("distinct_samples", {}).get("s"),
+             "peak_GiB": backward["g241_depth6_train_step"].get("peak_GiB")},
+        },
         "config": {"workload": f"GKN Darcy-2D {s}x{s} lattice radius graph r={r} N={n} E={e} per sample; NNConv_old fwd "
                                f"width=64; kernel MLP 6-{kw}-{kw}-4096; aggr=mean root+bias; one sample per GPU",
                    "graph": args.config, "edges_per_sample": e, "nodes_per_sample": n,
