@@ -718,7 +718,7 @@ def main():
             nodeattr = {"ms_per_forward": round(ms_n, 2), "M_edges_per_s": round(e / ms_n / 1e3, 2),
                         "bitwise_equal_to_tensor_path": bool(torch.equal(out_n, out)) if same_attr else None,
                         "attr_tensor_bytes_not_read": int(ea.numel() * 4 + e * 4),
-                        "note": "gpde_nnconv_fwd_nodeattr on gpde_fused_f16v6_kernel<false, NODEATTR>: slot d of edge (j -> i) from "
+                        "note": "node_attr of gpde_nnconv_fwd_mixed_keepz on gpde_fused_f16v6_kernel<false, NODEATTR>: slot d of edge (j -> i) from "
                                 "node_table[(j or i)][col] (SquareMeshGenerator.attributes recipe, utilities.py:274-277)"}
             log(f"[bench] node-table attributes: {nodeattr['ms_per_forward']} ms, {nodeattr['M_edges_per_s']} M-edges/s, "
                 f"bitwise equal: {nodeattr['bitwise_equal_to_tensor_path']}")
@@ -863,7 +863,7 @@ def main():
                                               "reuse": round(depth * e / gres["auto"][0] / 1e6, 1)},
                 "budget_GiB": round(gres["auto"][2] / 2 ** 30, 1), "nodes_served_from_H": gres["auto"][3], "nodes": n,
                 "rel_l2_between_paths": dg,
-                "note": "partial H: inference only (gpde_nnconv_fwd_mixed); budget = 70 % of HBM, at most free - 48 GB"}
+                "note": "partial H: inference only (gpde_nnconv_fwd_mixed_keepz); budget = 70 % of HBM, at most free - 48 GB"}
             del gres, yg, ent                            # `ent` holds the 170 GB partial H: it must not outlive this probe
             hidden_cache.clear()
             torch.cuda.empty_cache()

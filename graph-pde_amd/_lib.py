@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import re
 import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
@@ -22,10 +23,6 @@ GPDE_FWD_DEFAULT, GPDE_FWD_F16SPLIT = 0, 1
 GPDE_FWD_F16SPLIT_8WAVE, GPDE_FWD_STATIC_RANGES, GPDE_FWD_AGG_F16, GPDE_FWD_AGG_F32, GPDE_FWD_NO_EDGE_PATH = 2, 4, 16, 32, 64
 GPDE_WIDTH = 64
 
-c_i32p = ctypes.POINTER(ctypes.c_int32)
-c_i64p = ctypes.POINTER(ctypes.c_int64)
-
-
 class GpdeWeConvDesc(ctypes.Structure):
     """include/gpde.h `GpdeWeConvDesc`: one NNConv call given its per-edge weights (tests/test_abi.py checks the layout)."""
     _fields_ = [("x", ctypes.c_void_p), ("edge_weights", ctypes.c_void_p), ("rowptr", ctypes.c_void_p),
@@ -39,173 +36,49 @@ class GpdeNodeAttr(ctypes.Structure):
     _fields_ = [("table", ctypes.c_void_p), ("stride", ctypes.c_int32), ("n_slots", ctypes.c_int32), ("sel", ctypes.c_int32 * 8)]
 
 
-# name -> (restype, argtypes); mirrors include/gpde.h one to one (tests check the two agree)
-SIGNATURES = {
-    "gpde_version": (ctypes.c_int, []),
-    "gpde_last_error": (ctypes.c_char_p, []),
-    "gpde_reload_switches": (ctypes.c_int, []),
-    "gpde_csr_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64]),
-    "gpde_csr_from_coo": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
-                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
-                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
-                                         ctypes.c_void_p]),
-    "gpde_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
-    "gpde_mlp_pack_bytes": (ctypes.c_size_t, [ctypes.c_int, c_i32p]),
-    "gpde_mlp_pack": (ctypes.c_int, [ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p),
-                                     ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p,
-                                     ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_fwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64,
-                                                          ctypes.c_int, c_i32p]),
-    "gpde_nnconv_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
-                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p,
-                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                       ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p,
-                                       ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_fwd_act": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
-                                           ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p,
-                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                           ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_fwd_hidden_act": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
-                                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                                  ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.c_void_p,
-                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-                                                  ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
-                                                  ctypes.c_void_p]),
-    "gpde_nnconv_fwd_plan": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, c_i32p,
-                                            ctypes.c_size_t, c_i32p, c_i64p, c_i32p, c_i32p]),
-    "gpde_nnconv_fwd_kernel": (ctypes.c_char_p, [ctypes.c_int64, ctypes.c_int, c_i32p, ctypes.c_uint32]),
-    "gpde_nnconv_bwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64,
-                                                          ctypes.c_int, c_i32p]),
-    "gpde_nnconv_bwd_workspace_bytes_one_chunk": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, c_i32p]),
-    "gpde_csr_source_order": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
-                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_bwd_ordered": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
-                                               ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                               ctypes.c_void_p, ctypes.c_void_p,
-                                               ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p),
-                                               ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int,
-                                               ctypes.c_void_p, ctypes.c_void_p,
-                                               ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
-                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                               ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_bwd_hidden_ordered": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
-                                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                                      ctypes.c_void_p, ctypes.c_int, c_i32p,
-                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                                      ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_bwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
-                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                       ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p),
-                                       ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int,
-                                       ctypes.c_void_p, ctypes.c_void_p,
-                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
-                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                       ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_fwd_nodeattr": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32,
-                                                c_i32p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                                ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.c_void_p,
-                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32,
-                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
-                                                ctypes.c_void_p]),
-    "gpde_hidden_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, c_i32p]),
-    "gpde_hidden_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
-                                       ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.c_void_p,
-                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
-                                       ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                       ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_fwd_hidden": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
-                                              ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                              ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.c_void_p,
-                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
-                                              ctypes.c_void_p]),
-    "gpde_nnconv_fwd_mixed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
-                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                                             c_i32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                             ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
-                                             ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_bwd_hidden": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
-                                              ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p,
-                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                              ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                              ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_hidden_bwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
-                                       c_i32p, ctypes.POINTER(ctypes.c_void_p),
-                                       ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p,
-                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
-                                       ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_fwd_keepz": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                             ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                             ctypes.c_int, c_i32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                                             ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
-                                             ctypes.c_void_p]),
-    "gpde_nnconv_bwd_z": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
-                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p),
-                                         ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
-                                         ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                         ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_bwd_attr": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_bwd_deferred_supported": (ctypes.c_int, [ctypes.c_int, c_i32p]),
-    "gpde_nnconv_bwd_deferred_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, c_i32p, ctypes.c_int]),
-    "gpde_nnconv_bwd_light": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_bwd_deferred": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_fwd_mixed_keepz": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_edge_weights_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, c_i32p]),
-    "gpde_edge_weights_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_i32p, ctypes.c_void_p,
-                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                             ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_bwd_edgeweights_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64]),
-    "gpde_nnconv_bwd_edgeweights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_edge_weights_bwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, c_i32p]),
-    "gpde_edge_weights_bwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_i32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_fwd_edgeweights_group": (ctypes.c_int, [ctypes.POINTER(GpdeWeConvDesc), ctypes.c_int, ctypes.c_void_p]),
-    "gpde_nnconv_fwd_na": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(GpdeNodeAttr), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_hidden_fwd_na": (ctypes.c_int, [ctypes.POINTER(GpdeNodeAttr), ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_i32p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
-    "gpde_nnconv_bwd_na": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(GpdeNodeAttr), ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_bwd_light_na": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(GpdeNodeAttr), ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_nnconv_bwd_deferred_na": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(GpdeNodeAttr), ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_hidden_bwd_na": (ctypes.c_int, [ctypes.POINTER(GpdeNodeAttr), ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_radius_graph_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
-                                               ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
-    "gpde_radius_graph_fill": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
-                                              ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
-                                              ctypes.c_int64, ctypes.c_void_p]),
-    "gpde_radius_graph2_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
-                                                ctypes.c_double, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]),
-    "gpde_radius_graph2_fill": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
-                                               ctypes.c_double, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
-                                               ctypes.c_int64, ctypes.c_void_p]),
-    "gpde_radius_csr_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_double,
-                                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
-    "gpde_radius_csr_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
-                                             ctypes.c_double, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double),
-                                             ctypes.POINTER(ctypes.c_double), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
-                                             ctypes.c_void_p]),
-    "gpde_radius_csr_fill": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
-                                            ctypes.c_double, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double),
-                                            ctypes.POINTER(ctypes.c_double), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                            ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "gpde_profile_begin": (ctypes.c_int, []),
-    "gpde_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), c_i32p,
-                                        ctypes.POINTER(ctypes.c_double)]),
-    "gpde_profile_end_kinds": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), c_i32p]),
-}
+HEADER_PATH = os.environ.get("GPDE_HEADER", os.path.join(os.path.dirname(_PKG), "include", "gpde.h"))
+_SCALARS = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint32_t": ctypes.c_uint32,
+            "size_t": ctypes.c_size_t, "double": ctypes.c_double}
+
+
+def header_prototypes(path: str = None) -> dict:
+    """{name: (return C type, [argument C types])} of every `GPDE_API` prototype of include/gpde.h (comments stripped,
+    parameter names dropped, `T *` written `T*`)."""
+    src = open(path or HEADER_PATH).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"GPDE_API\s+([\w \*]+?)\s*\b(gpde_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
+        types = []
+        if args not in ("", "void"):
+            for a in args.split(","):
+                a = a.strip()
+                t = re.sub(r"\b\w+$", "", a).strip() if not a.endswith("*") else a       # drop the parameter name
+                types.append(t.replace(" *", "*"))
+        out[name] = (ret.replace(" *", "*"), types)
+    return out
+
+
+def _ctype(t: str, is_return: bool = False):
+    """The ctypes type of one C type of the header: scalars exactly; `const char*` results as bytes; every other pointer -
+    device arrays handed over as `tensor.data_ptr()` integers, host arrays, descriptors by reference, NULL - as `void*`."""
+    if t.endswith("*"):
+        return ctypes.c_char_p if is_return and t == "const char*" else ctypes.c_void_p
+    base = t.replace("const ", "").strip()
+    if base not in _SCALARS:
+        raise GpdeError(f"{HEADER_PATH}: C type {t!r} has no binding rule (graph-pde_amd/_lib.py:_ctype)")
+    return _SCALARS[base]
+
+
+def _signatures_from_header() -> dict:
+    """name -> (restype, argtypes), GENERATED from include/gpde.h: the header is the one statement of the ABI (round 4 kept a
+    hand-written mirror here, which is how 58 entry points became hard to follow; tests/test_abi.py checks the generated table
+    against `nm -D` of the library and the scalar mapping against the header text)."""
+    if not os.path.exists(HEADER_PATH):
+        raise GpdeError(f"{HEADER_PATH} not found: the binding is generated from the header (GPDE_HEADER overrides the path)")
+    return {name: (_ctype(ret, True), [_ctype(a) for a in args]) for name, (ret, args) in header_prototypes().items()}
+
+
 PROF_KINDS = ("fused", "gemm3", "epilogue", "prep", "other")        # GPDE_PROF_* of include/gpde.h
 
 
@@ -227,6 +100,9 @@ n_native_calls = 0          # incremented by every gpde_nnconv_fwd call (tests a
 
 class GpdeError(RuntimeError):
     pass
+
+
+SIGNATURES = _signatures_from_header()
 
 
 def lib() -> ctypes.CDLL:

@@ -110,7 +110,7 @@ class HiddenFunction(torch.autograd.Function):
 
 class NNConvHiddenFunction(torch.autograd.Function):
     """The operator given H: aggregation of x_j (x) H_e, last Linear, update() (gpde_nnconv_fwd_hidden /
-    gpde_nnconv_bwd_hidden)."""
+    gpde_nnconv_bwd in its `hidden` form)."""
 
     @staticmethod
     def forward(ctx, x, hidden, csr, pm, w_last, b_last, root, bias, aggr, hmax=None):

@@ -311,7 +311,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
              size_t ws_bytes, hipStream_t stream, int kt = 0, const int* sel = nullptr,
              const float* hidden_absmax = nullptr, int64_t hidden_nodes = -1, const float* residual = nullptr,
              int relu_out = 0, float* z_keep = nullptr) {
-    // hidden_nodes in [0, n_nodes): MIXED call (gpde_nnconv_fwd_mixed) -- `hidden` covers the in-edges of
+    // hidden_nodes in [0, n_nodes): MIXED call (gpde_nnconv_fwd_mixed_keepz) -- `hidden` covers the in-edges of
     // nodes [0, hidden_nodes) only (a graph whose H does not fit memory, e.g. 391 GB at the 241^2 graph);
     // those nodes aggregate from it, the others run the fused kernel on edge_attr
     const bool mixed = hidden && hidden_nodes >= 0 && hidden_nodes < n_nodes;
@@ -326,7 +326,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
     if (rc != GPDE_OK) return rc;
     const GpdePackLayout& L = P.L;
     const int mode = (hidden && !mixed) ? 2 : L.mode;
-    if (mixed && L.mode != 1) { gpde_set_error("gpde_nnconv_fwd_mixed: built for 3-Linear kernel MLPs"); return GPDE_EUNSUPPORTED; }
+    if (mixed && L.mode != 1) { gpde_set_error("gpde_nnconv_fwd_mixed_keepz: built for 3-Linear kernel MLPs"); return GPDE_EUNSUPPORTED; }
     const float* pk = (const float*)packed;
     char* w = (char*)ws;
     w = (char*)(((uintptr_t)w + kAlign - 1) / kAlign * kAlign);
@@ -414,7 +414,7 @@ int fwd_impl(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_
     const unsigned* scal = nullptr;
     const FusedChoice fc = choose_fused(L, mode, flags, n_edges, kt);
     if (kt && fc.kind == FK_GENERIC) {
-        gpde_set_error("gpde_nnconv_fwd_nodeattr: built for 3-Linear kernel MLPs on the f16-split kernel only");
+        gpde_set_error("gpde_nnconv_fwd_mixed_keepz (node_attr): built for 3-Linear kernel MLPs on the f16-split kernel only");
         return GPDE_EUNSUPPORTED;
     }
     if ((!hidden || mixed) && fc.g2f16) {
@@ -505,92 +505,47 @@ extern "C" int gpde_nnconv_fwd(const float* x, int64_t n_nodes, const float* edg
                     aggr, flags, nullptr, out, ws, ws_bytes, (hipStream_t)stream_);
 }
 
-extern "C" int gpde_nnconv_fwd_nodeattr(const float* x, int64_t n_nodes, const float* node_table, int32_t table_stride,
-                                        const int32_t* attr_sel, int64_t n_edges, const int32_t* rowptr,
-                                        const int32_t* src, const int32_t* dst, int n_layers,
-                                        const int32_t* dims, const void* packed, const float* root,
-                                        const float* bias, int aggr, uint32_t flags, float* out, void* ws,
-                                        size_t ws_bytes, void* stream_) {
-    if (n_nodes < 0 || n_edges < 0 || !dims || !packed || !rowptr || !attr_sel || table_stride < 1 ||
-        (n_nodes > 0 && (!x || !out || !node_table)) || (n_edges > 0 && (!src || !dst))) {
-        gpde_set_error("gpde_nnconv_fwd_nodeattr: null/negative argument");
-        return GPDE_EINVAL;
-    }
-    if (dims[0] < 1 || dims[0] > 7) { gpde_set_error("gpde_nnconv_fwd_nodeattr: 1..7 attribute slots, got %d", dims[0]); return GPDE_EUNSUPPORTED; }
-    int sel[8];
-    for (int d = 0; d < 8; ++d) {
-        sel[d] = attr_sel[d < dims[0] ? d : dims[0] - 1];
-        if ((sel[d] >> 8) < 0 || (sel[d] >> 8) > 1 || (sel[d] & 255) >= table_stride) {
-            gpde_set_error("gpde_nnconv_fwd_nodeattr: attr_sel[%d] = 0x%x (endpoint << 8 | column, column < %d)", d, sel[d], table_stride);
-            return GPDE_EINVAL;
-        }
-    }
-    return fwd_impl(x, n_nodes, node_table, n_edges, rowptr, src, dst, nullptr, n_layers, dims, packed, root, bias,
-                    aggr, flags, nullptr, out, ws, ws_bytes, (hipStream_t)stream_, table_stride, sel);
-}
-
-// The training-side forward with node-table attributes (include/gpde.h GpdeNodeAttr): gpde_nnconv_fwd_nodeattr + keep-Z +
-// the partial H of gpde_nnconv_fwd_mixed in one entry point.
-extern "C" int gpde_nnconv_fwd_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, const float* hidden_part,
-                                  const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges, const int32_t* rowptr,
-                                  const int32_t* src, const int32_t* dst, int n_layers, const int32_t* dims, const void* packed,
-                                  const float* root, const float* bias, int aggr, uint32_t flags, float* z_keep, float* out,
-                                  void* ws, size_t ws_bytes, void* stream_) {
-    if (!na || !na->table || na->stride < 1 || !dims || na->n_slots != dims[0] || dims[0] < 1 || dims[0] > 7) {
-        gpde_set_error("gpde_nnconv_fwd_na: GpdeNodeAttr must describe dims[0] = 1..7 slots of a node table");
-        return GPDE_EINVAL;
-    }
-    if (n_nodes < 0 || n_edges < 0 || !packed || !rowptr || (n_nodes > 0 && (!x || !out)) || (n_edges > 0 && (!src || !dst)) ||
-        hidden_nodes < 0 || hidden_nodes > n_nodes || (hidden_nodes > 0 && !hidden_part)) {
-        gpde_set_error("gpde_nnconv_fwd_na: null/negative argument");
-        return GPDE_EINVAL;
-    }
-    int sel[8];
-    for (int d = 0; d < 8; ++d) sel[d] = na->sel[d < dims[0] ? d : dims[0] - 1];
-    if (hidden_nodes == 0)
-        return fwd_impl(x, n_nodes, na->table, n_edges, rowptr, src, dst, nullptr, n_layers, dims, packed, root, bias, aggr, flags,
-                        nullptr, out, ws, ws_bytes, (hipStream_t)stream_, na->stride, sel, nullptr, -1, nullptr, 0, z_keep);
-    return fwd_impl(x, n_nodes, na->table, n_edges, rowptr, src, dst, nullptr, n_layers, dims, packed, root, bias, aggr, flags,
-                    hidden_part, out, ws, ws_bytes, (hipStream_t)stream_, na->stride, sel, hidden_absmax, hidden_nodes, nullptr, 0, z_keep);
-}
-
-extern "C" int gpde_nnconv_fwd_mixed(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
-                                     const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges,
-                                     const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                                     const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
-                                     const float* root, const float* bias, int aggr, uint32_t flags, float* out,
-                                     void* ws, size_t ws_bytes, void* stream_) {
-    if (n_nodes < 0 || n_edges < 0 || !dims || !packed || !rowptr || (n_nodes > 0 && (!x || !out)) ||
-        (n_edges > 0 && (!edge_attr || !src || !dst || !perm)) || hidden_nodes < 0 || hidden_nodes > n_nodes ||
-        (hidden_nodes > 0 && !hidden)) {
-        gpde_set_error("gpde_nnconv_fwd_mixed: null/negative argument");
-        return GPDE_EINVAL;
-    }
-    if (hidden_nodes == 0)
-        return fwd_impl(x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, n_layers, dims, packed, root, bias,
-                        aggr, flags, nullptr, out, ws, ws_bytes, (hipStream_t)stream_);
-    return fwd_impl(x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, n_layers, dims, packed, root, bias,
-                    aggr, flags, hidden, out, ws, ws_bytes, (hipStream_t)stream_, 0, nullptr, hidden_absmax,
-                    hidden_nodes);
-}
-
-extern "C" int gpde_nnconv_fwd_mixed_keepz(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
-                                           const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges,
+// The general forward (round 5: the mixed, node-table and node-table + partial-H forwards folded into one): attributes from `edge_attr` +
+// `perm` or from node data (`node_attr`: row f3; then edge_attr / perm are unused and may be NULL), optionally the part of the
+// hidden activations that fits memory (`hidden`: rows of the in-edges of nodes [0, hidden_nodes); 0 = none), optionally Z kept
+// for the backward (`z_keep`; NULL = none).
+extern "C" int gpde_nnconv_fwd_mixed_keepz(const float* x, int64_t n_nodes, const float* edge_attr, const GpdeNodeAttr* node_attr,
+                                           const float* hidden, const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges,
                                            const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                                            const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
                                            const float* root, const float* bias, int aggr, uint32_t flags, float* z_keep,
                                            float* out, void* ws, size_t ws_bytes, void* stream_) {
     if (n_nodes < 0 || n_edges < 0 || !dims || !packed || !rowptr || (n_nodes > 0 && (!x || !out)) ||
-        (n_edges > 0 && (!edge_attr || !src || !dst || !perm)) || hidden_nodes < 0 || hidden_nodes > n_nodes ||
+        (n_edges > 0 && (!src || !dst || (!node_attr && (!edge_attr || !perm)))) || hidden_nodes < 0 || hidden_nodes > n_nodes ||
         (hidden_nodes > 0 && !hidden)) {
         gpde_set_error("gpde_nnconv_fwd_mixed_keepz: null/negative argument");
         return GPDE_EINVAL;
     }
+    int kt = 0;
+    int sel[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float* attr = edge_attr;
+    if (node_attr) {
+        const GpdeNodeAttr* na = node_attr;
+        if (!na->table || na->stride < 1 || na->n_slots != dims[0] || dims[0] < 1 || dims[0] > 7) {
+            gpde_set_error("gpde_nnconv_fwd_mixed_keepz: GpdeNodeAttr must describe dims[0] = 1..7 slots of a node table");
+            return GPDE_EINVAL;
+        }
+        for (int d = 0; d < 8; ++d) {
+            sel[d] = na->sel[d < dims[0] ? d : dims[0] - 1];
+            if ((sel[d] >> 8) < 0 || (sel[d] >> 8) > 1 || (sel[d] & 255) >= na->stride) {
+                gpde_set_error("gpde_nnconv_fwd_mixed_keepz: GpdeNodeAttr.sel[%d] = 0x%x (endpoint << 8 | column, column < %d)", d, sel[d], na->stride);
+                return GPDE_EINVAL;
+            }
+        }
+        kt = na->stride;
+        attr = na->table;
+        perm = nullptr;
+    }
     if (hidden_nodes == 0)
-        return fwd_impl(x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, n_layers, dims, packed, root, bias,
-                        aggr, flags, nullptr, out, ws, ws_bytes, (hipStream_t)stream_, 0, nullptr, nullptr, -1, nullptr, 0, z_keep);
-    return fwd_impl(x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, n_layers, dims, packed, root, bias,
-                    aggr, flags, hidden, out, ws, ws_bytes, (hipStream_t)stream_, 0, nullptr, hidden_absmax,
+        return fwd_impl(x, n_nodes, attr, n_edges, rowptr, src, dst, perm, n_layers, dims, packed, root, bias,
+                        aggr, flags, nullptr, out, ws, ws_bytes, (hipStream_t)stream_, kt, kt ? sel : nullptr, nullptr, -1, nullptr, 0, z_keep);
+    return fwd_impl(x, n_nodes, attr, n_edges, rowptr, src, dst, perm, n_layers, dims, packed, root, bias,
+                    aggr, flags, hidden, out, ws, ws_bytes, (hipStream_t)stream_, kt, kt ? sel : nullptr, hidden_absmax,
                     hidden_nodes, nullptr, 0, z_keep);
 }
 
@@ -682,15 +637,3 @@ extern "C" int gpde_profile_end_kinds(double* ms_by_kind, int32_t* launches_by_k
     return GPDE_OK;
 }
 
-extern "C" int gpde_profile_end(double* fused_ms, int32_t* fused_launches, double* other_ms) {
-    double ms[GPDE_PROF_KINDS];
-    int32_t n[GPDE_PROF_KINDS];
-    int rc = gpde_profile_end_kinds(ms, n);
-    if (rc != GPDE_OK) return rc;
-    double o = 0.0;
-    for (int k = 0; k < GPDE_PROF_KINDS; ++k) if (k != GPDE_PROF_FUSED) o += ms[k];
-    if (fused_ms) *fused_ms = ms[GPDE_PROF_FUSED];
-    if (fused_launches) *fused_launches = n[GPDE_PROF_FUSED];
-    if (other_ms) *other_ms = o;
-    return GPDE_OK;
-}

@@ -23,7 +23,7 @@
 // of the last hidden layer of 3-Linear kernels, which reuses the forward's fused f16-split kernel with
 // its store epilogue (gpde_fused_f16v3_kernel<true, ...>).
 // Weight-gradient reductions use ordered split partials (deterministic).  dx_j: with the source-ordered slot list
-// (gpde_nnconv_bwd_ordered) per-edge contributions are written out and summed per source node in slot order by
+// (src_rowptr / src_slots given) per-edge contributions are written out and summed per source node in slot order by
 // k_dx_reduce (bit-reproducible); without it, fp32 atomics (as the reference's scatter backward does on a GPU).
 #include "gpde_common.h"
 #include <cstdlib>
@@ -1037,7 +1037,7 @@ namespace {
 // One implementation, three entry points (the cross-depth reuse of SURVEY.md §8 row f4 splits the
 // operator into hidden(edge_attr) -> H and conv(x, H)):
 //   BWD_FULL  gpde_nnconv_bwd         hidden chain recomputed per chunk, everything differentiated
-//   BWD_CONV  gpde_nnconv_bwd_hidden  H given ([CSR slot][K2P]); grads of x, W3, b3, root, bias and
+//   BWD_CONV  gpde_nnconv_bwd(hidden) H given ([CSR slot][K2P]); grads of x, W3, b3, root, bias and
 //                                     dL/dU of the last hidden layer ([CSR slot][K2P]) written out
 //   BWD_MLP   gpde_hidden_bwd         H and dL/dU given; grads of the hidden Linear layers
 //   BWD_LIGHT gpde_nnconv_bwd_light     one application of a depth-shared module: everything BUT the hidden layers' gradients
@@ -1058,7 +1058,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
              float* grad_attr = nullptr) {
     // grad_attr (BWD_FULL, tensor attributes of <= 8 slots): [E][k0] in the CALLER's edge order, dL/d edge_attr
     // kt > 0: `edge_attr` is a NODE table [n_nodes][kt] and slot d of an edge's attribute is table[(sel[d] >> 8 ? dst : src)][sel[d] & 255]
-    // (row f3: gpde_nnconv_fwd_nodeattr's convention); perm is unused
+    // (row f3: GpdeNodeAttr); perm is unused
     // hpart (BWD_LIGHT / BWD_DEFER): the last hidden activations of the in-edges of nodes [0, hpart_nodes) are GIVEN (a partial
     // H kept by the caller, CSR slots [0, rowptr[hpart_nodes])): node chunks below that bound read them instead of recomputing
     const bool do_conv = phase != BWD_MLP && phase != BWD_DEFER, do_mlp = phase != BWD_CONV && phase != BWD_LIGHT;
@@ -1515,48 +1515,61 @@ extern "C" size_t gpde_nnconv_bwd_workspace_bytes_one_chunk(int64_t n_nodes, int
     return P.one_chunk > P.total ? P.one_chunk : P.total;
 }
 
-extern "C" int gpde_nnconv_bwd_ordered(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
-                                       const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                                       const int32_t* perm, const int32_t* rowptr_host, const int32_t* src_rowptr,
-                                       const int32_t* src_slots, int n_layers,
-                                       const int32_t* dims, const float* const* W, const float* const* b,
-                                       const float* root, int aggr, const float* grad_out, float* grad_x,
-                                       float* const* grad_W, float* const* grad_b, float* grad_root,
-                                       float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
-    if (n_nodes < 0 || n_edges < 0 || !dims || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws ||
-        (n_nodes > 0 && !x) || (n_edges > 0 && (!edge_attr || !src || !dst || !perm))) {
+// attributes described by node data (include/gpde.h GpdeNodeAttr)
+namespace {
+bool na_ok(const GpdeNodeAttr* na, const int32_t* dims, const char* who) {
+    if (!na || !na->table || na->stride < 1 || !dims || na->n_slots != dims[0] || dims[0] < 1 || dims[0] > 7) {
+        gpde_set_error("%s: GpdeNodeAttr must describe dims[0] = 1..7 slots of a node table", who);
+        return false;
+    }
+    return true;
+}
+}  // namespace
+
+// The backward of the operator, one entry point for its forms (round 5: the plain / source-ordered / kept-Z / given-hidden /
+// edge-attribute-gradient / node-table calls of rounds 1-4 folded into this one):
+//   attributes  `edge_attr` + `perm` (a tensor in the caller's edge order) | `node_attr` (read from node data, row f3) |
+//               `hidden` (the last hidden activations given, [CSR slot][K2P]: only the last Linear, root, bias, x are
+//               differentiated and dL/dU of the last hidden layer is written to `grad_hidden`; W / b / grad_W / grad_b then
+//               carry their LAST entries only)
+//   src_rowptr / src_slots   (nullable) the CSR slots regrouped by source (gpde_csr_source_order): grad_x is summed in slot
+//               order, bit-reproducible; NULL: fp32 atomics
+//   z_saved     (nullable) Z of the keep-Z forward: dW_3 is taken from it instead of re-aggregating
+//   grad_edge_attr (nullable; tensor attributes of <= 8 slots only) dL/d edge_attr [E][k0] in the caller's edge order
+extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, const GpdeNodeAttr* node_attr,
+                               const float* hidden, int64_t n_edges, const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                               const int32_t* perm, const int32_t* rowptr_host, const int32_t* src_rowptr, const int32_t* src_slots,
+                               int n_layers, const int32_t* dims, const float* const* W, const float* const* b, const float* root,
+                               int aggr, const float* grad_out, const float* z_saved, float* grad_x, float* grad_hidden,
+                               float* grad_edge_attr, float* const* grad_W, float* const* grad_b, float* grad_root,
+                               float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || !dims || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws || !grad_W || !grad_b ||
+        n_layers < 2 || n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x || !grad_x)) || (n_edges > 0 && (!src || !dst))) {
         gpde_set_error("gpde_nnconv_bwd: null/negative argument");
         return GPDE_EINVAL;
     }
     if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
-    return bwd_impl(BWD_FULL, x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims,
-                    W, b, root, aggr, grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, nullptr, nullptr,
-                    nullptr, ws, ws_bytes, (hipStream_t)stream_, src_rowptr, src_slots);
-}
-
-// The same with Z saved by the forward (gpde_nnconv_fwd_keepz): z_saved [N][64][K2P]; `hidden` != NULL selects the
-// given-activations form (gpde_nnconv_bwd_hidden_ordered's arguments: edge_attr / perm / W / b of the hidden layers unused).
-extern "C" int gpde_nnconv_bwd_z(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden, int64_t n_edges,
-                                 const int32_t* rowptr, const int32_t* src, const int32_t* dst, const int32_t* perm,
-                                 const int32_t* rowptr_host, const int32_t* src_rowptr, const int32_t* src_slots, int n_layers,
-                                 const int32_t* dims, const float* const* W, const float* const* b, const float* root, int aggr,
-                                 const float* grad_out, const float* z_saved, float* grad_x, float* grad_hidden,
-                                 float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias, void* ws,
-                                 size_t ws_bytes, void* stream_) {
-    if (n_nodes < 0 || n_edges < 0 || !dims || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws || !z_saved || !grad_W || !grad_b ||
-        n_layers < 2 || n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x || !grad_x)) ||
-        (n_edges > 0 && (!src || !dst || (hidden ? !grad_hidden : (!edge_attr || !perm))))) {
-        gpde_set_error("gpde_nnconv_bwd_z: null/negative argument");
+    if ((hidden && node_attr) || (grad_edge_attr && (hidden || node_attr))) {
+        gpde_set_error("gpde_nnconv_bwd: one attribute source (edge_attr + perm | node_attr | hidden); grad_edge_attr needs the tensor");
         return GPDE_EINVAL;
     }
-    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_z: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
-    if (hidden)
+    hipStream_t st = (hipStream_t)stream_;
+    if (hidden) {
+        if (n_edges > 0 && !grad_hidden) { gpde_set_error("gpde_nnconv_bwd: grad_hidden is null"); return GPDE_EINVAL; }
         return bwd_impl(BWD_CONV, x, n_nodes, nullptr, n_edges, rowptr, src, dst, nullptr, rowptr_host, n_layers, dims, W, b, root,
                         aggr, grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, hidden, grad_hidden, nullptr, ws, ws_bytes,
-                        (hipStream_t)stream_, src_rowptr, src_slots, z_saved);
+                        st, src_rowptr, src_slots, z_saved);
+    }
+    if (node_attr) {
+        if (!na_ok(node_attr, dims, "gpde_nnconv_bwd")) return GPDE_EINVAL;
+        return bwd_impl(BWD_FULL, x, n_nodes, node_attr->table, n_edges, rowptr, src, dst, nullptr, rowptr_host, n_layers, dims, W, b, root,
+                        aggr, grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes, st,
+                        src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, nullptr, 0, node_attr->stride, node_attr->sel);
+    }
+    if (n_edges > 0 && (!edge_attr || !perm)) { gpde_set_error("gpde_nnconv_bwd: edge_attr / perm is null"); return GPDE_EINVAL; }
     return bwd_impl(BWD_FULL, x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims, W, b, root, aggr,
-                    grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes,
-                    (hipStream_t)stream_, src_rowptr, src_slots, z_saved);
+                    grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes, st,
+                    src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, n_edges > 0 ? grad_edge_attr : nullptr);
 }
 
 // ---- depth-deferred backward: a module applied `depth` times with the same edge_attr and weights ----------------------
@@ -1582,7 +1595,7 @@ extern "C" size_t gpde_nnconv_bwd_deferred_workspace_bytes(int64_t n_nodes, int6
     return P.total;
 }
 
-extern "C" int gpde_nnconv_bwd_light(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges, const int32_t* rowptr,
+extern "C" int gpde_nnconv_bwd_light(const float* x, int64_t n_nodes, const float* edge_attr, const GpdeNodeAttr* node_attr, int64_t n_edges, const int32_t* rowptr,
                                      const int32_t* src, const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host,
                                      const int32_t* src_rowptr, const int32_t* src_slots, int n_layers, const int32_t* dims,
                                      const float* const* W, const float* const* b, const float* root, int aggr, const float* grad_out,
@@ -1590,233 +1603,65 @@ extern "C" int gpde_nnconv_bwd_light(const float* x, int64_t n_nodes, const floa
                                      float* grad_w_last, float* grad_b_last, float* grad_root,
                                      float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
     if (n_nodes < 0 || n_edges < 0 || !dims || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws || n_layers < 2 ||
-        n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x || !grad_x)) || (n_edges > 0 && (!edge_attr || !src || !dst || !perm)) ||
+        n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x || !grad_x)) || (n_edges > 0 && (!src || !dst || (!node_attr && (!edge_attr || !perm)))) ||
         hidden_nodes < 0 || hidden_nodes > n_nodes || (hidden_nodes > 0 && !hidden_part)) {
         gpde_set_error("gpde_nnconv_bwd_light: null/negative argument");
         return GPDE_EINVAL;
     }
+    if (node_attr && !na_ok(node_attr, dims, "gpde_nnconv_bwd_light")) return GPDE_EINVAL;
     if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_light: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
     float* gW[GPDE_MAX_LAYERS] = {};
     float* gb[GPDE_MAX_LAYERS] = {};
     gW[n_layers - 1] = grad_w_last; gb[n_layers - 1] = grad_b_last;
-    return bwd_impl(BWD_LIGHT, x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims, W, b, root, aggr,
+    return bwd_impl(BWD_LIGHT, x, n_nodes, node_attr ? node_attr->table : edge_attr, n_edges, rowptr, src, dst, node_attr ? nullptr : perm,
+                    rowptr_host, n_layers, dims, W, b, root, aggr,
                     grad_out, grad_x, gW, gb, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream_,
-                    src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, hidden_nodes > 0 ? hidden_part : nullptr, hidden_nodes);
+                    src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, hidden_nodes > 0 ? hidden_part : nullptr, hidden_nodes,
+                    node_attr ? node_attr->stride : 0, node_attr ? node_attr->sel : nullptr);
 }
 
 extern "C" int gpde_nnconv_bwd_deferred(const float* x_stack, const float* grad_out_stack, int n_defer, int64_t n_nodes,
-                                        const float* edge_attr, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
+                                        const float* edge_attr, const GpdeNodeAttr* node_attr, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
                                         const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host, int n_layers,
                                         const int32_t* dims, const float* const* W, const float* const* b, int aggr,
                                         const float* hidden_part, int64_t hidden_nodes,
                                         float* const* grad_W, float* const* grad_b, void* ws, size_t ws_bytes, void* stream_) {
     if (n_nodes < 0 || n_edges < 0 || n_defer < 1 || !dims || !W || !b || !grad_W || !grad_b || !rowptr || !rowptr_host || !ws ||
         n_layers < 2 || n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x_stack || !grad_out_stack)) ||
-        (n_edges > 0 && (!edge_attr || !src || !dst || !perm)) || hidden_nodes < 0 || hidden_nodes > n_nodes ||
+        (n_edges > 0 && (!src || !dst || (!node_attr && (!edge_attr || !perm)))) || hidden_nodes < 0 || hidden_nodes > n_nodes ||
         (hidden_nodes > 0 && !hidden_part)) {
         gpde_set_error("gpde_nnconv_bwd_deferred: null/negative argument");
         return GPDE_EINVAL;
     }
+    if (node_attr && !na_ok(node_attr, dims, "gpde_nnconv_bwd_deferred")) return GPDE_EINVAL;
     if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_deferred: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
-    return bwd_impl(BWD_DEFER, nullptr, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims, W, b, nullptr,
+    return bwd_impl(BWD_DEFER, nullptr, n_nodes, node_attr ? node_attr->table : edge_attr, n_edges, rowptr, src, dst, node_attr ? nullptr : perm,
+                    rowptr_host, n_layers, dims, W, b, nullptr,
                     aggr, nullptr, nullptr, grad_W, grad_b, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
                     (hipStream_t)stream_, nullptr, nullptr, nullptr, n_defer, x_stack, grad_out_stack,
-                    hidden_nodes > 0 ? hidden_part : nullptr, hidden_nodes);
+                    hidden_nodes > 0 ? hidden_part : nullptr, hidden_nodes, node_attr ? node_attr->stride : 0,
+                    node_attr ? node_attr->sel : nullptr);
 }
 
-// gpde_nnconv_bwd_z / gpde_nnconv_bwd_ordered that also writes dL/d edge_attr ([E][k0], the caller's edge order): what autograd
-// hands `pseudo` when it requires a gradient (nn_conv.py:273-275 through DenseNet, utilities.py:223-227).
-extern "C" int gpde_nnconv_bwd_attr(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges, const int32_t* rowptr,
-                                    const int32_t* src, const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host,
-                                    const int32_t* src_rowptr, const int32_t* src_slots, int n_layers, const int32_t* dims,
-                                    const float* const* W, const float* const* b, const float* root, int aggr, const float* grad_out,
-                                    const float* z_saved, float* grad_x, float* grad_edge_attr, float* const* grad_W,
-                                    float* const* grad_b, float* grad_root, float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
-    if (n_nodes < 0 || n_edges < 0 || !dims || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws || !grad_W || !grad_b ||
-        (n_nodes > 0 && (!x || !grad_x)) || (n_edges > 0 && (!edge_attr || !src || !dst || !perm || !grad_edge_attr))) {
-        gpde_set_error("gpde_nnconv_bwd_attr: null/negative argument");
-        return GPDE_EINVAL;
-    }
-    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_attr: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
-    return bwd_impl(BWD_FULL, x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims, W, b, root, aggr,
-                    grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream_,
-                    src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, n_edges > 0 ? grad_edge_attr : nullptr);
-}
-
-extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
-                               const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                               const int32_t* perm, const int32_t* rowptr_host, int n_layers,
-                               const int32_t* dims, const float* const* W, const float* const* b,
-                               const float* root, int aggr, const float* grad_out, float* grad_x,
-                               float* const* grad_W, float* const* grad_b, float* grad_root,
-                               float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
-    return gpde_nnconv_bwd_ordered(x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, nullptr, nullptr,
-                                   n_layers, dims, W, b, root, aggr, grad_out, grad_x, grad_W, grad_b, grad_root,
-                                   grad_bias, ws, ws_bytes, stream_);
-}
-
-extern "C" int gpde_nnconv_bwd_hidden_ordered(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
-                                      const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                                      const int32_t* rowptr_host, const int32_t* src_rowptr,
-                                      const int32_t* src_slots, int n_layers, const int32_t* dims,
-                                      const float* w_last, const float* b_last, const float* root, int aggr,
-                                      const float* grad_out, float* grad_x, float* grad_hidden,
-                                      float* grad_w_last, float* grad_b_last, float* grad_root,
-                                      float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
-    if (n_nodes < 0 || n_edges < 0 || !dims || !w_last || !grad_out || !rowptr || !rowptr_host || !ws ||
-        n_layers < 2 || n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x || !grad_x)) ||
-        (n_edges > 0 && (!hidden || !grad_hidden || !src || !dst))) {
-        gpde_set_error("gpde_nnconv_bwd_hidden: null/negative argument");
-        return GPDE_EINVAL;
-    }
-    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_hidden: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
-    const float* W[GPDE_MAX_LAYERS] = {};
-    const float* b[GPDE_MAX_LAYERS] = {};
-    float* gW[GPDE_MAX_LAYERS] = {};
-    float* gb[GPDE_MAX_LAYERS] = {};
-    W[n_layers - 1] = w_last; b[n_layers - 1] = b_last;
-    gW[n_layers - 1] = grad_w_last; gb[n_layers - 1] = grad_b_last;
-    return bwd_impl(BWD_CONV, x, n_nodes, nullptr, n_edges, rowptr, src, dst, nullptr, rowptr_host, n_layers, dims,
-                    W, b, root, aggr, grad_out, grad_x, gW, gb, grad_root, grad_bias, hidden, grad_hidden, nullptr,
-                    ws, ws_bytes, (hipStream_t)stream_, src_rowptr, src_slots);
-}
-
-extern "C" int gpde_nnconv_bwd_hidden(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
-                                      const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                                      const int32_t* rowptr_host, int n_layers, const int32_t* dims,
-                                      const float* w_last, const float* b_last, const float* root, int aggr,
-                                      const float* grad_out, float* grad_x, float* grad_hidden,
-                                      float* grad_w_last, float* grad_b_last, float* grad_root,
-                                      float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
-    return gpde_nnconv_bwd_hidden_ordered(x, n_nodes, hidden, n_edges, rowptr, src, dst, rowptr_host, nullptr, nullptr,
-                                          n_layers, dims, w_last, b_last, root, aggr, grad_out, grad_x, grad_hidden,
-                                          grad_w_last, grad_b_last, grad_root, grad_bias, ws, ws_bytes, stream_);
-}
-
-extern "C" int gpde_hidden_bwd(const float* edge_attr, int64_t n_edges, const int32_t* perm, int n_layers,
+extern "C" int gpde_hidden_bwd(const float* edge_attr, const GpdeNodeAttr* node_attr, int64_t n_edges, const int32_t* perm,
+                               const int32_t* src, const int32_t* dst, int n_layers,
                                const int32_t* dims, const float* const* W, const float* const* b,
                                const float* grad_hidden, float* const* grad_W, float* const* grad_b, void* ws,
                                size_t ws_bytes, void* stream_) {
     if (n_edges < 0 || !dims || !W || !b || !ws || !grad_W || !grad_b ||
-        (n_edges > 0 && (!edge_attr || !perm || !grad_hidden))) {
+        (n_edges > 0 && (!grad_hidden || (node_attr ? (!src || !dst) : (!edge_attr || !perm))))) {
         gpde_set_error("gpde_hidden_bwd: null/negative argument");
         return GPDE_EINVAL;
+    }
+    if (node_attr) {
+        if (!na_ok(node_attr, dims, "gpde_hidden_bwd")) return GPDE_EINVAL;
+        return bwd_impl(BWD_MLP, nullptr, 0, node_attr->table, n_edges, nullptr, src, dst, nullptr, nullptr, n_layers, dims, W, b, nullptr,
+                        GPDE_AGGR_ADD, nullptr, nullptr, grad_W, grad_b, nullptr, nullptr, nullptr, nullptr, grad_hidden, ws, ws_bytes,
+                        (hipStream_t)stream_, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, node_attr->stride, node_attr->sel);
     }
     return bwd_impl(BWD_MLP, nullptr, 0, edge_attr, n_edges, nullptr, nullptr, nullptr, perm, nullptr, n_layers, dims,
                     W, b, nullptr, GPDE_AGGR_ADD, nullptr, nullptr, grad_W, grad_b, nullptr, nullptr, nullptr, nullptr,
                     grad_hidden, ws, ws_bytes, (hipStream_t)stream_);
-}
-
-
-// ---- training with the edge attributes read from a node table (include/gpde.h GpdeNodeAttr) ----------
-namespace {
-bool na_ok(const GpdeNodeAttr* na, const int32_t* dims, const char* who) {
-    if (!na || !na->table || na->stride < 1 || !dims || na->n_slots != dims[0] || dims[0] < 1 || dims[0] > 7) {
-        gpde_set_error("%s: GpdeNodeAttr must describe dims[0] = 1..7 slots of a node table", who);
-        return false;
-    }
-    return true;
-}
-}  // namespace
-
-extern "C" int gpde_nnconv_bwd_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr,
-                                  const int32_t* src, const int32_t* dst, const int32_t* rowptr_host, const int32_t* src_rowptr,
-                                  const int32_t* src_slots, int n_layers, const int32_t* dims, const float* const* W,
-                                  const float* const* b, const float* root, int aggr, const float* grad_out, const float* z_saved,
-                                  float* grad_x, float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias,
-                                  void* ws, size_t ws_bytes, void* stream_) {
-    if (!na_ok(na, dims, "gpde_nnconv_bwd_na")) return GPDE_EINVAL;
-    if (n_nodes < 0 || n_edges < 0 || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws || (n_nodes > 0 && (!x || !grad_x)) ||
-        (n_edges > 0 && (!src || !dst))) { gpde_set_error("gpde_nnconv_bwd_na: null/negative argument"); return GPDE_EINVAL; }
-    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_na: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
-    return bwd_impl(BWD_FULL, x, n_nodes, na->table, n_edges, rowptr, src, dst, nullptr, rowptr_host, n_layers, dims, W, b, root, aggr,
-                    grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream_,
-                    src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, nullptr, 0, na->stride, na->sel);
-}
-
-extern "C" int gpde_nnconv_bwd_light_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr,
-                                        const int32_t* src, const int32_t* dst, const int32_t* rowptr_host, const int32_t* src_rowptr,
-                                        const int32_t* src_slots, int n_layers, const int32_t* dims, const float* const* W,
-                                        const float* const* b, const float* root, int aggr, const float* grad_out, const float* z_saved,
-                                        const float* hidden_part, int64_t hidden_nodes, float* grad_x, float* grad_w_last,
-                                        float* grad_b_last, float* grad_root, float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
-    if (!na_ok(na, dims, "gpde_nnconv_bwd_light_na")) return GPDE_EINVAL;
-    if (n_nodes < 0 || n_edges < 0 || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws || n_layers < 2 || n_layers > GPDE_MAX_LAYERS ||
-        (n_nodes > 0 && (!x || !grad_x)) || (n_edges > 0 && (!src || !dst)) || hidden_nodes < 0 || hidden_nodes > n_nodes ||
-        (hidden_nodes > 0 && !hidden_part)) { gpde_set_error("gpde_nnconv_bwd_light_na: null/negative argument"); return GPDE_EINVAL; }
-    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_light_na: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
-    float* gW[GPDE_MAX_LAYERS] = {};
-    float* gb[GPDE_MAX_LAYERS] = {};
-    gW[n_layers - 1] = grad_w_last; gb[n_layers - 1] = grad_b_last;
-    return bwd_impl(BWD_LIGHT, x, n_nodes, na->table, n_edges, rowptr, src, dst, nullptr, rowptr_host, n_layers, dims, W, b, root, aggr,
-                    grad_out, grad_x, gW, gb, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream_,
-                    src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, hidden_nodes > 0 ? hidden_part : nullptr, hidden_nodes,
-                    na->stride, na->sel);
-}
-
-extern "C" int gpde_nnconv_bwd_deferred_na(const float* x_stack, const float* grad_out_stack, int n_defer, int64_t n_nodes,
-                                           const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
-                                           const int32_t* dst, const int32_t* rowptr_host, int n_layers, const int32_t* dims,
-                                           const float* const* W, const float* const* b, int aggr, const float* hidden_part,
-                                           int64_t hidden_nodes, float* const* grad_W, float* const* grad_b, void* ws,
-                                           size_t ws_bytes, void* stream_) {
-    if (!na_ok(na, dims, "gpde_nnconv_bwd_deferred_na")) return GPDE_EINVAL;
-    if (n_nodes < 0 || n_edges < 0 || n_defer < 1 || !W || !b || !grad_W || !grad_b || !rowptr || !rowptr_host || !ws || n_layers < 2 ||
-        n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x_stack || !grad_out_stack)) || (n_edges > 0 && (!src || !dst)) ||
-        hidden_nodes < 0 || hidden_nodes > n_nodes || (hidden_nodes > 0 && !hidden_part)) {
-        gpde_set_error("gpde_nnconv_bwd_deferred_na: null/negative argument");
-        return GPDE_EINVAL;
-    }
-    if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd_deferred_na: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
-    return bwd_impl(BWD_DEFER, nullptr, n_nodes, na->table, n_edges, rowptr, src, dst, nullptr, rowptr_host, n_layers, dims, W, b, nullptr,
-                    aggr, nullptr, nullptr, grad_W, grad_b, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
-                    (hipStream_t)stream_, nullptr, nullptr, nullptr, n_defer, x_stack, grad_out_stack,
-                    hidden_nodes > 0 ? hidden_part : nullptr, hidden_nodes, na->stride, na->sel);
-}
-
-extern "C" int gpde_hidden_bwd_na(const GpdeNodeAttr* na, int64_t n_edges, const int32_t* src, const int32_t* dst, int n_layers,
-                                  const int32_t* dims, const float* const* W, const float* const* b, const float* grad_hidden,
-                                  float* const* grad_W, float* const* grad_b, void* ws, size_t ws_bytes, void* stream_) {
-    if (!na_ok(na, dims, "gpde_hidden_bwd_na")) return GPDE_EINVAL;
-    if (n_edges < 0 || !W || !b || !ws || !grad_W || !grad_b || (n_edges > 0 && (!src || !dst || !grad_hidden))) {
-        gpde_set_error("gpde_hidden_bwd_na: null/negative argument");
-        return GPDE_EINVAL;
-    }
-    return bwd_impl(BWD_MLP, nullptr, 0, na->table, n_edges, nullptr, src, dst, nullptr, nullptr, n_layers, dims, W, b, nullptr,
-                    GPDE_AGGR_ADD, nullptr, nullptr, grad_W, grad_b, nullptr, nullptr, nullptr, nullptr, grad_hidden, ws, ws_bytes,
-                    (hipStream_t)stream_, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, na->stride, na->sel);
-}
-
-extern "C" int gpde_hidden_fwd_na(const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                                  int64_t n_nodes, int n_layers, const int32_t* dims, const void* packed, uint32_t flags, float* hidden,
-                                  float* hidden_absmax, void* stream_) {
-    hipStream_t st = (hipStream_t)stream_;
-    if (hidden_absmax) GP_HIP_CHECK(gpde_zero_async(hidden_absmax, sizeof(float), st));
-    if (!na_ok(na, dims, "gpde_hidden_fwd_na")) return GPDE_EINVAL;
-    if (n_edges < 0 || n_nodes < 0 || !packed || (n_edges > 0 && (!hidden || !rowptr || !src || !dst))) {
-        gpde_set_error("gpde_hidden_fwd_na: null/negative argument");
-        return GPDE_EINVAL;
-    }
-    if (n_edges == 0) return GPDE_OK;
-    GpdePackLayout L;
-    int rc = gpde_pack_layout(n_layers, dims, &L);
-    if (rc != GPDE_OK) return rc;
-    if (!(flags & GPDE_FWD_F16SPLIT) || L.mode != 1) { gpde_set_error("gpde_hidden_fwd_na: 3-Linear kernel MLPs on the split-f16 kernel only"); return GPDE_EUNSUPPORTED; }
-    const float* pk = (const float*)packed;
-    GpdeFusedArgs f{};
-    f.attr = na->table; f.rowptr = rowptr; f.src = src; f.dst = dst; f.kt = na->stride;
-    for (int d = 0; d < 8; ++d) f.sel[d] = na->sel[d < dims[0] ? d : dims[0] - 1];
-    f.w1 = pk + L.off_w1; f.w2t = pk + L.off_w2t; f.b2 = pk + L.off_b2;
-    f.w2h = pk + L.off_w2h; f.ucol = pk + L.off_ucol; f.w1h = pk + L.off_w1h; f.fcol = pk + L.off_fcol;
-    f.hout = hidden; f.hmax_out = (unsigned*)hidden_absmax; f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
-    f.nc0 = 0; f.nc1 = (int)n_nodes; f.e_chunk0 = 0;
-    const int ns = L.K2P / GP_TN;
-    int groups = gpde_num_cus() / ns; if (groups < 1) groups = 1;
-    const int64_t gcap = ((n_edges + GP_TE - 1) / GP_TE + GP_WAVES - 1) / GP_WAVES;
-    if (groups > gcap) groups = (int)gcap;
-    f.n_groups = groups;
-    if (!gpde_fused_f16v6_supported(f)) { gpde_set_error("gpde_hidden_fwd_na: kernel MLP outside the one-wave-per-SIMD store kernel (>= 8 k1 chunks)"); return GPDE_EUNSUPPORTED; }
-    return gpde_launch_fused_f16v6(f, st);
 }
 
 
@@ -1833,17 +1678,41 @@ extern "C" size_t gpde_hidden_workspace_bytes(int64_t n_edges, int n_layers, con
     return P.total;
 }
 
-extern "C" int gpde_hidden_fwd(const float* edge_attr, int64_t n_edges, const int32_t* rowptr, int64_t n_nodes,
-                               const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
+extern "C" int gpde_hidden_fwd(const float* edge_attr, const GpdeNodeAttr* node_attr, int64_t n_edges, const int32_t* rowptr, int64_t n_nodes,
+                               const int32_t* perm, const int32_t* src, const int32_t* dst, int n_layers, const int32_t* dims, const void* packed,
                                const float* const* W, const float* const* b, uint32_t flags, float* hidden,
                                float* hidden_absmax, void* ws, size_t ws_bytes, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
     // hidden_absmax (nullable, one float): max |H|, recorded by the fused path only (0 = not recorded);
     // it lets gpde_nnconv_fwd_hidden run the aggregation on split-f16 MFMA
-    if (hidden_absmax) GP_HIP_CHECK(gpde_zero_async(hidden_absmax, sizeof(float), st));
-    if (n_edges < 0 || n_nodes < 0 || !dims || (n_edges > 0 && (!edge_attr || !perm || !hidden || !rowptr))) {
+    if (n_edges < 0 || n_nodes < 0 || !dims || (n_edges > 0 && (!hidden || !rowptr || (node_attr ? (!src || !dst || !packed) : (!edge_attr || !perm))))) {
         gpde_set_error("gpde_hidden_fwd: null/negative argument");
         return GPDE_EINVAL;
+    }
+    if (node_attr && !na_ok(node_attr, dims, "gpde_hidden_fwd")) return GPDE_EINVAL;
+    if (hidden_absmax) GP_HIP_CHECK(gpde_zero_async(hidden_absmax, sizeof(float), st));
+    if (node_attr) {          // attributes from node data: the one-wave-per-SIMD store kernel reads the table
+        const GpdeNodeAttr* na = node_attr;
+        if (n_edges == 0) return GPDE_OK;
+        GpdePackLayout L;
+        int rc = gpde_pack_layout(n_layers, dims, &L);
+        if (rc != GPDE_OK) return rc;
+        if (!(flags & GPDE_FWD_F16SPLIT) || L.mode != 1) { gpde_set_error("gpde_hidden_fwd (node_attr): 3-Linear kernel MLPs on the split-f16 kernel only"); return GPDE_EUNSUPPORTED; }
+        const float* pk = (const float*)packed;
+        GpdeFusedArgs f{};
+        f.attr = na->table; f.rowptr = rowptr; f.src = src; f.dst = dst; f.kt = na->stride;
+        for (int d = 0; d < 8; ++d) f.sel[d] = na->sel[d < dims[0] ? d : dims[0] - 1];
+        f.w1 = pk + L.off_w1; f.w2t = pk + L.off_w2t; f.b2 = pk + L.off_b2;
+        f.w2h = pk + L.off_w2h; f.ucol = pk + L.off_ucol; f.w1h = pk + L.off_w1h; f.fcol = pk + L.off_fcol;
+        f.hout = hidden; f.hmax_out = (unsigned*)hidden_absmax; f.k0 = L.k0; f.K1P = L.K1P; f.K2P = L.K2P;
+        f.nc0 = 0; f.nc1 = (int)n_nodes; f.e_chunk0 = 0;
+        const int ns = L.K2P / GP_TN;
+        int groups = gpde_num_cus() / ns; if (groups < 1) groups = 1;
+        const int64_t gcap = ((n_edges + GP_TE - 1) / GP_TE + GP_WAVES - 1) / GP_WAVES;
+        if (groups > gcap) groups = (int)gcap;
+        f.n_groups = groups;
+        if (!gpde_fused_f16v6_supported(f)) { gpde_set_error("gpde_hidden_fwd (node_attr): kernel MLP outside the one-wave-per-SIMD store kernel (>= 8 k1 chunks)"); return GPDE_EUNSUPPORTED; }
+        return gpde_launch_fused_f16v6(f, st);
     }
     if (n_edges == 0) return GPDE_OK;
     GpdePackLayout L;

@@ -141,12 +141,3 @@ extern "C" int gpde_radius_graph2_fill(const double* pos_src, int64_t n_src, con
     GP_LAUNCH_CHECK("radius_graph_kernel<fill>");
     return GPDE_OK;
 }
-
-extern "C" int gpde_radius_graph_count(const double* pos, int64_t n, int dim, double r, int32_t* deg, void* stream_) {
-    return gpde_radius_graph2_count(pos, n, pos, n, dim, r, 0, deg, stream_);
-}
-
-extern "C" int gpde_radius_graph_fill(const double* pos, int64_t n, int dim, double r, const int64_t* offsets,
-                                      int64_t* edge_index, int64_t n_edges, void* stream_) {
-    return gpde_radius_graph2_fill(pos, n, pos, n, dim, r, 0, offsets, edge_index, n_edges, stream_);
-}

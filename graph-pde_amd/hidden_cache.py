@@ -17,7 +17,7 @@ Policy (`GPDE_HIDDEN_CACHE` = auto | on | off, default auto; budget `GPDE_HIDDEN
     goes back to the direct fused path.  "on" always materialises, "off" never does;
   * H is E x K2P x 4 bytes; larger than the budget -> direct path, or, for inference
     (`GPDE_HIDDEN_CACHE_PARTIAL`, default on), a PARTIAL H: the in-edges of the first `hn` nodes that fit
-    the budget are cached and served by the mixed forward (gpde_nnconv_fwd_mixed), the other nodes run
+    the budget are cached and served by the mixed forward (gpde_nnconv_fwd_mixed_keepz), the other nodes run
     the fused kernel.  G241 at k2 = 1024 needs 391 GB for the full H.
 The entry holds `edge_attr` (so its memory cannot be recycled for other data while the key is
 alive) and is invalidated when the backward of its H node has run.  Nothing is stored on the

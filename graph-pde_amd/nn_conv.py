@@ -116,8 +116,8 @@ class NNConv_old(MessagePassing):
             lin = ops.mlp_linears(self.nn)
             needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
             if torch.is_grad_enabled() and edge_attr.table.requires_grad:
-                # a node table that wants a gradient (learned positions / coefficients): the `_na` kernels do not differentiate
-                # the table, the materialised tensor does (differentiable gather -> gpde_nnconv_bwd_attr) - ADVICE r4
+                # a node table that wants a gradient (learned positions / coefficients): the node-table kernels do not differentiate
+                # the table, the materialised tensor does (differentiable gather -> grad_edge_attr of gpde_nnconv_bwd) - ADVICE r4
                 edge_attr = edge_attr.materialize(edge_index.edge_index if isinstance(edge_index, ops.Csr) else edge_index)
                 pseudo = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
                 return self.propagate(edge_index, x=x, pseudo=pseudo)
@@ -130,7 +130,7 @@ class NNConv_old(MessagePassing):
                     self.out_channels == ops.WIDTH and all(l.bias is not None for l in lin) and \
                     ops.nodeattr_train_supported([lin[0].in_features] + [l.out_features for l in lin]):
                 # training from node data (round 4): the descriptor travels the ordinary path - direct operator, shared hidden
-                # activations or the virtual-H node - and every native call reads the table (`_na` entry points)
+                # activations or the virtual-H node - and every native call reads the table (`node_attr` of the entry points)
                 return self.propagate(edge_index, x=x, pseudo=edge_attr)
             edge_attr = edge_attr.materialize(edge_index.edge_index if isinstance(edge_index, ops.Csr) else edge_index)
         pseudo = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr

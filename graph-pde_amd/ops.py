@@ -656,7 +656,7 @@ class NodeAttr:
         return self.table.device
 
     def c_struct(self):
-        """include/gpde.h GpdeNodeAttr for the `_na` entry points (keeps nothing alive: hold `self` during the call)."""
+        """include/gpde.h GpdeNodeAttr, the `node_attr` argument of the entry points (keeps nothing alive: hold `self` during the call)."""
         na = _lib.GpdeNodeAttr()
         na.table, na.stride, na.n_slots = self.table.data_ptr(), int(self.table.size(1)), self.k0
         for d in range(8):
@@ -674,7 +674,7 @@ def nnconv_forward_nodeattr_raw(x: torch.Tensor, csr: Csr, na: NodeAttr, pm: Pac
                                 root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,
                                 out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
                                 precision: Optional[str] = None) -> torch.Tensor:
-    """One gpde_nnconv_fwd_nodeattr call: the forward with edge attributes read from a node table."""
+    """The forward with edge attributes read from a node table (`node_attr` of gpde_nnconv_fwd_mixed_keepz, no kept H, no kept Z)."""
     lib = _lib.lib()
     _require_cuda(x, "x")
     _require_cuda(na.table, "node table")
@@ -687,7 +687,7 @@ def nnconv_forward_nodeattr_raw(x: torch.Tensor, csr: Csr, na: NodeAttr, pm: Pac
     if na.table.size(0) != n or na.k0 != pm.dims[0]:
         raise ValueError(f"node table must have {n} rows and {pm.dims[0]} slots, got {na.table.size(0)} / {na.k0}")
     x = x.contiguous()
-    sel_c = (ctypes.c_int32 * na.k0)(*[(ep << 8) | col for ep, col in na.sel])
+    nas = na.c_struct()
     root_c = None if root is None else root.detach().contiguous()
     bias_c = None if bias is None else bias.detach().contiguous()
     if out is None:
@@ -695,14 +695,14 @@ def nnconv_forward_nodeattr_raw(x: torch.Tensor, csr: Csr, na: NodeAttr, pm: Pac
     if ws is None:
         ws = _alloc_ws(workspace_bytes(n, e, pm), x.device)
     with torch.cuda.device(x.device):
-        rc = lib.gpde_nnconv_fwd_nodeattr(x.data_ptr(), n, na.table.data_ptr(), na.table.size(1), sel_c, e,
-                                          csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(),
-                                          len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(),
-                                          None if root_c is None else root_c.data_ptr(),
-                                          None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
-                                          _PRECISION[precision], out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                          _stream_ptr(x.device))
-    _lib.check(rc, "gpde_nnconv_fwd_nodeattr")
+        rc = lib.gpde_nnconv_fwd_mixed_keepz(x.data_ptr(), n, None, ctypes.byref(nas), None, None, 0, e,
+                                             csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), None,
+                                             len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(),
+                                             None if root_c is None else root_c.data_ptr(),
+                                             None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
+                                             _PRECISION[precision], None, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             _stream_ptr(x.device))
+    _lib.check(rc, "gpde_nnconv_fwd_mixed_keepz (node table)")
     _lib.n_native_calls += 1
     return out
 
@@ -733,9 +733,9 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
                         root: Optional[torch.Tensor], aggr: str, grad_out: torch.Tensor,
                         need_root: bool = True, need_bias: bool = True,
                         ws: Optional[torch.Tensor] = None, z_saved: Optional[torch.Tensor] = None, need_attr: bool = False):
-    """One gpde_nnconv_bwd call on the current stream (`z_saved`: the keep-Z forward's buffer -> gpde_nnconv_bwd_z).
+    """One gpde_nnconv_bwd call on the current stream (`z_saved`: the keep-Z forward's buffer; `edge_attr`: a tensor or a NodeAttr).
     Returns (grad_x, [grad_W_l], [grad_b_l or None], grad_root or None, grad_bias or None); with `need_attr` a sixth element,
-    dL/d edge_attr [E, k0] in the caller's edge order (gpde_nnconv_bwd_attr)."""
+    dL/d edge_attr [E, k0] in the caller's edge order (`grad_edge_attr` of the call)."""
     lib = _lib.lib()
     for t, nm in ((x, "x"), (edge_attr, "edge_attr"), (grad_out, "grad_out")):
         _require_cuda(t, nm)
@@ -768,56 +768,18 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
         ws = alloc_bwd_ws(lib, n, e, nl, dims_c, dev)
     rph = csr.rowptr_host
     srp, ssl = csr.src_order
-    if is_na:
-        na = edge_attr.c_struct()
-        with torch.cuda.device(dev):
-            rc = lib.gpde_nnconv_bwd_na(x.data_ptr(), n, ctypes.byref(na), e, csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(),
-                                        rph.data_ptr(), None if srp is None else srp.data_ptr(), None if ssl is None else ssl.data_ptr(),
-                                        nl, dims_c, arr(ws_), arr(bs_), None if root_c is None else root_c.data_ptr(), _AGGR[aggr],
-                                        grad_out.data_ptr(), None if z_saved is None else z_saved.data_ptr(), gx.data_ptr(), arr(gW), arr(gb),
-                                        None if groot is None else groot.data_ptr(), None if gbias is None else gbias.data_ptr(),
-                                        ws.data_ptr(), ws.numel(), _stream_ptr(dev))
-        _lib.check(rc, "gpde_nnconv_bwd_na")
-        _lib.n_native_calls += 1
-        return gx, gW, gb, groot, gbias
-    if need_attr:
-        ga = torch.zeros(e, dims[0], dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            rc = lib.gpde_nnconv_bwd_attr(x.data_ptr(), n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), csr.src.data_ptr(),
-                                          csr.dst.data_ptr(), perm.data_ptr(), rph.data_ptr(), None if srp is None else srp.data_ptr(),
-                                          None if ssl is None else ssl.data_ptr(), nl, dims_c, arr(ws_), arr(bs_),
-                                          None if root_c is None else root_c.data_ptr(), _AGGR[aggr], grad_out.data_ptr(),
-                                          None if z_saved is None else z_saved.data_ptr(), gx.data_ptr(), ga.data_ptr(), arr(gW), arr(gb),
-                                          None if groot is None else groot.data_ptr(), None if gbias is None else gbias.data_ptr(),
-                                          ws.data_ptr(), ws.numel(), _stream_ptr(dev))
-        _lib.check(rc, "gpde_nnconv_bwd_attr")
-        _lib.n_native_calls += 1
-        return gx, gW, gb, groot, gbias, ga
-    if z_saved is not None:
-        with torch.cuda.device(dev):
-            rc = lib.gpde_nnconv_bwd_z(x.data_ptr(), n, edge_attr.data_ptr(), None, e, csr.rowptr.data_ptr(), csr.src.data_ptr(),
-                                       csr.dst.data_ptr(), perm.data_ptr(), rph.data_ptr(), None if srp is None else srp.data_ptr(),
-                                       None if ssl is None else ssl.data_ptr(), nl, dims_c, arr(ws_), arr(bs_),
-                                       None if root_c is None else root_c.data_ptr(), _AGGR[aggr], grad_out.data_ptr(),
-                                       z_saved.data_ptr(), gx.data_ptr(), None, arr(gW), arr(gb),
-                                       None if groot is None else groot.data_ptr(), None if gbias is None else gbias.data_ptr(),
-                                       ws.data_ptr(), ws.numel(), _stream_ptr(dev))
-        _lib.check(rc, "gpde_nnconv_bwd_z")
-        _lib.n_native_calls += 1
-        return gx, gW, gb, groot, gbias
+    p = lambda t: None if t is None else t.data_ptr()
+    nas = edge_attr.c_struct() if is_na else None
+    ga = torch.zeros(e, dims[0], dtype=torch.float32, device=dev) if need_attr else None
     with torch.cuda.device(dev):
-        rc = lib.gpde_nnconv_bwd_ordered(x.data_ptr(), n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(),
-                                 csr.src.data_ptr(), csr.dst.data_ptr(), perm.data_ptr(),
-                                 rph.data_ptr(), None if srp is None else srp.data_ptr(),
-                                 None if ssl is None else ssl.data_ptr(), nl, dims_c, arr(ws_), arr(bs_),
-                                 None if root_c is None else root_c.data_ptr(), _AGGR[aggr],
-                                 grad_out.data_ptr(), gx.data_ptr(), arr(gW), arr(gb),
-                                 None if groot is None else groot.data_ptr(),
-                                 None if gbias is None else gbias.data_ptr(), ws.data_ptr(),
-                                 ws.numel(), _stream_ptr(dev))
+        rc = lib.gpde_nnconv_bwd(x.data_ptr(), n, None if is_na else edge_attr.data_ptr(), None if nas is None else ctypes.byref(nas),
+                                 None, e, csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), None if is_na else perm.data_ptr(),
+                                 rph.data_ptr(), p(srp), p(ssl), nl, dims_c, arr(ws_), arr(bs_), p(root_c), _AGGR[aggr],
+                                 grad_out.data_ptr(), p(z_saved), gx.data_ptr(), None, p(ga), arr(gW), arr(gb), p(groot), p(gbias),
+                                 ws.data_ptr(), ws.numel(), _stream_ptr(dev))
     _lib.check(rc, "gpde_nnconv_bwd")
     _lib.n_native_calls += 1
-    return gx, gW, gb, groot, gbias
+    return (gx, gW, gb, groot, gbias, ga) if need_attr else (gx, gW, gb, groot, gbias)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -829,7 +791,7 @@ def deferred_supported(dims: Sequence[int]) -> bool:
 
 
 def nodeattr_train_supported(dims: Sequence[int]) -> bool:
-    """Training with node-table attributes (the `_na` entry points): 3-Linear kernel MLPs on the one-wave-per-SIMD kernels
+    """Training with node-table attributes (the `node_attr` argument): 3-Linear kernel MLPs on the one-wave-per-SIMD kernels
     (>= 8 chunks of 32 first-layer units), <= 7 attribute slots, and the split-f16 backward GEMMs (deferred_supported)."""
     return len(dims) == 4 and 1 <= dims[0] <= 7 and (int(dims[1]) + 31) // 32 >= 8 and deferred_supported(dims) and \
         DEFAULT_PRECISION == "f16split"
@@ -877,21 +839,11 @@ def nnconv_backward_light_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor
     ws = _alloc_ws(nbytes, dev)
     srp, ssl = csr.src_order
     p = lambda t: None if t is None else t.data_ptr()
-    if is_na:
-        na = edge_attr.c_struct()
-        with torch.cuda.device(dev):
-            rc = lib.gpde_nnconv_bwd_light_na(x.data_ptr(), n, ctypes.byref(na), e, csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(),
-                                              csr.rowptr_host.data_ptr(), p(srp), p(ssl), nl, dims_c, _ptr_array(ws_), _ptr_array(bs_),
-                                              p(root_c), _AGGR[aggr], grad_out.data_ptr(), p(z_saved),
-                                              p(hidden_part) if hidden_nodes > 0 else None, int(hidden_nodes) if hidden_part is not None else 0,
-                                              gx.data_ptr(), gw.data_ptr(), p(gb), p(groot), p(gbias), ws.data_ptr(), ws.numel(),
-                                              _stream_ptr(dev))
-        _lib.check(rc, "gpde_nnconv_bwd_light_na")
-        _lib.n_native_calls += 1
-        return gx, gw, gb, groot, gbias
+    nas = edge_attr.c_struct() if is_na else None
     with torch.cuda.device(dev):
-        rc = lib.gpde_nnconv_bwd_light(x.data_ptr(), n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), csr.src.data_ptr(),
-                                       csr.dst.data_ptr(), perm.data_ptr(), csr.rowptr_host.data_ptr(), p(srp), p(ssl), nl, dims_c,
+        rc = lib.gpde_nnconv_bwd_light(x.data_ptr(), n, None if is_na else edge_attr.data_ptr(), None if nas is None else ctypes.byref(nas),
+                                       e, csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), None if is_na else perm.data_ptr(),
+                                       csr.rowptr_host.data_ptr(), p(srp), p(ssl), nl, dims_c,
                                        _ptr_array(ws_), _ptr_array(bs_), p(root_c), _AGGR[aggr], grad_out.data_ptr(), p(z_saved),
                                        p(hidden_part) if hidden_nodes > 0 else None, int(hidden_nodes) if hidden_part is not None else 0,
                                        gx.data_ptr(), gw.data_ptr(), p(gb), p(groot), p(gbias), ws.data_ptr(), ws.numel(),
@@ -932,21 +884,12 @@ def nnconv_backward_deferred_raw(xs: Sequence[torch.Tensor], gs: Sequence[torch.
     if nbytes == 0:
         _lib.check(-2, "gpde_nnconv_bwd_deferred_workspace_bytes")
     ws = _alloc_ws(nbytes, dev)
-    if is_na:
-        na = edge_attr.c_struct()
-        with torch.cuda.device(dev):
-            rc = lib.gpde_nnconv_bwd_deferred_na(x_stack.data_ptr(), g_stack.data_ptr(), L, n, ctypes.byref(na), e, csr.rowptr.data_ptr(),
-                                                 csr.src.data_ptr(), csr.dst.data_ptr(), csr.rowptr_host.data_ptr(), nl, dims_c,
-                                                 _ptr_array(ws_), _ptr_array(bs_), _AGGR[aggr],
-                                                 hidden_part.data_ptr() if (hidden_part is not None and hidden_nodes > 0) else None,
-                                                 int(hidden_nodes) if hidden_part is not None else 0,
-                                                 _ptr_array(gW), _ptr_array(gb), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
-        _lib.check(rc, "gpde_nnconv_bwd_deferred_na")
-        _lib.n_native_calls += 1
-        return gW[:-1], gb[:-1]
+    nas = edge_attr.c_struct() if is_na else None
     with torch.cuda.device(dev):
-        rc = lib.gpde_nnconv_bwd_deferred(x_stack.data_ptr(), g_stack.data_ptr(), L, n, edge_attr.data_ptr(), e, csr.rowptr.data_ptr(),
-                                          csr.src.data_ptr(), csr.dst.data_ptr(), perm.data_ptr(), csr.rowptr_host.data_ptr(), nl, dims_c,
+        rc = lib.gpde_nnconv_bwd_deferred(x_stack.data_ptr(), g_stack.data_ptr(), L, n, None if is_na else edge_attr.data_ptr(),
+                                          None if nas is None else ctypes.byref(nas), e, csr.rowptr.data_ptr(),
+                                          csr.src.data_ptr(), csr.dst.data_ptr(), None if is_na else perm.data_ptr(),
+                                          csr.rowptr_host.data_ptr(), nl, dims_c,
                                           _ptr_array(ws_), _ptr_array(bs_), _AGGR[aggr],
                                           hidden_part.data_ptr() if (hidden_part is not None and hidden_nodes > 0) else None,
                                           int(hidden_nodes) if hidden_part is not None else 0,
@@ -988,10 +931,10 @@ def hidden_forward_raw(csr: Csr, edge_attr: torch.Tensor, pm: PackedMlp,
         hmax = torch.zeros(1, dtype=torch.float32, device=dev)
         na = edge_attr.c_struct()
         with torch.cuda.device(dev):
-            rc = lib.gpde_hidden_fwd_na(ctypes.byref(na), e, csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), n_lim,
-                                        len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(), _PRECISION[precision], hidden.data_ptr(),
-                                        hmax.data_ptr(), _stream_ptr(dev))
-        _lib.check(rc, "gpde_hidden_fwd_na")
+            rc = lib.gpde_hidden_fwd(None, ctypes.byref(na), e, csr.rowptr.data_ptr(), n_lim, None, csr.src.data_ptr(), csr.dst.data_ptr(),
+                                     len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(), None, None, _PRECISION[precision],
+                                     hidden.data_ptr(), hmax.data_ptr(), None, 0, _stream_ptr(dev))
+        _lib.check(rc, "gpde_hidden_fwd (node table)")
         _lib.n_native_calls += 1
         return hidden, hmax
     if edge_attr.dtype != torch.float32 or edge_attr.dim() != 2 or edge_attr.size(0) != e or \
@@ -1011,16 +954,16 @@ def hidden_forward_raw(csr: Csr, edge_attr: torch.Tensor, pm: PackedMlp,
     ws = torch.empty(1 if fast else max(nbytes, 1), dtype=torch.uint8, device=dev)
     hmax = torch.zeros(1, dtype=torch.float32, device=dev) if fast else None
     with torch.cuda.device(dev):
-        rc = lib.gpde_hidden_fwd(edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), n_lim,
-                                 perm.data_ptr(), nl, pm.dims_c, pm.packed.data_ptr(),
+        rc = lib.gpde_hidden_fwd(edge_attr.data_ptr(), None, e, csr.rowptr.data_ptr(), n_lim,
+                                 perm.data_ptr(), None, None, nl, pm.dims_c, pm.packed.data_ptr(),
                                  _ptr_array(ws_), _ptr_array(bs_), _PRECISION[precision],
                                  hidden.data_ptr(), None if hmax is None else hmax.data_ptr(),
                                  ws.data_ptr(), ws.numel(), _stream_ptr(dev))
         if rc in (-1, -3) and fast:    # shape not covered by the fused kernel: the general path needs ws
             ws = _alloc_ws(nbytes, dev)
             hmax = None                # ... and does not record max |H|
-            rc = lib.gpde_hidden_fwd(edge_attr.data_ptr(), e, csr.rowptr.data_ptr(), n_lim,
-                                     perm.data_ptr(), nl, pm.dims_c, pm.packed.data_ptr(),
+            rc = lib.gpde_hidden_fwd(edge_attr.data_ptr(), None, e, csr.rowptr.data_ptr(), n_lim,
+                                     perm.data_ptr(), None, None, nl, pm.dims_c, pm.packed.data_ptr(),
                                      _ptr_array(ws_), _ptr_array(bs_), _PRECISION[precision],
                                      hidden.data_ptr(), None, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
     _lib.check(rc, "gpde_hidden_fwd")
@@ -1229,9 +1172,9 @@ def nnconv_forward_mixed_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
                              root: Optional[torch.Tensor], bias: Optional[torch.Tensor], aggr: str,
                              precision: Optional[str] = None, z_keep: Optional[torch.Tensor] = None,
                              out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """gpde_nnconv_fwd_mixed(_keepz): nodes [0, hidden_nodes) aggregate from `hidden` (their in-edges' rows), the
+    """gpde_nnconv_fwd_mixed_keepz: nodes [0, hidden_nodes) aggregate from `hidden` (their in-edges' rows), the
     rest run the fused kernel -- for graphs whose full H does not fit memory.  `z_keep`: as nnconv_forward_raw.
-    `edge_attr` may be a NodeAttr (gpde_nnconv_fwd_na; `hidden` None / hidden_nodes 0: no partial H)."""
+    `edge_attr` may be a NodeAttr (the call's `node_attr`; `hidden` None / hidden_nodes 0: no partial H)."""
     lib = _lib.lib()
     _require_cuda(x, "x")
     precision = DEFAULT_PRECISION if precision is None else precision
@@ -1250,31 +1193,23 @@ def nnconv_forward_mixed_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
         out = torch.empty(n, WIDTH, dtype=torch.float32, device=x.device)
     if ws is None:
         ws = _alloc_ws(workspace_bytes(n, e, pm), x.device)
-    if isinstance(edge_attr, NodeAttr):
+    is_na = isinstance(edge_attr, NodeAttr)
+    nas, perm = None, None
+    if is_na:
         if edge_attr.table.size(0) != n or edge_attr.k0 != pm.dims[0]:
             raise ValueError(f"node table must have {n} rows and {pm.dims[0]} slots")
-        na = edge_attr.c_struct()
-        with torch.cuda.device(x.device):
-            rc = lib.gpde_nnconv_fwd_na(x.data_ptr(), n, ctypes.byref(na), None if hidden_nodes <= 0 else hidden.data_ptr(),
-                                        None if hmax is None else hmax.data_ptr(), max(int(hidden_nodes), 0), e, csr.rowptr.data_ptr(),
-                                        csr.src.data_ptr(), csr.dst.data_ptr(), len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(),
-                                        None if root_c is None else root_c.data_ptr(), None if bias_c is None else bias_c.data_ptr(),
-                                        _AGGR[aggr], _PRECISION[precision], None if z_keep is None else z_keep.data_ptr(),
-                                        out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
-        _lib.check(rc, "gpde_nnconv_fwd_na")
-        _lib.n_native_calls += 1
-        return out
-    edge_attr, perm = attr_in_slot_order(csr, edge_attr.detach().contiguous())
+        nas = edge_attr.c_struct()
+    else:
+        edge_attr, perm = attr_in_slot_order(csr, edge_attr.detach().contiguous())
+    p = lambda t: None if t is None else t.data_ptr()
     with torch.cuda.device(x.device):
-        rc = lib.gpde_nnconv_fwd_mixed_keepz(x.data_ptr(), n, edge_attr.data_ptr(), hidden.data_ptr(),
-                                             None if hmax is None else hmax.data_ptr(), hidden_nodes, e,
+        rc = lib.gpde_nnconv_fwd_mixed_keepz(x.data_ptr(), n, None if is_na else edge_attr.data_ptr(), None if nas is None else ctypes.byref(nas),
+                                             p(hidden) if hidden_nodes > 0 else None, p(hmax), max(int(hidden_nodes), 0), e,
                                              csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(),
-                                             perm.data_ptr(), len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(),
-                                             None if root_c is None else root_c.data_ptr(),
-                                             None if bias_c is None else bias_c.data_ptr(), _AGGR[aggr],
-                                             _PRECISION[precision], None if z_keep is None else z_keep.data_ptr(),
+                                             p(perm), len(pm.dims) - 1, pm.dims_c, pm.packed.data_ptr(),
+                                             p(root_c), p(bias_c), _AGGR[aggr], _PRECISION[precision], p(z_keep),
                                              out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
-    _lib.check(rc, "gpde_nnconv_fwd_mixed")
+    _lib.check(rc, "gpde_nnconv_fwd_mixed_keepz")
     _lib.n_native_calls += 1
     return out
 
@@ -1283,7 +1218,7 @@ def nnconv_backward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, 
                                w_last: torch.Tensor, b_last: Optional[torch.Tensor],
                                root: Optional[torch.Tensor], aggr: str, grad_out: torch.Tensor,
                                need_root: bool = True, need_bias: bool = True, z_saved: Optional[torch.Tensor] = None):
-    """gpde_nnconv_bwd_hidden (`z_saved`: gpde_nnconv_bwd_z).  Returns (grad_x, grad_hidden [E,K2P], grad_w_last, grad_b_last or None,
+    """gpde_nnconv_bwd in its `hidden` form (the last hidden activations given; `z_saved`: the keep-Z forward's buffer).  Returns (grad_x, grad_hidden [E,K2P], grad_w_last, grad_b_last or None,
     grad_root or None, grad_bias or None)."""
     lib = _lib.lib()
     n, e, dev = csr.n_nodes, csr.n_edges, x.device
@@ -1306,27 +1241,17 @@ def nnconv_backward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, 
     ws = _alloc_ws(nbytes, dev)
     p = lambda t: None if t is None else t.data_ptr()
     srp, ssl = csr.src_order
-    if z_saved is not None:
-        P_ = ctypes.c_void_p
-        Wa = (P_ * nl)(*([None] * (nl - 1) + [w_last.data_ptr()]))
-        Ba = (P_ * nl)(*([None] * (nl - 1) + [p(b_c)]))
-        gWa = (P_ * nl)(*([None] * (nl - 1) + [gw.data_ptr()]))
-        gBa = (P_ * nl)(*([None] * (nl - 1) + [p(gb)]))
-        with torch.cuda.device(dev):
-            rc = lib.gpde_nnconv_bwd_z(x.data_ptr(), n, None, hidden.data_ptr(), e, csr.rowptr.data_ptr(), csr.src.data_ptr(),
-                                       csr.dst.data_ptr(), None, csr.rowptr_host.data_ptr(), p(srp), p(ssl), nl, dims_c, Wa, Ba,
-                                       p(root_c), _AGGR[aggr], grad_out.data_ptr(), z_saved.data_ptr(), gx.data_ptr(), gh.data_ptr(),
-                                       gWa, gBa, p(groot), p(gbias), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
-        _lib.check(rc, "gpde_nnconv_bwd_z")
-        _lib.n_native_calls += 1
-        return gx, gh, gw, gb, groot, gbias
+    P_ = ctypes.c_void_p                                   # the hidden form: the arrays carry their LAST entries only
+    Wa = (P_ * nl)(*([None] * (nl - 1) + [w_last.data_ptr()]))
+    Ba = (P_ * nl)(*([None] * (nl - 1) + [p(b_c)]))
+    gWa = (P_ * nl)(*([None] * (nl - 1) + [gw.data_ptr()]))
+    gBa = (P_ * nl)(*([None] * (nl - 1) + [p(gb)]))
     with torch.cuda.device(dev):
-        rc = lib.gpde_nnconv_bwd_hidden_ordered(x.data_ptr(), n, hidden.data_ptr(), e, csr.rowptr.data_ptr(),
-                                        csr.src.data_ptr(), csr.dst.data_ptr(), csr.rowptr_host.data_ptr(),
-                                        p(srp), p(ssl), nl, dims_c, w_last.data_ptr(), p(b_c), p(root_c), _AGGR[aggr],
-                                        grad_out.data_ptr(), gx.data_ptr(), gh.data_ptr(), gw.data_ptr(),
-                                        p(gb), p(groot), p(gbias), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
-    _lib.check(rc, "gpde_nnconv_bwd_hidden")
+        rc = lib.gpde_nnconv_bwd(x.data_ptr(), n, None, None, hidden.data_ptr(), e, csr.rowptr.data_ptr(), csr.src.data_ptr(),
+                                 csr.dst.data_ptr(), None, csr.rowptr_host.data_ptr(), p(srp), p(ssl), nl, dims_c, Wa, Ba,
+                                 p(root_c), _AGGR[aggr], grad_out.data_ptr(), p(z_saved), gx.data_ptr(), gh.data_ptr(), None,
+                                 gWa, gBa, p(groot), p(gbias), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "gpde_nnconv_bwd (hidden given)")
     _lib.n_native_calls += 1
     return gx, gh, gw, gb, groot, gbias
 
@@ -1352,16 +1277,10 @@ def hidden_backward_raw(csr: Csr, edge_attr: torch.Tensor, dims: Sequence[int],
     gW = [torch.empty_like(w) for w in ws_[:-1]] + [None]
     gb = [None if b is None else torch.empty_like(b) for b in bs_[:-1]] + [None]
     ws = alloc_bwd_ws(lib, 0, e, nl, dims_c, dev)
-    if is_na:
-        na = edge_attr.c_struct()
-        with torch.cuda.device(dev):
-            rc = lib.gpde_hidden_bwd_na(ctypes.byref(na), e, csr.src.data_ptr(), csr.dst.data_ptr(), nl, dims_c, _ptr_array(ws_), _ptr_array(bs_),
-                                        grad_hidden.data_ptr(), _ptr_array(gW), _ptr_array(gb), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
-        _lib.check(rc, "gpde_hidden_bwd_na")
-        _lib.n_native_calls += 1
-        return gW[:-1], gb[:-1]
+    nas = edge_attr.c_struct() if is_na else None
     with torch.cuda.device(dev):
-        rc = lib.gpde_hidden_bwd(edge_attr.data_ptr(), e, perm.data_ptr(), nl, dims_c,
+        rc = lib.gpde_hidden_bwd(None if is_na else edge_attr.data_ptr(), None if nas is None else ctypes.byref(nas), e,
+                                 None if is_na else perm.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), nl, dims_c,
                                  _ptr_array(ws_), _ptr_array(bs_), grad_hidden.data_ptr(),
                                  _ptr_array(gW), _ptr_array(gb), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
     _lib.check(rc, "gpde_hidden_bwd")

@@ -71,6 +71,16 @@ enum {
 #define GPDE_MAX_LAYERS 8
 #define GPDE_WIDTH 64 /* node-feature width (in_channels == out_channels) the kernels are built for */
 
+/* Edge attributes described by NODE data instead of an [E][k0] tensor (details at gpde_nnconv_fwd_mixed_keepz):
+ * slot d of edge (j -> i) is table[(sel[d] >> 8 ? i : j) * stride + (sel[d] & 255)].  A HOST struct; every entry point that takes
+ * `edge_attr` + `perm` also takes a `const GpdeNodeAttr* node_attr` (NULL = the tensor) - round 5 folded the `_na` twins into it. */
+typedef struct GpdeNodeAttr {
+    const float* table;   /* device [n_nodes][stride] */
+    int32_t stride;
+    int32_t n_slots;      /* = dims[0], 1..7 */
+    int32_t sel[8];       /* slot d: endpoint << 8 | column (endpoint 0 = source j, 1 = target i) */
+} GpdeNodeAttr;
+
 GPDE_API int gpde_version(void);
 GPDE_API const char* gpde_last_error(void);
 /* The library's developer / A-B switches (GPDE_BWD_*, GPDE_EDGE_BWD, GPDE_DEBUG_SKEW_US, ...: INTEGRATION.md) are environment
@@ -183,8 +193,8 @@ GPDE_API const char* gpde_nnconv_fwd_kernel(int64_t n_edges, int n_layers, const
  *   or whole arrays may be NULL to skip), grad_root [64][64], grad_bias [64] (NULL to skip).
  * W, b, grad_W, grad_b are HOST arrays of device pointers; rowptr_host is a HOST copy of rowptr
  * (the edge chunks are planned on the host).  Hidden activations are recomputed per node-aligned
- * chunk of edges; nothing from the forward needs to be saved.  Edge-attribute gradients are not
- * produced (the reference never asks for them).  fp32 MFMA throughout. */
+ * chunk of edges; nothing from the forward needs to be saved (z_saved is an option, below).  fp32-class
+ * arithmetic throughout (fp32 MFMA; split-f16 MFMA at < 2^-21 per product where DESIGN.md §6b says so). */
 GPDE_API size_t gpde_nnconv_bwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers,
                                        const int32_t* dims);
 /* The workspace with which the backward runs ALL edges and nodes as ONE chunk (the call above caps its answer at ~26 GB and
@@ -194,35 +204,28 @@ GPDE_API size_t gpde_nnconv_bwd_workspace_bytes(int64_t n_nodes, int64_t n_edges
  * memory). */
 GPDE_API size_t gpde_nnconv_bwd_workspace_bytes_one_chunk(int64_t n_nodes, int64_t n_edges, int n_layers,
                                                  const int32_t* dims);
-GPDE_API int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
-                    const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                    const int32_t* perm, const int32_t* rowptr_host, int n_layers,
-                    const int32_t* dims, const float* const* W, const float* const* b,
-                    const float* root, int aggr, const float* grad_out, float* grad_x,
-                    float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias,
-                    void* ws, size_t ws_bytes, void* stream);
-/* The same with a bit-reproducible grad_x.  gpde_nnconv_bwd accumulates dx_j over the out-edges of j by fp32
- * atomics (run-to-run differences at the 1e-7 level, like the reference's index_select backward on a GPU);
- * given the CSR slots regrouped by source node (gpde_csr_source_order below: src_rowptr [N+1], src_slots [E]) the
- * per-edge contributions are written out and summed per source in ascending slot order by one owner per element.
- * src_rowptr == NULL or src_slots == NULL selects the atomic path.  Weight gradients are ordered either way. */
-GPDE_API int gpde_nnconv_bwd_ordered(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges,
-                            const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                            const int32_t* perm, const int32_t* rowptr_host, const int32_t* src_rowptr,
-                            const int32_t* src_slots, int n_layers,
-                            const int32_t* dims, const float* const* W, const float* const* b,
-                            const float* root, int aggr, const float* grad_out, float* grad_x,
-                            float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias,
-                            void* ws, size_t ws_bytes, void* stream);
-/* The same (z_saved: NULL or the keep-Z forward's buffer) that also writes grad_edge_attr [E][k0] = dL/d edge_attr in the
- * caller's edge order - what autograd hands `pseudo` when it requires a gradient (no reference script asks for it).  Attribute
- * tensors of <= 8 slots. */
-GPDE_API int gpde_nnconv_bwd_attr(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges, const int32_t* rowptr,
-                         const int32_t* src, const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host,
-                         const int32_t* src_rowptr, const int32_t* src_slots, int n_layers, const int32_t* dims,
-                         const float* const* W, const float* const* b, const float* root, int aggr, const float* grad_out,
-                         const float* z_saved, float* grad_x, float* grad_edge_attr, float* const* grad_W,
-                         float* const* grad_b, float* grad_root, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
+GPDE_API int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, const GpdeNodeAttr* node_attr,
+                    const float* hidden, int64_t n_edges, const int32_t* rowptr, const int32_t* src, const int32_t* dst,
+                    const int32_t* perm, const int32_t* rowptr_host, const int32_t* src_rowptr, const int32_t* src_slots,
+                    int n_layers, const int32_t* dims, const float* const* W, const float* const* b, const float* root,
+                    int aggr, const float* grad_out, const float* z_saved, float* grad_x, float* grad_hidden,
+                    float* grad_edge_attr, float* const* grad_W, float* const* grad_b, float* grad_root,
+                    float* grad_bias, void* ws, size_t ws_bytes, void* stream);
+/* ^ ONE backward entry point for every form of the operator (round 5 folded seven: the plain, source-ordered, kept-Z,
+ *   given-hidden, edge-attribute-gradient and node-table calls of rounds 1-4 were this call with some arguments fixed):
+ *   attribute source   edge_attr + perm (tensor, caller's edge order) | node_attr (node data) | hidden (the last hidden
+ *                      activations given, [CSR slot][K2P], e.g. from gpde_hidden_fwd: only x, the LAST Linear (W / b / grad_W /
+ *                      grad_b carry their last entries), root and bias are differentiated, and dL/dU of the last hidden layer
+ *                      is written to grad_hidden [CSR slot][K2P] for gpde_hidden_bwd).  Exactly one of the three.
+ *   src_rowptr, src_slots  nullable: the CSR slots regrouped by source node (gpde_csr_source_order) - grad_x is then summed per
+ *                      source in slot order, bit-reproducible and independent of the chunking; NULL: fp32 atomics.
+ *   z_saved            nullable: the Z buffer of gpde_nnconv_fwd_keepz / _mixed_keepz - dW_3 is taken from it.
+ *   grad_hidden        the `hidden` form only.   grad_edge_attr  nullable, tensor form with <= 8 slots only: dL/d edge_attr
+ *                      [E][k0] in the caller's edge order (what autograd hands `pseudo`, nn_conv.py:273-275; no reference
+ *                      script asks for it).
+ * On grad_x: without the source order dx_j is accumulated over the out-edges of j by fp32 atomics (run-to-run differences at
+ * the 1e-7 level, like the reference's index_select backward on a GPU); with it the per-edge contributions are written out
+ * and summed per source in ascending slot order by one owner per element.  Weight gradients are ordered either way. */
 /* src_slots = CSR slots 0..E-1 stably sorted by their source node, src_rowptr[j] = first position of source j;
  * `src` is the array gpde_csr_from_coo wrote; workspace: gpde_csr_workspace_bytes(n_edges, n_nodes). */
 GPDE_API int gpde_csr_source_order(const int32_t* src, int64_t n_edges, int64_t n_nodes, int32_t* src_rowptr,
@@ -240,7 +243,7 @@ GPDE_API int gpde_csr_source_order(const int32_t* src, int64_t n_edges, int64_t 
  *                            order, K2P = dims[n_layers-1] rounded up to 128, padding columns zero
  *   gpde_nnconv_fwd_hidden:  (x, H) -> out             aggregation + last Linear + update()
  * and, for training, their backward halves
- *   gpde_nnconv_bwd_hidden:  grad_out -> grad_x, grad of the last Linear / root / bias, and
+ *   gpde_nnconv_bwd(hidden): grad_out -> grad_x, grad of the last Linear / root / bias, and
  *                            grad_hidden = dL/dU of the last hidden layer (already multiplied by the
  *                            ReLU mask H > 0), [E][K2P], overwritten
  *   gpde_hidden_bwd:         grad_hidden (summed over the `depth` uses by the caller's autograd)
@@ -252,76 +255,45 @@ GPDE_API int gpde_csr_source_order(const int32_t* src, int64_t n_edges, int64_t 
  * gpde_hidden_fwd: with flags & GPDE_FWD_F16SPLIT, `packed` (gpde_mlp_pack) and a 3-Linear MLP the
  * fused f16-split kernel computes H (same arithmetic as gpde_nnconv_fwd); otherwise the layers run
  * as fp32-MFMA GEMMs over chunks of edges and W, b (HOST arrays of device pointers, torch layouts)
- * and ws (gpde_hidden_workspace_bytes) are required.  Workspaces of the *_hidden entry points:
- * gpde_nnconv_fwd_workspace_bytes / gpde_nnconv_bwd_workspace_bytes; gpde_hidden_bwd:
+ * and ws (gpde_hidden_workspace_bytes) are required.  Workspaces: gpde_nnconv_fwd_hidden ->
+ * gpde_nnconv_fwd_workspace_bytes; gpde_nnconv_bwd -> gpde_nnconv_bwd_workspace_bytes; gpde_hidden_bwd:
  * gpde_nnconv_bwd_workspace_bytes(0, E, ...).
  * hidden_absmax (nullable, one device float): gpde_hidden_fwd records max |H| there when its fused
  * path computed H (the general path leaves 0: the value is then NOT a maximum and must not be
  * passed on).  Given back to gpde_nnconv_fwd_hidden it lets the aggregation run on split-f16 MFMA
  * from 32768 edges on; NULL: fp32 MFMA. */
 GPDE_API size_t gpde_hidden_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims);
-GPDE_API int gpde_hidden_fwd(const float* edge_attr, int64_t n_edges, const int32_t* rowptr, int64_t n_nodes,
-                    const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
-                    const float* const* W, const float* const* b, uint32_t flags, float* hidden,
-                    float* hidden_absmax, void* ws, size_t ws_bytes, void* stream);
+GPDE_API int gpde_hidden_fwd(const float* edge_attr, const GpdeNodeAttr* node_attr, int64_t n_edges, const int32_t* rowptr,
+                    int64_t n_nodes, const int32_t* perm, const int32_t* src, const int32_t* dst, int n_layers,
+                    const int32_t* dims, const void* packed, const float* const* W, const float* const* b, uint32_t flags,
+                    float* hidden, float* hidden_absmax, void* ws, size_t ws_bytes, void* stream);
+/* ^ node_attr != NULL: attributes from node data (src / dst required, edge_attr / perm / W / b / ws unused; 3-Linear kernel MLPs of
+ *   >= 8 k1 chunks on GPDE_FWD_F16SPLIT); else src / dst may be NULL. */
 GPDE_API int gpde_nnconv_fwd_hidden(const float* x, int64_t n_nodes, const float* hidden,
                            const float* hidden_absmax, int64_t n_edges,
                            const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                            int n_layers, const int32_t* dims, const void* packed, const float* root,
                            const float* bias, int aggr, float* out, void* ws, size_t ws_bytes,
                            void* stream);
-/* Mixed call for graphs whose H does not fit memory (E * K2P * 4 bytes: 391 GB at the 241^2 graph):
- * `hidden` holds the rows of the in-edges of nodes [0, hidden_nodes) only (CSR slots
- * [0, rowptr[hidden_nodes]); build it with gpde_hidden_fwd(..., n_edges = rowptr[hidden_nodes],
- * n_nodes = hidden_nodes)); those nodes aggregate from it, all others run the fused kernel on
- * edge_attr.  Same result as gpde_nnconv_fwd.  3-Linear kernel MLPs; forward only. */
-GPDE_API int gpde_nnconv_fwd_mixed(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
-                          const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges,
-                          const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                          const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
-                          const float* root, const float* bias, int aggr, uint32_t flags, float* out,
-                          void* ws, size_t ws_bytes, void* stream);
-GPDE_API int gpde_nnconv_bwd_hidden(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
-                           const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                           const int32_t* rowptr_host, int n_layers, const int32_t* dims,
-                           const float* w_last, const float* b_last, const float* root, int aggr,
-                           const float* grad_out, float* grad_x, float* grad_hidden,
-                           float* grad_w_last, float* grad_b_last, float* grad_root, float* grad_bias,
-                           void* ws, size_t ws_bytes, void* stream);
-/* bit-reproducible grad_x, as gpde_nnconv_bwd_ordered */
-GPDE_API int gpde_nnconv_bwd_hidden_ordered(const float* x, int64_t n_nodes, const float* hidden, int64_t n_edges,
-                                   const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                                   const int32_t* rowptr_host, const int32_t* src_rowptr,
-                                   const int32_t* src_slots, int n_layers, const int32_t* dims,
-                                   const float* w_last, const float* b_last, const float* root, int aggr,
-                                   const float* grad_out, float* grad_x, float* grad_hidden,
-                                   float* grad_w_last, float* grad_b_last, float* grad_root, float* grad_bias,
-                                   void* ws, size_t ws_bytes, void* stream);
-GPDE_API int gpde_hidden_bwd(const float* edge_attr, int64_t n_edges, const int32_t* perm, int n_layers,
+/* attributes: edge_attr + perm, or node_attr + src + dst (as gpde_hidden_fwd) */
+GPDE_API int gpde_hidden_bwd(const float* edge_attr, const GpdeNodeAttr* node_attr, int64_t n_edges, const int32_t* perm,
+                    const int32_t* src, const int32_t* dst, int n_layers,
                     const int32_t* dims, const float* const* W, const float* const* b,
                     const float* grad_hidden, float* const* grad_W, float* const* grad_b, void* ws,
                     size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Keep-Z pair (training): the forward already forms Z_i = sum_{e -> i} x_j (x) h_e for every node and the
- * backward's dW_3 = sum_i gT_i (x) Z_i needs exactly that; without these two entry points the backward re-aggregates it from
+ * backward's dW_3 = sum_i gT_i (x) Z_i needs exactly that; without it the backward re-aggregates it from
  * the recomputed (or given) hidden activations.  gpde_nnconv_fwd_keepz = gpde_nnconv_fwd (hidden == NULL) or
  * gpde_nnconv_fwd_hidden (hidden != NULL; edge_attr / perm unused) writing Z into z_keep [N][64][K2P] (K2P = last hidden
  * width padded to 128; ZERO-INITIALISED by the caller: nodes without in-edges are not written); the per-edge last layer of
- * low in-degree graphs is not taken.  gpde_nnconv_bwd_z = gpde_nnconv_bwd_ordered / gpde_nnconv_bwd_hidden_ordered with
- * that Z (W / b: all n_layers entries for the full form; only the last for the hidden form). */
+ * low in-degree graphs is not taken.  The backward takes that buffer as `z_saved` (gpde_nnconv_bwd, gpde_nnconv_bwd_light). */
 GPDE_API int gpde_nnconv_fwd_keepz(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
                           const float* hidden_absmax, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
                           const int32_t* dst, const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
                           const float* root, const float* bias, int aggr, uint32_t flags, float* z_keep, float* out,
                           void* ws, size_t ws_bytes, void* stream);
-GPDE_API int gpde_nnconv_bwd_z(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden, int64_t n_edges,
-                      const int32_t* rowptr, const int32_t* src, const int32_t* dst, const int32_t* perm,
-                      const int32_t* rowptr_host, const int32_t* src_rowptr, const int32_t* src_slots, int n_layers,
-                      const int32_t* dims, const float* const* W, const float* const* b, const float* root, int aggr,
-                      const float* grad_out, const float* z_saved, float* grad_x, float* grad_hidden,
-                      float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias, void* ws,
-                      size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Depth-deferred backward (SURVEY.md §8 rows f1 x f4 when the hidden activations do NOT fit memory: H of the 241^2 graph is
@@ -331,7 +303,7 @@ GPDE_API int gpde_nnconv_bwd_z(const float* x, int64_t n_nodes, const float* edg
  *   dU_2[e][k] = (sum_l sum_c x_j^(l)[c] dZ_i^(l)[c][k]) (.) [H_2[e][k] > 0]       one K = 64 * depth contraction per edge
  * so the two 1024 x 1024 GEMMs per edge (dU_1, dW_2), the transposes and dW_1 / db_* run ONCE per step.
  *   gpde_nnconv_bwd_light     one application: grad_x, grad of the last Linear (grad_w_last [4096][k2], grad_b_last [4096]),
- *                             grad_root, grad_bias - everything gpde_nnconv_bwd_ordered writes except the hidden layers'
+ *                             grad_root, grad_bias - everything gpde_nnconv_bwd writes except the hidden layers'
  *                             gradients.  z_saved: NULL or the keep-Z forward's buffer (gpde_nnconv_fwd_keepz).
  *                             Workspace: gpde_nnconv_bwd_workspace_bytes.
  *   gpde_nnconv_bwd_deferred  all applications: x_stack [Lp][N][64] = the inputs x^(l) of the n_defer applications, ZERO
@@ -340,16 +312,17 @@ GPDE_API int gpde_nnconv_bwd_z(const float* x, int64_t n_nodes, const float* edg
  *                             the hidden layers l = 0 .. n_layers - 2 (the last entries are ignored).  Workspace:
  *                             gpde_nnconv_bwd_deferred_workspace_bytes.
  * hidden_part / hidden_nodes (both entry points; NULL / 0: none): the last hidden activations of the in-edges of nodes
- * [0, hidden_nodes) as gpde_hidden_fwd(n_nodes = hidden_nodes) wrote them (the partial H of gpde_nnconv_fwd_mixed) - node
+ * [0, hidden_nodes) as gpde_hidden_fwd(n_nodes = hidden_nodes) wrote them (the partial H of gpde_nnconv_fwd_mixed_keepz) - node
  * chunks below that bound read them instead of recomputing the hidden chain (the 241^2 graph: 44 % of the edges fit 170 GB).
  * Built for the kernel MLPs gpde_nnconv_bwd_deferred_supported() accepts (3 Linear layers, hidden widths multiples of 128,
  * at most 7 attributes: the split-f16 path); others return GPDE_EUNSUPPORTED - use gpde_nnconv_bwd per application.
- * Results: grad_x etc. of the light pass are the bits of gpde_nnconv_bwd_ordered; the hidden layers' gradients equal the
+ * Results: grad_x etc. of the light pass are the bits of gpde_nnconv_bwd (source-ordered); the hidden layers' gradients equal the
  * sum of the per-application ones up to fp32 / split-f16 summation order (tests/test_gpu_deferred.py: <= 2e-5). */
 GPDE_API int gpde_nnconv_bwd_deferred_supported(int n_layers, const int32_t* dims);
 GPDE_API size_t gpde_nnconv_bwd_deferred_workspace_bytes(int64_t n_nodes, int64_t n_edges, int n_layers, const int32_t* dims,
                                                 int n_defer);
-GPDE_API int gpde_nnconv_bwd_light(const float* x, int64_t n_nodes, const float* edge_attr, int64_t n_edges, const int32_t* rowptr,
+GPDE_API int gpde_nnconv_bwd_light(const float* x, int64_t n_nodes, const float* edge_attr, const GpdeNodeAttr* node_attr,
+                          int64_t n_edges, const int32_t* rowptr,
                           const int32_t* src, const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host,
                           const int32_t* src_rowptr, const int32_t* src_slots, int n_layers, const int32_t* dims,
                           const float* const* W, const float* const* b, const float* root, int aggr, const float* grad_out,
@@ -357,18 +330,24 @@ GPDE_API int gpde_nnconv_bwd_light(const float* x, int64_t n_nodes, const float*
                           float* grad_w_last, float* grad_b_last, float* grad_root,
                           float* grad_bias, void* ws, size_t ws_bytes, void* stream);
 GPDE_API int gpde_nnconv_bwd_deferred(const float* x_stack, const float* grad_out_stack, int n_defer, int64_t n_nodes,
-                             const float* edge_attr, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
-                             const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host, int n_layers,
-                             const int32_t* dims, const float* const* W, const float* const* b, int aggr,
+                             const float* edge_attr, const GpdeNodeAttr* node_attr, int64_t n_edges, const int32_t* rowptr,
+                             const int32_t* src, const int32_t* dst, const int32_t* perm, const int32_t* rowptr_host,
+                             int n_layers, const int32_t* dims, const float* const* W, const float* const* b, int aggr,
                              const float* hidden_part, int64_t hidden_nodes,
                              float* const* grad_W, float* const* grad_b, void* ws, size_t ws_bytes, void* stream);
-/* The mixed forward (gpde_nnconv_fwd_mixed) that also leaves Z_i for the backward (z_keep as in gpde_nnconv_fwd_keepz; NULL: none). */
-GPDE_API int gpde_nnconv_fwd_mixed_keepz(const float* x, int64_t n_nodes, const float* edge_attr, const float* hidden,
-                                const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges,
+/* The GENERAL forward.  Mixed call for graphs whose H does not fit memory (E * K2P * 4 bytes: 391 GB at the 241^2 graph):
+ * `hidden` holds the rows of the in-edges of nodes [0, hidden_nodes) only (CSR slots [0, rowptr[hidden_nodes]); build it with
+ * gpde_hidden_fwd(..., n_edges = rowptr[hidden_nodes], n_nodes = hidden_nodes)); those nodes aggregate from it, all others run the
+ * fused kernel on the attributes.  Same result as gpde_nnconv_fwd.  3-Linear kernel MLPs. */
+GPDE_API int gpde_nnconv_fwd_mixed_keepz(const float* x, int64_t n_nodes, const float* edge_attr, const GpdeNodeAttr* node_attr,
+                                const float* hidden, const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges,
                                 const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                                 const int32_t* perm, int n_layers, const int32_t* dims, const void* packed,
                                 const float* root, const float* bias, int aggr, uint32_t flags, float* z_keep, float* out,
                                 void* ws, size_t ws_bytes, void* stream);
+/* ^ attributes from edge_attr + perm or from node_attr (then edge_attr / perm may be NULL); hidden_nodes = 0 / hidden = NULL: no
+ *   partial H; z_keep (as in gpde_nnconv_fwd_keepz) = NULL: Z not kept.  (Round 5 folded the mixed, node-table and node-table +
+ *   partial-H forwards of round 4 into this call.) */
 
 /* ---------------------------------------------------------------------------------------------
  * The operator given the PER-EDGE WEIGHTS (second half; row a6 'max').
@@ -424,80 +403,27 @@ GPDE_API int gpde_edge_weights_bwd(const float* grad_edge_weights, const float* 
                           float* grad_b_last, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Edge attributes on the fly (opt-in).  The reference materialises
- * edge_attr[e] = [pos_src(2), pos_dst(2), a_src, a_dst] from node data (SquareMeshGenerator.attributes,
- * utilities.py:274-277; multi_pole_grid1d, multipole utilities.py:1771-1777): 24 of the 40
- * algorithmic bytes per edge and a 2.3 GB tensor on the 241^2 graph.  Here the fused kernel reads
- * them from a node table instead: slot d of edge (j -> i) is
- *     node_table[(attr_sel[d] >> 8 ? i : j) * table_stride + (attr_sel[d] & 255)]
- * attr_sel: HOST array of dims[0] ints (endpoint << 8 | column; endpoint 0 = source j, 1 = target i).
- * Same result as gpde_nnconv_fwd on the materialised tensor (bitwise: the attribute values are the
- * same floats).  Built for 3-Linear kernel MLPs on the default GPDE_FWD_F16SPLIT kernel; anything
- * else returns GPDE_EUNSUPPORTED.  `perm` is not needed.
- *
- * Training (round 4): the `_na` entry points below are the training-side calls with the attributes described by a
- * GpdeNodeAttr (HOST struct) instead of an [E][k0] tensor + perm - forward with keep-Z / the partial H, the store of the
- * hidden activations, full / light / deferred backward, the hidden layers' backward - so that a training step on a graph
- * built from positions (gpde_radius_csr_*) needs neither the [E][k0] tensor (2.3 GB on the 241^2 graph) nor its slot-order
- * copy.  Arguments otherwise as their tensor counterparts; results are bitwise those of the materialised tensor
- * (tests/test_gpu_nodeattr_train.py).  3-Linear kernel MLPs of >= 8 k1 chunks (the one-wave-per-SIMD kernels). */
-typedef struct GpdeNodeAttr {
-    const float* table;   /* device [n_nodes][stride] */
-    int32_t stride;
-    int32_t n_slots;      /* = dims[0], 1..7 */
-    int32_t sel[8];       /* slot d: endpoint << 8 | column (endpoint 0 = source j, 1 = target i) */
-} GpdeNodeAttr;
-GPDE_API int gpde_nnconv_fwd_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, const float* hidden_part,
-                       const float* hidden_absmax, int64_t hidden_nodes, int64_t n_edges, const int32_t* rowptr,
-                       const int32_t* src, const int32_t* dst, int n_layers, const int32_t* dims, const void* packed,
-                       const float* root, const float* bias, int aggr, uint32_t flags, float* z_keep, float* out, void* ws,
-                       size_t ws_bytes, void* stream);
-GPDE_API int gpde_hidden_fwd_na(const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                       int64_t n_nodes, int n_layers, const int32_t* dims, const void* packed, uint32_t flags, float* hidden,
-                       float* hidden_absmax, void* stream);
-GPDE_API int gpde_nnconv_bwd_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr,
-                       const int32_t* src, const int32_t* dst, const int32_t* rowptr_host, const int32_t* src_rowptr,
-                       const int32_t* src_slots, int n_layers, const int32_t* dims, const float* const* W, const float* const* b,
-                       const float* root, int aggr, const float* grad_out, const float* z_saved, float* grad_x,
-                       float* const* grad_W, float* const* grad_b, float* grad_root, float* grad_bias, void* ws, size_t ws_bytes,
-                       void* stream);
-GPDE_API int gpde_nnconv_bwd_light_na(const float* x, int64_t n_nodes, const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr,
-                             const int32_t* src, const int32_t* dst, const int32_t* rowptr_host, const int32_t* src_rowptr,
-                             const int32_t* src_slots, int n_layers, const int32_t* dims, const float* const* W,
-                             const float* const* b, const float* root, int aggr, const float* grad_out, const float* z_saved,
-                             const float* hidden_part, int64_t hidden_nodes, float* grad_x, float* grad_w_last,
-                             float* grad_b_last, float* grad_root, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
-GPDE_API int gpde_nnconv_bwd_deferred_na(const float* x_stack, const float* grad_out_stack, int n_defer, int64_t n_nodes,
-                                const GpdeNodeAttr* na, int64_t n_edges, const int32_t* rowptr, const int32_t* src,
-                                const int32_t* dst, const int32_t* rowptr_host, int n_layers, const int32_t* dims,
-                                const float* const* W, const float* const* b, int aggr, const float* hidden_part,
-                                int64_t hidden_nodes, float* const* grad_W, float* const* grad_b, void* ws, size_t ws_bytes,
-                                void* stream);
-GPDE_API int gpde_hidden_bwd_na(const GpdeNodeAttr* na, int64_t n_edges, const int32_t* src, const int32_t* dst, int n_layers,
-                       const int32_t* dims, const float* const* W, const float* const* b, const float* grad_hidden,
-                       float* const* grad_W, float* const* grad_b, void* ws, size_t ws_bytes, void* stream);
-GPDE_API int gpde_nnconv_fwd_nodeattr(const float* x, int64_t n_nodes, const float* node_table,
-                             int32_t table_stride, const int32_t* attr_sel, int64_t n_edges,
-                             const int32_t* rowptr, const int32_t* src, const int32_t* dst,
-                             int n_layers, const int32_t* dims, const void* packed, const float* root,
-                             const float* bias, int aggr, uint32_t flags, float* out, void* ws,
-                             size_t ws_bytes, void* stream);
+ * Edge attributes on the fly (opt-in): the `node_attr` argument (GpdeNodeAttr, declared at the top).
+ * The reference materialises edge_attr[e] = [pos_src(2), pos_dst(2), a_src, a_dst] from node data
+ * (SquareMeshGenerator.attributes, utilities.py:274-277; multi_pole_grid1d, multipole utilities.py:1771-1777): 24 of the 40
+ * algorithmic bytes per edge and a 2.3 GB tensor on the 241^2 graph.  With node_attr the kernels read them from a node table
+ * instead: slot d of edge (j -> i) is
+ *     table[(sel[d] >> 8 ? i : j) * stride + (sel[d] & 255)]        (endpoint 0 = source j, 1 = target i)
+ * Same result as the call on the materialised tensor (bitwise: the attribute values are the same floats;
+ * tests/test_gpu_nodeattr.py, test_gpu_nodeattr_train.py).  Taken by the general forward, gpde_hidden_fwd, gpde_nnconv_bwd,
+ * gpde_nnconv_bwd_light, gpde_nnconv_bwd_deferred and gpde_hidden_bwd - a training step on a graph built from positions
+ * (gpde_radius_csr_*) needs neither the [E][k0] tensor nor its slot-order copy.  Built for 3-Linear kernel MLPs of >= 8 k1
+ * chunks on the default GPDE_FWD_F16SPLIT kernels, 1..7 slots; anything else returns GPDE_EUNSUPPORTED / GPDE_EINVAL. */
 
 /* ---------------------------------------------------------------------------------------------
  * Radius graph on the GPU.  Replaces SquareMeshGenerator / RandomMeshGenerator.ball_connectivity
- * (utilities.py:250-255, 362-368: dense float64 pairwise_distances + np.where).  pos [n][dim]
+ * (utilities.py:250-255, 362-368: dense float64 pairwise_distances + np.where).  pos_src / pos_dst [n][dim]
  * float64 (dim 1..3).  Pass 1 writes the out-degree of every source; the caller forms the
  * exclusive prefix sum `offsets` [n+1] (int64) and allocates edge_index int64 [2][E], E =
- * offsets[n]; pass 2 fills it: edge (j -> i) iff |pos_j - pos_i|^2 <= r^2 (float64, exact sum of
- * squares), self-loops included, sorted by source then target — the reference's order. */
-GPDE_API int gpde_radius_graph_count(const double* pos, int64_t n, int dim, double r, int32_t* deg,
-                            void* stream);
-GPDE_API int gpde_radius_graph_fill(const double* pos, int64_t n, int dim, double r, const int64_t* offsets,
-                           int64_t* edge_index, int64_t n_edges, void* stream);
-
-/* The same between TWO point sets - edges (j in pos_src -> i in pos_dst), row-major np.where order - which is what
+ * offsets[n]; pass 2 fills it: edges (j in pos_src -> i in pos_dst) within distance r, self-loops included, sorted by
+ * source then target (row-major np.where) - the reference's order.  Two point sets, because that is what
  * the inner (pos_dst == pos_src) and inter-level graphs of RandomMultiMeshGenerator.ball_connectivity are
- * (multipole-graph-neural-operator/utilities.py:602-640: pairwise_distances(X, Y) <= r), and with the choice of
+ * (multipole-graph-neural-operator/utilities.py:602-640: pairwise_distances(X, Y) <= r).  The choice of
  * arithmetic: flags = 0 tests sum_k (dx_k)^2 <= r^2 exactly in float64 (symmetric graphs);
  * GPDE_RADIUS_REFERENCE_TIES evaluates scikit-learn's dot-product expansion operation by operation, so that pairs at
  * exactly distance r are kept or dropped as in the reference (its default s = 61, r = 0.10 graph: 376,471 edges).
@@ -527,12 +453,10 @@ GPDE_API int gpde_radius_csr_fill(const double* pos_src, int64_t n_src, const do
 
 /* HIP-event timing of the kernels launched by gpde_nnconv_fwd on the calling thread (used by
  * bench.py for the roofline figure; events are recorded on the same stream as the kernels).
- * gpde_profile_begin() arms it; gpde_profile_end() disarms it, SYNCHRONISES on the recorded
- * events and returns the summed duration (ms) and launch count of the fused edge kernel and the
- * summed duration of the node-side kernels (gemm3 + epilogue).  Not for production calls. */
+ * gpde_profile_begin() arms it; gpde_profile_end_kinds() disarms it, SYNCHRONISES on the recorded
+ * events and returns the summed duration (ms) and launch count per kernel kind: ms_by_kind / launches_by_kind are arrays of
+ * GPDE_PROF_KINDS entries.  Not for production calls. */
 GPDE_API int gpde_profile_begin(void);
-GPDE_API int gpde_profile_end(double* fused_ms, int32_t* fused_launches, double* other_ms);
-/* The same, split by kernel kind: ms_by_kind / launches_by_kind are arrays of GPDE_PROF_KINDS entries. */
 enum {
     GPDE_PROF_FUSED = 0,     /* fused edge kernel (gpde_nnconv_fwd_kernel names it) or gpde_zagg_kernel */
     GPDE_PROF_GEMM3 = 1,     /* per-node last Linear Z . W3 */

@@ -1,6 +1,6 @@
 """Depth-6 inference on the headline graph (G241, 95.5 M edges, kernel MLP 6-1024-1024-4096) on ONE GPU with the
 cross-depth reuse of the hidden activations at different budgets: the full H is 391 GB, so the cache is
-PARTIAL - the in-edges of the first nodes that fit are served from H, the rest recomputed (gpde_nnconv_fwd_mixed)."""
+PARTIAL - the in-edges of the first nodes that fit are served from H, the rest recomputed (gpde_nnconv_fwd_mixed_keepz)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

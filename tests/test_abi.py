@@ -171,18 +171,25 @@ def test_argument_validation_without_gpu():
     assert rc == -1
     # the split operator, the mixed forward and the node-table forward validate before touching the device
     d3 = _lib.dims_array([6, 16, 32, 4096])
-    sel = (ctypes.c_int32 * 6)(0, 1, 256, 257, 2, 258)
-    assert l.gpde_hidden_fwd(None, 8, None, 4, None, 3, d3, None, None, None, 1, None, None, None, 0, None) == -1
-    assert l.gpde_hidden_fwd(None, 0, None, 4, None, 3, d3, None, None, None, 1, None, None, None, 0, None) == 0   # no edges
+    # gpde_hidden_fwd(edge_attr, node_attr, n_edges, rowptr, n_nodes, perm, src, dst, n_layers, dims, packed, W, b, flags, ...)
+    assert l.gpde_hidden_fwd(None, None, 8, None, 4, None, None, None, 3, d3, None, None, None, 1, None, None, None, 0, None) == -1
+    assert l.gpde_hidden_fwd(None, None, 0, None, 4, None, None, None, 3, d3, None, None, None, 1, None, None, None, 0, None) == 0   # no edges
     assert l.gpde_nnconv_fwd_hidden(None, 4, None, None, 8, None, None, None, 3, d3, None, None, None, 1,
                                     None, None, 0, None) == -1
-    assert l.gpde_nnconv_fwd_mixed(None, 4, None, None, None, 9, 8, None, None, None, None, 3, d3, None, None,
-                                   None, 1, 1, None, None, 0, None) == -1
-    assert l.gpde_nnconv_bwd_hidden(None, 4, None, 8, None, None, None, None, 3, d3, None, None, None, 1, None,
-                                    None, None, None, None, None, None, None, 0, None) == -1
-    assert l.gpde_hidden_bwd(None, 8, None, 3, d3, None, None, None, None, None, None, 0, None) == -1
-    assert l.gpde_nnconv_fwd_nodeattr(None, 4, None, 3, sel, 8, None, None, None, 3, d3, None, None, None, 1, 1,
-                                      None, None, 0, None) == -1
+    # gpde_nnconv_fwd_mixed_keepz(x, n, edge_attr, node_attr, hidden, hidden_absmax, hidden_nodes, n_edges, rowptr, src, dst, perm, ...)
+    assert l.gpde_nnconv_fwd_mixed_keepz(None, 4, None, None, None, None, 9, 8, None, None, None, None, 3, d3, None, None,
+                                         None, 1, 1, None, None, None, 0, None) == -1
+    # the backward in its `hidden` form: null arrays are refused before any device work
+    assert l.gpde_nnconv_bwd(None, 4, None, None, None, 8, None, None, None, None, None, None, None, 3, d3, None, None, None, 1, None,
+                             None, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert l.gpde_hidden_bwd(None, None, 8, None, None, None, 3, d3, None, None, None, None, None, None, 0, None) == -1
+    # ... and two attribute sources at once (hidden + node_attr) are an argument error, not a guess
+    na = _lib.GpdeNodeAttr()
+    one = (ctypes.c_void_p * 3)()
+    buf = ctypes.create_string_buffer(64)
+    assert l.gpde_nnconv_bwd(None, 0, None, ctypes.byref(na), buf, 0, buf, None, None, None, buf, None, None, 3, d3, one, one, None, 1, buf,
+                             None, None, None, None, one, one, None, None, buf, 64, None) == -1
+    assert b"one attribute source" in l.gpde_last_error()
     assert l.gpde_hidden_workspace_bytes(1000, 3, d3) > 0 and l.gpde_hidden_workspace_bytes(-1, 3, d3) == 0
 
 
@@ -230,7 +237,7 @@ def test_weconv_descriptor_layout_matches_the_header():
 
 def test_node_attr_descriptor_layout_matches_the_header():
     """ctypes mirror of `GpdeNodeAttr` (include/gpde.h): pointer + 2 int32 + 8 int32 = 48 bytes; ops.NodeAttr.c_struct fills it
-    as the header says; the `_na` entry points validate on the host."""
+    as the header says; the entry points taking `node_attr` validate it on the host."""
     import torch
     from graph_pde_amd import ops
     src = open(os.path.join(REPO, "include", "gpde.h")).read()
@@ -244,11 +251,14 @@ def test_node_attr_descriptor_layout_matches_the_header():
     assert (c.stride, c.n_slots) == (3, 6) and list(c.sel)[:6] == [0, 1, 256, 257, 2, 258] and c.table == na.table.data_ptr()
     l = _lib.lib()
     dims = _lib.dims_array([6, 256, 256, 4096])
-    assert l.gpde_hidden_fwd_na(None, 5, None, None, None, 5, 3, dims, None, 1, None, None, None) == -1
+    c.n_slots = 5                                                # disagrees with dims[0]: refused on the host by every entry point
+    buf = ctypes.create_string_buffer(64)
+    assert l.gpde_hidden_fwd(None, ctypes.byref(c), 5, buf, 5, None, buf, buf, 3, dims, buf, None, None, 1, buf, None, None, 0, None) == -1
     assert b"GpdeNodeAttr" in l.gpde_last_error()
-    c.n_slots = 5                                                # disagrees with dims[0]
-    assert l.gpde_nnconv_bwd_na(None, 0, ctypes.byref(c), 0, None, None, None, None, None, None, 3, dims, None, None, None, 1, None,
-                                None, None, None, None, None, None, None, 0, None) == -1
+    arr = (ctypes.c_void_p * 3)()
+    assert l.gpde_nnconv_bwd(None, 0, None, ctypes.byref(c), None, 0, buf, None, None, None, buf, None, None, 3, dims, arr, arr, None, 1,
+                             buf, None, None, None, None, arr, arr, None, None, buf, 64, None) == -1
+    assert b"GpdeNodeAttr" in l.gpde_last_error()
     assert l.gpde_nnconv_bwd_deferred_supported(3, dims) == 1 and l.gpde_nnconv_bwd_deferred_supported(3, _lib.dims_array([6, 64, 128, 4096])) == 0
     assert l.gpde_nnconv_bwd_deferred_workspace_bytes(100, 5000, 3, dims, 6) > l.gpde_nnconv_bwd_workspace_bytes(100, 5000, 3, dims)
     # the one-chunk size: never below the default, and for a graph far beyond the default's chunk far above it

@@ -58,7 +58,7 @@ def test_backward_with_split_f16_du1_matches_reference_autograd(dims, n, e, monk
 @pytest.mark.parametrize("variant", ["1", "2", "3"])      # per-MFMA operands / staged fp32 MFMA / staged split-f16 MFMA
 def test_all_gradients_are_bit_reproducible(variant, monkeypatch):
     """Weight gradients: ordered split partials.  grad_x: per-edge contributions summed per source node in slot order
-    (gpde_nnconv_bwd_ordered + gpde_csr_source_order) instead of atomics - for both per-edge kernels, and identical
+    (src_rowptr / src_slots of gpde_nnconv_bwd, from gpde_csr_source_order) instead of atomics - for both per-edge kernels, and identical
     whether the edges are processed in one chunk or in several (a smaller workspace)."""
     monkeypatch.setenv("GPDE_EDGE_BWD", variant)
     x, ei, ea, ws_, bs_, root, bias, gout = _case([6, 256, 256, 4096], 200, 9000, 5)
@@ -173,7 +173,7 @@ def test_first_hidden_layer_is_not_materialised_and_changes_only_the_dw2_roundin
 
 @pytest.mark.parametrize("cached", [False, True])
 def test_keep_z_forward_feeds_the_backward(cached, monkeypatch):
-    """gpde_nnconv_fwd_keepz / gpde_nnconv_bwd_z (round 3): the forward leaves Z_i = sum_e x_j (x) h_e of every node for the
+    """gpde_nnconv_fwd_keepz / `z_saved` of gpde_nnconv_bwd (round 3): the forward leaves Z_i = sum_e x_j (x) h_e of every node for the
     backward's dW_3 instead of the backward re-aggregating it.  Through the module (direct operator and the hidden-activation
     split): output bit-identical, every gradient within rounding of the path without it and within the tolerance of float64
     autograd; nodes without in-edges and a 2-chunk-sized graph included."""
@@ -223,7 +223,7 @@ def test_keep_z_forward_feeds_the_backward(cached, monkeypatch):
 
 
 def test_gradient_of_the_edge_attributes_matches_float64_autograd():
-    """dL/d edge_attr (gpde_nnconv_bwd_attr): the reference's `pseudo` is an ordinary autograd input (nn_conv.py:273-275);
+    """dL/d edge_attr (`grad_edge_attr` of gpde_nnconv_bwd): the reference's `pseudo` is an ordinary autograd input (nn_conv.py:273-275);
     no script differentiates it, the module does when asked.  Rows go back in the CALLER's edge order; the other gradients
     are the bits of the call without it."""
     import graph_pde_amd as gp

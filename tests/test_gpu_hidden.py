@@ -1,5 +1,5 @@
 """GPU tier, SURVEY.md §8 row f4: the operator split into hidden(edge_attr) -> H and conv(x, H)
-(gpde_hidden_fwd / gpde_nnconv_fwd_hidden / gpde_nnconv_bwd_hidden / gpde_hidden_bwd) against the
+(gpde_hidden_fwd / gpde_nnconv_fwd_hidden / gpde_nnconv_bwd with `hidden` / gpde_hidden_bwd) against the
 float64 oracle, and the per-module reuse policy of graph_pde_amd/hidden_cache.py.  The reference
 pattern being served: one conv module applied `depth` times with the same edge_attr and weights
 (graph-neural-operator/UAI1_full_resolution.py:29-30)."""
@@ -278,7 +278,7 @@ def test_streaming_aggregation_on_split_f16_from_32768_edges():
 
 def test_partial_hidden_cache_and_mixed_forward(monkeypatch):
     """H larger than the budget (391 GB at the 241^2 graph): for inference the in-edges of the leading
-    nodes that fit are cached and gpde_nnconv_fwd_mixed serves those nodes from H, the rest through the
+    nodes that fit are cached and gpde_nnconv_fwd_mixed_keepz serves those nodes from H, the rest through the
     fused kernel.  Same output class as the direct path; a call that needs gradients does not use it."""
     from tests.test_host_logic import DenseNet
     d = dev()

@@ -128,7 +128,7 @@ def _assert_same(ref, cur, what):
 @pytest.mark.parametrize("variant", ["1", "2", "3"])
 @pytest.mark.parametrize("which", ["random_256", "lattice41_1024"])
 def test_backward_is_reproducible_under_memory_pressure(which, variant, monkeypatch):
-    """gpde_nnconv_bwd_ordered, both per-edge kernels, 200 repeats with 1 GiB fills (constants incl. NaN / -3e38, and
+    """gpde_nnconv_bwd (source-ordered grad_x), both per-edge kernels, 200 repeats with 1 GiB fills (constants incl. NaN / -3e38, and
     random data) between calls: every gradient identical to the first call, bit for bit."""
     d = torch.device("cuda:0")
     monkeypatch.setenv("GPDE_EDGE_BWD", variant)
