@@ -297,6 +297,12 @@ def lookup_edge_weights_train(module: torch.nn.Module, hidden: torch.Tensor, csr
         stats["we_hits"] += 1
         return ent.twe
     ent.twe, ent.twe_key, ent.twe_token, ent.twe_h = None, None, None, None
+    # memory of the training form: W_e, one dL/dW_e per application in flight and autograd's running sum of them - 16 KiB per
+    # edge each (the budget bounded W_e only).  When three of them do not fit what is free, the H path runs.
+    free, _ = ops.device_free_bytes(hidden.device)
+    if 3 * csr.n_edges * 4096 * 4 > free:
+        stats["we_train_no_room"] = stats.get("we_train_no_room", 0) + 1
+        return None
     token = HiddenToken()
     try:
         we = EdgeWeightsFunction.apply(hidden, pm, w_last, b_last, token)
