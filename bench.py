@@ -75,8 +75,8 @@ PEAK_HBM_GBS = 8000.0
 # full K-loop model rows of profiles/r03_kloop_model_power.txt: 1.64 - 1.76 PFLOP/s, the clock falling to ~1.6 GHz under a
 # 100 % busy matrix pipe).  Reported NEXT TO `frac` (which stays against the nominal dense peak), never instead of it.
 SUSTAINED_F16_MFMA_TFLOPS = 1700.0
-TRAFFIC_FILE = next((f for f in (os.path.join(REPO, "profiles", f"traffic_r0{k}.json") for k in (4, 3)) if os.path.exists(f)),
-                    os.path.join(REPO, "profiles", "traffic_r04.json"))      # newest committed PMC record of the headline kernel
+TRAFFIC_FILE = next((f for f in (os.path.join(REPO, "profiles", f"traffic_r0{k}.json") for k in (5, 4, 3)) if os.path.exists(f)),
+                    os.path.join(REPO, "profiles", "traffic_r05.json"))      # newest committed PMC record of the headline kernel
 
 
 def log(*a):
@@ -902,7 +902,7 @@ def main():
             f32_bwd = 2 * (2 * 64 * 64 * kwp) * nb_ / max(int(eib.shape[1]), 1)
             bwd_rate = eb_ / tb_med / 1e12
             trec = None
-            tfile = os.path.join(REPO, "profiles", "traffic_r04_bwd.json")
+            tfile = next((f for f in (os.path.join(REPO, "profiles", f"traffic_r0{k}_bwd.json") for k in (5, 4)) if os.path.exists(f)), "")
             if os.path.exists(tfile):
                 try:
                     trec = json.load(open(tfile))
