@@ -150,8 +150,11 @@ def measure_traffic(args, kernel):
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
-            r = subprocess.run(["rocprofv3", "--output-format", "csv", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "run", "--"] + child,
-                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+            try:       # a pass takes ~40 s (import torch + graph build + one step under the counter service); never let it hold the bench
+                r = subprocess.run(["rocprofv3", "--output-format", "csv", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "run", "--"] + child,
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {ctr} pass exceeded 240 s"
             fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not fs:
                 return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stderr[-300:]}"
