@@ -73,9 +73,9 @@ def _floats_after(line, key):
 def test_uai1_full_resolution_runs_unchanged():
     """GKN Darcy: trains at s=61 on cuda, then `model.cpu()` and evaluates at 16 / 31 / 61 on CPU tensors
     (UAI1_full_resolution.py:287-303) - the CPU-tensor staging path."""
-    # ntest=1: the composite arm evaluates s=61 (386 k edges x depth 6 at width 1024) with stock torch ops on the HOST after
-    # `model.cpu()` - 2 test samples made this one test 167 s of the tier's 456 s
-    sets = ["ntrain=2", "ntest=1", "epochs=2"]
+    sets = ["ntrain=2", "ntest=2", "epochs=2"]          # ntest = batch_size2 = 2 (:55,224-226): ONE test batch of two graphs, as the
+    # script forms them - the composite arm evaluates it (s=61: 2 x 386 k edges x depth 6 at width 1024) with stock torch ops on the
+    # HOST after `model.cpu()`, which is most of this test's ~170 s
 
     def numbers(out):
         lines = out.splitlines()
