@@ -883,29 +883,53 @@ def main():
         try:
             eib, eab, nb_ = synth.darcy_graph(121, 0.1, device=dev, seed=0)
             xb = torch.randn(nb_, 64, device=dev, requires_grad=True)
-            tb = []
-            for it in range(4):
-                conv.zero_grad(set_to_none=True)
-                xb.grad = None
-                yb = conv(xb, eib, eab)
-                lossb = yb.square().mean()
-                torch.cuda.synchronize()
-                tq = time.perf_counter()
-                lossb.backward()
-                torch.cuda.synchronize()
-                tb.append(time.perf_counter() - tq)
-            tb_med = sorted(tb[1:])[1]
+
+            def fwd_bwd_pairs(reps):
+                """[(training-forward s, backward s)] of `reps` forward + backward pairs of one NNConv call"""
+                out_ = []
+                for it in range(reps):
+                    conv.zero_grad(set_to_none=True)
+                    xb.grad = None
+                    torch.cuda.synchronize()
+                    tq0 = time.perf_counter()
+                    yb = conv(xb, eib, eab)
+                    lossb = yb.square().mean()
+                    torch.cuda.synchronize()
+                    tq = time.perf_counter()
+                    lossb.backward()
+                    torch.cuda.synchronize()
+                    out_.append((tq - tq0, time.perf_counter() - tq))
+                return out_
+            # the DEFAULT policy (round 5): when 4 KiB per edge fit, the training forward KEEPS the last hidden activations (store
+            # kernel + aggregation from them) and the backward reads them instead of recomputing (ops.keep_hidden) ...
+            kept_h = ops.keep_hidden(ops.csr_for(eib, nb_), [6, kw, kw, 4096], dev)
+            prs = fwd_bwd_pairs(4)
+            tb_med = sorted(t[1] for t in prs[1:])[1]
+            tf_med = sorted(t[0] for t in prs[1:])[1]
+            # ... and the recompute form of rounds 2 - 4 (GPDE_SAVE_H_GB=0: nothing but Z goes from the forward to the backward)
+            save_h0 = ops.SAVE_H_BYTES
+            ops.SAVE_H_BYTES = 0
+            try:
+                prs_r = fwd_bwd_pairs(4)
+            finally:
+                ops.SAVE_H_BYTES = save_h0
+            tbr_med = sorted(t[1] for t in prs_r[1:])[1]
+            tfr_med = sorted(t[0] for t in prs_r[1:])[1]
             eb_ = int(eib.shape[1])
             # executed MFMA work of one backward per edge (3-Linear kernel, split-f16 GEMMs): recompute of H_2 on the forward's
             # kernel (3 x hidden + H1 regeneration), dU_1 and dW_2 (3 x hidden each) and - round 4, gpde_edge_bwd3.hip - the
             # per-edge kernel's two 64 x k2 products (3 MFMAs per product as well) on the f16 pipe; what is left on the fp32
             # pipe is per NODE (dZ = gT . W3, dW_3 = gT^T . Z: 2 x 2 x 64 x 64 x k2 per node; Z comes from the forward: keep-Z)
             kwp = (kw + 127) // 128 * 128
-            f16_bwd = 3 * (3 * 2 * kwp * kwp) + 2 * 2 * 16 * kwp * (kwp // 128) + 2 * (3 * 2 * 64 * kwp)
+            f16_rec = 3 * 2 * kwp * kwp + 2 * 2 * 16 * kwp * (kwp // 128)         # the recompute's share: hidden GEMM + H1 regeneration
+            f16_bwd_r = 3 * (3 * 2 * kwp * kwp) + 2 * 2 * 16 * kwp * (kwp // 128) + 2 * (3 * 2 * 64 * kwp)
+            f16_bwd = f16_bwd_r - (f16_rec if kept_h else 0)
             f32_bwd = 2 * (2 * 64 * 64 * kwp) * nb_ / max(int(eib.shape[1]), 1)
             bwd_rate = eb_ / tb_med / 1e12
             trec = None
-            tfile = next((f for f in (os.path.join(REPO, "profiles", f"traffic_r0{k}_bwd.json") for k in (5, 4)) if os.path.exists(f)), "")
+            tfile = next((f for f in (os.path.join(REPO, "profiles", f"traffic_r05{'k' if kept_h else ''}_bwd.json"),
+                                      os.path.join(REPO, "profiles", "traffic_r05_bwd.json"),
+                                      os.path.join(REPO, "profiles", "traffic_r04_bwd.json")) if os.path.exists(f)), "")
             if os.path.exists(tfile):
                 try:
                     trec = json.load(open(tfile))
@@ -914,6 +938,14 @@ def main():
             alg_bwd = 40.0 * eb_ + 3 * 256.0 * nb_ + 8.0 * sum(p_.numel() for p_ in conv.parameters())
             backward = {"graph": "g121 (N=%d, E=%d)" % (nb_, eb_), "ms": round(1e3 * tb_med, 2),
                         "M_edges_per_s": round(eb_ / tb_med / 1e6, 2),
+                        "hidden_kept_by_forward": bool(kept_h),
+                        "training_forward_ms": round(1e3 * tf_med, 2), "pair_ms": round(1e3 * (tf_med + tb_med), 2),
+                        "recompute_form": {
+                            "ms": round(1e3 * tbr_med, 2), "M_edges_per_s": round(eb_ / tbr_med / 1e6, 2),
+                            "training_forward_ms": round(1e3 * tfr_med, 2), "pair_ms": round(1e3 * (tfr_med + tbr_med), 2),
+                            "frac_f16_peak": round(f16_bwd_r * eb_ / tbr_med / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                            "note": "GPDE_SAVE_H_GB=0: the backward of rounds 2 - 4, H_2 recomputed inside it (one more K loop of the hidden "
+                                    "layer); `ms` above is the default policy - the forward wrote H_2 (4 KiB per edge) and this backward read it"},
                         "roofline": {
                             "bound": "mfma", "pipe": "f16 MFMA (2-term split operands) for the three k1 x k2 products and the per-edge 64 x k2 products; fp32 MFMA for the per-node dZ / dW_3 products",
                             "executed_flop_per_edge": {"f16_mfma": f16_bwd, "fp32_mfma": f32_bwd},
@@ -931,8 +963,11 @@ def main():
                         "grads_finite": bool(torch.isfinite(xb.grad).all()) and
                         all(bool(torch.isfinite(p_.grad).all()) for p_ in conv.parameters()),
                         "arithmetic": "dU_1 and dW_2 GEMMs (gpde_gemm_f16s_nt_kernel) and the per-edge products (gpde_edge_bwd3_kernel) on the "
-                                      "2-term f16 split, recompute of H_2 on the forward's kernel, per-node products fp32 MFMA",
-                        "workspace_GiB": round(ops.bwd_workspace_bytes(_lib.lib(), nb_, eb_, 3, _lib.dims_array([6, kw, kw, 4096]), dev) / 2**30, 1),
+                                      "2-term f16 split, H_2 kept by the forward (or recomputed on the forward's kernel: recompute_form), "
+                                      "per-node products fp32 MFMA",
+                        "workspace_GiB": round(ops.bwd_workspace_bytes(_lib.lib(), nb_, eb_, 3, _lib.dims_array([6, kw, kw, 4096]), dev,
+                                                                       eb_ * kwp * 4 if kept_h else 0) / 2**30, 1),
+                        "kept_hidden_GiB": round(eb_ * kwp * 4 / 2**30, 1) if kept_h else 0.0,
                         "note": "median of 3 timed backward passes after one warm-up; parity of every gradient "
                                 "against float64 autograd: tests/test_gpu_bwd.py, tests/test_gpu_parity.py"}
             # the same backward under the library's DEFAULT workspace plan (~26 GB, ten edge chunks) instead of the one-chunk
@@ -956,7 +991,7 @@ def main():
             finally:
                 ops.BWD_WS_FRACTION = frac0
             log(f"[bench] backward g121: {backward['ms']} ms, {backward['M_edges_per_s']} M-edges/s; default workspace {backward.get('default_workspace_ms')} ms")
-            del eib, eab, xb, yb, lossb
+            del eib, eab, xb, yb, lossb, prs, prs_r
             # ---- the same at the headline size, and BASELINE config 5's per-GPU unit of work: one training step of the
             #      depth-6 GKN on ONE 241^2 sample (UAI1_full_resolution.py:258-273: forward, L1 loss, backward, Adam).
             #      H of this graph is 391 GB (> HBM): nothing is cached, every layer recomputes its hidden chain.
@@ -1077,6 +1112,10 @@ def main():
                                                              "grouped": v_.get("ms_per_forward_grouped")} for k_, v_ in mgkn.items()},
             "mgkn_train_step_ms": None if not mgkn else {k_: {"direct": v_.get("train_step_ms"), "captured": v_.get("train_step_captured_ms")} for k_, v_ in mgkn.items()},
             "backward_g121": None if not backward else {"ms": backward.get("ms"), "M_edges_per_s": backward.get("M_edges_per_s"),
+                                                        "hidden_kept_by_forward": backward.get("hidden_kept_by_forward"),
+                                                        "training_forward_ms": backward.get("training_forward_ms"), "pair_ms": backward.get("pair_ms"),
+                                                        "recompute_form": {k_: backward.get("recompute_form", {}).get(k_) for k_ in
+                                                                           ("ms", "training_forward_ms", "pair_ms", "frac_f16_peak")},
                                                         "default_workspace_ms": backward.get("default_workspace_ms"),
                                                         "frac_f16_peak": backward.get("roofline", {}).get("frac")},
             "g241_depth6_train_step_s": None if not backward or "g241_depth6_train_step" not in backward else

@@ -46,7 +46,19 @@ class NNConvFunction(torch.autograd.Function):
         pm = ops.pack_mlp(weights, biases)
         # training: keep Z for the backward's dW_3 (ops.z_buffer: None when it does not pay / fit)
         ctx.z = ops.z_buffer(csr, pm.dims, x.device) if any(ctx.needs_input_grad) and aggr in ("add", "mean") else None
-        out = ops.nnconv_forward_raw(x.detach(), csr, edge_attr.detach(), pm, root, bias, aggr, z_keep=ctx.z)
+        ctx.h = None
+        if ctx.z is not None and not edge_attr.requires_grad and ops.keep_hidden(csr, pm.dims, x.device):
+            # round 5: the last hidden activations are WRITTEN by the forward (store kernel), aggregated from there, and handed to
+            # the backward, which then does not recompute them (ops.keep_hidden: when 4 KiB per edge fit)
+            try:
+                ctx.h, hmax = ops.hidden_forward_raw(csr, edge_attr.detach(), pm, weights, biases)
+            except torch.OutOfMemoryError:
+                ctx.h = None
+        if ctx.h is not None:
+            ops.n_kept_hidden += 1
+            out = ops.nnconv_forward_hidden_raw(x.detach(), csr, ctx.h, pm, root, bias, aggr, hmax=hmax, z_keep=ctx.z)
+        else:
+            out = ops.nnconv_forward_raw(x.detach(), csr, edge_attr.detach(), pm, root, bias, aggr, z_keep=ctx.z)
         ctx.csr, ctx.aggr, ctx.n_layers = csr, aggr, n_layers
         ctx.has_bias = bias is not None
         ctx.attr_needs_grad = edge_attr.requires_grad
@@ -62,9 +74,9 @@ class NNConvFunction(torch.autograd.Function):
         weights, biases = list(params[:n]), list(params[n:])
         res = ops.nnconv_backward_raw(
             x, ctx.csr, edge_attr, weights, biases, root, ctx.aggr, grad_out,
-            need_root=root is not None, need_bias=ctx.has_bias, z_saved=ctx.z, need_attr=ctx.attr_needs_grad)
+            need_root=root is not None, need_bias=ctx.has_bias, z_saved=ctx.z, need_attr=ctx.attr_needs_grad, hidden_saved=ctx.h)
         gx, gW, gb, groot, gbias = res[:5]
-        ctx.z = None
+        ctx.z = ctx.h = None
         # dL/d edge_attr (round 4): only this direct operator differentiates the attributes - the cached paths step aside for an
         # edge_attr that requires a gradient (hidden_cache.lookup)
         return (gx, None, res[5] if ctx.attr_needs_grad else None, groot, gbias if ctx.has_bias else None, None, None, *gW, *gb)

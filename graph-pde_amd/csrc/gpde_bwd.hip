@@ -712,8 +712,10 @@ struct BwdPlan {
     size_t one_chunk;                 // workspace bytes with which everything is one chunk
 };
 
+// h_given: the last hidden activations of EVERY edge come from the caller (kept by the forward): their per-chunk buffer
+// (KP[n-1] floats per edge) is not part of the workspace - the same bytes hold more edges per chunk
 int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_t ws_bytes, bool sizing,
-                  BwdPlan* P, int n_defer = 0) {
+                  BwdPlan* P, int n_defer = 0, bool h_given = false) {
     if (n_layers < 2 || n_layers > GPDE_MAX_LAYERS) { gpde_set_error("kernel MLP must have 2..%d Linear layers", GPDE_MAX_LAYERS); return GPDE_EUNSUPPORTED; }
     if (dims[n_layers] != GP_W * GP_W) { gpde_set_error("last layer must emit %d values", GP_W * GP_W); return GPDE_EUNSUPPORTED; }
     P->n_layers = n_layers; P->nh = n_layers - 1;
@@ -722,6 +724,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     size_t hsum = P->KP[0];
     for (int l = 1; l < n_layers; ++l) { P->KP[l] = gp_round_up(dims[l], 128); kmax = kmax > P->KP[l] ? kmax : P->KP[l]; hsum += P->KP[l]; }
     P->K2P = P->KP[n_layers - 1];
+    if (h_given) hsum -= P->KP[n_layers - 1];
     size_t off = 0;
     auto take = [&](size_t floats) { size_t o = off; off += al(floats * 4); return o; };
     size_t wmax = 0;
@@ -784,7 +787,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     if (Nc < 1) Nc = 1;
     P->Ec = Ec; P->Nc = Nc;
     P->off_H[0] = take((size_t)Ec * P->KP[0]);
-    for (int l = 1; l < n_layers; ++l) P->off_H[l] = take((size_t)Ec * P->KP[l]);
+    for (int l = 1; l < n_layers; ++l) P->off_H[l] = take(h_given && l == n_layers - 1 ? 1 : (size_t)Ec * P->KP[l]);
     P->off_dU[0] = take((size_t)Ec * kmax); P->off_dU[1] = take((size_t)Ec * kmax);
     P->off_Z = take((size_t)Nc * GP_W * P->K2P); P->off_dZ = take((size_t)Nc * GP_W * P->K2P);
     P->off_gT = take((size_t)Nc * GP_W); P->off_S = take((size_t)Nc * GP_W); P->off_dS = take((size_t)Nc * GP_W);
@@ -1064,7 +1067,8 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     const bool do_conv = phase != BWD_MLP && phase != BWD_DEFER, do_mlp = phase != BWD_CONV && phase != BWD_LIGHT;
     const GpdeSwitches& SW = gpde_switches();       // developer / A-B switches, read once per process (gpde_common.h)
     BwdPlan P;
-    int rc = make_bwd_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P, phase == BWD_DEFER ? n_defer : 0);
+    const bool h_all = phase == BWD_FULL && hpart && hpart_nodes >= n_nodes;     // H of every edge kept by the forward
+    int rc = make_bwd_plan(n_nodes, n_edges, n_layers, dims, ws_bytes, false, &P, phase == BWD_DEFER ? n_defer : 0, h_all);
     if (rc != GPDE_OK) return rc;
     const int n = n_layers, K2P = P.K2P;
     const int N = (int)n_nodes;
@@ -1166,7 +1170,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             else hipLaunchKernelGGL(k_gather_attr, dim3(nblk((size_t)rows * P.KP[0])), dim3(T), 0, st, edge_attr, perm, e0,
                                     rows, dims[0], P.KP[0], F(P.off_H[0]));
         }
-        if (fast_last && last == n - 1 && chunk_h) last = n - 2;
+        if (last == n - 1 && chunk_h) last = n - 2;          // given (partial H of the caller / H kept by the forward): read, not recomputed
         else if (fast_last && last == n - 1 && skip_store) last = n - 2;
         else if (fast_last && last == n - 1) {
             const float* pk = F(P.off_pack);
@@ -1549,12 +1553,17 @@ extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edg
         return GPDE_EINVAL;
     }
     if (aggr != GPDE_AGGR_ADD && aggr != GPDE_AGGR_MEAN) { gpde_set_error("gpde_nnconv_bwd: aggr %d", aggr); return GPDE_EUNSUPPORTED; }
-    if ((hidden && node_attr) || (grad_edge_attr && (hidden || node_attr))) {
+    // `hidden` TOGETHER with an attribute source and no grad_hidden: the FULL backward with the last hidden activations kept by the
+    // forward (gpde_hidden_fwd + gpde_nnconv_fwd_keepz(hidden)) - read where they would be recomputed (round 5)
+    const bool h_kept = hidden && !grad_hidden && (node_attr || (edge_attr && perm));
+    if ((hidden && !h_kept && node_attr) || (grad_edge_attr && (hidden || node_attr))) {
         gpde_set_error("gpde_nnconv_bwd: one attribute source (edge_attr + perm | node_attr | hidden); grad_edge_attr needs the tensor");
         return GPDE_EINVAL;
     }
     hipStream_t st = (hipStream_t)stream_;
-    if (hidden) {
+    const float* hk = h_kept ? hidden : nullptr;
+    const int64_t hk_nodes = h_kept ? n_nodes : 0;
+    if (hidden && !h_kept) {
         if (n_edges > 0 && !grad_hidden) { gpde_set_error("gpde_nnconv_bwd: grad_hidden is null"); return GPDE_EINVAL; }
         return bwd_impl(BWD_CONV, x, n_nodes, nullptr, n_edges, rowptr, src, dst, nullptr, rowptr_host, n_layers, dims, W, b, root,
                         aggr, grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, hidden, grad_hidden, nullptr, ws, ws_bytes,
@@ -1564,12 +1573,12 @@ extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edg
         if (!na_ok(node_attr, dims, "gpde_nnconv_bwd")) return GPDE_EINVAL;
         return bwd_impl(BWD_FULL, x, n_nodes, node_attr->table, n_edges, rowptr, src, dst, nullptr, rowptr_host, n_layers, dims, W, b, root,
                         aggr, grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes, st,
-                        src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, nullptr, 0, node_attr->stride, node_attr->sel);
+                        src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, hk, hk_nodes, node_attr->stride, node_attr->sel);
     }
     if (n_edges > 0 && (!edge_attr || !perm)) { gpde_set_error("gpde_nnconv_bwd: edge_attr / perm is null"); return GPDE_EINVAL; }
     return bwd_impl(BWD_FULL, x, n_nodes, edge_attr, n_edges, rowptr, src, dst, perm, rowptr_host, n_layers, dims, W, b, root, aggr,
                     grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, nullptr, nullptr, nullptr, ws, ws_bytes, st,
-                    src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, n_edges > 0 ? grad_edge_attr : nullptr);
+                    src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, hk, hk_nodes, 0, nullptr, n_edges > 0 ? grad_edge_attr : nullptr);
 }
 
 // ---- depth-deferred backward: a module applied `depth` times with the same edge_attr and weights ----------------------

@@ -437,12 +437,14 @@ def workspace_bytes(n_nodes: int, n_edges: int, pm: PackedMlp) -> int:
 
 SAVE_Z_BYTES = int(float(os.environ.get("GPDE_SAVE_Z_GB", "16")) * (1 << 30))     # per call; 0 disables
 SAVE_Z_RESERVE_BYTES = int(float(os.environ.get("GPDE_SAVE_Z_RESERVE_GB", "48")) * (1 << 30))   # device memory left free by a kept Z
+SAVE_H_BYTES = int(float(os.environ.get("GPDE_SAVE_H_GB", "32")) * (1 << 30))     # kept hidden activations per call (keep_hidden); 0 disables
+SAVE_H_MIN_EDGES = 262144                                                          # below: one fused launch beats store + aggregation
 
 
 BWD_WS_FRACTION = float(os.environ.get("GPDE_BWD_WS_FRACTION", "0.6"))      # of the free device memory a full backward's workspace may take
 
 
-def bwd_workspace_bytes(lib, n: int, e: int, nl: int, dims_c, dev) -> int:
+def bwd_workspace_bytes(lib, n: int, e: int, nl: int, dims_c, dev, h_given_bytes: int = 0) -> int:
     """Workspace of a full backward (gpde_nnconv_bwd*): the library's default (~26 GB at k = 1024: node-aligned chunks of
     ~640 k edges), or its one-chunk size when that is below GPDE_BWD_WS_FRACTION of what the device has free - one chunk =
     fewer launches, GEMM tile rounds and split-K reductions (s=121, 5.9 M edges: 139.4 -> 135.5 ms).  All or nothing: sizes
@@ -453,7 +455,9 @@ def bwd_workspace_bytes(lib, n: int, e: int, nl: int, dims_c, dev) -> int:
     if nbytes == 0:
         _lib.check(-2, "gpde_nnconv_bwd_workspace_bytes")
     if BWD_WS_FRACTION > 0:
-        one = int(lib.gpde_nnconv_bwd_workspace_bytes_one_chunk(n, e, nl, dims_c))
+        # (`h_given_bytes`: the last hidden activations come from the forward - gpde_nnconv_bwd's plan then leaves their
+        # per-chunk buffer, E * K2P * 4 bytes in one chunk, out of the workspace)
+        one = int(lib.gpde_nnconv_bwd_workspace_bytes_one_chunk(n, e, nl, dims_c)) - int(h_given_bytes)
         free, _ = device_free_bytes(dev)
         if nbytes < one <= int(BWD_WS_FRACTION * free):
             nbytes = one
@@ -469,12 +473,12 @@ def device_free_bytes(dev):
     return free + max(0, cached), total
 
 
-def alloc_bwd_ws(lib, n: int, e: int, nl: int, dims_c, dev) -> torch.Tensor:
+def alloc_bwd_ws(lib, n: int, e: int, nl: int, dims_c, dev, h_given_bytes: int = 0) -> torch.Tensor:
     """Workspace of a full backward.  The one-chunk size (`bwd_workspace_bytes`) is an optimisation worth ~3 %: its estimate of
     the free memory is racy (other ranks / processes on the device, torch's cached blocks), so when that allocation fails the
     library's default plan (~26 GB) is taken instead - BEFORE any cache is dropped; only the default size goes through
     `_alloc_ws`'s release-and-retry (a run that fitted with the default plan must keep fitting)."""
-    nbytes = bwd_workspace_bytes(lib, n, e, nl, dims_c, dev)
+    nbytes = bwd_workspace_bytes(lib, n, e, nl, dims_c, dev, h_given_bytes)
     default = int(lib.gpde_nnconv_bwd_workspace_bytes(n, e, nl, dims_c))
     if nbytes > default:
         try:
@@ -485,6 +489,7 @@ def alloc_bwd_ws(lib, n: int, e: int, nl: int, dims_c, dev) -> torch.Tensor:
     return _alloc_ws(default, dev)
 
 
+n_kept_hidden = 0           # training forwards that kept their last hidden activations for the backward (keep_hidden; tests)
 n_bwd_ws_fallbacks = 0      # times the one-chunk workspace did not fit and the default plan ran (tests / diagnostics)
 
 
@@ -523,6 +528,22 @@ def z_buffer(csr: Csr, dims: Sequence[int], device) -> Optional[torch.Tensor]:
         return torch.zeros(csr.n_nodes, WIDTH * hidden_width(dims), dtype=torch.float32, device=device)
     except torch.OutOfMemoryError:       # keeping Z is an optimisation: without it the backward re-aggregates
         return None
+
+
+def keep_hidden(csr: Csr, dims: Sequence[int], device) -> bool:
+    """Whether a training forward should KEEP the last hidden activations H_2 [E, K2P] (4 KiB per edge at k2 = 1024) for its own
+    backward (round 5): forward = store kernel + aggregation from H (gpde_hidden_fwd, gpde_nnconv_fwd_keepz(hidden)), backward =
+    gpde_nnconv_bwd with `hidden` - the hidden layer's K loop runs once per step instead of twice (s=121: forward 34.8 -> ~41 ms,
+    backward 137 -> ~105 ms).  Only 3-Linear kernel MLPs on the split-f16 store kernel, graphs large enough for two launches not
+    to matter, tensors up to GPDE_SAVE_H_GB (default 32) and only while GPDE_SAVE_Z_RESERVE_GB of the device stay free
+    afterwards (the backward's workspace needs the room; keeping H is an optimisation)."""
+    nbytes = csr.n_edges * hidden_width(dims) * 4
+    if SAVE_H_BYTES <= 0 or nbytes > SAVE_H_BYTES or len(dims) != 4 or csr.n_edges < SAVE_H_MIN_EDGES or \
+            DEFAULT_PRECISION != "f16split" or not 1 <= dims[0] <= 8 or (int(dims[1]) + 31) // 32 < 8 or \
+            csr.n_edges < 32 * csr.n_nodes:          # (>= 8 k1 chunks: the one-wave-per-SIMD store kernel; low in-degree: §3e's path)
+        return False
+    free, _ = device_free_bytes(device)
+    return free - nbytes >= SAVE_Z_RESERVE_BYTES
 
 
 def _check_residual(residual, x, n):
@@ -732,8 +753,10 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
                         weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
                         root: Optional[torch.Tensor], aggr: str, grad_out: torch.Tensor,
                         need_root: bool = True, need_bias: bool = True,
-                        ws: Optional[torch.Tensor] = None, z_saved: Optional[torch.Tensor] = None, need_attr: bool = False):
-    """One gpde_nnconv_bwd call on the current stream (`z_saved`: the keep-Z forward's buffer; `edge_attr`: a tensor or a NodeAttr).
+                        ws: Optional[torch.Tensor] = None, z_saved: Optional[torch.Tensor] = None, need_attr: bool = False,
+                        hidden_saved: Optional[torch.Tensor] = None):
+    """One gpde_nnconv_bwd call on the current stream (`z_saved`: the keep-Z forward's buffer; `edge_attr`: a tensor or a NodeAttr;
+    `hidden_saved`: the last hidden activations [E, K2P] the forward kept (hidden_forward_raw) - read instead of recomputed).
     Returns (grad_x, [grad_W_l], [grad_b_l or None], grad_root or None, grad_bias or None); with `need_attr` a sixth element,
     dL/d edge_attr [E, k0] in the caller's edge order (`grad_edge_attr` of the call)."""
     lib = _lib.lib()
@@ -765,15 +788,18 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
     P = ctypes.c_void_p
     arr = lambda ts: (P * nl)(*[None if t is None else t.data_ptr() for t in ts])
     if ws is None:
-        ws = alloc_bwd_ws(lib, n, e, nl, dims_c, dev)
+        ws = alloc_bwd_ws(lib, n, e, nl, dims_c, dev, 0 if hidden_saved is None else e * hidden_width(dims) * 4)
     rph = csr.rowptr_host
     srp, ssl = csr.src_order
     p = lambda t: None if t is None else t.data_ptr()
     nas = edge_attr.c_struct() if is_na else None
     ga = torch.zeros(e, dims[0], dtype=torch.float32, device=dev) if need_attr else None
+    if hidden_saved is not None and (need_attr or hidden_saved.dtype != torch.float32 or not hidden_saved.is_contiguous() or
+                                     tuple(hidden_saved.shape) != (e, hidden_width(dims))):
+        raise ValueError(f"hidden_saved must be contiguous float32 [{e},{hidden_width(dims)}] (and excludes need_attr)")
     with torch.cuda.device(dev):
         rc = lib.gpde_nnconv_bwd(x.data_ptr(), n, None if is_na else edge_attr.data_ptr(), None if nas is None else ctypes.byref(nas),
-                                 None, e, csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), None if is_na else perm.data_ptr(),
+                                 p(hidden_saved), e, csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), None if is_na else perm.data_ptr(),
                                  rph.data_ptr(), p(srp), p(ssl), nl, dims_c, arr(ws_), arr(bs_), p(root_c), _AGGR[aggr],
                                  grad_out.data_ptr(), p(z_saved), gx.data_ptr(), None, p(ga), arr(gW), arr(gb), p(groot), p(gbias),
                                  ws.data_ptr(), ws.numel(), _stream_ptr(dev))

@@ -216,7 +216,11 @@ GPDE_API int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_
  *   attribute source   edge_attr + perm (tensor, caller's edge order) | node_attr (node data) | hidden (the last hidden
  *                      activations given, [CSR slot][K2P], e.g. from gpde_hidden_fwd: only x, the LAST Linear (W / b / grad_W /
  *                      grad_b carry their last entries), root and bias are differentiated, and dL/dU of the last hidden layer
- *                      is written to grad_hidden [CSR slot][K2P] for gpde_hidden_bwd).  Exactly one of the three.
+ *                      is written to grad_hidden [CSR slot][K2P] for gpde_hidden_bwd).  Exactly one of the three - except:
+ *   hidden + an attribute source, grad_hidden == NULL   the FULL backward (every layer differentiated) with the last hidden
+ *                      activations KEPT BY THE FORWARD (gpde_hidden_fwd, then gpde_nnconv_fwd_keepz on them): read where they would
+ *                      be recomputed - the K loop of the hidden layer runs once per training step instead of twice, for 4 KiB
+ *                      per edge of memory between forward and backward (the host mirror keeps them when they fit, GPDE_SAVE_H_GB).
  *   src_rowptr, src_slots  nullable: the CSR slots regrouped by source node (gpde_csr_source_order) - grad_x is then summed per
  *                      source in slot order, bit-reproducible and independent of the chunking; NULL: fp32 atomics.
  *   z_saved            nullable: the Z buffer of gpde_nnconv_fwd_keepz / _mixed_keepz - dW_3 is taken from it.

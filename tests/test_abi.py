@@ -188,8 +188,9 @@ def test_argument_validation_without_gpu():
     one = (ctypes.c_void_p * 3)()
     buf = ctypes.create_string_buffer(64)
     assert l.gpde_nnconv_bwd(None, 0, None, ctypes.byref(na), buf, 0, buf, None, None, None, buf, None, None, 3, d3, one, one, None, 1, buf,
-                             None, None, None, None, one, one, None, None, buf, 64, None) == -1
+                             None, None, buf, None, one, one, None, None, buf, 64, None) == -1
     assert b"one attribute source" in l.gpde_last_error()
+    # (hidden + an attribute source WITHOUT grad_hidden is the full backward with the forward's kept activations - legal)
     assert l.gpde_hidden_workspace_bytes(1000, 3, d3) > 0 and l.gpde_hidden_workspace_bytes(-1, 3, d3) == 0
 
 
