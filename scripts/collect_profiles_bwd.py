@@ -22,7 +22,10 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(REPO, "gpurun_out", f"prof_{tag}_bwd")
 out = os.path.join(REPO, "profiles")
 PASSES = 3                         # forward + backward pairs of scripts/time_bwd.py
-FWD_ONLY = ("gpde_fused_f16v6_kernel<false", "gpde_gemm3_kernel", "gpde_epilogue_kernel", "k_block_bounds", "k_absmax_x", "k_attr_bound", "k_split_x")
+FWD_ONLY = ("gpde_fused_f16v6_kernel<false", "gpde_fused_f16v6_kernel<0", "gpde_gemm3_kernel", "gpde_epilogue_kernel", "k_block_bounds", "k_absmax_x",
+            "k_attr_bound", "k_split_x")
+if "--kept-h" in sys.argv:      # round 5: the training forward wrote H_2 (store kernel) and aggregated from it - those launches are the forward's
+    FWD_ONLY += ("gpde_fused_f16v6_kernel<1", "gpde_zagg_kernel")
 
 
 def sym(name):
