@@ -548,3 +548,41 @@ def test_backward_workspace_is_one_chunk_or_the_default_never_in_between(monkeyp
     # the headline graph: one chunk (2.4 TB) never fits - default
     g_small = int(lib.gpde_nnconv_bwd_workspace_bytes(58081, 95539625, 3, dims_c))
     assert ops.bwd_workspace_bytes(lib, 58081, 95539625, 3, dims_c, None) == g_small
+
+
+def test_keep_hidden_policy_and_its_workspace_host_logic(monkeypatch):
+    """ops.keep_hidden (round 5: when a training forward keeps the last hidden activations for its own backward) and the
+    one-chunk workspace of that backward, which leaves the kept tensor's bytes out - pure host logic."""
+    from graph_pde_amd import _lib, ops
+    n, e = 14641, 5931137                                            # the s=121 graph: 24.3 GB of H_2 at k2 = 1024
+    z32 = torch.zeros(1, dtype=torch.int32)
+    csr = ops.Csr(n, e, z32, z32, z32, z32)
+    dims = [6, 1024, 1024, 4096]
+    monkeypatch.setattr(ops, "DEFAULT_PRECISION", "f16split")
+    monkeypatch.setattr(ops, "SAVE_H_BYTES", 32 << 30)
+    monkeypatch.setattr(ops, "SAVE_Z_RESERVE_BYTES", 48 << 30)
+    monkeypatch.setattr(ops, "device_free_bytes", lambda dev: (250 << 30, 288 << 30))
+    assert ops.keep_hidden(csr, dims, None)
+    assert not ops.keep_hidden(csr, [6, 1024, 4096], None)                       # 2-Linear: no store kernel of that form
+    assert not ops.keep_hidden(csr, [6, 128, 1024, 4096], None)                  # < 8 first-layer chunks: the 8-wave kernel's shape
+    assert not ops.keep_hidden(csr, [9, 1024, 1024, 4096], None)                 # > 8 attribute slots
+    assert not ops.keep_hidden(ops.Csr(n, 200000, z32, z32, z32, z32), dims, None)            # two launches instead of one do not pay
+    assert not ops.keep_hidden(ops.Csr(400000, e, z32, z32, z32, z32), dims, None)            # mean in-degree < 32: §3e's path
+    assert not ops.keep_hidden(ops.Csr(58081, 95539625, z32, z32, z32, z32), dims, None)      # the headline graph: 391 GB
+    monkeypatch.setattr(ops, "device_free_bytes", lambda dev: (70 << 30, 288 << 30))          # 70 - 24.3 < 48 GB reserve
+    assert not ops.keep_hidden(csr, dims, None)
+    monkeypatch.setattr(ops, "device_free_bytes", lambda dev: (250 << 30, 288 << 30))
+    monkeypatch.setattr(ops, "SAVE_H_BYTES", 0)
+    assert not ops.keep_hidden(csr, dims, None)
+    monkeypatch.setattr(ops, "DEFAULT_PRECISION", "f32")
+    monkeypatch.setattr(ops, "SAVE_H_BYTES", 32 << 30)
+    assert not ops.keep_hidden(csr, dims, None)
+    # the backward's one-chunk workspace with H given: smaller by exactly the tensor
+    lib = _lib.lib()
+    dims_c = _lib.dims_array(dims)
+    one = int(lib.gpde_nnconv_bwd_workspace_bytes_one_chunk(n, e, 3, dims_c))
+    hb = e * 1024 * 4
+    monkeypatch.setattr(ops, "BWD_WS_FRACTION", 0.6)
+    monkeypatch.setattr(ops, "device_free_bytes", lambda dev: (int((one - hb) / 0.6) + (1 << 20), 288 << 30))
+    assert ops.bwd_workspace_bytes(lib, n, e, 3, dims_c, None, hb) == one - hb          # fits only because H is left out
+    assert ops.bwd_workspace_bytes(lib, n, e, 3, dims_c, None) == int(lib.gpde_nnconv_bwd_workspace_bytes(n, e, 3, dims_c))
