@@ -7,8 +7,9 @@ case here, at the reference's own training resolution: every gradient the native
 application, the three Linear layers, root, bias - against float64 autograd through the oracle
 (`oracle.nnconv_grads_shared`, pinned on CPU to the sum of per-application `nnconv_grads`, themselves pinned to the
 reference's own module), for
-  * the single-call backward in its default plan (split-f16 dU_1 / dW_2 GEMMs, on-the-fly H_1, the one-pass / per-edge kernels'
-    by-products; one chunk) through the module's autograd (keep-Z forward),
+  * the single-call backward in its default plan (split-f16 dU_1 / dW_2 GEMMs, on-the-fly H_1, the per-edge kernel's
+    by-products; one chunk) through the module's autograd - keep-Z forward that, since the second half of round 5, also KEEPS the
+    last hidden activations for the backward (ops.keep_hidden: this graph has 380 k edges; tests/test_gpu_keep_hidden.py),
   * the same with a workspace that forces several node / edge chunks,
   * the light + depth-deferred pair (gpde_nnconv_bwd_light x 6, gpde_nnconv_bwd_deferred x 1).
 The graph is the lattice minus the ~1 % of edges with a hidden pre-activation on the ReLU kink (tests/helpers/kinks.py): masks
