@@ -22,6 +22,7 @@ GPDE_FWD_DEFAULT, GPDE_FWD_F16SPLIT = 0, 1
 # the other forward flags of include/gpde.h (A/B switches; tests/test_abi.py checks these values against the header)
 GPDE_FWD_F16SPLIT_8WAVE, GPDE_FWD_STATIC_RANGES, GPDE_FWD_AGG_F16, GPDE_FWD_AGG_F32, GPDE_FWD_NO_EDGE_PATH = 2, 4, 16, 32, 64
 GPDE_WIDTH = 64
+GPDE_BWD_ACCUMULATE_GRAD_HIDDEN = 1        # gpde_nnconv_bwd `flags` (tests/test_abi.py checks the value against the header)
 
 class GpdeWeConvDesc(ctypes.Structure):
     """include/gpde.h `GpdeWeConvDesc`: one NNConv call given its per-edge weights (tests/test_abi.py checks the layout)."""

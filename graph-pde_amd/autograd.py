@@ -15,6 +15,8 @@ them, and that ONE gpde_nnconv_bwd_deferred pass forms the hidden layers' gradie
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -33,6 +35,10 @@ def _save_attr(ctx, edge_attr):
 
 def _saved_attr(ctx, t):
     return t if ctx.node_attr is None else ctx.node_attr
+
+
+# dL/dH of the applications of a module sharing H: summed inside the per-edge kernel (NNConvHiddenFunction.backward) unless "0"
+ACCUMULATE_GRAD_HIDDEN = os.environ.get("GPDE_ACCUMULATE_DLDH", "1") != "0"
 
 
 class NNConvFunction(torch.autograd.Function):
@@ -85,11 +91,14 @@ class NNConvFunction(torch.autograd.Function):
 class HiddenToken:
     """Validity flag shared between a cached H and its autograd node: once the node's backward has
     run, the graph behind H is gone and the cached tensor must not be reused for a new forward."""
-    __slots__ = ("valid", "hmax")
+    __slots__ = ("valid", "hmax", "gh_acc", "gh_tid", "gh_adds")
 
     def __init__(self):
         self.valid = True
         self.hmax = None        # device scalar max |H| when the fused kernel recorded it
+        self.gh_acc = None      # the running sum of dL/dH of the applications of ONE backward pass (NNConvHiddenFunction.backward)
+        self.gh_tid = -1        # ... and that pass (autograd graph task id)
+        self.gh_adds = 0        # ... and how many applications added to it in place
 
 
 class HiddenFunction(torch.autograd.Function):
@@ -112,7 +121,15 @@ class HiddenFunction(torch.autograd.Function):
         if ctx.attr_needs_grad:
             raise NotImplementedError(
                 "gradient with respect to edge_attr is not built (no reference script needs it)")
-        ctx.token.valid = False
+        tok = ctx.token
+        tok.valid = False
+        if tok.gh_acc is not None and tok.gh_adds > 0 and hasattr(torch._C, "_current_graph_task_id") and \
+                tok.gh_tid == torch._C._current_graph_task_id() and grad_h.data_ptr() != tok.gh_acc.data_ptr():
+            # applications added their dL/dH in place to the tensor the first one returned - and autograd hands over another one
+            # (a second kind of consumer of H contributed and the sum was formed out of place): those additions are not in grad_h
+            raise RuntimeError("graph_pde_amd: the in-place sum of dL/dH lost its buffer (H has a consumer outside NNConvHiddenFunction); "
+                               "set GPDE_ACCUMULATE_DLDH=0")
+        tok.gh_acc, tok.gh_adds = None, 0   # (grad_h IS that buffer when the applications summed in place: held by autograd from here)
         edge_attr, *params = ctx.saved_tensors
         edge_attr = _saved_attr(ctx, edge_attr)
         n = ctx.n_hidden
@@ -125,10 +142,11 @@ class NNConvHiddenFunction(torch.autograd.Function):
     gpde_nnconv_bwd in its `hidden` form)."""
 
     @staticmethod
-    def forward(ctx, x, hidden, csr, pm, w_last, b_last, root, bias, aggr, hmax=None):
+    def forward(ctx, x, hidden, csr, pm, w_last, b_last, root, bias, aggr, hmax=None, token=None):
         ctx.z = ops.z_buffer(csr, pm.dims, x.device) if any(ctx.needs_input_grad) else None
         out = ops.nnconv_forward_hidden_raw(x.detach(), csr, hidden.detach(), pm, root, bias, aggr, hmax=hmax, z_keep=ctx.z)
         ctx.csr, ctx.dims, ctx.aggr = csr, tuple(pm.dims), aggr
+        ctx.token = token           # the HiddenToken of the shared H (None: H is the caller's own tensor)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, hidden, w_last, b_last, root)
         return out
@@ -137,11 +155,29 @@ class NNConvHiddenFunction(torch.autograd.Function):
     @once_differentiable        # the native backward is not itself differentiable: create_graph=True raises
     def backward(ctx, grad_out):
         x, hidden, w_last, b_last, root = ctx.saved_tensors
+        # The applications of a module that shares H each produce dL/dH [E, K2P]; autograd would keep the first and add the others
+        # to it one by one (at s=61, depth 6: 4 of a 38 ms step; at s=121 five 72 GB passes).  Here the first application of a
+        # backward pass hands autograd its tensor and remembers it on the H token; the others ADD to it inside the per-edge
+        # kernel (same additions, same order: the same bits) and return nothing.  Keyed on the autograd graph task: a new
+        # backward pass (retain_graph, a checkpointed segment, a pass abandoned half way) always starts a new tensor.
+        tok, acc, tid = ctx.token, None, -1
+        share = tok is not None and ACCUMULATE_GRAD_HIDDEN and ctx.needs_input_grad[1] and \
+            ctx.csr.n_edges >= 32 * ctx.csr.n_nodes and hasattr(torch._C, "_current_graph_task_id")
+        if share:
+            tid = torch._C._current_graph_task_id()
+            if tid >= 0 and tok.gh_acc is not None and tok.gh_tid == tid and tok.gh_acc.shape == hidden.shape:
+                acc = tok.gh_acc
         gx, gh, gw, gb, groot, gbias = ops.nnconv_backward_hidden_raw(
             x, ctx.csr, hidden, ctx.dims, w_last, b_last, root, ctx.aggr, grad_out,
-            need_root=root is not None, need_bias=ctx.has_bias, z_saved=ctx.z)
+            need_root=root is not None, need_bias=ctx.has_bias, z_saved=ctx.z, grad_hidden_acc=acc)
         ctx.z = None
-        return (gx, gh, None, None, gw, gb, groot, gbias if ctx.has_bias else None, None, None)
+        if acc is not None:
+            gh = None                       # added in place to the tensor the first application returned
+            tok.gh_adds += 1
+            ops.n_grad_hidden_accumulated += 1
+        elif share and tid >= 0:
+            tok.gh_acc, tok.gh_tid, tok.gh_adds = gh, tid, 0
+        return (gx, gh, None, None, gw, gb, groot, gbias if ctx.has_bias else None, None, None, None)
 
 
 class DeferredToken:

@@ -1058,7 +1058,9 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
              size_t ws_bytes, hipStream_t st, const int32_t* src_rowptr = nullptr, const int32_t* src_slots = nullptr,
              const float* z_saved = nullptr, int n_defer = 0, const float* x_stack = nullptr, const float* g_stack = nullptr,
              const float* hpart = nullptr, int64_t hpart_nodes = 0, int kt = 0, const int32_t* sel = nullptr,
-             float* grad_attr = nullptr) {
+             float* grad_attr = nullptr, bool gh_accumulate = false) {
+    // gh_accumulate (BWD_CONV): dL/dU of the last hidden layer is ADDED to grad_hidden_out (the applications of a module sharing its
+    // hidden activations sum it there, in call order - the same additions autograd would make with six [E][K2P] tensors)
     // grad_attr (BWD_FULL, tensor attributes of <= 8 slots): [E][k0] in the CALLER's edge order, dL/d edge_attr
     // kt > 0: `edge_attr` is a NODE table [n_nodes][kt] and slot d of an edge's attribute is table[(sel[d] >> 8 ? dst : src)][sel[d] & 255]
     // (row f3: GpdeNodeAttr); perm is unused
@@ -1464,11 +1466,14 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 if (!dx) { gpde_set_error("gpde_nnconv_bwd: grad_x must be provided"); return GPDE_EINVAL; }
                 // staged kernel where a 128-slot group rarely spans more than two destinations
                 const int force = SW.edge_bwd;                     // GPDE_EDGE_BWD = 1 / 2 / 3: force a variant (tests, A/B)
-                const bool staged = force ? force >= 2 : (int64_t)rows >= (int64_t)32 * nn;
+                // (accumulating dL/dU lives in the split-f16 kernel: it is correct for any in-degree, the host asks for it on dense graphs)
+                const bool gh_acc = gh_accumulate && phase == BWD_CONV;
+                const bool staged = force ? force >= 2 : (gh_acc || (int64_t)rows >= (int64_t)32 * nn);
                 du_pre = false;
                 if (staged && force != 2 && K2P % 32 == 0) {      // split-f16 MFMA (default); GPDE_EDGE_BWD=2: the fp32-MFMA staged kernel
                     if ((rc = gpde_launch_dz_split(dZ, nn, K2P, F(P.off_dzun), st)) != GPDE_OK) return rc;
                     GpdeEdgeBwd3Args e3{x, src, dst, dZ, F(P.off_dzun), dS, Hlast, dUc, dx, ordered ? F(P.off_dxe) : nullptr, e0, e1, na, K2P};
+                    e3.du_accumulate = gh_acc;
                     // full backward on the split GEMMs: the kernel also leaves what the dW_2 GEMM's pass over dU_2 would form
                     // (mlp_backward's tn_split && du_one_pass case; GPDE_BWD_DU_TRANSPOSE_PASS=1: that pass, A/B)
                     if (phase == BWD_FULL && n == 3 && f16s_dw2 && f16s_du1 && rows >= 8192 && !SW.bwd_du_passes &&
@@ -1479,6 +1484,10 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                         du_pre = true;
                     }
                     if ((rc = gpde_launch_edge_bwd3(e3, st)) != GPDE_OK) return rc;
+                } else if (gh_acc) {
+                    gpde_set_error("gpde_nnconv_bwd: GPDE_BWD_ACCUMULATE_GRAD_HIDDEN is built into the split-f16 per-edge kernel only "
+                                   "(GPDE_EDGE_BWD=2 forces the other one)");
+                    return GPDE_EUNSUPPORTED;
                 } else if (staged) hipLaunchKernelGGL(gpde_edge_bwd2_kernel, dim3(((rows + 127) / 128 + 7) / 8 * 8), dim3(T), lds2, st, ea);
                 else hipLaunchKernelGGL(gpde_edge_bwd_kernel, dim3((rows + 127) / 128), dim3(T), lds, st, ea);
                 if (ordered) hipLaunchKernelGGL(k_dx_reduce, dim3((N + 3) / 4), dim3(T), 0, st, F(P.off_dxe), src_rowptr, src_slots, N, e0, e1, dx, 1, (size_t)0);
@@ -1546,7 +1555,7 @@ extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edg
                                int n_layers, const int32_t* dims, const float* const* W, const float* const* b, const float* root,
                                int aggr, const float* grad_out, const float* z_saved, float* grad_x, float* grad_hidden,
                                float* grad_edge_attr, float* const* grad_W, float* const* grad_b, float* grad_root,
-                               float* grad_bias, void* ws, size_t ws_bytes, void* stream_) {
+                               float* grad_bias, uint32_t flags, void* ws, size_t ws_bytes, void* stream_) {
     if (n_nodes < 0 || n_edges < 0 || !dims || !W || !b || !grad_out || !rowptr || !rowptr_host || !ws || !grad_W || !grad_b ||
         n_layers < 2 || n_layers > GPDE_MAX_LAYERS || (n_nodes > 0 && (!x || !grad_x)) || (n_edges > 0 && (!src || !dst))) {
         gpde_set_error("gpde_nnconv_bwd: null/negative argument");
@@ -1560,6 +1569,10 @@ extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edg
         gpde_set_error("gpde_nnconv_bwd: one attribute source (edge_attr + perm | node_attr | hidden); grad_edge_attr needs the tensor");
         return GPDE_EINVAL;
     }
+    if ((flags & GPDE_BWD_ACCUMULATE_GRAD_HIDDEN) && !(hidden && !h_kept)) {
+        gpde_set_error("gpde_nnconv_bwd: GPDE_BWD_ACCUMULATE_GRAD_HIDDEN belongs to the `hidden` form (grad_hidden given)");
+        return GPDE_EINVAL;
+    }
     hipStream_t st = (hipStream_t)stream_;
     const float* hk = h_kept ? hidden : nullptr;
     const int64_t hk_nodes = h_kept ? n_nodes : 0;
@@ -1567,7 +1580,8 @@ extern "C" int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edg
         if (n_edges > 0 && !grad_hidden) { gpde_set_error("gpde_nnconv_bwd: grad_hidden is null"); return GPDE_EINVAL; }
         return bwd_impl(BWD_CONV, x, n_nodes, nullptr, n_edges, rowptr, src, dst, nullptr, rowptr_host, n_layers, dims, W, b, root,
                         aggr, grad_out, grad_x, grad_W, grad_b, grad_root, grad_bias, hidden, grad_hidden, nullptr, ws, ws_bytes,
-                        st, src_rowptr, src_slots, z_saved);
+                        st, src_rowptr, src_slots, z_saved, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr,
+                        (flags & GPDE_BWD_ACCUMULATE_GRAD_HIDDEN) != 0);
     }
     if (node_attr) {
         if (!na_ok(node_attr, dims, "gpde_nnconv_bwd")) return GPDE_EINVAL;

@@ -335,6 +335,7 @@ struct GpdeEdgeBwd3Args {
     float* dUt; int ldt;        // transposed copy [K2P][ldt], column e - e0 (columns >= e1 - e0 are the caller's to zero)
     float* row_sc; float* row_isc;               // [e1 - e0] 2^(13 - E(max_n |dU[e][n]|)) and its reciprocal
     float* csum_part; unsigned* cmax_part;       // [(e1 - e0 + 31) / 32][K2P] per 32-slot tile: column sums, column max bits
+    int du_accumulate;          // dU += instead of dU = (no by-products then): the applications of a module sharing H sum dL/dU in place
 };
 int gpde_launch_dz_split(float* dZ, int nn, int K2P, float* unscale, hipStream_t stream);
 int gpde_launch_edge_bwd3(const GpdeEdgeBwd3Args& a, hipStream_t stream);

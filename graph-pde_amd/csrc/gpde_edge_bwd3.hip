@@ -108,7 +108,9 @@ __global__ __launch_bounds__(256) void k_dz_split(float* __restrict__ dZ, int ro
 }
 
 // ---- the edge kernel ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void gpde_edge_bwd3_kernel(GpdeEdgeBwd3Args a) {
+// ACC: dU is ACCUMULATED into (dU[e][n] += ...) instead of written - the `depth` applications of a module that shares its hidden
+// activations sum their dL/dU there (autograd.NNConvHiddenFunction; otherwise autograd adds six [E][K2P] tensors out of the kernel)
+template <bool ACC> __device__ __forceinline__ void edge_bwd3_body(const GpdeEdgeBwd3Args& a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dZs = smem;                                      // [2 buf][2 node][64 c][128 B: hi 32 | lo 32]
     float* Hs_all = smem + 2 * E3_DZ;                       // [4 waves][2 buf][32 e][32 n] fp32
@@ -270,6 +272,12 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd3_kernel(GpdeEdgeBwd3Args
 #pragma unroll
             for (int r = 0; r < 16; ++r) dxa[cb][r] = fmaf(d2[cb][r], ish, dxa[cb][r]);
         if (!a.dU) continue;
+        f32x4 du_old[4];
+        if constexpr (ACC) {          // the running sum's piece of this lane: requested before P1's MFMAs, added after them
+            const float* du = a.dU + (size_t)((vL ? eL : a.e0) - a.e0) * a.K2P + nc + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) du_old[g] = *(const f32x4*)(du + 8 * g);
+        }
         // ---- P1: D1[n][e] = sum_c dZ[c][n] x_e[c]; both nodes' products on all lanes, selected per lane ----------------
         auto p1 = [&](int nd) {
             f32x16 d;
@@ -317,7 +325,11 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd3_kernel(GpdeEdgeBwd3Args
         if (mine) {
             float* du = a.dU + (size_t)(eL - a.e0) * a.K2P + nc + 4 * h;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *(f32x4*)(du + 8 * g) = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+                if constexpr (ACC) v += du_old[g];
+                *(f32x4*)(du + 8 * g) = v;
+            }
         }
         if (a.dUt) {
             // ---- what the dW_2 GEMM and the dU_1 GEMM need from a pass over dU, formed here where the tile sits in registers
@@ -396,6 +408,8 @@ __global__ __launch_bounds__(256, 2) void gpde_edge_bwd3_kernel(GpdeEdgeBwd3Args
             }
     }
 }
+__global__ __launch_bounds__(256, 2) void gpde_edge_bwd3_kernel(GpdeEdgeBwd3Args a) { edge_bwd3_body<false>(a); }
+__global__ __launch_bounds__(256, 2) void gpde_edge_bwd3_acc_kernel(GpdeEdgeBwd3Args a) { edge_bwd3_body<true>(a); }
 
 }  // namespace
 
@@ -413,8 +427,11 @@ int gpde_launch_edge_bwd3(const GpdeEdgeBwd3Args& a, hipStream_t stream) {
     if (a.K2P % E3_NC != 0) { gpde_set_error("gpde_launch_edge_bwd3: K2P = %d", a.K2P); return GPDE_EINVAL; }
     const size_t lds = (size_t)(2 * E3_DZ + 4 * 2 * E3_H) * 4;
     static GpdeLdsOnce once;
-    if (int rc = once.ensure(gpde_edge_bwd3_kernel)) return rc;
-    hipLaunchKernelGGL(gpde_edge_bwd3_kernel, dim3(((rows + 127) / 128 + 7) / 8 * 8), dim3(256), lds, stream, a);
+    if (int rc = once.ensure(gpde_edge_bwd3_kernel, gpde_edge_bwd3_acc_kernel)) return rc;
+    if (a.du_accumulate) {
+        if (!a.dU || a.dUt) { gpde_set_error("gpde_launch_edge_bwd3: accumulation needs dU and excludes the by-products"); return GPDE_EINVAL; }
+        hipLaunchKernelGGL(gpde_edge_bwd3_acc_kernel, dim3(((rows + 127) / 128 + 7) / 8 * 8), dim3(256), lds, stream, a);
+    } else hipLaunchKernelGGL(gpde_edge_bwd3_kernel, dim3(((rows + 127) / 128 + 7) / 8 * 8), dim3(256), lds, stream, a);
     GP_LAUNCH_CHECK("gpde_edge_bwd3_kernel");
     return GPDE_OK;
 }

@@ -223,6 +223,13 @@ def defer_possible(edge_attr: torch.Tensor, pm, weights, biases, aggr: str) -> b
         any(p is not None and p.requires_grad for p in list(weights[:-1]) + list(biases[:-1])) and ops.deferred_supported(pm.dims)
 
 
+def token_of(module: torch.nn.Module, hidden: torch.Tensor):
+    """The HiddenToken of `hidden` if that is the module's cached full H (the applications sharing it sum their dL/dH on it:
+    autograd.NNConvHiddenFunction.backward), else None."""
+    ent = _entries.get(module)
+    return ent.token if ent is not None and ent.hidden is hidden and ent.token is not None and ent.token.valid else None
+
+
 def lookup_deferred(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, biases, aggr: str,
                     precision: Optional[str] = None, hpart=None):
     """(virtual H tensor, token) for a call that needs gradients, right after `lookup` returned None (or a PARTIAL H: `hpart`

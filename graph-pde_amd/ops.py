@@ -489,6 +489,7 @@ def alloc_bwd_ws(lib, n: int, e: int, nl: int, dims_c, dev, h_given_bytes: int =
     return _alloc_ws(default, dev)
 
 
+n_grad_hidden_accumulated = 0   # backward passes of applications sharing H that ADDED their dL/dH in the per-edge kernel (tests)
 n_kept_hidden = 0           # training forwards that kept their last hidden activations for the backward (keep_hidden; tests)
 n_bwd_ws_fallbacks = 0      # times the one-chunk workspace did not fit and the default plan ran (tests / diagnostics)
 
@@ -801,7 +802,7 @@ def nnconv_backward_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
         rc = lib.gpde_nnconv_bwd(x.data_ptr(), n, None if is_na else edge_attr.data_ptr(), None if nas is None else ctypes.byref(nas),
                                  p(hidden_saved), e, csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), None if is_na else perm.data_ptr(),
                                  rph.data_ptr(), p(srp), p(ssl), nl, dims_c, arr(ws_), arr(bs_), p(root_c), _AGGR[aggr],
-                                 grad_out.data_ptr(), p(z_saved), gx.data_ptr(), None, p(ga), arr(gW), arr(gb), p(groot), p(gbias),
+                                 grad_out.data_ptr(), p(z_saved), gx.data_ptr(), None, p(ga), arr(gW), arr(gb), p(groot), p(gbias), 0,
                                  ws.data_ptr(), ws.numel(), _stream_ptr(dev))
     _lib.check(rc, "gpde_nnconv_bwd")
     _lib.n_native_calls += 1
@@ -1243,8 +1244,10 @@ def nnconv_forward_mixed_raw(x: torch.Tensor, csr: Csr, edge_attr: torch.Tensor,
 def nnconv_backward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, dims: Sequence[int],
                                w_last: torch.Tensor, b_last: Optional[torch.Tensor],
                                root: Optional[torch.Tensor], aggr: str, grad_out: torch.Tensor,
-                               need_root: bool = True, need_bias: bool = True, z_saved: Optional[torch.Tensor] = None):
-    """gpde_nnconv_bwd in its `hidden` form (the last hidden activations given; `z_saved`: the keep-Z forward's buffer).  Returns (grad_x, grad_hidden [E,K2P], grad_w_last, grad_b_last or None,
+                               need_root: bool = True, need_bias: bool = True, z_saved: Optional[torch.Tensor] = None,
+                               grad_hidden_acc: Optional[torch.Tensor] = None):
+    """gpde_nnconv_bwd in its `hidden` form (the last hidden activations given; `z_saved`: the keep-Z forward's buffer;
+    `grad_hidden_acc`: a [E, K2P] tensor dL/dU is ADDED to instead of a fresh one - GPDE_BWD_ACCUMULATE_GRAD_HIDDEN).  Returns (grad_x, grad_hidden [E,K2P], grad_w_last, grad_b_last or None,
     grad_root or None, grad_bias or None)."""
     lib = _lib.lib()
     n, e, dev = csr.n_nodes, csr.n_edges, x.device
@@ -1256,7 +1259,10 @@ def nnconv_backward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, 
     b_c = None if b_last is None else b_last.detach().contiguous()
     root_c = None if root is None else root.detach().contiguous()
     gx = torch.empty(n, WIDTH, dtype=torch.float32, device=dev)
-    gh = torch.empty_like(hidden)
+    accumulate = grad_hidden_acc is not None
+    if accumulate and (grad_hidden_acc.shape != hidden.shape or grad_hidden_acc.dtype != torch.float32 or not grad_hidden_acc.is_contiguous()):
+        raise ValueError("grad_hidden_acc must be a contiguous float32 tensor of the shape of `hidden`")
+    gh = grad_hidden_acc if accumulate else torch.empty_like(hidden)
     gw = torch.empty_like(w_last)
     gb = None if b_c is None else torch.empty_like(b_c)
     groot = torch.empty(WIDTH, WIDTH, dtype=torch.float32, device=dev) if (need_root and root is not None) else None
@@ -1276,7 +1282,8 @@ def nnconv_backward_hidden_raw(x: torch.Tensor, csr: Csr, hidden: torch.Tensor, 
         rc = lib.gpde_nnconv_bwd(x.data_ptr(), n, None, None, hidden.data_ptr(), e, csr.rowptr.data_ptr(), csr.src.data_ptr(),
                                  csr.dst.data_ptr(), None, csr.rowptr_host.data_ptr(), p(srp), p(ssl), nl, dims_c, Wa, Ba,
                                  p(root_c), _AGGR[aggr], grad_out.data_ptr(), p(z_saved), gx.data_ptr(), gh.data_ptr(), None,
-                                 gWa, gBa, p(groot), p(gbias), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+                                 gWa, gBa, p(groot), p(gbias), _lib.GPDE_BWD_ACCUMULATE_GRAD_HIDDEN if accumulate else 0,
+                                 ws.data_ptr(), ws.numel(), _stream_ptr(dev))
     _lib.check(rc, "gpde_nnconv_bwd (hidden given)")
     _lib.n_native_calls += 1
     return gx, gh, gw, gb, groot, gbias

@@ -204,13 +204,14 @@ GPDE_API size_t gpde_nnconv_bwd_workspace_bytes(int64_t n_nodes, int64_t n_edges
  * memory). */
 GPDE_API size_t gpde_nnconv_bwd_workspace_bytes_one_chunk(int64_t n_nodes, int64_t n_edges, int n_layers,
                                                  const int32_t* dims);
+enum { GPDE_BWD_ACCUMULATE_GRAD_HIDDEN = 1 /* gpde_nnconv_bwd `flags`, `hidden` form: grad_hidden += dL/dU instead of = (see below) */ };
 GPDE_API int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_attr, const GpdeNodeAttr* node_attr,
                     const float* hidden, int64_t n_edges, const int32_t* rowptr, const int32_t* src, const int32_t* dst,
                     const int32_t* perm, const int32_t* rowptr_host, const int32_t* src_rowptr, const int32_t* src_slots,
                     int n_layers, const int32_t* dims, const float* const* W, const float* const* b, const float* root,
                     int aggr, const float* grad_out, const float* z_saved, float* grad_x, float* grad_hidden,
                     float* grad_edge_attr, float* const* grad_W, float* const* grad_b, float* grad_root,
-                    float* grad_bias, void* ws, size_t ws_bytes, void* stream);
+                    float* grad_bias, uint32_t flags, void* ws, size_t ws_bytes, void* stream);
 /* ^ ONE backward entry point for every form of the operator (round 5 folded seven: the plain, source-ordered, kept-Z,
  *   given-hidden, edge-attribute-gradient and node-table calls of rounds 1-4 were this call with some arguments fixed):
  *   attribute source   edge_attr + perm (tensor, caller's edge order) | node_attr (node data) | hidden (the last hidden
@@ -224,6 +225,11 @@ GPDE_API int gpde_nnconv_bwd(const float* x, int64_t n_nodes, const float* edge_
  *   src_rowptr, src_slots  nullable: the CSR slots regrouped by source node (gpde_csr_source_order) - grad_x is then summed per
  *                      source in slot order, bit-reproducible and independent of the chunking; NULL: fp32 atomics.
  *   z_saved            nullable: the Z buffer of gpde_nnconv_fwd_keepz / _mixed_keepz - dW_3 is taken from it.
+ *   flags              0, or GPDE_BWD_ACCUMULATE_GRAD_HIDDEN (the `hidden` form): dL/dU is ADDED to grad_hidden.  A module applied
+ *                      `depth` times on shared hidden activations (UAI1_full_resolution.py:29-30) sums the dL/dU of its applications
+ *                      before gpde_hidden_bwd: the first application's backward writes the tensor, the others add to it in the per-edge
+ *                      kernel, in call order - the additions autograd would make with `depth` [E][K2P] tensors, without the tensors
+ *                      (built into the split-f16 per-edge kernel; GPDE_EUNSUPPORTED elsewhere).
  *   grad_hidden        the `hidden` form only.   grad_edge_attr  nullable, tensor form with <= 8 slots only: dL/d edge_attr
  *                      [E][k0] in the caller's edge order (what autograd hands `pseudo`, nn_conv.py:273-275; no reference
  *                      script asks for it).

@@ -181,15 +181,21 @@ def test_argument_validation_without_gpu():
                                          None, 1, 1, None, None, None, 0, None) == -1
     # the backward in its `hidden` form: null arrays are refused before any device work
     assert l.gpde_nnconv_bwd(None, 4, None, None, None, 8, None, None, None, None, None, None, None, 3, d3, None, None, None, 1, None,
-                             None, None, None, None, None, None, None, None, None, 0, None) == -1
+                             None, None, None, None, None, None, None, None, 0, None, 0, None) == -1
     assert l.gpde_hidden_bwd(None, None, 8, None, None, None, 3, d3, None, None, None, None, None, None, 0, None) == -1
     # ... and two attribute sources at once (hidden + node_attr) are an argument error, not a guess
     na = _lib.GpdeNodeAttr()
     one = (ctypes.c_void_p * 3)()
     buf = ctypes.create_string_buffer(64)
     assert l.gpde_nnconv_bwd(None, 0, None, ctypes.byref(na), buf, 0, buf, None, None, None, buf, None, None, 3, d3, one, one, None, 1, buf,
-                             None, None, buf, None, one, one, None, None, buf, 64, None) == -1
+                             None, None, buf, None, one, one, None, None, 0, buf, 64, None) == -1
     assert b"one attribute source" in l.gpde_last_error()
+    # the accumulate flag belongs to the `hidden` form
+    assert l.gpde_nnconv_bwd(None, 0, buf, None, None, 0, buf, None, None, buf, buf, None, None, 3, d3, one, one, None, 1, buf,
+                             None, None, None, None, one, one, None, None, _lib.GPDE_BWD_ACCUMULATE_GRAD_HIDDEN, buf, 64, None) == -1
+    assert b"ACCUMULATE" in l.gpde_last_error()
+    hdr = open(os.path.join(REPO, "include", "gpde.h")).read()
+    assert int(re.search(r"GPDE_BWD_ACCUMULATE_GRAD_HIDDEN = (\d+)", hdr).group(1)) == _lib.GPDE_BWD_ACCUMULATE_GRAD_HIDDEN
     # (hidden + an attribute source WITHOUT grad_hidden is the full backward with the forward's kept activations - legal)
     assert l.gpde_hidden_workspace_bytes(1000, 3, d3) > 0 and l.gpde_hidden_workspace_bytes(-1, 3, d3) == 0
 
@@ -258,7 +264,7 @@ def test_node_attr_descriptor_layout_matches_the_header():
     assert b"GpdeNodeAttr" in l.gpde_last_error()
     arr = (ctypes.c_void_p * 3)()
     assert l.gpde_nnconv_bwd(None, 0, None, ctypes.byref(c), None, 0, buf, None, None, None, buf, None, None, 3, dims, arr, arr, None, 1,
-                             buf, None, None, None, None, arr, arr, None, None, buf, 64, None) == -1
+                             buf, None, None, None, None, arr, arr, None, None, 0, buf, 64, None) == -1
     assert b"GpdeNodeAttr" in l.gpde_last_error()
     assert l.gpde_nnconv_bwd_deferred_supported(3, dims) == 1 and l.gpde_nnconv_bwd_deferred_supported(3, _lib.dims_array([6, 64, 128, 4096])) == 0
     assert l.gpde_nnconv_bwd_deferred_workspace_bytes(100, 5000, 3, dims, 6) > l.gpde_nnconv_bwd_workspace_bytes(100, 5000, 3, dims)
