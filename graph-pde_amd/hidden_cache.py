@@ -223,11 +223,17 @@ def defer_possible(edge_attr: torch.Tensor, pm, weights, biases, aggr: str) -> b
         any(p is not None and p.requires_grad for p in list(weights[:-1]) + list(biases[:-1])) and ops.deferred_supported(pm.dims)
 
 
-def token_of(module: torch.nn.Module, hidden: torch.Tensor):
+def token_of(module: torch.nn.Module, hidden: torch.Tensor, csr=None):
     """The HiddenToken of `hidden` if that is the module's cached full H (the applications sharing it sum their dL/dH on it:
-    autograd.NNConvHiddenFunction.backward), else None."""
+    autograd.NNConvHiddenFunction.backward), else None.  None too for a graph on which the per-edge weight form may run
+    (edge_weights_qualify): there W_e's backward is a second kind of consumer of H, and an application can fall from one form to the
+    other when memory is short - the in-place sum wants NNConvHiddenFunction to be H's only consumer."""
     ent = _entries.get(module)
-    return ent.token if ent is not None and ent.hidden is hidden and ent.token is not None and ent.token.valid else None
+    if ent is None or ent.hidden is not hidden or ent.token is None or not ent.token.valid:
+        return None
+    if csr is not None and WE_MODE == "auto" and edge_weights_qualify(csr):
+        return None
+    return ent.token
 
 
 def lookup_deferred(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, biases, aggr: str,

@@ -238,7 +238,7 @@ class NNConv_old(MessagePassing):
                     if we is not None:
                         return WeConvFunction.apply(x, we, csr, root, bias, self.aggr)
                 return NNConvHiddenFunction.apply(x, hidden, csr, pm, weights[-1], biases[-1],
-                                                  root, bias, self.aggr, hmax, hidden_cache.token_of(self, hidden))
+                                                  root, bias, self.aggr, hmax, hidden_cache.token_of(self, hidden, csr))
             if not no_grad:
                 # H wanted but too large for the device (the 241^2 graph: 391 GB): the applications of this forward share a
                 # "virtual H" node instead - light backward per application, ONE deferred pass for the hidden layers; the

@@ -586,3 +586,30 @@ def test_keep_hidden_policy_and_its_workspace_host_logic(monkeypatch):
     monkeypatch.setattr(ops, "device_free_bytes", lambda dev: (int((one - hb) / 0.6) + (1 << 20), 288 << 30))
     assert ops.bwd_workspace_bytes(lib, n, e, 3, dims_c, None, hb) == one - hb          # fits only because H is left out
     assert ops.bwd_workspace_bytes(lib, n, e, 3, dims_c, None) == int(lib.gpde_nnconv_bwd_workspace_bytes(n, e, 3, dims_c))
+
+
+def test_token_of_hands_out_the_shared_h_token_only_where_h_has_one_kind_of_consumer(monkeypatch):
+    """hidden_cache.token_of: the applications of a module sum their dL/dH in place on the token of its cached full H
+    (autograd.NNConvHiddenFunction.backward) - not for another tensor, not after the H node's backward, and not on a graph where the
+    per-edge weight form may run (its backward is a second consumer of H)."""
+    from graph_pde_amd import hidden_cache, ops
+    from graph_pde_amd.autograd import HiddenToken
+    m = torch.nn.Linear(2, 2)
+    z32 = torch.zeros(1, dtype=torch.int32)
+    dense = ops.Csr(1681, 75000, z32, z32, z32, z32)               # mean in-degree 45: the re-associated path
+    sparse = ops.Csr(8192, 16384, z32, z32, z32, z32)              # 2 in-edges per node: qualifies for W_e
+    small = ops.Csr(100, 3200, z32, z32, z32, z32)                 # in-degree 32 but <= WE_SMALL_EDGES edges: qualifies too
+    h = torch.zeros(4, 4)
+    ent = hidden_cache._Entry()
+    ent.hidden, ent.token = h, HiddenToken()
+    monkeypatch.setitem(hidden_cache._entries, m, ent)
+    monkeypatch.setattr(hidden_cache, "MODE", "auto")
+    monkeypatch.setattr(hidden_cache, "WE_MODE", "auto")
+    assert hidden_cache.token_of(m, h, dense) is ent.token
+    assert hidden_cache.token_of(m, torch.zeros(4, 4), dense) is None
+    assert hidden_cache.token_of(m, h, sparse) is None and hidden_cache.token_of(m, h, small) is None
+    monkeypatch.setattr(hidden_cache, "WE_MODE", "off")
+    assert hidden_cache.token_of(m, h, sparse) is ent.token
+    ent.token.valid = False
+    assert hidden_cache.token_of(m, h, dense) is None
+    assert hidden_cache.token_of(torch.nn.Linear(2, 2), h, dense) is None
