@@ -143,7 +143,9 @@ def _rows_worker(rank, world, port, q):
     loss = torch.norm(out - y, 1)
     loss.backward()
     parallel.allreduce_gradients(model.parameters(), average=True)
-    q.put((rank, sizes, out.detach(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+    # (numpy: pickled by value - torch tensors travel through shared-memory handles that die with this process, and the parent
+    # may unpickle after it has exited: ConnectionResetError / EOFError in q.get)
+    q.put((rank, sizes, out.detach().numpy().copy(), {k: p.grad.numpy().copy() for k, p in model.named_parameters()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -166,9 +168,9 @@ def test_row_partitioned_graph_gather_and_gradients_gloo_ws2():
     assert (lo0, hi1) == (0, n) and hi0 == lo1 and e0 + e1 == ei.shape[1]
     assert abs(e0 - e1) <= int(torch.bincount(ei[1]).max())            # balanced on in-edges up to one node's worth
     for rank, _, out, grads in res:
-        assert torch.allclose(out, ref.detach(), rtol=1e-12, atol=1e-12), rank   # every rank holds the full result
+        assert torch.allclose(torch.from_numpy(out), ref.detach(), rtol=1e-12, atol=1e-12), rank   # every rank holds the full result
         for k, p in model.named_parameters():
-            assert torch.allclose(grads[k], p.grad, rtol=1e-10, atol=1e-12), (rank, k)
+            assert torch.allclose(torch.from_numpy(grads[k]), p.grad, rtol=1e-10, atol=1e-12), (rank, k)
 
 
 # ---- the same from POSITIONS: no rank holds the whole edge list (parallel.partition_rows_by_position) ------------------
