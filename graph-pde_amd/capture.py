@@ -13,8 +13,16 @@ What is recorded is exactly what the uncaptured call launches - the same kernels
 the result is bit-identical to calling the function directly.  Everything the host decides (CSR look-ups, weight packing,
 the cache policies of hidden_cache.py) is decided during the warm-up / recording call and frozen:
   * tensors passed as arguments are copied into static buffers at every call; everything else the function reads (weights,
-    edge_index, edge_attr) is read from where it lay at recording time - in-place updates of those tensors (an optimizer
-    step) are seen, NEW tensors are not: re-capture then;
+    edge_index, edge_attr) is read from where it lay at recording time, and what the library DERIVED from them during the
+    warm-up - packed weight images, hidden activations H, per-edge weights W_e, CSRs - is frozen with the recording: a replay
+    does not re-pack or rebuild.  An in-place update of such a tensor outside the graph (`p.mul_()`, an `optimizer.step()`
+    between replays) therefore makes the recording STALE.  The recording notes every tensor a cache key was built from with
+    its version counter; a replay that finds one moved records again first (warm-up + one recorded call: `recordings` counts
+    them), so the result is that of a direct call with the new values.  Writes that do not move the counter (`p.data.add_()`)
+    are invisible to it, as they are to the caches themselves (ops.clear_caches); NEW tensors need a new capture;
+  * the device buffers the recorded kernels read but the library's caches own (CSR arrays, slot-ordered attribute copies,
+    packed weights, cached H / W_e) are pinned on the `Captured` object: cache eviction, `hidden_cache.clear()` (every later
+    `gp.capture` calls it), `release_all` under memory pressure or `ops.clear_caches()` cannot free them under the graph;
   * the outputs live in the graph's memory pool and are overwritten by the next replay (`copy_outputs=True` returns clones);
   * a whole training step can be recorded too (`zero_grad(set_to_none=True)`, forward, `loss.backward()`, `optimizer.step()`
     inside `fn`): the optimizer must be capturable (`torch.optim.Adam(..., capturable=True)`: its step count lives on the
@@ -49,12 +57,20 @@ class Captured:
         self._static_in = [a.clone() if isinstance(a, torch.Tensor) else a for a in args]
         self._copy_outputs = copy_outputs
         self._updates_parameters = updates_parameters
-        dev = next(iter(devs)) if devs else torch.device("cuda", torch.cuda.current_device())
+        self._fn, self._warmup = fn, warmup
+        self._dev = next(iter(devs)) if devs else torch.device("cuda", torch.cuda.current_device())
+        self.replays = 0
+        self.recordings = 0
+        self._retired = []           # earlier recordings (graph, outputs, pins): kept - a caller may still hold their outputs
+        self._record()
+
+    def _record(self):
+        fn, warmup, dev = self._fn, self._warmup, self._dev
         # The caches keep tensors WITH their autograd history (a shared H node, W_e): as long as such a graph lives, the
         # parameters' AccumulateGrad nodes live - bound to the stream of the step that created them, usually the default stream of
         # earlier direct calls.  Recorded that way the gradient accumulation is an unjoined fork onto the legacy stream
         # (hipStreamEndCapture crashed on it).  Drop them: the warm-up below rebuilds everything on the recording stream.
-        from . import hidden_cache
+        from . import hidden_cache, ops
         hidden_cache.clear()
         import gc
         gc.collect()
@@ -72,10 +88,29 @@ class Captured:
         # (recorded on the warm-up's stream: autograd's AccumulateGrad nodes - created by the warm-up steps, one per parameter,
         # alive across iterations - run on the stream they were created on; on another stream the gradient accumulation of a
         # recorded training step is an unjoined fork of the capture)
-        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="relaxed"):
-            self._static_out = fn(*self._static_in)
+        outer, ops._capture_watch = ops._capture_watch, []
+        try:
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode="relaxed"):
+                self._static_out = fn(*self._static_in)
+            watched = ops._capture_watch
+        finally:
+            ops._capture_watch = outer
         torch.cuda.synchronize(dev)
-        self.replays = 0
+        # the tensors the recorded call's cache keys were built from, with the version each had (one entry per tensor: the
+        # version it had when LAST keyed - a recorded training step moves its weights' counters itself)
+        seen = {}
+        for t, v in watched:
+            seen[id(t)] = (t, v)
+        self._watched = list(seen.values())
+        # what the recorded kernels read from cache-owned memory: pinned for the life of this recording
+        self._pins = (ops.cache_snapshot(), hidden_cache.snapshot())
+        self.recordings += 1
+
+    def stale(self) -> bool:
+        """A tensor one of the recording's cache keys was built from has been modified in place since (version counter)."""
+        if self._updates_parameters:
+            return False            # the graph itself rewrites the weights and re-derives everything from them every replay
+        return any(t._version != v for t, v in self._watched)
 
     def __call__(self, *args):
         if len(args) != len(self._static_in):
@@ -88,6 +123,11 @@ class Captured:
                     s.copy_(a)
             elif a != s:
                 raise ValueError("non-tensor arguments are frozen at capture time")
+        if self.stale():
+            # weights / attributes / indices changed in place outside the graph: the packed images, H, W_e the recording
+            # reads belong to the old values.  Record again (the old graph and its pool stay alive: its outputs may be held)
+            self._retired.append((self.graph, self._static_out, self._pins))
+            self._record()
         self.graph.replay()
         self.replays += 1
         if self._updates_parameters:

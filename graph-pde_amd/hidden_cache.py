@@ -121,6 +121,8 @@ def release_all() -> bool:
     for ent in list(_entries.values()):
         if ent.hidden is not None or ent.we is not None:
             freed = True
+        if ent.token is not None:
+            ent.token.gh_acc, ent.token.gh_adds = None, 0
         ent.hidden, ent.key, ent.token, ent.attr_ref, ent.csr = None, None, None, None, None
         ent.we, ent.we_key, ent.we_refs = None, None, None
         ent.twe, ent.twe_key, ent.twe_token, ent.twe_h = None, None, None, None     # (nodes of a live graph keep their own references)
@@ -131,7 +133,19 @@ def release_all() -> bool:
     return freed
 
 
+def snapshot() -> list:
+    """Strong references to every tensor the entries hold right now (capture.py: a recorded graph reads H / W_e / the virtual
+    node's partial H at the addresses they had at recording time; `clear()`, `release_all()` and rebuilt entries must not free
+    them under it - ADVICE r5)."""
+    pins = []
+    for ent in list(_entries.values()):
+        pins.append((ent.hidden, ent.we, ent.twe, ent.twe_h, ent.attr_ref, ent.csr, ent.we_refs, ent.drefs, ent.dvirtual,
+                     None if ent.dtoken is None else ent.dtoken.hpart))
+    return pins
+
+
 def _key(edge_attr, csr, hidden_params: List[Optional[torch.Tensor]], precision: str):
+    ops.watch(edge_attr.table if isinstance(edge_attr, ops.NodeAttr) else edge_attr, *hidden_params)
     if isinstance(edge_attr, ops.NodeAttr):      # attributes described by node data: keyed on the table's memory + version + slots
         tb = edge_attr.table
         grad = torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in hidden_params)
@@ -163,6 +177,9 @@ def lookup(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, b
         ent = _entries[module] = _Entry()
     if ent.hidden is not None and ent.key == key and ent.token.valid:
         ent.hits_on_hidden += 1
+        # a backward pass that never reached the H node (input gradients only, an exception) left its running dL/dH sum on the
+        # token: [E, K2P], 24 GB at s=121.  No pass is in flight at forward time - drop it
+        ent.token.gh_acc, ent.token.gh_adds = None, 0
         if ent.hn == csr.n_nodes or allow_partial:
             stats["hits"] += 1
             if ent.hn < csr.n_nodes:
@@ -231,7 +248,7 @@ def token_of(module: torch.nn.Module, hidden: torch.Tensor, csr=None):
     ent = _entries.get(module)
     if ent is None or ent.hidden is not hidden or ent.token is None or not ent.token.valid:
         return None
-    if csr is not None and WE_MODE == "auto" and edge_weights_qualify(csr):
+    if csr is not None and WE_MODE != "off" and edge_weights_qualify(csr, explicit=True):
         return None
     return ent.token
 

@@ -286,6 +286,7 @@ def csr_for(edge_index: torch.Tensor, n_nodes: int) -> Csr:
             raise ValueError(f"the CSR was built for {edge_index.n_nodes} nodes, x has {n_nodes} rows")
         return edge_index
     storage = edge_index.untyped_storage()
+    watch(edge_index)
     key = (str(edge_index.device), storage.data_ptr(), edge_index.storage_offset(),
            tuple(edge_index.shape), tuple(edge_index.stride()), _ver(edge_index), n_nodes)
     hit = _csr_cache.pop(key, None)
@@ -298,6 +299,30 @@ def csr_for(edge_index: torch.Tensor, n_nodes: int) -> Csr:
             (len(_csr_cache) > 1 and sum(v[1] for v in _csr_cache.values()) > _CSR_CACHE_MAX_BYTES):
         _csr_cache.pop(next(iter(_csr_cache)))
     return csr
+
+
+_capture_watch: "list | None" = None      # capture.py: while a call is being recorded, the tensors cache keys were built from
+
+
+def watch(*tensors):
+    """capture.py's staleness check: a recorded call replays what the caches held at recording time (packed weights, hidden
+    activations, CSRs) - every tensor such a cache key is built from is noted while `_capture_watch` is a list, with its version."""
+    if _capture_watch is not None:
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and not t.is_inference():
+                _capture_watch.append((t, t._version))
+
+
+def cache_snapshot() -> list:
+    """Strong references to every device buffer the caches of this module own right now (CSRs with their source-order arrays
+    and slot-ordered attribute copies, packed weights, staged constants): capture.py pins them for the lifetime of a recorded
+    graph, whose kernels read those addresses whatever the LRU policies do afterwards."""
+    pins = [v for v in _csr_cache.values()] + [v[1] for v in _pack_cache.values()] + [v for v in _stage_cache.values()]
+    for v in _csr_cache.values():
+        srt = v[2]._attr_sorted
+        if srt:
+            pins.extend(srt.values())
+    return pins
 
 
 def clear_param_caches():
@@ -376,6 +401,7 @@ def pack_mlp(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Te
         if w.dtype != torch.float32:
             raise NotImplementedError(f"kernel-network weights must be float32, got {w.dtype}")
     dims = tuple([int(weights[0].size(1))] + [int(w.size(0)) for w in weights])
+    watch(*weights, *biases)
     ptrs = tuple(w.data_ptr() for w in weights) + tuple(0 if b is None else b.data_ptr() for b in biases) + (dims,)
     key = tuple((w.data_ptr(), _ver(w)) for w in weights) + \
         tuple((0, 0) if b is None else (b.data_ptr(), _ver(b)) for b in biases) + (dims,)

@@ -216,6 +216,37 @@ def nnconv_grads_shared(xs: Sequence[torch.Tensor], edge_index: torch.Tensor, ed
             None if r is None else zero(r), None if bb is None else zero(bb))
 
 
+def nnconv_grad_x_rows(rows: torch.Tensor, edge_index_out: torch.Tensor, edge_attr_out: torch.Tensor,
+                       weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
+                       root: Optional[torch.Tensor], grad_out: torch.Tensor, in_degree: Optional[torch.Tensor],
+                       chunk_edges: int = 16384) -> torch.Tensor:
+    """float64 rows `rows` of d loss / d x for loss = sum(out * grad_out), given ALL out-edges of those nodes
+    (`edge_index_out` [2, E'] with the graph's own node ids, `edge_attr_out` [E', k0]) - for graphs whose full backward does not
+    fit a CPU (the 241^2 graph: 95.5 M edges).  The operator is linear in x (nn_conv.py:273-282:
+    out_i = sum_{e: j -> i} x_j . W_e / deg_i + x_i . root + bias with W_e = view(nn(pseudo_e), in, out)), so
+        d loss / d x_j = sum_{e: j -> i} W_e . (grad_out_i / deg_i) + root . grad_out_j
+    needs the out-edges of j only and no x.  `in_degree`: the FULL graph's in-degree per node for aggr='mean'
+    (clamp(count, 1)), None for 'add'.  Pinned on CPU to autograd through the restated forward
+    (tests/test_oracle_golden.py::test_grad_x_rows_is_autograds_grad_x)."""
+    src, dst = edge_index_out[0], edge_index_out[1]
+    gT = grad_out.double()
+    if in_degree is not None:
+        gT = gT / in_degree.clamp(min=1).double().unsqueeze(1)
+    Ws = [w.double() for w in weights]
+    Bs = [None if b is None else b.double() for b in biases]
+    n, cin = grad_out.shape[0], Ws[-1].shape[0] // grad_out.shape[1]
+    dx = torch.zeros(n, cin, dtype=torch.float64)
+    e = int(src.numel())
+    with torch.no_grad():
+        for lo in range(0, e, max(1, chunk_edges)):
+            sl = slice(lo, lo + chunk_edges)
+            we = densenet_forward(edge_attr_out[sl].double(), Ws, Bs).view(-1, cin, grad_out.shape[1])      # nn_conv.py:274
+            dx.index_add_(0, src[sl], torch.matmul(we, gT[dst[sl]].unsqueeze(2)).squeeze(2))
+        if root is not None:
+            dx += grad_out.double() @ root.double().t()
+    return dx[rows]
+
+
 def rel_l2(y: torch.Tensor, y_ref: torch.Tensor) -> float:
     """Relative L2 over the whole output, the `LpLoss.rel` formula for one sample
     (/root/reference/graph-neural-operator/utilities.py:184-196)."""

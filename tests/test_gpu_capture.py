@@ -33,11 +33,47 @@ def test_captured_mgkn_forward_is_bitwise_the_direct_calls(name):
         for m in wl.modules:
             for p in m.parameters():
                 p.mul_(1.01)
+    # the OLD recording replayed after the update.  Its packed weights / H / W_e were derived from the old values:
+    # the replay notices the moved version counters and records again first - the result is the direct call's for the NEW weights
+    assert cap.stale() and cap.recordings == 1
+    out3 = [t.clone() for t in cap()]
+    assert cap.recordings == 2 and not cap.stale()
     for _ in range(3):
         ref2 = [t.clone() for t in wl.forward()]           # (the caches rebuild for the new weight versions and settle again)
-    cap2 = gp.capture(wl.forward)                          # new cached tensors: a new recording
+    assert all(torch.equal(a, b) for a, b in zip(out3, ref2))
+    cap2 = gp.capture(wl.forward)                          # an explicit new recording agrees
     assert all(torch.equal(a, b) for a, b in zip(cap2(), ref2))
     assert not torch.equal(ref2[0], ref[0])
+
+
+@pytest.mark.parametrize("name", sorted(mgkn_workloads.WORKLOADS))
+def test_a_recording_keeps_the_cached_buffers_it_reads_alive(name):
+    """the recorded kernels read CSR arrays, slot-ordered attributes, packed weights and cached H / W_e at the
+    addresses they had at recording time, and only the library's caches owned them.  Everything that empties those caches -
+    a second capture (hidden_cache.clear), release_all under memory pressure, ops.clear_caches - followed by allocations that
+    would recycle the freed blocks must leave the first recording's replays unchanged."""
+    from graph_pde_amd import ops
+    d = torch.device("cuda:0")
+    hidden_cache.clear()
+    wl = mgkn_workloads.WORKLOADS[name](d)
+    for _ in range(3):
+        ref = [t.clone() for t in wl.forward()]
+    cap = gp.capture(wl.forward, copy_outputs=True)
+    assert all(torch.equal(a, b) for a, b in zip(cap(), ref))
+    wl_b = mgkn_workloads.WORKLOADS[name](d)               # another model + another recording alive beside the first
+    cap_b = gp.capture(wl_b.forward, copy_outputs=True)
+    ref_b = cap_b()
+    hidden_cache.release_all()
+    hidden_cache.clear()
+    ops.clear_caches()
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 26,), float("nan"), device=d) for _ in range(8)]      # 2 GiB of NaN over whatever was freed
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(cap(), ref))
+    assert all(torch.equal(a, b) for a, b in zip(cap_b(), ref_b))
+    del junk
 
 
 def test_captured_call_takes_new_inputs_and_checks_shapes():

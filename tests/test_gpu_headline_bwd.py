@@ -164,3 +164,66 @@ def test_light_and_deferred_pair_vs_float64(case):
     dW, db = ops.nnconv_backward_deferred_raw(xs, gs, csr, ea, W, B, "mean")
     torch.cuda.synchronize()
     _compare("light x 6 + deferred", gxs, list(dW) + [w3], list(db) + [b3], sroot, sbias, case["ref"], case.get("e32"))
+
+
+def _module_step(case, d, ei, ea, xs_dev=None):
+    """Six applications of the ONE module on the module's own autograd, loss = sum_l <conv(x_l), g_l>, backward: what
+    `loss.backward()` differentiates at UAI1_full_resolution.py:258-273 (with the applications' inputs given)."""
+    conv = case["conv"]
+    lin = ops.mlp_linears(conv.nn)
+    conv.zero_grad(set_to_none=True)
+    xin = [x.to(d).requires_grad_(True) for x in case["xs"]] if xs_dev is None else [x.detach().requires_grad_(True) for x in xs_dev]
+    loss = sum((conv(x, ei, ea) * g.to(d)).sum() for x, g in zip(xin, case["gs"]))
+    loss.backward()
+    return [x.grad for x in xin], [l.weight.grad for l in lin], [l.bias.grad for l in lin], conv.root.grad, conv.bias.grad
+
+
+def test_shared_hidden_path_vs_float64(case, monkeypatch):
+    """the DEFAULT training path of the reference's own configuration (UAI1_full_resolution.py:39-57: s=61,
+    `[6,1024,1024,4096]`, depth 6) is the shared-H one - `HiddenFunction` builds H once, the six applications run
+    `NNConvHiddenFunction` (gpde_nnconv_bwd with `hidden` given; from the second on their dL/dH is ADDED inside the per-edge kernel)
+    and ONE gpde_hidden_bwd differentiates the hidden layers on the sum.  Held to float64 here at its own width, through the
+    module's autograd; the counters prove the path."""
+    monkeypatch.setattr(hidden_cache, "MODE", "on")
+    hidden_cache.clear()
+    d = case["d"]
+    ei, ea = case["ei"].to(d), case["ea"].to(d)
+    if "e32" not in case:                                      # (run alone: the yardstick of _compare from the same plan on exact fp32 GEMMs)
+        monkeypatch.setenv("GPDE_BWD_GEMM_F32", "1")
+        case["e32"] = _errors(*_module_step(case, d, ei, ea), case["ref"])
+        monkeypatch.delenv("GPDE_BWD_GEMM_F32")
+        hidden_cache.clear()
+    acc0, builds0, hits0, kept0 = ops.n_grad_hidden_accumulated, hidden_cache.stats["builds"], hidden_cache.stats["hits"], ops.n_kept_hidden
+    got = _module_step(case, d, ei, ea)
+    torch.cuda.synchronize()
+    assert hidden_cache.stats["builds"] - builds0 == 1 and hidden_cache.stats["hits"] - hits0 == DEPTH - 1      # one H, five hits
+    assert ops.n_grad_hidden_accumulated - acc0 == DEPTH - 1                                                      # dL/dH summed in-kernel
+    assert ops.n_kept_hidden == kept0                                                                             # not the kept-H direct operator
+    _compare("module autograd, shared H (HiddenFunction + 6 x NNConvHiddenFunction)", *got, case["ref"], case["e32"])
+    hidden_cache.clear()
+
+
+def test_captured_training_pass_vs_float64(case, monkeypatch):
+    """Same step recorded by `gp.capture` (forward + backward of the six applications as ONE HIP graph, default cache policy as it
+    settles during the warm-up) and replayed on NEW inputs: the gradients a replay leaves are held to the float64 oracle, not to
+    the direct step (last sentence)."""
+    hidden_cache.clear()
+    d, conv = case["d"], case["conv"]
+    ei, ea = case["ei"].to(d), case["ea"].to(d)
+    lin = ops.mlp_linears(conv.nn)
+    gs = torch.stack([g.to(d) for g in case["gs"]])
+
+    def step(X):
+        conv.zero_grad(set_to_none=True)
+        xin = [X[l].detach().requires_grad_(True) for l in range(DEPTH)]
+        loss = sum((conv(x, ei, ea) * gs[l]).sum() for l, x in enumerate(xin))
+        loss.backward()
+        return [x.grad for x in xin], [l.weight.grad for l in lin], [l.bias.grad for l in lin], conv.root.grad, conv.bias.grad
+    X = torch.stack([x.to(d) for x in case["xs"]])
+    cap = gp.capture(step, torch.randn_like(X), copy_outputs=True)          # recorded on OTHER inputs
+    calls = _lib.n_native_calls
+    got = cap(X)
+    torch.cuda.synchronize()
+    assert _lib.n_native_calls == calls and cap.recordings == 1
+    _compare("captured forward + backward, replayed on new inputs", *got, case["ref"], case.get("e32"))
+    hidden_cache.clear()

@@ -213,6 +213,25 @@ def test_oracle_shared_application_gradients_equal_the_sum_over_applications(nam
         assert rel_l2(groot, sroot) <= tol
 
 
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_grad_x_rows_is_the_pinned_grad_x(name):
+    """oracle.nnconv_grad_x_rows - rows of d loss / d x from the out-edges of the chosen nodes only, the checker of grad_x at the
+    241^2 scale (tests/test_gpu_headline_train.py) - against the gradients pinned to autograd through the reference's own module
+    (tests/golden/<name>_grad.npz), on a subset of the nodes fed with exactly their out-edges."""
+    from oracle.nnconv_oracle import nnconv_grad_x_rows
+    from tests.conftest import load_golden
+    g, r = load_golden(name), load_golden_grads(name)
+    ei, n = g["edge_index"], g["x"].shape[0]
+    rows = torch.arange(0, n, 3)
+    keep = torch.isin(ei[0], rows)
+    deg = torch.bincount(ei[1], minlength=n) if g["aggr"] == "mean" else None
+    ea = g["edge_attr"] if g["edge_attr"].dim() == 2 else g["edge_attr"].unsqueeze(-1)
+    gx = nnconv_grad_x_rows(rows, ei[:, keep], ea[keep], g["weights"], g["biases"], g["root"], r["gout"], deg,
+                            chunk_edges=max(1, int(keep.sum()) // 3))
+    ref = r["gx"] if r["gx"].dim() == 2 else r["gx"].unsqueeze(-1)
+    assert rel_l2(gx, ref[rows]) <= 1e-12
+
+
 def _lattice(s):
     import numpy as np
     g = np.linspace(0.0, 1.0, s)
