@@ -15,7 +15,13 @@ independent sample: weak scaling, no data-path collective.  Rank 0 prints ONE JS
 
 `value` = whole-job M-edges/s over the K timed steps bracketed by barrier + synchronize (max over ranks);
 `median_step_ms` / `value_at_median` come from per-step HIP events on the kernels' stream (SURVEY.md §8d asks
-for the median).  Objects on the line:
+for the median).
+
+Round 6: the printed line is <= 2.5 KB - the contract's keys, a compact `roofline` and `cpu_baseline`, and `summary` with every
+other leg's headline figure (graph preparation, MGKN forwards / training steps, the backward in both forms with its roofline
+fraction and traffic, the G241 depth-6 training step on the same sample / distinct samples with its peak memory).  EVERYTHING
+measured - the full objects described below, per-kernel counters, notes - goes to `bench_detail.json` (`--detail-out`), whose path
+the line carries as `detail`.  Objects (in the detail file; `roofline` / `cpu_baseline` compact on the line):
   roofline      of the dominant kernel (its symbol from gpde_nnconv_fwd_kernel).  The path is compute bound
                 (SURVEY.md §8d), so `bound` = "mfma".  `achieved` = MFMA FLOPs the kernel EXECUTES per launch /
                 average launch duration (HIP events inside libgpde.so on the kernel's own stream), `peak` = the
@@ -385,10 +391,15 @@ def train_mode(args, rank, world, dev, use_dist, barrier):
     barrier()
     elapsed = time.perf_counter() - t0
     ar_ms = sum(a.elapsed_time(b) for a, b, _ in evs) / max(args.steps, 1)
+    mine = {"rank": rank, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 2), "allreduce_ms": round(ar_ms, 3),
+            "peak_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
+    per_rank = [mine]
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank != 0:
         return None
     ms = 1e3 * elapsed / args.steps
@@ -407,6 +418,9 @@ def train_mode(args, rank, world, dev, use_dist, barrier):
         "M_edge_applications_per_s": round(world * args.depth * e / (ms * 1e-3) / 1e6, 2),
         "allreduce": {"elements": evs[-1][2], "ms_per_step": round(ar_ms, 3), "share_of_step": round(ar_ms / ms, 5),
                       "backend": "nccl (RCCL)" if use_dist else "none (single process)"},
+        "per_rank": per_rank,
+        "samples_per_step": world, "config5_note": f"BASELINE config 5 = 256 samples per optimizer step: {256 // max(world, 1)} such steps per rank "
+                                                    "with gradients accumulated, ONE all-reduce (tests/test_parallel_gloo.py ws-8)",
     }
 
 
@@ -521,6 +535,7 @@ def main():
     ap.add_argument("--no-measure-traffic", action="store_true", help="roofline.traffic from the committed profiles/traffic_r*.json")
     ap.add_argument("--precision", default=None, choices=["f32", "f16split", "f16split_8wave", "f16split_static", "f16split_agg16", "f16split_agg32", "f16split_noedge"],
                     help="arithmetic of the hidden layer (default: graph_pde_amd.ops.DEFAULT_PRECISION)")
+    ap.add_argument("--detail-out", default=None, help="where the full record goes (default: ./bench_detail.json); the JSON line stays <= 2.5 KB")
     ap.add_argument("--train", action="store_true", help="training-step mode (see the module docstring)")
     ap.add_argument("--depth", type=int, default=6, help="--train: NNConv applications per forward")
     ap.add_argument("--split-from-edges", action="store_true",
@@ -970,11 +985,12 @@ def main():
                         "kept_hidden_GiB": round(eb_ * kwp * 4 / 2**30, 1) if kept_h else 0.0,
                         "note": "median of 3 timed backward passes after one warm-up; parity of every gradient "
                                 "against float64 autograd: tests/test_gpu_bwd.py, tests/test_gpu_parity.py"}
-            # the same backward under the library's DEFAULT workspace plan (~26 GB, ten edge chunks) instead of the one-chunk
-            # workspace ops.bwd_workspace_bytes takes when 0.6 of the free memory allows (workspace_GiB above)
+            # the same backward with the opt-in ONE-CHUNK workspace (GPDE_BWD_WS_FRACTION=0.6: the whole s=121 graph as one edge chunk,
+            # ~125 GiB) instead of the library's default plan (~26 GB, ten edge chunks: the default since round 6, `ms` above)
+            backward["default_workspace_GiB"] = backward["workspace_GiB"]
             try:
                 frac0 = ops.BWD_WS_FRACTION
-                ops.BWD_WS_FRACTION = 0.0
+                ops.BWD_WS_FRACTION = 0.6
                 td = []
                 for it in range(3):
                     conv.zero_grad(set_to_none=True)
@@ -986,11 +1002,12 @@ def main():
                     lossb.backward()
                     torch.cuda.synchronize()
                     td.append(time.perf_counter() - tq)
-                backward["default_workspace_ms"] = round(1e3 * sorted(td[1:])[0], 2)
-                backward["default_workspace_GiB"] = round(ops.bwd_workspace_bytes(_lib.lib(), nb_, eb_, 3, _lib.dims_array([6, kw, kw, 4096]), dev) / 2**30, 1)
+                backward["one_chunk_workspace_ms"] = round(1e3 * sorted(td[1:])[0], 2)
+                backward["one_chunk_workspace_GiB"] = round(ops.bwd_workspace_bytes(_lib.lib(), nb_, eb_, 3, _lib.dims_array([6, kw, kw, 4096]), dev,
+                                                                                    eb_ * kwp * 4 if kept_h else 0) / 2**30, 1)
             finally:
                 ops.BWD_WS_FRACTION = frac0
-            log(f"[bench] backward g121: {backward['ms']} ms, {backward['M_edges_per_s']} M-edges/s; default workspace {backward.get('default_workspace_ms')} ms")
+            log(f"[bench] backward g121: {backward['ms']} ms, {backward['M_edges_per_s']} M-edges/s; one-chunk workspace (opt-in) {backward.get('one_chunk_workspace_ms')} ms")
             del eib, eab, xb, yb, lossb, prs, prs_r
             # ---- the same at the headline size, and BASELINE config 5's per-GPU unit of work: one training step of the
             #      depth-6 GKN on ONE 241^2 sample (UAI1_full_resolution.py:258-273: forward, L1 loss, backward, Adam).
@@ -1095,49 +1112,74 @@ def main():
             hidden_cache.clear()
         torch.cuda.empty_cache()
 
+    def pick(dct, *keys):
+        return None if not dct else {k_: dct.get(k_) for k_ in keys}
+
+    g241t = None if not backward else backward.get("g241_depth6_train_step")
+    bwd_roof = {} if not backward else backward.get("roofline", {})
+    # ---- everything measured (per-kernel counters, notes, every leg's full object): bench_detail.json beside the line
+    detail = {
+        "metric": "M-edges/s through fused NNConv fwd (width=64)", "value": round(value, 3), "unit": "M-edges/s",
+        "precision": precision, "median_step_ms": round(med, 3), "value_at_median": round(world * e / med / 1e3, 3),
+        "config": {"workload": f"GKN Darcy-2D {s}x{s} lattice radius graph r={r} N={n} E={e} per sample; NNConv_old fwd "
+                               f"width=64; kernel MLP 6-{kw}-{kw}-4096; aggr=mean root+bias; one sample per GPU",
+                   "graph": args.config, "edges_per_sample": e, "nodes_per_sample": n, "plan": plan},
+        "graph_prep": graph_prep, "rel_l2_sample": rel, "alt_precision": alt, "node_table_attributes": nodeattr,
+        "roofline": roofline, "cpu_baseline": cpu, "mgkn": mgkn, "depth_reuse": reuse, "backward": backward,
+    }
+    detail_path = args.detail_out or os.path.join(os.getcwd(), "bench_detail.json")
+    try:
+        os.makedirs(os.path.dirname(detail_path) or ".", exist_ok=True)
+        with open(detail_path, "w") as fh:
+            json.dump(detail, fh, indent=1)
+    except OSError as ex:
+        detail_path = f"(not written: {ex})"
+    # ---- the ONE JSON line, <= 2.5 KB: the contract's keys, a compact roofline / cpu_baseline, and every other leg's headline figure
+    # (the driver keeps key names + a 2-3 KB tail - a 20 KB line hid half of what it measured)
     line = {
         "metric": "M-edges/s through fused NNConv fwd (width=64)",
         "value": round(value, 3), "unit": "M-edges/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if precision == "f32" else "f32 (hidden layer + aggregation: 2-term f16-split MFMA, f32 accumulate)",
-        "precision": precision, "data": "synthetic",
-        "median_step_ms": round(med, 3), "value_at_median": round(world * e / med / 1e3, 3),
+        "data": "synthetic",
+        "config": {"workload": f"GKN Darcy-2D {s}x{s} radius graph r={r} N={n} E={e}; NNConv_old fwd width=64; kernel MLP 6-{kw}-{kw}-4096; "
+                               "aggr=mean root+bias; one sample per GPU", "graph": args.config},
         "rccl_ranks": world if use_dist else 0,
-        # the other legs' headline figures, up front (the full objects follow `cpu_baseline`; a reader of a truncated line still
-        # sees these)
+        "rel_l2_sample": None if rel is None else float(f"{rel:.3e}"),
+        "roofline": None if not roofline else {k_: roofline.get(k_) for k_ in (
+            "kernel", "bound", "achieved", "peak", "unit", "frac", "frac_of_sustained", "traffic", "algorithmic_bytes_per_launch",
+            "traffic_over_algorithmic", "avg_launch_ms", "launches_per_step", "hbm_frac")},
+        "cpu_baseline": None if not cpu else dict(pick(cpu, "value", "unit", "cores", "kind"), sample=str(cpu.get("sample", ""))[:96]),
         "summary": {
-            "graph_prep_ms": None if graph_prep is None else {"csr_build": graph_prep.get("csr_build_ms"), "attr_reorder": graph_prep.get("attr_reorder_ms")},
-            "mgkn_ms_per_forward": None if not mgkn else {k_: {"unmodified_calls": v_.get("ms_per_forward"), "captured": v_.get("ms_per_forward_captured"),
-                                                             "grouped": v_.get("ms_per_forward_grouped")} for k_, v_ in mgkn.items()},
-            "mgkn_train_step_ms": None if not mgkn else {k_: {"direct": v_.get("train_step_ms"), "captured": v_.get("train_step_captured_ms")} for k_, v_ in mgkn.items()},
-            "backward_g121": None if not backward else {"ms": backward.get("ms"), "M_edges_per_s": backward.get("M_edges_per_s"),
-                                                        "hidden_kept_by_forward": backward.get("hidden_kept_by_forward"),
-                                                        "training_forward_ms": backward.get("training_forward_ms"), "pair_ms": backward.get("pair_ms"),
-                                                        "recompute_form": {k_: backward.get("recompute_form", {}).get(k_) for k_ in
-                                                                           ("ms", "training_forward_ms", "pair_ms", "frac_f16_peak")},
-                                                        "default_workspace_ms": backward.get("default_workspace_ms"),
-                                                        "frac_f16_peak": backward.get("roofline", {}).get("frac")},
-            "g241_depth6_train_step_s": None if not backward or "g241_depth6_train_step" not in backward else
-            {"same_sample": backward["g241_depth6_train_step"].get("s"),
-             "distinct_samples": backward["g241_depth6_train_step"].get("distinct_samples", {}).get("s"),
-             "peak_GiB": backward["g241_depth6_train_step"].get("peak_GiB")},
+            "graph_prep_ms": pick(graph_prep, "csr_build_ms", "attr_reorder_ms"),
+            "node_table_M_edges_s": None if not nodeattr else nodeattr.get("M_edges_per_s", nodeattr.get("value")),
+            "mgkn_fwd_ms": None if not mgkn else {k_[5:12]: [v_.get("ms_per_forward"), v_.get("ms_per_forward_captured"), v_.get("ms_per_forward_grouped")]
+                                                  for k_, v_ in mgkn.items()},
+            "mgkn_train_ms": None if not mgkn else {k_[5:12]: [v_.get("train_step_ms"), v_.get("train_step_captured_ms")] for k_, v_ in mgkn.items()},
+            "mgkn_keys": "[unmodified calls, captured, grouped] / [direct, captured]",
+            "bwd_g121": None if not backward else {
+                "ms": backward.get("ms"), "M_edges_s": backward.get("M_edges_per_s"), "fwd_ms": backward.get("training_forward_ms"),
+                "pair_ms": backward.get("pair_ms"), "frac": bwd_roof.get("frac"), "traffic": bwd_roof.get("traffic"),
+                "traffic_over_algorithmic": bwd_roof.get("traffic_over_algorithmic"),
+                "recompute_form": pick(backward.get("recompute_form"), "ms", "pair_ms", "frac_f16_peak"),
+                "one_chunk_ms": backward.get("one_chunk_workspace_ms"), "workspace_GiB": backward.get("default_workspace_GiB")},
+            "bwd_g241_one_layer": None if not backward else pick(backward.get("g241_one_layer"), "ms", "M_edges_per_s"),
+            "g241_depth6_train_step": None if not g241t else {
+                "s": g241t.get("s"), "first_s": g241t.get("first_step_s"), "distinct_samples_s": g241t.get("distinct_samples", {}).get("s"),
+                "peak_GiB": g241t.get("peak_GiB"), "M_edge_applications_s": g241t.get("M_edge_applications_per_s")},
+            "depth6_fwd": None if not reuse else {k_: (v_.get("ms") if isinstance(v_, dict) else v_) for k_, v_ in list(reuse.items())[:3]},
         },
-        "config": {"workload": f"GKN Darcy-2D {s}x{s} lattice radius graph r={r} N={n} E={e} per sample; NNConv_old fwd "
-                               f"width=64; kernel MLP 6-{kw}-{kw}-4096; aggr=mean root+bias; one sample per GPU",
-                   "graph": args.config, "edges_per_sample": e, "nodes_per_sample": n,
-                   "plan": plan},
-        "graph_prep": graph_prep,
-        "rel_l2_sample": rel,
-        "alt_precision": alt,
-        "node_table_attributes": nodeattr,
-        "roofline": roofline,
-        "cpu_baseline": cpu,
-        "mgkn": mgkn,
-        "depth_reuse": reuse,
-        "backward": backward,
+        "detail": detail_path,
     }
-    print(json.dumps(line), flush=True)
+    txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) > 2500:                                  # never let the line outgrow the driver's tail: drop the least essential
+        for k_ in ("depth6_fwd", "mgkn_keys", "node_table_M_edges_s", "bwd_g241_one_layer"):
+            line["summary"].pop(k_, None)
+            txt = json.dumps(line, separators=(",", ":"))
+            if len(txt) <= 2500:
+                break
+    print(txt, flush=True)
     if use_dist:
         dist.destroy_process_group()
 

@@ -467,12 +467,15 @@ SAVE_H_BYTES = int(float(os.environ.get("GPDE_SAVE_H_GB", "32")) * (1 << 30))   
 SAVE_H_MIN_EDGES = 262144                                                          # below: one fused launch beats store + aggregation
 
 
-BWD_WS_FRACTION = float(os.environ.get("GPDE_BWD_WS_FRACTION", "0.6"))      # of the free device memory a full backward's workspace may take
+# Fraction of the free device memory a full backward's workspace may take for the ONE-CHUNK plan.  Default 0 = the library's default
+# plan (~26 GB at k = 1024) since round 6: at s=121 one chunk asks for 125 GiB to be 2.5 % faster (105.5 vs 108.2 ms) - the wrong default
+# on a device that also holds a DDP replica's optimizer state and 32 samples' graphs.  Opt in: GPDE_BWD_WS_FRACTION=0.6
+BWD_WS_FRACTION = float(os.environ.get("GPDE_BWD_WS_FRACTION", "0"))
 
 
 def bwd_workspace_bytes(lib, n: int, e: int, nl: int, dims_c, dev, h_given_bytes: int = 0) -> int:
     """Workspace of a full backward (gpde_nnconv_bwd*): the library's default (~26 GB at k = 1024: node-aligned chunks of
-    ~640 k edges), or its one-chunk size when that is below GPDE_BWD_WS_FRACTION of what the device has free - one chunk =
+    ~640 k edges), or - opt-in, GPDE_BWD_WS_FRACTION > 0 - its one-chunk size when that is below that fraction of what the device has free - one chunk =
     fewer launches, GEMM tile rounds and split-K reductions (s=121, 5.9 M edges: 139.4 -> 135.5 ms).  All or nothing: sizes
     in between were tried (G241: one NNConv backward 2.57 -> 2.11 s with 0.6 of the free memory) and dropped - in a training
     run on a graph whose hidden activations take most of the device an odd-sized 40 GB block fragments torch's cache until
