@@ -28,6 +28,9 @@ the cache policies of hidden_cache.py) is decided during the warm-up / recording
     inside `fn`): the optimizer must be capturable (`torch.optim.Adam(..., capturable=True)`: its step count lives on the
     device) and `capture(..., updates_parameters=True)` must be said, because the recorded step rewrites the weights behind
     Python's back (tests/test_gpu_capture.py).
+    No autograd graph of an EARLIER direct step may still be alive when a training step is recorded (a `loss` tensor kept in a
+    variable is enough): its AccumulateGrad nodes stay bound to the stream that step ran on, and the recorded gradient
+    accumulation would fork onto that stream - `hipStreamEndCapture` aborts the process on such an unjoined fork.
 Not a tracing compiler: nothing is transformed, fused or re-ordered.
 """
 from __future__ import annotations

@@ -76,15 +76,16 @@ def make_burgers_mat(path, n, s, seed):
 def prepare_workdir(script: str, workdir: str, n_samples: int):
     for d in ("data", "model", "results", "image"):
         os.makedirs(os.path.join(workdir, d), exist_ok=True)
-    base = os.path.basename(script)
-    if base.startswith("MGKN_orthogonal") :
+    # which data set a script reads is in its source: `burgers_data_R10.mat` (a, u [N, 8192]), `piececonst_r241_...` or
+    # `piececonst_r421_...` (literally, or as 'piececonst_r'+str(s0) with s0 = 421: UAI7_evaluate*.py:38-41)
+    with open(script) as fh:
+        src = fh.read()
+    if "TRAIN_PATH = 'data/burgers_data_R10.mat'" in src:
         make_burgers_mat(os.path.join(workdir, "data", "burgers_data_R10.mat"), n_samples, 8192, 0)
-    elif base.startswith("MGKN_general") or base.startswith("neurips"):
-        for i in (1, 2):
-            make_darcy_mat(os.path.join(workdir, "data", f"piececonst_r421_N1024_smooth{i}.mat"), n_samples, 421, i)
-    else:
-        for i in (1, 2):
-            make_darcy_mat(os.path.join(workdir, "data", f"piececonst_r241_N1024_smooth{i}.mat"), n_samples, 241, i)
+        return
+    res = 421 if ("piececonst_r421" in src and "TRAIN_PATH = 'data/piececonst_r421" in src) or "s0 = 421" in src else 241
+    for i in (1, 2):
+        make_darcy_mat(os.path.join(workdir, "data", f"piececonst_r{res}_N1024_smooth{i}.mat"), n_samples, res, i)
 
 
 def install_torch_drift_compat():
@@ -134,6 +135,28 @@ def install_torch_drift_compat():
         return _getitem(self, idx)
 
     torch.Tensor.__getitem__ = getitem
+
+
+def install_cpu_dryrun():
+    """Developer aid (build container, no GPU): `.cuda()` / `.to('cuda')` become no-ops so that a script's data pipeline, batch
+    collation, splitters and model classes can be exercised on the HOST with the stock-torch composite (--composite is implied).
+    Never used by a test: the tests run the scripts on the MI355X."""
+    import torch
+
+    def ident(self, *a, **k):
+        return self
+    torch.Tensor.cuda = ident
+    torch.nn.Module.cuda = ident
+    _t_to, _m_to = torch.Tensor.to, torch.nn.Module.to
+
+    def fix(a):
+        if isinstance(a, torch.device) and a.type == "cuda":
+            return torch.device("cpu")
+        if isinstance(a, str) and a.startswith("cuda"):
+            return "cpu"
+        return a
+    torch.Tensor.to = lambda self, *a, **k: _t_to(self, *[fix(x) for x in a], **{k_: fix(v) for k_, v in k.items()})
+    torch.nn.Module.to = lambda self, *a, **k: _m_to(self, *[fix(x) for x in a], **{k_: fix(v) for k_, v in k.items()})
 
 
 def run(script: str, overrides: dict, workdir: str | None = None, n_samples: int | None = None, seed: int | None = 0,
@@ -203,6 +226,7 @@ def main():
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--samples", type=int, default=None, help="samples in the synthetic .mat files")
     ap.add_argument("--seed", type=int, default=0, help="torch / numpy / random seed set before the script starts")
+    ap.add_argument("--cpu-dryrun", action="store_true", help="developer aid: no GPU - .cuda() is a no-op, composite operator on the host")
     ap.add_argument("--composite", action="store_true",
                     help="test harness: run the script on the stock-torch-ops composite of the operator instead of libgpde.so")
     args = ap.parse_args()
@@ -210,6 +234,9 @@ def main():
     for kv in args.set:
         k, v = kv.split("=", 1)
         overrides[k] = ast.literal_eval(v)
+    if args.cpu_dryrun:
+        install_cpu_dryrun()
+        args.composite = True
     ns = run(args.script, overrides, args.workdir, args.samples, args.seed, args.composite)
     print(f"[run_reference_script] {os.path.basename(args.script)} finished; overrides {overrides}")
     from graph_pde_amd import _lib

@@ -10,8 +10,14 @@ H live.  Checked here:
     on exactly those nodes' out-edges (~0.9 M edges; the operator is linear in x, so the rows need nothing else:
     oracle.nnconv_grad_x_rows, pinned on CPU to autograd through the reference's module) - <= 2e-5;
   * dW_1..3, db_1..3, droot, dbias against the same step with GPDE_HIDDEN_CACHE=off - every application's own full backward
-    (gpde_nnconv_bwd, recompute form at this size), the plan tests/test_gpu_headline_bwd.py holds to float64 - <= 2e-5 (the hidden
-    layers: <= 5e-5, the stated split-f16 bound of that file);
+    (gpde_nnconv_bwd, recompute form at this size), the plan tests/test_gpu_headline_bwd.py holds to float64 - <= 2e-5; the two
+    hidden layers' gradients <= 2e-4.  Why that bound: profiles/r06_g241_grad_truth.txt (scripts/g241_grad_truth.py, ~3 PFLOP of
+    float64 on the device, a one-off) holds THIS step against float64 autograd through the reference's op chain on the full graph:
+    grad_x 1.5e-7 on all 58,081 rows, dW_3 / db_3 / root / bias <= 8e-7, and dW_1, db_1, dW_2, db_2 4.0e-4 - 5.3e-4 for BOTH plans
+    AND for the same plan with its k1 x k2 GEMMs on exact fp32 MFMA (4.0e-4): at 95.5 M edges x 1024 units the hidden layers'
+    gradients carry an fp32-class floor of 4e-4 that is not the split arithmetic's (ReLU masks of pre-activations inside fp32
+    rounding of zero differ from float64's; sums of both signs over 3 x 95.5 M edges) - the two plans differ from each other by
+    8e-5 / 1.2e-4 (dW_1 / db_1) and 1.9e-5 / 1.7e-5 (dW_2 / db_2), a fifth of that floor;
   * grad_x of the two plans agree everywhere (all 58,081 rows, all applications) to 2e-5."""
 import pytest
 import torch
@@ -23,7 +29,7 @@ from oracle.nnconv_oracle import nnconv_grad_x_rows, rel_l2
 pytestmark = pytest.mark.gpu
 DIMS = [6, 1024, 1024, 4096]
 TOL = 2e-5
-TOL_HIDDEN = 5e-5
+TOL_HIDDEN = 2e-4
 APPS = 3            # applications per step: with 2 the policy (rightly) stops sharing - a virtual H that served ONE application
 
 
