@@ -136,6 +136,18 @@ def install_torch_drift_compat():
 
     torch.Tensor.__getitem__ = getitem
 
+    # Third drift (graph-neural-operator/utilities.py:607, DownsampleGridSplitter.sample, reached by UAI7_evaluate.py:140):
+    # `torch.tensor([x, y])` with x, y one-element tensors from `torch.randint(0, r, (1,))`.  The torch of 2020 read such a list
+    # as two scalars; torch 2.x walks into the elements and raises "len() of a 0-d tensor".  Restore the old reading.
+    _tensor = torch.tensor
+
+    def tensor(data, *a, **k):
+        if isinstance(data, (list, tuple)) and data and all(isinstance(t, torch.Tensor) and t.numel() == 1 for t in data):
+            data = [t.item() for t in data]
+        return _tensor(data, *a, **k)
+
+    torch.tensor = tensor
+
 
 def install_cpu_dryrun():
     """Developer aid (build container, no GPU): `.cuda()` / `.to('cuda')` become no-ops so that a script's data pipeline, batch

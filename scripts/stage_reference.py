@@ -16,10 +16,13 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DST = os.path.join(REPO, "oracle", "_ref")
 SRC = "/root/reference"
 PROJECTS = ("graph-neural-operator", "multipole-graph-neural-operator")
-# what the three unmodified-script tests execute: the scripts themselves and the `utilities` module each imports
+# what the unmodified-script tests execute (round 6: every NNConv script of the reference; neurips4_GCN.py is another operator): the scripts themselves and the `utilities` module each imports
 # (nn_conv / torch_geometric / h5py resolve to graph-pde_amd/shims and are NOT staged)
-NEEDED = {"graph-neural-operator": ("UAI1_full_resolution.py", "utilities.py"),
-          "multipole-graph-neural-operator": ("MGKN_general_darcy2d.py", "MGKN_orthogonal_burgers1d.py", "utilities.py")}
+NEEDED = {"graph-neural-operator": ("UAI1_full_resolution.py", "UAI2_full_equation.py", "UAI3_resolution.py", "UAI4_equation_sample.py",
+                                    "UAI5_sample_generalize.py", "UAI6_sample_radius.py", "UAI7_evaluate.py", "UAI7_evaluate2.py",
+                                    "UAI8_kernel.py", "utilities.py"),
+          "multipole-graph-neural-operator": ("MGKN_general_darcy2d.py", "MGKN_orthogonal_burgers1d.py", "neurips1_GKN.py", "neurips5_GKN.py",
+                                              "neurips1_MGKN.py", "neurips2_MGKN.py", "neurips3_MGKN.py", "utilities.py")}
 
 
 def stage(src_root: str = SRC, dst: str = DST, everything: bool = False) -> int:
