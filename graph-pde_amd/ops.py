@@ -218,7 +218,12 @@ def attr_in_slot_order(csr: "Csr", edge_attr: torch.Tensor):
     if csr._identity is None:
         csr._identity = torch.arange(e, dtype=torch.int32, device=csr.perm.device)
         csr._attr_sorted = {}
-        csr._perm_is_identity = bool(torch.equal(csr.perm, csr._identity))
+        # is `perm` the identity (a graph already in slot order)?  A full comparison is a pass over 95.5 M indices plus a byte mask
+        # of the same length on the headline graph - 21 of the 23 ms a NEW sample's first call spent here (profiles/
+        # r06_attr_reorder_probe.txt; the gather itself is 2.2 ms).  A graph in the reference's source-major order fails the
+        # comparison at almost every slot: 4096 sampled slots decide it; only a sample that passes is followed by the full check.
+        probe = torch.linspace(0, e - 1, min(e, 4096), device=csr.perm.device).to(torch.int32)
+        csr._perm_is_identity = bool(torch.equal(csr.perm[probe.long()], probe)) and bool(torch.equal(csr.perm, csr._identity))
     if csr._perm_is_identity:
         return edge_attr, csr.perm
     st = edge_attr.untyped_storage()
