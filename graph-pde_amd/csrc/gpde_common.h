@@ -81,6 +81,7 @@ struct GpdeSwitches {
     bool bwd_recompute_f32;      // GPDE_BWD_RECOMPUTE_F32: H recomputed by fp32 GEMMs in the full backward
     bool bwd_h1_materialize;     // GPDE_BWD_H1_MATERIALIZE: round-2 plan (H_1 written)
     bool bwd_h1_gemm;            // GPDE_BWD_H1_GEMM
+    bool bwd_h1_image;           // GPDE_BWD_H1_IMAGE: rounds 3-5 plan (H_1^T split image + mask bits written by k_first_layer_pack) - A/B
     bool bwd_dw1_gemm;           // GPDE_BWD_DW1_GEMM
     bool bwd_du_passes;          // GPDE_BWD_DU_PASSES: separate bias / maxima / transpose passes over dU_2
     bool bwd_du_transpose_pass;  // GPDE_BWD_DU_TRANSPOSE_PASS: k_transpose_stats instead of the per-edge kernel's by-products
@@ -316,6 +317,18 @@ struct GpdeGemmF16sArgs {
     size_t g_layer_stride;              // floats between the node tables of consecutive layers (K = 64 * layers)
     size_t g_bnode_bytes;               // bytes of one node's split tile image [N/128][K/32][16 KiB]
     const float* g_unscale;             // [nodes] 2^-t of the node's image
+    // first hidden layer generated INSIDE the kernel (round 6; gpde_launch_gemm_f16s_tn / the dU_1 launch of gpde_bwd.hip):
+    // H_1[e][n] * sc[n] = relu(sum_d attr'[e][d] * w'[n][d]) on the split-f16 MFMA pair of the forward kernel, attr'[d] = attr[d] *
+    // alpha[d] (+ 1 in the bias slot), w' = the per-column image of k_first_layer_wimg.  fl_mode 1 (split-K form): the B chunk
+    // images [128 n][32 edges] are generated from the attributes instead of read from memory (no H_1^T image, no k_first_layer_pack);
+    // fl_mode 2 (plain row tiles): the epilogue's ReLU mask is the sign of the same product (no mask bits)
+    int fl_mode;
+    const float* fl_attr; int fl_ld0;   // gathered attributes [fl_rows][fl_ld0] (the first 8 floats of a row are used), slots >= k0 zero
+    int fl_rows;                        // rows of fl_attr that exist (edges beyond it are zero columns of the K padding)
+    const void* fl_wimg;                // [N][2][8] f16: w'_hi | w'_lo per column
+    const float* fl_alpha;              // [16]: alpha[d] (0 in the bias slot and beyond), then beta[d] (1 in the bias slot, else 0)
+    const float* fl_wp; int fl_ldw;     // fl_mode 2: the padded fp32 first layer [N][fl_ldw] and bias [N] - an H_1 value whose split-f16
+    const float* fl_bp;                 // product lies inside its own error bound of zero gets its sign from the exact fp32 fmaf chain
 };
 bool gpde_gemm_f16s_supported(int M, int N, int K, int lda);
 
@@ -356,8 +369,15 @@ struct GpdeFirstLayerSpec {
     const float* H0; int ld0;            // gathered attributes [rows][ld0], slots >= k0 zero (ld0 >= 8)
     const float* Wp; int ldw;            // padded first-layer weight [n_in][ldw] (ldw >= 8), bias bp [n_in]
     const float* bp;
-    uint32_t* maskbits;                  // out: [rows][n_in / 32]
+    uint32_t* maskbits;                  // out: [rows][n_in / 32] - or, in-kernel generation (k0 given, <= 7): the buffer
+                                         // receives the operand image instead: [n_in][16] f16 (w'_hi | w'_lo) then 16 floats (alpha,
+                                         // beta) at byte offset n_in * 32 (gpde_first_layer_image_*), for the dU_1 launch that follows
+    int k0;                              // attribute slots in use (the bias takes slot k0); 0: unknown -> image path
 };
+// (in-kernel generation) where the operand image and the slot scales sit inside the `maskbits` buffer of the spec
+static inline const void* gpde_first_layer_wimg(const void* buf) { return buf; }
+static inline const float* gpde_first_layer_alpha(const void* buf, int n_in) { return (const float*)((const char*)buf + (size_t)n_in * 32); }
+bool gpde_first_layer_in_kernel(const GpdeFirstLayerSpec& f, int rows, int ksplits);
 // Optional by-products of the pass that transposes dU (it reads every element once): the bias gradient and the per-row
 // scales the NEXT GEMM over dU (dU_1 = dU . W^T) needs - instead of two more passes over dU (k_colsum, k_row_scale_kernel).
 struct GpdeDuStats {

@@ -77,13 +77,27 @@ constexpr int A_SLOT = NW * TE * 128;      // 32 KiB: one 32-k chunk of the work
 // one layer, a full 128-byte line); B depends on the destination node: a workgroup tile is 256 consecutive slots of ONE node
 // (g_tile), its four waves share that node's image through the ring.  Row scales are per SOURCE node (sc / isc indexed by
 // g_src), the image carries one scale per node (g_unscale).
-template <bool GATHER>
+// FL (round 6, GpdeGemmF16sArgs::fl_mode): the first hidden layer H_1 = relu(W_1 . attr + b_1) of the kernel MLP is produced INSIDE
+// this kernel from the 8 attribute slots of an edge, by the forward kernel's split-f16 MFMA pair ([a_hi|a_hi] x [w_hi;w_lo] +
+// [a_lo|a_lo] x [w_hi;0], gpde_fused_f16v6.hip), with A = attributes (rows = edges) and B = the column image: D[edge][n] has the
+// accumulator layout of this kernel's tiles AND - eight consecutive registers of a lane - the B-operand layout of its K loop when the
+// contraction runs over the edges.
+//   FL == 1 (split-K form, dW_2 = dU_2^T . H_1): wave w generates column block w of chunk c + 2's B image during chunk c - 2 MFMAs,
+//     8 conversion pairs, 4 ds_write_b128 into the ring slot the DMA used to fill.  The H_1^T split image (4 bytes per edge and
+//     column: 25.8 GB written and read back per backward at s=121) and k_first_layer_pack (9 ms) are gone.  The chunk's attributes
+//     (1 KiB) arrive by ONE LDS-DMA per wave and chunk into a private 3-slot stage, issued five chunks ahead in front of the A pieces.
+//   FL == 2 (plain row tiles, dU_1 = (dU_2 . W_2) (.) [H_1 > 0]): the epilogue recomputes H_1 of its 64 x 128 tile (16 MFMAs against
+//     1536 of the K loop) and masks by its sign - the same MFMA sequence on the same operands as FL == 1, hence the same bits; the
+//     mask words (128 bytes per edge written by the pack kernel, read here) are gone.
+template <bool GATHER, int FL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
+    static_assert(!(GATHER && FL != 0), "the gather form takes its mask from memory");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;                                               // [3][16 KiB]  B chunk images
     char* aring = smem + NS * TILE_B;                                // [3][4 waves][64 rows][128 B]  A chunks (fp32)
     float* Es_all = (float*)(aring + NS * A_SLOT);                   // [4][64] per-row un-scales
+    [[maybe_unused]] char* flst_all = (char*)(Es_all + NW * TE) + 64;   // FL == 1: [4 waves][3][1 KiB] attribute stage
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -172,6 +186,95 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
     const int sw = (l31 >> 1) & 7;
     const int boff[2] = {l31 * 128 + (((0 + h) ^ sw) << 4), l31 * 128 + (((2 + h) ^ sw) << 4)};
 
+    // ---- FL: operands of the H_1 MFMA pair --------------------------------------------------------------------------
+    [[maybe_unused]] float fl_al[8], fl_be[8];
+    [[maybe_unused]] h8 flB1 = {}, flB2 = {};          // FL == 1: this wave's column block (nb = wave) of the image: h ? w_lo : w_hi ; h ? 0 : w_hi
+    [[maybe_unused]] char* flst = flst_all + wave * (3 * 1024);
+    // (FL == 2: the slice's 128 image rows, 4 KiB, are copied to LDS once - eight global round trips per tile epilogue otherwise:
+    //  +0.4 ms per 850 k-row launch, measured)
+    auto fl_wops = [&](int nb, h8& b1, h8& b2) {
+        const char* wp = FL == 2 ? flst_all + (nb * 32 + l31) * 32 : (const char*)a.fl_wimg + (size_t)(slice * GP_TN + nb * 32 + l31) * 32;
+        const h8 whi = *(const h8*)wp, wlo = *(const h8*)(wp + 16);
+        const h8 zero = {};
+        b1 = h ? wlo : whi;
+        b2 = h ? zero : whi;
+    };
+    if constexpr (FL != 0) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { fl_al[d] = a.fl_alpha[d]; fl_be[d] = a.fl_alpha[8 + d]; }
+        if constexpr (FL == 1) fl_wops(wave, flB1, flB2);
+        if constexpr (FL == 2) ((f32x4*)flst_all)[tid] = ((const f32x4*)((const char*)a.fl_wimg + (size_t)slice * GP_TN * 32))[tid];   // (visible after the prologue's barrier)
+    }
+    // attributes of one edge (8 slots) -> the A operands [a_hi | a_hi] and [a_lo | a_lo] (both lane halves hold the same edge)
+    auto fl_aops = [&](f32x4 v0, f32x4 v1, bool valid, h8& a1, h8& a2) {
+        float q[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const float t = fmaf(d < 4 ? v0[d & 3] : v1[d & 3], fl_al[d], fl_be[d]);     // (alpha = 0 in the bias slot: t = 1)
+            q[d] = valid ? t : 0.f;
+        }
+        u4 ph, pl;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            unsigned hh, ll;
+            asm("v_cvt_pkrtz_f16_f32 %0, %2, %3\n\t"
+                "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+                "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                : "=&v"(hh), "=&v"(ll) : "v"(q[2 * p]), "v"(q[2 * p + 1]));
+            ph[p] = hh; pl[p] = ll;
+        }
+        a1 = __builtin_bit_cast(h8, ph);
+        a2 = __builtin_bit_cast(h8, pl);
+    };
+    // D[edge][n] = [a_hi|a_hi] x [w_hi;w_lo] + [a_lo|a_lo] x [w_hi;0]  (asm: VGPR destination; the leading s_nop covers a VALU write
+    // of an operand right in front - gpde_fused_f16v6.hip)
+    auto fl_h1gen = [&](f32x16& dd, h8 a1, h8 a2, h8 b1, h8 b2) {
+        asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(dd) : "v"(a1), "v"(b1));
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(dd) : "v"(a2), "v"(b2));
+    };
+    // relu + split of a pair of H_1 values (the forward's conv_a / conv_b: v_max_i32 is the ReLU on the bit pattern)
+    auto fl_conv = [&](float v0, float v1, unsigned& ph, unsigned& pl) {
+        unsigned t0_, t1_;
+        asm("v_max_i32 %1, 0, %3\n\t"
+            "v_max_i32 %2, 0, %4\n\t"
+            "v_cvt_pkrtz_f16_f32 %0, %1, %2"
+            : "=&v"(ph), "=&v"(t0_), "=&v"(t1_) : "v"(v0), "v"(v1));
+        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(pl) : "v"(t0_), "v"(t1_), "v"(ph));
+    };
+    // FL == 1: the attribute rows of chunk `ch` (32 edges x the first 32 bytes of each row) -> the 1 KiB stage slot ch % 3 by ONE LDS-DMA
+    // (lane = 16 bytes; rows beyond fl_rows are clamped here and zeroed when read)
+    auto fl_issue_attr = [&](int ch) {
+        const int e = min(kc(min(ch, NKC - 1)) * GP_BK + (lane >> 1), a.fl_rows - 1);
+        GPDE_GLDS(a.fl_attr + (size_t)e * a.fl_ld0 + 4 * (lane & 1), flst + (ch % 3) * 1024, 0);
+    };
+    // ... read back by lane (edge = l31) and turned into the A operands
+    auto fl_read_attr = [&](int ch, h8& a1, h8& a2) {
+        const char* l = flst + (ch % 3) * 1024 + l31 * 32;
+        const f32x4 v0 = *(const f32x4*)l, v1 = *(const f32x4*)(l + 16);
+        const bool valid = kc(min(ch, NKC - 1)) * GP_BK + l31 < a.fl_rows && ch < NKC;
+        fl_aops(v0, v1, valid, a1, a2);
+    };
+    // ... and the generated column block of chunk `ch` written into ring slot `sl`: lane (n = l31 of block `wave`, half h) holds the
+    // edges 16 m + {4h .. 4h+3, 8+4h .. 8+4h+3} of k16 step m in registers 8 m .. 8 m + 7 = unit 2 m + h of its row (hi), unit
+    // 4 + 2 m + h (lo) - the layout of gpde_pack.hip's chunk images (k_pack_split_kn)
+    auto fl_store = [&](const f32x16& dd, int sl) {
+        char* row = ring + sl * TILE_B + wave * 4096 + l31 * 128;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            u4 ph, pl;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                unsigned hh, ll;
+                fl_conv(dd[8 * m + 2 * p], dd[8 * m + 2 * p + 1], hh, ll);
+                ph[p] = hh; pl[p] = ll;
+            }
+            *(u4*)(row + (((2 * m + h) ^ sw) << 4)) = ph;
+            *(u4*)(row + (((4 + 2 * m + h) ^ sw) << 4)) = pl;
+        }
+    };
+
     // conversion of a pair of raw values: y = v * row scale, hi = rtz16(y), lo = rn16(y - hi)
     auto conv_a = [&](float v0, float v1, float sc, unsigned& ph, unsigned& t0_, unsigned& t1_) {
         asm("v_mul_f32 %1, %5, %3\n\t"
@@ -185,7 +288,47 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
             : "=&v"(pl) : "v"(t0_), "v"(t1_), "v"(ph));
     };
 
-    {   // chunks 0 and 1 of this slice's B
+    [[maybe_unused]] h8 fl_a1 = {}, fl_a2 = {};      // FL == 1: A operands of the chunk whose image is generated next (chunk c + 2 in chunk c)
+    [[maybe_unused]] f32x16 fl_d;
+    // ... and the pieces of one chunk's generation, spread over the MFMA gaps of the K loop (state between the gaps:)
+    [[maybe_unused]] f32x4 fl_v0 = {}, fl_v1 = {};   // raw attributes of chunk c + 3
+    [[maybe_unused]] float fl_q[8];
+    [[maybe_unused]] u4 fl_oh = {}, fl_ol = {};      // the four pairs of one 16-byte unit of the generated row
+    auto fl_dpair = [&](int p) {
+        unsigned hh, ll;
+        fl_conv(fl_d[2 * p], fl_d[2 * p + 1], hh, ll);
+        fl_oh[p & 3] = hh; fl_ol[p & 3] = ll;
+    };
+    auto fl_dwrite = [&](int m, int sl) {
+        char* row = ring + sl * TILE_B + wave * 4096 + l31 * 128;
+        *(u4*)(row + (((2 * m + h) ^ sw) << 4)) = fl_oh;
+        *(u4*)(row + (((4 + 2 * m + h) ^ sw) << 4)) = fl_ol;
+    };
+    auto fl_apair = [&](int p) {
+        unsigned hh, ll;
+        asm("v_cvt_pkrtz_f16_f32 %0, %2, %3\n\t"
+            "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(hh), "=&v"(ll) : "v"(fl_q[2 * p]), "v"(fl_q[2 * p + 1]));
+        u4 t1 = __builtin_bit_cast(u4, fl_a1), t2 = __builtin_bit_cast(u4, fl_a2);
+        t1[p] = hh; t2[p] = ll;
+        fl_a1 = __builtin_bit_cast(h8, t1); fl_a2 = __builtin_bit_cast(h8, t2);
+    };
+    if constexpr (FL == 1) {
+        // chunks 0 and 1 of this slice's B generated here, the A operands of chunk 2 prepared, the attributes of chunks 3 and 4 staged
+        fl_issue_attr(0); fl_issue_attr(1); fl_issue_attr(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            fl_read_attr(c, fl_a1, fl_a2);
+            fl_h1gen(fl_d, fl_a1, fl_a2, flB1, flB2);
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // MFMA result -> VALU read (asm operands are not padded)
+            fl_store(fl_d, c);
+        }
+        fl_read_attr(2, fl_a1, fl_a2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        fl_issue_attr(3); fl_issue_attr(4);
+    } else {   // chunks 0 and 1 of this slice's B
         const char* g0 = b_src(kc(0), bbase);
         char* l0 = ring + wave * 4096;
         GPDE_GLDS(g0, l0, 0); GPDE_GLDS(g0, l0, 1024); GPDE_GLDS(g0, l0, 2048); GPDE_GLDS(g0, l0, 3072);
@@ -356,7 +499,41 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                         }
                         if (j == 1) blo[nb] = *(const h8*)(rn + nb * 4096 + (bo ^ 64));
                         if (j == 5) bhi[nb] = *(const h8*)(rn + nb * 4096 + bo);
-                        if (m == 0) {
+                        if constexpr (FL == 1) {
+                            // chunk c + 2's column block of the B image is GENERATED: H_1 MFMA pair early in the chunk, its
+                            // conversion + the four ds_write_b128 well behind it, then the A operands of chunk c + 3 from the
+                            // staged attributes; the attribute DMA of chunk c + 5 goes out in front of the A pieces (vmcnt order)
+                            // (one small piece per MFMA gap: issued as blocks - 40 VALU + 4 LDS writes in one gap, 28 + 2 reads in
+                            //  another - the K loop was 19 % slower than with the image DMA; the forward kernel's rule, <= ~5 per gap)
+                            if (m == 0) {
+                                if (i == 2) fl_h1gen(fl_d, fl_a1, fl_a2, flB1, flB2);
+                                if (i == 4) fl_issue_attr(c + 5);
+                                if (i == 5) {
+                                    const char* l = flst + ((c + 3) % 3) * 1024 + l31 * 32;
+                                    fl_v0 = *(const f32x4*)l; fl_v1 = *(const f32x4*)(l + 16);
+                                }
+                                if (i == 8) fl_dpair(0);
+                                if (i == 11) fl_dpair(1);
+                                if (i == 14) fl_dpair(2);
+                                if (i == 17) { fl_dpair(3); fl_dwrite(0, slot2); }
+                                if (i == 20) fl_dpair(4);
+                                if (i == 23) fl_dpair(5);
+                            } else {
+                                if (i == 5) fl_dpair(6);
+                                if (i == 11) { fl_dpair(7); fl_dwrite(1, slot2); }
+                                if (i == 13) {
+#pragma unroll
+                                    for (int d = 0; d < 8; ++d) fl_q[d] = fmaf(d < 4 ? fl_v0[d & 3] : fl_v1[d & 3], fl_al[d], fl_be[d]);
+                                }
+                                if (i == 16) {
+                                    const bool valid = kc(min(c + 3, NKC - 1)) * GP_BK + l31 < a.fl_rows && c + 3 < NKC;
+#pragma unroll
+                                    for (int d = 0; d < 8; ++d) fl_q[d] = valid ? fl_q[d] : 0.f;
+                                }
+                                if (i == 17) { fl_apair(0); fl_apair(1); }
+                                if (i == 23) { fl_apair(2); fl_apair(3); }
+                            }
+                        } else if (m == 0) {
                             if (i == 2) GPDE_GLDS(gsrc, ldst, 0);
                             if (i == 8) GPDE_GLDS(gsrc, ldst, 1024);
                             if (i == 14) GPDE_GLDS(gsrc, ldst, 2048);
@@ -372,7 +549,8 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                     }
                 }
             }
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // B(c + 2) and A(c + 2) landed; A(c + 3) flies
+            if constexpr (FL == 1) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");   // A(c + 2), attr(c + 4) landed, the generated block is in the ring; A(c + 3) + attr(c + 5) fly
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // B(c + 2) and A(c + 2) landed; A(c + 3) flies
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             slot = slot1;
@@ -387,8 +565,17 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
         // requested before the drain below, used after it: the mask words of this tile's rows (lane = row) and the next
         // tile's row scales
         [[maybe_unused]] u4 mw = {0u, 0u, 0u, 0u};
+        [[maybe_unused]] f32x4 fa[2][2];
+        if constexpr (FL == 2) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float* ap = a.fl_attr + (size_t)min(r0 + 32 * e + l31, min(rmax, a.fl_rows - 1)) * a.fl_ld0;
+                fa[e][0] = *(const f32x4*)ap;
+                fa[e][1] = *(const f32x4*)(ap + 4);
+            }
+        }
         if constexpr (!GATHER) {
-            if (a.maskbits && !a.xc_x) mw = *(const u4*)(a.maskbits + (size_t)min(r0 + lane, rmax) * a.ldmb + slice * (GP_TN / 32));
+            if (FL != 2 && a.maskbits && !a.xc_x) mw = *(const u4*)(a.maskbits + (size_t)min(r0 + lane, rmax) * a.ldmb + slice * (GP_TN / 32));
             if (nxt_ok) {
                 scn[0] = a.sc[r0 + drows + l31];
                 scn[1] = a.sc[r0 + drows + 32 + l31];
@@ -434,6 +621,52 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                 };
                 if (r0 + TE <= rend) store_rows(std::true_type{});
                 else store_rows(std::false_type{});
+            }
+            NT_MARK(tm_epi);
+            continue;
+        }
+        if constexpr (FL == 2) {
+            // ReLU mask = sign of H_1 recomputed for the tile: D[edge][n] of the MFMA pair has the accumulators' own layout
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                h8 a1, a2;
+                fl_aops(fa[e][0], fa[e][1], true, a1, a2);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    h8 b1, b2;
+                    fl_wops(nb, b1, b2);
+                    f32x16 dd;
+                    fl_h1gen(dd, a1, a2, b1, b2);
+                    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // MFMA result -> VALU read (asm operands are not padded)
+                    auto store_col = [&](auto full_tag) {
+                        constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rr = 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            const int row = r0 + rr;
+                            float v = acc[e][nb][r] * (Es[rr] * ucv[nb]);
+                            acc[e][nb][r] = 0.f;
+                            float hv = dd[r];
+                            // |split product - exact| < 2^-4 in the image's scaled units (8 products of < 2^14, 2^-21 each): inside
+                            // 2^-2 of zero the sign is taken from the exact fp32 chain of k_first_layer_pack / k_first_layer (b, then
+                            // d ascending) - the mask is the image path's bit for bit, whatever the chunk's scales.  Rare: ~2^-14 of
+                            // the elements; the branch is skipped unless a lane of the wave needs it
+                            if (__builtin_expect(fabsf(hv) < 0.25f, 0)) {
+                                const int col = slice * GP_TN + nb * 32 + l31;
+                                // this lane's row r of block e = the attribute row held by lane (rr & 31) of its own half
+                                float t = a.fl_bp[col];
+                                const float* ar = a.fl_attr + (size_t)min(row, min(rmax, a.fl_rows - 1)) * a.fl_ld0;
+#pragma unroll
+                                for (int d = 0; d < 8; ++d) t = fmaf(a.fl_wp[(size_t)col * a.fl_ldw + d], ar[d], t);
+                                hv = t;
+                            }
+                            v = hv > 0.f ? v : 0.f;
+                            if (FULL || row < rend) Cout[(size_t)row * a.ldc + slice * GP_TN + nb * 32 + l31] = v;
+                        }
+                    };
+                    if (r0 + TE <= rend) store_col(std::true_type{});
+                    else store_col(std::false_type{});
+                }
             }
             NT_MARK(tm_epi);
             continue;
@@ -581,8 +814,19 @@ int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a_in, float* row_scale_ws, 
     a.n_groups = groups;
     const size_t lds = (size_t)NS * TILE_B + (size_t)NS * A_SLOT + NW * TE * 4 + 64;
     static GpdeLdsOnce once;
-    if (int rc = once.ensure(gpde_gemm_f16s_nt_kernel<false>, gpde_gemm_f16s_nt_kernel<true>)) return rc;
-    hipLaunchKernelGGL(gpde_gemm_f16s_nt_kernel<false>, dim3(groups * ns), dim3(256), lds, stream, a);
+    if (int rc = once.ensure(gpde_gemm_f16s_nt_kernel<false, 0>, gpde_gemm_f16s_nt_kernel<true, 0>, gpde_gemm_f16s_nt_kernel<false, 1>,
+                             gpde_gemm_f16s_nt_kernel<false, 2>)) return rc;
+    if (a.fl_mode) {
+        // the first hidden layer generated in the kernel (see the kernel's header): split-K form -> B chunks, row tiles -> mask
+        if ((a.fl_mode == 1) != (a.ksplits > 1) || a.fl_mode > 2 || !a.fl_attr || !a.fl_wimg || !a.fl_alpha || (a.fl_mode == 2 && (!a.fl_wp || !a.fl_bp)) || a.fl_ld0 < 8 || a.fl_ld0 % 4 != 0 || a.fl_rows < 1 ||
+            a.xc_x || a.mask || a.maskbits || (a.fl_mode == 1 && a.K / a.ksplits / GP_BK < 6)) {
+            gpde_set_error("gpde_gemm_f16s_nt: inconsistent in-kernel first-layer arguments (mode %d, ksplits %d)", a.fl_mode, a.ksplits);
+            return GPDE_EINVAL;
+        }
+        if (a.fl_mode == 1) hipLaunchKernelGGL((gpde_gemm_f16s_nt_kernel<false, 1>), dim3(groups * ns), dim3(256), lds + NW * 3 * 1024, stream, a);
+        else hipLaunchKernelGGL((gpde_gemm_f16s_nt_kernel<false, 2>), dim3(groups * ns), dim3(256), lds + 4096, stream, a);
+    } else
+        hipLaunchKernelGGL((gpde_gemm_f16s_nt_kernel<false, 0>), dim3(groups * ns), dim3(256), lds, stream, a);
     GP_LAUNCH_CHECK("gpde_gemm_f16s_nt_kernel");
     return GPDE_OK;
 }
@@ -823,6 +1067,44 @@ __global__ void k_first_layer_scales(const float* __restrict__ Wp, int ldw, cons
     sc[i] = ok ? __int_as_float((267 - eb) << 23) : 1.f;
     usc[i] = ok ? __int_as_float((eb - 13) << 23) : 1.f;
 }
+// Operands of the IN-KERNEL first layer (GpdeGemmF16sArgs::fl_mode): per input slot d < k0 the attribute scale alpha[d] =
+// 2^-E(amax[d]) (|attr'| < 2), beta = 1 in the bias slot k0 (alpha = 0 there and beyond); per column n the scale sc[n] of
+// k_first_layer_scales and the split image of w'[n][d] = Wp[n][d] * sc[n] / alpha[d] (d < k0), w'[n][k0] = bp[n] * sc[n]:
+// |w'[n][d] * attr'[d]| <= bound * sc < 2^14, |w'| < 2^15 - inside the f16 range; all scales are powers of two (exact).
+__global__ void k_first_layer_wimg(const float* __restrict__ Wp, int ldw, const float* __restrict__ bp, const unsigned* __restrict__ amax,
+                                   int k0, int n, float* __restrict__ sc, float* __restrict__ usc, _Float16* __restrict__ wimg,
+                                   float* __restrict__ alpha) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float al[8], ial[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const int eb = (int)((amax[d] >> 23) & 0xff);
+        const bool ok = d < k0 && eb >= 20 && eb <= 230;
+        al[d] = d < k0 ? (ok ? __int_as_float((254 - eb) << 23) : 1.f) : 0.f;           // 2^-(eb - 127)
+        ial[d] = d < k0 ? (ok ? __int_as_float(eb << 23) : 1.f) : 0.f;
+    }
+    if (i == 0) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { alpha[d] = al[d]; alpha[8 + d] = d == k0 ? 1.f : 0.f; }
+    }
+    if (i >= n) return;
+    float b = fabsf(bp[i]);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) b = fmaf(fabsf(Wp[(size_t)i * ldw + d]), __uint_as_float(amax[d]), b);
+    const int eb = (int)((__float_as_uint(b) >> 23) & 0xff);
+    const bool ok = eb >= 20 && eb <= 230;
+    const float s = ok ? __int_as_float((267 - eb) << 23) : 1.f;
+    sc[i] = s;
+    usc[i] = ok ? __int_as_float((eb - 13) << 23) : 1.f;
+    _Float16* o = wimg + (size_t)i * 16;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const float w = d < k0 ? Wp[(size_t)i * ldw + d] * s * ial[d] : d == k0 ? bp[i] * s : 0.f;
+        const _Float16 hi = (_Float16)w;             // (rn here, rtz in the kernels' operand conversions: any split hi + lo = w to 2^-22 serves)
+        o[d] = hi;
+        o[8 + d] = (_Float16)(w - (float)hi);
+    }
+}
 // k_pack_split_kn with H computed on the fly: B[n][k = edge] = relu(bp[n] + sum_d Wp[n][d] H0[edge][d]) * sc[n], plus
 // the ReLU mask bits [rows][n_in / 32].  Workgroup = one 16 KiB tile (slice of 128 n, chunk of 32 edges), thread =
 // (n, k16 step m).  The fp32 fmaf chain is the one k_first_layer / the fp32 GEMM path evaluate (d ascending from the bias).
@@ -960,12 +1242,20 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
         hipLaunchKernelGGL(k_scales_from_max, dim3((n_out + 255) / 256), dim3(256), 0, stream, bits, n_out, sca, isca);
         hipLaunchKernelGGL(k_transpose_pad, dim3(epad / 64, n_out / 64), dim3(256), 0, stream, dU, rows, ldu, At, epad);
     }
+    const bool fl_gen = fl && gpde_first_layer_in_kernel(*fl, rows, ksplits);
     if (fl) {
         int nb = (rows + 31) / 32; if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(k_attr_absmax8, dim3(nb), dim3(256), 0, stream, fl->H0, rows, fl->ld0, bits + n_out);
-        hipLaunchKernelGGL(k_first_layer_scales, dim3((n_in + 255) / 256), dim3(256), 0, stream, fl->Wp, fl->ldw, fl->bp,
-                           bits + n_out, n_in, scb, ucolb);
-        hipLaunchKernelGGL(k_first_layer_pack, dim3((epad / 32 + FLP_TILES - 1) / FLP_TILES, n_in / 128), dim3(256), 0, stream, *fl, rows, n_in, scb, epad / 32, Bimg);
+        if (fl_gen) {
+            // round 6: no image, no mask bits - the GEMM below (and the dU_1 GEMM after it) generate H_1 from the attributes; the
+            // spec's `maskbits` buffer carries the column image + slot scales to both
+            hipLaunchKernelGGL(k_first_layer_wimg, dim3((n_in + 255) / 256), dim3(256), 0, stream, fl->Wp, fl->ldw, fl->bp, bits + n_out,
+                               fl->k0, n_in, scb, ucolb, (_Float16*)fl->maskbits, (float*)gpde_first_layer_alpha(fl->maskbits, n_in));
+        } else {
+            hipLaunchKernelGGL(k_first_layer_scales, dim3((n_in + 255) / 256), dim3(256), 0, stream, fl->Wp, fl->ldw, fl->bp,
+                               bits + n_out, n_in, scb, ucolb);
+            hipLaunchKernelGGL(k_first_layer_pack, dim3((epad / 32 + FLP_TILES - 1) / FLP_TILES, n_in / 128), dim3(256), 0, stream, *fl, rows, n_in, scb, epad / 32, Bimg);
+        }
     } else {
         hipLaunchKernelGGL(k_colabsmax, dim3((n_in + 255) / 256, splits), dim3(256), 0, stream, H, rows, n_in, ldh, splits, bits + n_out);
         hipLaunchKernelGGL(k_scales_from_max, dim3((n_in + 255) / 256), dim3(256), 0, stream, bits + n_out, n_in, scb, ucolb);
@@ -976,7 +1266,18 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
     g.A = At; g.lda = epad; g.M = n_out; g.bsplit = Bimg; g.ucol = ucolb; g.mask = nullptr; g.ldmask = 0;
     g.C = part; g.ldc = n_in; g.K = epad; g.N = n_in; g.sc = sca; g.isc = isca;
     g.ksplits = ksplits; g.cstride = (size_t)n_out * n_in;
+    if (fl_gen) {
+        g.fl_mode = 1; g.fl_attr = fl->H0; g.fl_ld0 = fl->ld0; g.fl_rows = rows;
+        g.fl_wimg = gpde_first_layer_wimg(fl->maskbits); g.fl_alpha = gpde_first_layer_alpha(fl->maskbits, n_in);
+    }
     return gpde_launch_gemm_f16s_nt(g, nullptr, stream);
+}
+
+// Whether gpde_launch_gemm_f16s_tn generates the first hidden layer inside its GEMM for this spec (then `maskbits` holds the operand
+// image, not mask words, and the dU_1 launch must use fl_mode 2): a free slot for the bias, 16-byte aligned attribute rows,
+// the split-K form (ksplits > 1), and not switched off (GPDE_BWD_H1_IMAGE=1: rounds 3-5's image + mask bits, A/B)
+bool gpde_first_layer_in_kernel(const GpdeFirstLayerSpec& f, int rows, int ksplits) {
+    return f.k0 >= 1 && f.k0 <= 7 && f.ld0 >= 8 && f.ld0 % 4 == 0 && rows >= 1 && ksplits > 1 && !gpde_switches().bwd_h1_image;     // (a K split is >= 256 edges = 8 chunks)
 }
 
 // ---- gather form: operands and launcher (depth-deferred backward, gpde_bwd.hip) ------------------------------------------
