@@ -186,6 +186,30 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ M, int
     }
 }
 
+// amax[d] = max over rows of |T[row][col_d]| (fp32 bit patterns, zeroed by the caller), col_d = d for an attribute tensor [rows][k0],
+// (a node table is read through the edge's end points): the maximum of every edge's slot d over the WHOLE call - the in-kernel first layer
+// (gpde_gemm_f16s.hip, fl_mode) scales its operands from it, so that every edge chunk of the call - and every chunking - uses the
+// same scales and forms the same H_1 bits (ReLU mask included) for an edge
+__global__ __launch_bounds__(256) void k_attr_absmax_all(const float* __restrict__ T, int64_t rows, int ld, int k0, NodeAttrSel nas,
+                                                         const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                         unsigned* __restrict__ amax) {
+    // rows = edges.  Attribute tensor: T[edge][d]; node table (nas.kt > 0): slot d of edge e = T[(sel[d] >> 8 ? dst : src)[e]][sel[d] & 255]
+    // - the maximum over the EDGES in both cases, i.e. the same number for a table and for the tensor materialised from it
+    unsigned m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+        const int64_t js = nas.kt ? src[r] : r, jd = nas.kt ? dst[r] : r;
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+            if (d < k0) m[d] = max(m[d], __float_as_uint(nas.kt ? T[((nas.sel[d] >> 8) ? jd : js) * ld + (nas.sel[d] & 255)] : T[r * ld + d]) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m[d] = max(m[d], (unsigned)__shfl_xor((int)m[d], o));
+        if ((threadIdx.x & 63) == 0 && m[d]) atomicMax(amax + d, m[d]);
+    }
+}
+
 // First-layer gradients in ONE pass over dU_1:  P[split][k][d] = sum_rows dU[row][k] * H0[row][d]  (d < 8: the gathered
 // edge attributes, zero padded) and P[split][K*8 + k] = sum_rows dU[row][k]  (the bias gradient).  The product is
 // 1024 x 8 wide and E deep: pure streaming of dU (4 KiB per edge); the fp32 GEMM read it at 1.5 TB/s with 8-column
@@ -707,6 +731,7 @@ struct BwdPlan {
     size_t off_dzstack, off_dzimg, off_nbits, off_nscale, off_tiles, off_xsc;
     size_t off_dzun;                  // per chunk node un-scale of its split dZ image (gpde_edge_bwd3.hip)
     size_t off_tcs, off_tcm;          // per 32-slot tile column sums / max bits of dU_2 [Ec / 32 + 1][KP2] (gpde_edge_bwd3.hip -> dW_2 GEMM)
+    size_t off_amax8;                 // [8] words: bits of max |attribute slot d| over ALL edges of the call (in-kernel first layer: one set of scales for every chunk)
     size_t off_scal;                  // [2] words: bits of max_e B_e for the one-pass kernel's global H scale (gpde_launch_attr_bound)
     size_t total;
     size_t one_chunk;                 // workspace bytes with which everything is one chunk
@@ -757,6 +782,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     if (n_defer > 0 && P->Lp < 4) P->Lp = 4;
     P->off_xsc = take(n_defer > 0 ? (size_t)2 * (N > 0 ? N : 1) : 1);      // per source node row scales of the layer-input stack
     P->off_scal = take(4);
+    P->off_amax8 = take(16);
     const size_t fixed = off;
     // per-chunk buffers: per edge (hsum + 2*kmax) floats (+ KP1 + KP2 for the transposed operands of dW_2), per node
     // (2*64*K2P + 3*64) floats
@@ -1132,6 +1158,17 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
     const bool h1_on_the_fly = n == 3 && f16s_du1 && f16s_dw2 && dims[0] <= 8 && P.KP[0] >= 8 && !SW.bwd_h1_materialize &&
                                !SW.bwd_h1_gemm;
     auto skip_h1 = [&](int rows) { return h1_on_the_fly && rows >= 8192; };
+    const bool call_amax = do_mlp && h1_on_the_fly && n_edges > 0 && dims[0] <= 7 && (!kt || (src && dst));
+    if (call_amax) {
+        // one bound per attribute slot for the whole call (k_attr_absmax_all): 24 bytes per edge read once - 0.1 ms at s=121
+        GP_HIP_CHECK(gpde_zero_async(F(P.off_amax8), 16 * 4, st));
+        NodeAttrSel ns_{};
+        ns_.kt = kt;
+        for (int d_ = 0; d_ < 8; ++d_) ns_.sel[d_] = (kt && sel) ? sel[d_ < dims[0] ? d_ : dims[0] - 1] : 0;
+        int nb_ = (int)((n_edges + 255) / 256); if (nb_ > 4096) nb_ = 4096;
+        hipLaunchKernelGGL(k_attr_absmax_all, dim3(nb_), dim3(256), 0, st, edge_attr, n_edges, kt ? kt : dims[0], dims[0], ns_, src, dst,
+                           (unsigned*)F(P.off_amax8));
+    }
     if ((phase == BWD_LIGHT && !fast_last) || (phase == BWD_DEFER && !(fast_last && f16s_du1 && f16s_dw2 && n == 3))) {
         gpde_set_error("gpde_nnconv_bwd_%s: kernel MLP outside the depth-deferred form (3 Linear layers of widths that are multiples of 128, "
                        "k0 <= 7): use gpde_nnconv_bwd", phase == BWD_LIGHT ? "light" : "deferred");
@@ -1230,12 +1267,14 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         // reading - the intermittent 1e-3 error in grad_W1)
         int nb_ = dUlast == bufs[0] ? 1 : 0;
         bool fl_in_kernel = false;           // the dW_2 GEMM of this chunk generated H_1 itself (no mask bits for the dU_1 GEMM)
+        bool dw1_done = false;               // the dU_1 GEMM's epilogue formed dW_1 / db_1 (k_dw_first has nothing left to do)
         for (int l = n - 1; l >= 1; --l) {
             const int Kl = P.KP[l], Kin = P.KP[l - 1];
             int rc2;
             if (l == 1 && grad_attr)         // dU_1 is complete here: the gradient of the attributes through W_1
                 hipLaunchKernelGGL(k_grad_attr, dim3((rows + 3) / 4), dim3(T), 0, st, dUc, Kl, F(P.off_wp[1]), Kin, perm, mlp_e0, rows,
                                    dims[0], grad_attr);
+            if (l == 1 && dw1_done) continue;
             if (l == 1 && dims[0] <= 8 && Kin >= 8 && Kin % 4 == 0 && Kl % 4 == 0 && rows >= 1024 && !SW.bwd_dw1_gemm) {
                 // dW_1 and db_1 from one pass over dU_1 (k_dw_first; attribute slots beyond k0 are zero columns of H_0)
                 const int cb = (Kl + 255) / 256;
@@ -1263,7 +1302,8 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
             }
             if (tn_split) {
                 // dW_2 += dU_2^T . H_1 on the split-f16 GEMM (contraction over the edges: both operands transposed)
-                GpdeFirstLayerSpec fl{F(P.off_H[0]), P.KP[0], F(P.off_wp[1]), P.KP[0], F(P.off_bp[1]), (uint32_t*)F(P.off_maskbits), dims[0]};
+                GpdeFirstLayerSpec fl{F(P.off_H[0]), P.KP[0], F(P.off_wp[1]), P.KP[0], F(P.off_bp[1]), (uint32_t*)F(P.off_maskbits), dims[0],
+                                      call_amax ? (const unsigned*)F(P.off_amax8) : nullptr};
                 fl_in_kernel = skip_h1(rows) && gpde_first_layer_in_kernel(fl, rows, tn_ksplits(rows));
                 GpdeDuStats dst_{F(P.off_dbp[l]), F(P.off_rowsc), F(P.off_rowsc) + rows,
                                  du_pre ? F(P.off_tcs) : nullptr, du_pre ? (const unsigned*)F(P.off_tcm) : nullptr};
@@ -1286,6 +1326,14 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                     g.maskbits = nullptr; g.ldmb = 0; g.fl_mode = 2; g.fl_attr = F(P.off_H[0]); g.fl_ld0 = P.KP[0]; g.fl_rows = rows;
                     g.fl_wimg = gpde_first_layer_wimg(F(P.off_maskbits)); g.fl_alpha = gpde_first_layer_alpha(F(P.off_maskbits), Kin);
                     g.fl_wp = F(P.off_wp[1]); g.fl_ldw = P.KP[0]; g.fl_bp = F(P.off_bp[1]);
+                    // ... and forms dW_1 / db_1 from the tile in its registers: dU_1 (4 KiB per edge) is then neither written nor read
+                    // back by k_dw_first - unless the attribute gradient wants the tensor (GPDE_BWD_DW1_PASS=1: the separate pass, A/B)
+                    // (scratch of the tile partials: the dU_1 buffer itself when the tensor is not written - 512 bytes per row of its 4 KiB)
+                    if (!SW.bwd_dw1_pass && dims[0] <= 7 && !grad_attr && gpde_gemm_f16s_dw_part_floats(rows, Kin) <= (size_t)rows * Kin) {
+                        g.fl_dw_part = dUo; g.fl_dw_out = F(P.off_dwp[1]); g.fl_dw_ld = P.KP[0]; g.fl_db_out = F(P.off_dbp[1]);
+                        g.fl_skip_store = 1;
+                        dw1_done = true;
+                    }
                 }
                 // (row scales: a pass over dU_2, 3.9 ms at s=121.  Collecting the row maxima inside gpde_edge_bwd2_kernel was
                 // tried in round 3: 16 more registers spill 15 VGPRs of a kernel that sits at its 256-register limit, +5 ms.)

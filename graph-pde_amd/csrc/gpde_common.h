@@ -81,6 +81,7 @@ struct GpdeSwitches {
     bool bwd_recompute_f32;      // GPDE_BWD_RECOMPUTE_F32: H recomputed by fp32 GEMMs in the full backward
     bool bwd_h1_materialize;     // GPDE_BWD_H1_MATERIALIZE: round-2 plan (H_1 written)
     bool bwd_h1_gemm;            // GPDE_BWD_H1_GEMM
+    bool bwd_dw1_pass;           // GPDE_BWD_DW1_PASS: dW_1 / db_1 from k_dw_first's pass over a materialised dU_1 (rounds 2-5) - A/B
     bool bwd_h1_image;           // GPDE_BWD_H1_IMAGE: rounds 3-5 plan (H_1^T split image + mask bits written by k_first_layer_pack) - A/B
     bool bwd_dw1_gemm;           // GPDE_BWD_DW1_GEMM
     bool bwd_du_passes;          // GPDE_BWD_DU_PASSES: separate bias / maxima / transpose passes over dU_2
@@ -329,7 +330,13 @@ struct GpdeGemmF16sArgs {
     const float* fl_alpha;              // [16]: alpha[d] (0 in the bias slot and beyond), then beta[d] (1 in the bias slot, else 0)
     const float* fl_wp; int fl_ldw;     // fl_mode 2: the padded fp32 first layer [N][fl_ldw] and bias [N] - an H_1 value whose split-f16
     const float* fl_bp;                 // product lies inside its own error bound of zero gets its sign from the exact fp32 fmaf chain
+    // fl_mode 2, optional: the FIRST layer's gradients from the epilogue - dW_1[n][d] += sum_rows C[row][n] * attr[row][d] (d < 7),
+    // db_1[n] += sum_rows C[row][n] - per 64-row tile a partial [N][8], summed in tile order by the launcher (deterministic, independent of
+    // the launch geometry).  fl_dw_part: gpde_gemm_f16s_dw_part_floats(M, N) floats of scratch; with fl_skip_store C is not written at
+    // all (nothing else reads dU_1: 4 KiB per edge neither written nor read back by k_dw_first - its buffer can be that scratch)
+    float* fl_dw_part; float* fl_dw_out; int fl_dw_ld; float* fl_db_out; int fl_skip_store;
 };
+size_t gpde_gemm_f16s_dw_part_floats(int M, int N);
 bool gpde_gemm_f16s_supported(int M, int N, int K, int lda);
 
 // Per-edge backward through the aggregation on split-f16 MFMA (gpde_edge_bwd3.hip): dU[e][n] = (x_j . dZ_i)[n] [H > 0],
@@ -373,6 +380,9 @@ struct GpdeFirstLayerSpec {
                                          // receives the operand image instead: [n_in][16] f16 (w'_hi | w'_lo) then 16 floats (alpha,
                                          // beta) at byte offset n_in * 32 (gpde_first_layer_image_*), for the dU_1 launch that follows
     int k0;                              // attribute slots in use (the bias takes slot k0); 0: unknown -> image path
+    const unsigned* amax_bits;           // [8] optional: bits of a bound of |slot d| over ALL rows the caller will ever pass (every chunk of a
+                                         // backward call): the in-kernel first layer then uses ONE set of scales per call - the same H_1 bits,
+                                         // ReLU mask included, for an edge whatever the chunking.  NULL: the maxima of these rows
 };
 // (in-kernel generation) where the operand image and the slot scales sit inside the `maskbits` buffer of the spec
 static inline const void* gpde_first_layer_wimg(const void* buf) { return buf; }

@@ -88,7 +88,10 @@ constexpr int A_SLOT = NW * TE * 128;      // 32 KiB: one 32-k chunk of the work
 //     (1 KiB) arrive by ONE LDS-DMA per wave and chunk into a private 3-slot stage, issued five chunks ahead in front of the A pieces.
 //   FL == 2 (plain row tiles, dU_1 = (dU_2 . W_2) (.) [H_1 > 0]): the epilogue recomputes H_1 of its 64 x 128 tile (16 MFMAs against
 //     1536 of the K loop) and masks by its sign - the same MFMA sequence on the same operands as FL == 1, hence the same bits; the
-//     mask words (128 bytes per edge written by the pack kernel, read here) are gone.
+//     mask words (128 bytes per edge written by the pack kernel, read here) are gone.  The operand scales come from ONE bound per
+//     attribute slot for the whole backward call (GpdeFirstLayerSpec::amax_bits), not from the chunk: an edge's H_1 bits - its mask -
+//     do not depend on the chunking; a product inside its own error bound of zero takes its sign from the exact fp32 chain
+//     (wave-uniform rare branch in the epilogue): the mask is the fp32 arithmetic's, as with the image.
 template <bool GATHER, int FL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
@@ -228,9 +231,15 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
     };
     // D[edge][n] = [a_hi|a_hi] x [w_hi;w_lo] + [a_lo|a_lo] x [w_hi;0]  (asm: VGPR destination; the leading s_nop covers a VALU write
     // of an operand right in front - gpde_fused_f16v6.hip)
+    // BOTH MFMAs in ONE asm statement: as two statements the compiler scheduled the VALU that forms b2 (h ? 0 : w_hi) between them,
+    // right in front of the second MFMA - it does not know that asm is an MFMA, inserted no wait states, and the matrix pipe read b2
+    // before the write had landed: the a_lo . w_hi term (2^-11 of the value) came out wrong now and then, signs of near-zero H_1 values
+    // flipped from run to run (found in the ISA after two hours of looking elsewhere)
     auto fl_h1gen = [&](f32x16& dd, h8 a1, h8 a2, h8 b1, h8 b2) {
-        asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(dd) : "v"(a1), "v"(b1));
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(dd) : "v"(a2), "v"(b2));
+        asm volatile("s_nop 4\n\t"
+                     "v_mfma_f32_32x32x16_f16 %0, %1, %2, 0\n\t"
+                     "v_mfma_f32_32x32x16_f16 %0, %3, %4, %0"
+                     : "=&v"(dd) : "v"(a1), "v"(b1), "v"(a2), "v"(b2));
     };
     // relu + split of a pair of H_1 values (the forward's conv_a / conv_b: v_max_i32 is the ReLU on the bit pattern)
     auto fl_conv = [&](float v0, float v1, unsigned& ph, unsigned& pl) {
@@ -322,7 +331,8 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
         for (int c = 0; c < 2; ++c) {
             fl_read_attr(c, fl_a1, fl_a2);
             fl_h1gen(fl_d, fl_a1, fl_a2, flB1, flB2);
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // MFMA result -> VALU read (asm operands are not padded)
+            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(fl_d));            // MFMA result -> VALU read: not padded for an asm MFMA, and - tied to
+                                                                           // the register - not reorderable behind the first reader
             fl_store(fl_d, c);
         }
         fl_read_attr(2, fl_a1, fl_a2);
@@ -348,6 +358,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
             for (int r = 0; r < 16; ++r) acc[e][nb][r] = 0.f;
     int slot = 0;           // B ring slot of the current chunk
     int aslot = 0;          // A ring slot of the current chunk
+    [[maybe_unused]] char* flas = flst_all + 4096 + wave * 2048;       // FL == 2: the tile's 64 attribute rows (32 bytes each) of this wave
 
     // Plain (non-gather) row tiles, one after the other per wave: the A chunks 0..2, the row scales and (bit masks) the
     // mask words of the NEXT tile are requested before this tile's results are stored, so that a tile boundary costs one
@@ -627,6 +638,17 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
         }
         if constexpr (FL == 2) {
             // ReLU mask = sign of H_1 recomputed for the tile: D[edge][n] of the MFMA pair has the accumulators' own layout
+            const bool dw_on = a.fl_dw_part != nullptr;
+            float dws[4][8];          // this tile's partial first-layer gradients: column (nb, l31), slot d < 7 | 7 = bias, over the lane's 32 rows
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int d = 0; d < 8; ++d) dws[nb][d] = 0.f;
+            {     // the tile's attribute rows where every lane can read the rows its accumulator registers belong to (rows beyond the
+                  // end hold a clamped copy: their sums are masked by the row's validity, their stores skipped)
+                *(f32x4*)(flas + lane * 32) = h ? fa[1][0] : fa[0][0];
+                *(f32x4*)(flas + lane * 32 + 16) = h ? fa[1][1] : fa[0][1];
+            }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 h8 a1, a2;
@@ -637,7 +659,46 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                     fl_wops(nb, b1, b2);
                     f32x16 dd;
                     fl_h1gen(dd, a1, a2, b1, b2);
-                    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // MFMA result -> VALU read (asm operands are not padded)
+                    // MFMA result -> VALU read: the hardware interlock is the compiler's job, and it does not know this asm is an MFMA.
+                    // The wait is TIED to the result (as a free-standing asm it orders nothing but other volatile asms: the first reader
+                    // could be scheduled in front of it) and to the operands (dead after the asm, yet still being read by the matrix pipe)
+                    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(dd), "+v"(a1), "+v"(a2), "+v"(b1), "+v"(b2));
+                    unsigned fixmask = 0u, fixsign = 0u;      // elements whose sign comes from the exact chain, and that sign (dd itself is not touched)
+                    {
+                        // |split product - exact| < 2^-4 in the image's scaled units (8 products of < 2^14, 2^-21 each).  A mask taken from
+                        // the split product alone differs from the fp32 chain's - the reference arithmetic's - for pre-activations within
+                        // ~2^-18 of the column's bound instead of ~2^-24: on zero-mean attributes that moved dW_1 2.4e-4 from float64 where
+                        // the fp32 mask sits at 7e-7.  So a value inside 2^-3 of zero (twice the bound) takes its sign from the exact chain of k_first_layer
+                        // (b, then d ascending): the mask is the image path's bit for bit.  Rare (~2^-14 of the elements), and WAVE-UNIFORM:
+                        // the branch is taken by all lanes when any lane needs it.  (The signs are collected in two 16-bit words; the MFMA's result
+                        // registers are not written.)
+                        // (the common path is ONE running minimum over the 16 values - v_min3 - and one compare: building the bit word
+                        //  element by element cost 5 ms per backward in v_cmp -> SGPR -> v_cndmask sequences with their wait states)
+                        float mn = fabsf(dd[0]);
+#pragma unroll
+                        for (int r = 1; r < 16; ++r) mn = fminf(mn, fabsf(dd[r]));
+                        if (__builtin_amdgcn_ballot_w64(mn < 0.125f) != 0ull) {
+                            unsigned nearm = 0u;              // bit r: |dd[r]| < 2^-3
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) nearm |= (fabsf(dd[r]) < 0.125f ? 1u : 0u) << r;
+                            const int col = slice * GP_TN + nb * 32 + l31;
+                            float wv[8];
+#pragma unroll
+                            for (int d = 0; d < 8; ++d) wv[d] = a.fl_wp[(size_t)col * a.fl_ldw + d];
+                            const float bv = a.fl_bp[col];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                // (the tile's attribute rows are staged in LDS for the first-layer gradients: no global round trip per row)
+                                const int rr = 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                const f32x4 t0 = *(const f32x4*)(flas + rr * 32), t1 = *(const f32x4*)(flas + rr * 32 + 16);
+                                float t = bv;
+#pragma unroll
+                                for (int d = 0; d < 8; ++d) t = fmaf(wv[d], d < 4 ? t0[d & 3] : t1[d & 3], t);
+                                fixsign |= (t > 0.f ? 1u : 0u) << r;
+                            }
+                            fixmask = nearm;
+                        }
+                    }
                     auto store_col = [&](auto full_tag) {
                         constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
@@ -646,26 +707,41 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                             const int row = r0 + rr;
                             float v = acc[e][nb][r] * (Es[rr] * ucv[nb]);
                             acc[e][nb][r] = 0.f;
-                            float hv = dd[r];
-                            // |split product - exact| < 2^-4 in the image's scaled units (8 products of < 2^14, 2^-21 each): inside
-                            // 2^-2 of zero the sign is taken from the exact fp32 chain of k_first_layer_pack / k_first_layer (b, then
-                            // d ascending) - the mask is the image path's bit for bit, whatever the chunk's scales.  Rare: ~2^-14 of
-                            // the elements; the branch is skipped unless a lane of the wave needs it
-                            if (__builtin_expect(fabsf(hv) < 0.25f, 0)) {
-                                const int col = slice * GP_TN + nb * 32 + l31;
-                                // this lane's row r of block e = the attribute row held by lane (rr & 31) of its own half
-                                float t = a.fl_bp[col];
-                                const float* ar = a.fl_attr + (size_t)min(row, min(rmax, a.fl_rows - 1)) * a.fl_ld0;
-#pragma unroll
-                                for (int d = 0; d < 8; ++d) t = fmaf(a.fl_wp[(size_t)col * a.fl_ldw + d], ar[d], t);
-                                hv = t;
+                            const bool pos = ((fixmask >> r) & 1u) ? ((fixsign >> r) & 1u) != 0u : dd[r] > 0.f;
+                            v = pos ? v : 0.f;
+                            if (!a.fl_skip_store && (FULL || row < rend)) Cout[(size_t)row * a.ldc + slice * GP_TN + nb * 32 + l31] = v;
+                            if (dw_on) {
+                                // dW_1[col][d] += v * attr[row][d], db_1[col] += v  (rows beyond the end: v is whatever the clamped
+                                // loads gave - their staged attribute row is zero, the bias sum takes the row's validity)
+                                const f32x4 t0 = *(const f32x4*)(flas + rr * 32), t1 = *(const f32x4*)(flas + rr * 32 + 16);
+                                const float vb = (FULL || row < rend) ? v : 0.f;
+                                dws[nb][0] = fmaf(vb, t0[0], dws[nb][0]); dws[nb][1] = fmaf(vb, t0[1], dws[nb][1]);
+                                dws[nb][2] = fmaf(vb, t0[2], dws[nb][2]); dws[nb][3] = fmaf(vb, t0[3], dws[nb][3]);
+                                dws[nb][4] = fmaf(vb, t1[0], dws[nb][4]); dws[nb][5] = fmaf(vb, t1[1], dws[nb][5]);
+                                dws[nb][6] = fmaf(vb, t1[2], dws[nb][6]); dws[nb][7] += vb;
                             }
-                            v = hv > 0.f ? v : 0.f;
-                            if (FULL || row < rend) Cout[(size_t)row * a.ldc + slice * GP_TN + nb * 32 + l31] = v;
                         }
                     };
                     if (r0 + TE <= rend) store_col(std::true_type{});
                     else store_col(std::false_type{});
+                }
+            }
+            if (dw_on && r0 < rend) {
+                // the two lane halves hold different rows of the same column: fold them; the lower half writes the TILE's partial
+                // [tile][col][8] (one writer per element; summed over the tiles in tile order by the launcher: deterministic and
+                // independent of which wave ran the tile and of the launch geometry; running sums over a wave's tiles would be 32
+                // more registers that must survive the 512-register K loop)
+                float* pp = a.fl_dw_part + ((size_t)(r0 / TE) * a.N + slice * GP_TN) * 8;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    float o[8];
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) o[d] = dws[nb][d] + __shfl_xor(dws[nb][d], 32);
+                    if (h == 0) {
+                        f32x4* q = (f32x4*)(pp + (size_t)(nb * 32 + l31) * 8);
+                        q[0] = f32x4{o[0], o[1], o[2], o[3]};
+                        q[1] = f32x4{o[4], o[5], o[6], o[7]};
+                    }
                 }
             }
             NT_MARK(tm_epi);
@@ -763,6 +839,18 @@ extern "C" GPDE_API int gpde_debug_nt_timing(unsigned long long* out16, int rese
 }
 #endif
 
+namespace {
+// dW[col][d] += T[col][d] (d < 7), db[col] += T[col][7]: the summed tile partials of the dU_1 epilogue into the padded gradient buffers
+__global__ void k_dw_part_scatter(const float* __restrict__ T, int N, int ldw, float* __restrict__ dW, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * 8) return;
+    if ((i & 7) < 7) dW[(size_t)(i >> 3) * ldw + (i & 7)] += T[i];
+    else db[i >> 3] += T[i];
+}
+}  // namespace
+// scratch of the dU_1 epilogue's first-layer gradients for M rows: one [N][8] block per 64-row tile + one for their sum
+size_t gpde_gemm_f16s_dw_part_floats(int M, int N) { return ((size_t)(M + TE - 1) / TE + 1) * (size_t)N * 8; }
+
 size_t gpde_gemm_f16s_workspace_floats(int M) { return (size_t)2 * (M > 0 ? M : 1); }
 
 // K a multiple of 128 and >= 256 (the chunk loop is unrolled by four, three chunks of rows are in flight),
@@ -818,13 +906,22 @@ int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a_in, float* row_scale_ws, 
                              gpde_gemm_f16s_nt_kernel<false, 2>)) return rc;
     if (a.fl_mode) {
         // the first hidden layer generated in the kernel (see the kernel's header): split-K form -> B chunks, row tiles -> mask
-        if ((a.fl_mode == 1) != (a.ksplits > 1) || a.fl_mode > 2 || !a.fl_attr || !a.fl_wimg || !a.fl_alpha || (a.fl_mode == 2 && (!a.fl_wp || !a.fl_bp)) || a.fl_ld0 < 8 || a.fl_ld0 % 4 != 0 || a.fl_rows < 1 ||
+        if ((a.fl_mode == 1) != (a.ksplits > 1) || a.fl_mode > 2 || !a.fl_attr || !a.fl_wimg || !a.fl_alpha || a.fl_ld0 < 8 || a.fl_ld0 % 4 != 0 || a.fl_rows < 1 || (a.fl_mode == 2 && (!a.fl_wp || !a.fl_bp)) ||
             a.xc_x || a.mask || a.maskbits || (a.fl_mode == 1 && a.K / a.ksplits / GP_BK < 6)) {
             gpde_set_error("gpde_gemm_f16s_nt: inconsistent in-kernel first-layer arguments (mode %d, ksplits %d)", a.fl_mode, a.ksplits);
             return GPDE_EINVAL;
         }
         if (a.fl_mode == 1) hipLaunchKernelGGL((gpde_gemm_f16s_nt_kernel<false, 1>), dim3(groups * ns), dim3(256), lds + NW * 3 * 1024, stream, a);
-        else hipLaunchKernelGGL((gpde_gemm_f16s_nt_kernel<false, 2>), dim3(groups * ns), dim3(256), lds + 4096, stream, a);
+        else {
+            if (a.fl_dw_part && (!a.fl_dw_out || !a.fl_db_out || a.fl_dw_ld < 8)) { gpde_set_error("gpde_gemm_f16s_nt: first-layer gradient outputs missing"); return GPDE_EINVAL; }
+            hipLaunchKernelGGL((gpde_gemm_f16s_nt_kernel<false, 2>), dim3(groups * ns), dim3(256), lds + 4096 + NW * 2048, stream, a);
+            if (a.fl_dw_part) {
+                // tile partials [ntile][N][8] -> their ordered sum [N][8] (behind the partials) -> dW_1 / db_1
+                float* tot = a.fl_dw_part + (size_t)ntile * a.N * 8;
+                if (int rc = gpde_launch_reduce_splits(a.fl_dw_part, (size_t)a.N * 8, ntile, (size_t)a.N * 8, tot, 0, stream)) return rc;
+                hipLaunchKernelGGL(k_dw_part_scatter, dim3((a.N * 8 + 255) / 256), dim3(256), 0, stream, tot, a.N, a.fl_dw_ld, a.fl_dw_out, a.fl_db_out);
+            }
+        }
     } else
         hipLaunchKernelGGL((gpde_gemm_f16s_nt_kernel<false, 0>), dim3(groups * ns), dim3(256), lds, stream, a);
     GP_LAUNCH_CHECK("gpde_gemm_f16s_nt_kernel");
@@ -1245,7 +1342,8 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
     const bool fl_gen = fl && gpde_first_layer_in_kernel(*fl, rows, ksplits);
     if (fl) {
         int nb = (rows + 31) / 32; if (nb > 2048) nb = 2048;
-        hipLaunchKernelGGL(k_attr_absmax8, dim3(nb), dim3(256), 0, stream, fl->H0, rows, fl->ld0, bits + n_out);
+        if (fl_gen && fl->amax_bits) GP_HIP_CHECK(gpde_copy_async(bits + n_out, fl->amax_bits, 8 * 4, stream));     // the call-wide bound (see GpdeFirstLayerSpec)
+        else hipLaunchKernelGGL(k_attr_absmax8, dim3(nb), dim3(256), 0, stream, fl->H0, rows, fl->ld0, bits + n_out);
         if (fl_gen) {
             // round 6: no image, no mask bits - the GEMM below (and the dU_1 GEMM after it) generate H_1 from the attributes; the
             // spec's `maskbits` buffer carries the column image + slot scales to both

@@ -122,8 +122,10 @@ def test_dw2_on_the_split_f16_gemm_matches_reference_autograd(monkeypatch):
     assert not torch.equal(gW[1], fW[1])                    # the split path did run
     assert rel_l2(gW[1].cpu(), fW[1].cpu()) <= 2e-6
     assert torch.equal(gW[1], g2[1][1])                     # and is bit-reproducible
-    for l in (0, 2):
-        assert torch.equal(gW[l], fW[l])
+    assert torch.equal(gW[2], fW[2])
+    # (round 6: with the split dW_2 GEMM, dW_1 is summed per 64-row tile in the dU_1 GEMM's epilogue - the fp32 form sums the same
+    #  products in k_dw_first's order)
+    assert torch.equal(gW[0], g2[1][0]) and rel_l2(gW[0].cpu(), fW[0].cpu()) <= 2e-6
 
 
 def test_dw2_split_gemm_at_headline_widths_agrees_with_fp32(monkeypatch):
@@ -152,8 +154,11 @@ def test_first_hidden_layer_is_not_materialised_and_changes_only_the_dw2_roundin
     monkeypatch.setenv("GPDE_BWD_H1_MATERIALIZE", "1")
     fx, fW, fb, froot, fbias = _native(x, ei, ea, ws_, bs_, root, gout)
     assert torch.equal(gx, fx)
-    for l in (0, 2):
-        assert torch.equal(gW[l], fW[l]) and torch.equal(gb[l], fb[l]), l
+    assert torch.equal(gW[2], fW[2]) and torch.equal(gb[2], fb[2])
+    # round 6: H_1 comes from the split-f16 MFMA pair inside the GEMMs; a product within its error bound of zero takes its sign from
+    # this very fmaf chain, so the MASK is still the materialised tensor's bit for bit - dU_1 too - while dW_1 / db_1 are now summed
+    # per 64-row tile in the dU_1 GEMM's epilogue (another order of the same fp32 products)
+    assert rel_l2(gW[0].cpu(), fW[0].cpu()) <= 2e-6 and rel_l2(gb[0].cpu(), fb[0].cpu()) <= 2e-6, (rel_l2(gW[0].cpu(), fW[0].cpu()), rel_l2(gb[0].cpu(), fb[0].cpu()))
     assert torch.equal(gb[1], fb[1])
     assert rel_l2(gW[1].cpu(), fW[1].cpu()) <= 2e-6
     def row_err(g, r):          # per row of dW_2; hidden units that never fire have an all-zero row in both (0 / 0)
@@ -252,8 +257,11 @@ def test_gradient_of_the_edge_attributes_matches_float64_autograd():
     torch.cuda.synchronize()
     assert rel_l2(got[5].cpu(), at.grad) <= TOL, rel_l2(got[5].cpu(), at.grad)
     assert torch.equal(got[5], got2[5]) and torch.equal(got[0], plain[0])
-    for l in range(3):
+    for l in (1, 2):
         assert torch.equal(got[1][l], plain[1][l]) and torch.equal(got[2][l], plain[2][l])
+    # (with the attribute gradient dU_1 is materialised and dW_1 / db_1 come from k_dw_first's pass; without it they are summed per
+    #  tile in the dU_1 GEMM's epilogue when the chunk has >= 8192 rows - here both take the pass: bits)
+    assert rel_l2(got[1][0].cpu(), plain[1][0].cpu()) <= 2e-6 and rel_l2(got[2][0].cpu(), plain[2][0].cpu()) <= 2e-6
     # through the module: an edge_attr that requires a gradient takes the direct operator and receives it
     conv = gp.NNConv_old(64, 64, DenseNet(dims, torch.nn.ReLU), aggr="mean").to(d)
     lin = ops.mlp_linears(conv.nn)
