@@ -821,7 +821,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     P->off_dxe = take((size_t)Ec * GP_W);
     P->off_tnws = take(P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats((int)Ec, P->KP[2], P->KP[1], tn_ksplits(Ec)) : 1);
     P->off_dubits = take((size_t)(kmax > 0 ? kmax : 1));
-    P->off_maskbits = take(P->f16s_dw2 ? std::max((size_t)Ec * (P->KP[1] / 32), (size_t)P->KP[1] * 8 + 32) : 1);   // (or the in-kernel first layer's operand image)
+    P->off_maskbits = take(P->f16s_dw2 ? (size_t)Ec * (P->KP[1] / 32) : 1);
     P->off_dzstack = take(n_defer > 0 ? (size_t)P->L * Nc * GP_W * P->K2P : 1);
     P->off_dzimg = take(n_defer > 0 ? (size_t)P->Lp * Nc * GP_W * P->K2P : 1);
     P->off_nbits = take(n_defer > 0 ? (size_t)Nc : 1);
@@ -1266,7 +1266,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         // started at bufs[0]: a workgroup that finished its tile early overwrote rows a sibling slice was still
         // reading - the intermittent 1e-3 error in grad_W1)
         int nb_ = dUlast == bufs[0] ? 1 : 0;
-        bool fl_in_kernel = false;           // the dW_2 GEMM of this chunk generated H_1 itself (no mask bits for the dU_1 GEMM)
+        bool fl_in_kernel = false;           // the dW_2 GEMM of this chunk generated H_1 itself (round 6 plan)
         bool dw1_done = false;               // the dU_1 GEMM's epilogue formed dW_1 / db_1 (k_dw_first has nothing left to do)
         for (int l = n - 1; l >= 1; --l) {
             const int Kl = P.KP[l], Kin = P.KP[l - 1];
@@ -1320,20 +1320,15 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 g.A = dUc; g.lda = Kl; g.M = rows; g.bsplit = F(P.off_w2ts); g.ucol = F(P.off_ucol2);
                 g.mask = F(P.off_H[l - 1]); g.ldmask = Kin; g.C = dUo; g.ldc = Kin; g.K = Kl; g.N = Kin;
                 if (tn_split && skip_h1(rows)) { g.mask = nullptr; g.ldmask = 0; g.maskbits = (const uint32_t*)F(P.off_maskbits); g.ldmb = Kin / 32; }
-                if (tn_split && fl_in_kernel) {
-                    // round 6: the dW_2 GEMM above generated H_1 from the attributes and left no mask bits - this GEMM's epilogue takes
-                    // the ReLU mask from the same product (the buffer holds the operand image: gpde_first_layer_wimg / _alpha)
-                    g.maskbits = nullptr; g.ldmb = 0; g.fl_mode = 2; g.fl_attr = F(P.off_H[0]); g.fl_ld0 = P.KP[0]; g.fl_rows = rows;
-                    g.fl_wimg = gpde_first_layer_wimg(F(P.off_maskbits)); g.fl_alpha = gpde_first_layer_alpha(F(P.off_maskbits), Kin);
-                    g.fl_wp = F(P.off_wp[1]); g.fl_ldw = P.KP[0]; g.fl_bp = F(P.off_bp[1]);
-                    // ... and forms dW_1 / db_1 from the tile in its registers: dU_1 (4 KiB per edge) is then neither written nor read
-                    // back by k_dw_first - unless the attribute gradient wants the tensor (GPDE_BWD_DW1_PASS=1: the separate pass, A/B)
-                    // (scratch of the tile partials: the dU_1 buffer itself when the tensor is not written - 512 bytes per row of its 4 KiB)
-                    if (!SW.bwd_dw1_pass && dims[0] <= 7 && !grad_attr && gpde_gemm_f16s_dw_part_floats(rows, Kin) <= (size_t)rows * Kin) {
-                        g.fl_dw_part = dUo; g.fl_dw_out = F(P.off_dwp[1]); g.fl_dw_ld = P.KP[0]; g.fl_db_out = F(P.off_dbp[1]);
-                        g.fl_skip_store = 1;
-                        dw1_done = true;
-                    }
+                if (tn_split && fl_in_kernel && !SW.bwd_dw1_pass && dims[0] <= 7 && !grad_attr &&
+                    gpde_gemm_f16s_dw_part_floats(rows, Kin) <= (size_t)rows * Kin) {
+                    // round 6: this GEMM's epilogue forms dW_1 / db_1 from the tile in its registers: dU_1 (4 KiB per edge) is neither
+                    // written nor read back by k_dw_first - unless the attribute gradient wants the tensor (GPDE_BWD_DW1_PASS=1: the
+                    // separate pass, A/B).  Scratch of the tile partials: the dU_1 buffer itself (512 bytes per row of its 4 KiB)
+                    g.fl_mode = 2; g.fl_attr = F(P.off_H[0]); g.fl_ld0 = P.KP[0]; g.fl_rows = rows;
+                    g.fl_dw_part = dUo; g.fl_dw_out = F(P.off_dwp[1]); g.fl_dw_ld = P.KP[0]; g.fl_db_out = F(P.off_dbp[1]);
+                    g.fl_skip_store = 1;
+                    dw1_done = true;
                 }
                 // (row scales: a pass over dU_2, 3.9 ms at s=121.  Collecting the row maxima inside gpde_edge_bwd2_kernel was
                 // tried in round 3: 16 more registers spill 15 VGPRs of a kernel that sits at its 256-register limit, +5 ms.)

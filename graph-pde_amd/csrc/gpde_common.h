@@ -322,15 +322,13 @@ struct GpdeGemmF16sArgs {
     // H_1[e][n] * sc[n] = relu(sum_d attr'[e][d] * w'[n][d]) on the split-f16 MFMA pair of the forward kernel, attr'[d] = attr[d] *
     // alpha[d] (+ 1 in the bias slot), w' = the per-column image of k_first_layer_wimg.  fl_mode 1 (split-K form): the B chunk
     // images [128 n][32 edges] are generated from the attributes instead of read from memory (no H_1^T image, no k_first_layer_pack);
-    // fl_mode 2 (plain row tiles): the epilogue's ReLU mask is the sign of the same product (no mask bits)
+    // fl_mode 2 (plain row tiles): the epilogue forms dW_1 / db_1 from the tile and the attribute rows (below)
     int fl_mode;
     const float* fl_attr; int fl_ld0;   // gathered attributes [fl_rows][fl_ld0] (the first 8 floats of a row are used), slots >= k0 zero
     int fl_rows;                        // rows of fl_attr that exist (edges beyond it are zero columns of the K padding)
-    const void* fl_wimg;                // [N][2][8] f16: w'_hi | w'_lo per column
-    const float* fl_alpha;              // [16]: alpha[d] (0 in the bias slot and beyond), then beta[d] (1 in the bias slot, else 0)
-    const float* fl_wp; int fl_ldw;     // fl_mode 2: the padded fp32 first layer [N][fl_ldw] and bias [N] - an H_1 value whose split-f16
-    const float* fl_bp;                 // product lies inside its own error bound of zero gets its sign from the exact fp32 fmaf chain
-    // fl_mode 2, optional: the FIRST layer's gradients from the epilogue - dW_1[n][d] += sum_rows C[row][n] * attr[row][d] (d < 7),
+    const void* fl_wimg;                // fl_mode 1: [N][2][8] f16: w'_hi | w'_lo per column
+    const float* fl_alpha;              // fl_mode 1: [16]: alpha[d] (0 in the bias slot and beyond), then beta[d] (1 in the bias slot, else 0)
+    // fl_mode 2: the FIRST layer's gradients from the epilogue (mask: `maskbits`) - dW_1[n][d] += sum_rows C[row][n] * attr[row][d] (d < 7),
     // db_1[n] += sum_rows C[row][n] - per 64-row tile a partial [N][8], summed in tile order by the launcher (deterministic, independent of
     // the launch geometry).  fl_dw_part: gpde_gemm_f16s_dw_part_floats(M, N) floats of scratch; with fl_skip_store C is not written at
     // all (nothing else reads dU_1: 4 KiB per edge neither written nor read back by k_dw_first - its buffer can be that scratch)
@@ -376,17 +374,12 @@ struct GpdeFirstLayerSpec {
     const float* H0; int ld0;            // gathered attributes [rows][ld0], slots >= k0 zero (ld0 >= 8)
     const float* Wp; int ldw;            // padded first-layer weight [n_in][ldw] (ldw >= 8), bias bp [n_in]
     const float* bp;
-    uint32_t* maskbits;                  // out: [rows][n_in / 32] - or, in-kernel generation (k0 given, <= 7): the buffer
-                                         // receives the operand image instead: [n_in][16] f16 (w'_hi | w'_lo) then 16 floats (alpha,
-                                         // beta) at byte offset n_in * 32 (gpde_first_layer_image_*), for the dU_1 launch that follows
+    uint32_t* maskbits;                  // out: [rows][n_in / 32]
     int k0;                              // attribute slots in use (the bias takes slot k0); 0: unknown -> image path
     const unsigned* amax_bits;           // [8] optional: bits of a bound of |slot d| over ALL rows the caller will ever pass (every chunk of a
                                          // backward call): the in-kernel first layer then uses ONE set of scales per call - the same H_1 bits,
                                          // ReLU mask included, for an edge whatever the chunking.  NULL: the maxima of these rows
 };
-// (in-kernel generation) where the operand image and the slot scales sit inside the `maskbits` buffer of the spec
-static inline const void* gpde_first_layer_wimg(const void* buf) { return buf; }
-static inline const float* gpde_first_layer_alpha(const void* buf, int n_in) { return (const float*)((const char*)buf + (size_t)n_in * 32); }
 bool gpde_first_layer_in_kernel(const GpdeFirstLayerSpec& f, int rows, int ksplits);
 // Optional by-products of the pass that transposes dU (it reads every element once): the bias gradient and the per-row
 // scales the NEXT GEMM over dU (dU_1 = dU . W^T) needs - instead of two more passes over dU (k_colsum, k_row_scale_kernel).

@@ -86,12 +86,14 @@ constexpr int A_SLOT = NW * TE * 128;      // 32 KiB: one 32-k chunk of the work
 //     8 conversion pairs, 4 ds_write_b128 into the ring slot the DMA used to fill.  The H_1^T split image (4 bytes per edge and
 //     column: 25.8 GB written and read back per backward at s=121) and k_first_layer_pack (9 ms) are gone.  The chunk's attributes
 //     (1 KiB) arrive by ONE LDS-DMA per wave and chunk into a private 3-slot stage, issued five chunks ahead in front of the A pieces.
-//   FL == 2 (plain row tiles, dU_1 = (dU_2 . W_2) (.) [H_1 > 0]): the epilogue recomputes H_1 of its 64 x 128 tile (16 MFMAs against
-//     1536 of the K loop) and masks by its sign - the same MFMA sequence on the same operands as FL == 1, hence the same bits; the
-//     mask words (128 bytes per edge written by the pack kernel, read here) are gone.  The operand scales come from ONE bound per
-//     attribute slot for the whole backward call (GpdeFirstLayerSpec::amax_bits), not from the chunk: an edge's H_1 bits - its mask -
-//     do not depend on the chunking; a product inside its own error bound of zero takes its sign from the exact fp32 chain
-//     (wave-uniform rare branch in the epilogue): the mask is the fp32 arithmetic's, as with the image.
+//   FL == 2 (plain row tiles, dU_1 = (dU_2 . W_2) (.) [H_1 > 0]): the epilogue also forms the FIRST layer's gradients from the tile in
+//     its registers - dW_1[n][d] += dU_1[e][n] . attr[e][d], db_1[n] += dU_1[e][n], one [128][8] partial per 64-row tile summed in tile
+//     order by the launcher - so dU_1 (4 KiB per edge) is neither written nor read back by k_dw_first.  The ReLU mask comes as bits from
+//     k_first_layer_maskbits (the exact fp32 fmaf chain of the forward's first layer).
+//     (Tried first, and measured: the mask from the same in-kernel MFMA product as FL == 1.  Its sign differs from the fp32 chain's for
+//     pre-activations within 2^-18 of the column bound instead of 2^-24 - on zero-mean attributes that put dW_1 2.4e-4 from float64
+//     where the fp32 mask sits at 7e-7 - so values inside the product's error bound of zero needed the exact chain in a rare branch;
+//     MFMAs + wait states + that branch cost the dU_1 GEMM 10 % and cancelled the gain.  A separate 2 ms pass for the bits is cheaper.)
 template <bool GATHER, int FL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
@@ -193,10 +195,8 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
     [[maybe_unused]] float fl_al[8], fl_be[8];
     [[maybe_unused]] h8 flB1 = {}, flB2 = {};          // FL == 1: this wave's column block (nb = wave) of the image: h ? w_lo : w_hi ; h ? 0 : w_hi
     [[maybe_unused]] char* flst = flst_all + wave * (3 * 1024);
-    // (FL == 2: the slice's 128 image rows, 4 KiB, are copied to LDS once - eight global round trips per tile epilogue otherwise:
-    //  +0.4 ms per 850 k-row launch, measured)
     auto fl_wops = [&](int nb, h8& b1, h8& b2) {
-        const char* wp = FL == 2 ? flst_all + (nb * 32 + l31) * 32 : (const char*)a.fl_wimg + (size_t)(slice * GP_TN + nb * 32 + l31) * 32;
+        const char* wp = (const char*)a.fl_wimg + (size_t)(slice * GP_TN + nb * 32 + l31) * 32;
         const h8 whi = *(const h8*)wp, wlo = *(const h8*)(wp + 16);
         const h8 zero = {};
         b1 = h ? wlo : whi;
@@ -206,7 +206,6 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
 #pragma unroll
         for (int d = 0; d < 8; ++d) { fl_al[d] = a.fl_alpha[d]; fl_be[d] = a.fl_alpha[8 + d]; }
         if constexpr (FL == 1) fl_wops(wave, flB1, flB2);
-        if constexpr (FL == 2) ((f32x4*)flst_all)[tid] = ((const f32x4*)((const char*)a.fl_wimg + (size_t)slice * GP_TN * 32))[tid];   // (visible after the prologue's barrier)
     }
     // attributes of one edge (8 slots) -> the A operands [a_hi | a_hi] and [a_lo | a_lo] (both lane halves hold the same edge)
     auto fl_aops = [&](f32x4 v0, f32x4 v1, bool valid, h8& a1, h8& a2) {
@@ -358,7 +357,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
             for (int r = 0; r < 16; ++r) acc[e][nb][r] = 0.f;
     int slot = 0;           // B ring slot of the current chunk
     int aslot = 0;          // A ring slot of the current chunk
-    [[maybe_unused]] char* flas = flst_all + 4096 + wave * 2048;       // FL == 2: the tile's 64 attribute rows (32 bytes each) of this wave
+    [[maybe_unused]] char* flas = flst_all + wave * 2048;       // FL == 2: the tile's 64 attribute rows (32 bytes each) of this wave
 
     // Plain (non-gather) row tiles, one after the other per wave: the A chunks 0..2, the row scales and (bit masks) the
     // mask words of the NEXT tile are requested before this tile's results are stored, so that a tile boundary costs one
@@ -586,7 +585,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
             }
         }
         if constexpr (!GATHER) {
-            if (FL != 2 && a.maskbits && !a.xc_x) mw = *(const u4*)(a.maskbits + (size_t)min(r0 + lane, rmax) * a.ldmb + slice * (GP_TN / 32));
+            if (a.maskbits && !a.xc_x) mw = *(const u4*)(a.maskbits + (size_t)min(r0 + lane, rmax) * a.ldmb + slice * (GP_TN / 32));
             if (nxt_ok) {
                 scn[0] = a.sc[r0 + drows + l31];
                 scn[1] = a.sc[r0 + drows + 32 + l31];
@@ -637,7 +636,6 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
             continue;
         }
         if constexpr (FL == 2) {
-            // ReLU mask = sign of H_1 recomputed for the tile: D[edge][n] of the MFMA pair has the accumulators' own layout
             const bool dw_on = a.fl_dw_part != nullptr;
             float dws[4][8];          // this tile's partial first-layer gradients: column (nb, l31), slot d < 7 | 7 = bias, over the lane's 32 rows
 #pragma unroll
@@ -651,54 +649,8 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                h8 a1, a2;
-                fl_aops(fa[e][0], fa[e][1], true, a1, a2);
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) {
-                    h8 b1, b2;
-                    fl_wops(nb, b1, b2);
-                    f32x16 dd;
-                    fl_h1gen(dd, a1, a2, b1, b2);
-                    // MFMA result -> VALU read: the hardware interlock is the compiler's job, and it does not know this asm is an MFMA.
-                    // The wait is TIED to the result (as a free-standing asm it orders nothing but other volatile asms: the first reader
-                    // could be scheduled in front of it) and to the operands (dead after the asm, yet still being read by the matrix pipe)
-                    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(dd), "+v"(a1), "+v"(a2), "+v"(b1), "+v"(b2));
-                    unsigned fixmask = 0u, fixsign = 0u;      // elements whose sign comes from the exact chain, and that sign (dd itself is not touched)
-                    {
-                        // |split product - exact| < 2^-4 in the image's scaled units (8 products of < 2^14, 2^-21 each).  A mask taken from
-                        // the split product alone differs from the fp32 chain's - the reference arithmetic's - for pre-activations within
-                        // ~2^-18 of the column's bound instead of ~2^-24: on zero-mean attributes that moved dW_1 2.4e-4 from float64 where
-                        // the fp32 mask sits at 7e-7.  So a value inside 2^-3 of zero (twice the bound) takes its sign from the exact chain of k_first_layer
-                        // (b, then d ascending): the mask is the image path's bit for bit.  Rare (~2^-14 of the elements), and WAVE-UNIFORM:
-                        // the branch is taken by all lanes when any lane needs it.  (The signs are collected in two 16-bit words; the MFMA's result
-                        // registers are not written.)
-                        // (the common path is ONE running minimum over the 16 values - v_min3 - and one compare: building the bit word
-                        //  element by element cost 5 ms per backward in v_cmp -> SGPR -> v_cndmask sequences with their wait states)
-                        float mn = fabsf(dd[0]);
-#pragma unroll
-                        for (int r = 1; r < 16; ++r) mn = fminf(mn, fabsf(dd[r]));
-                        if (__builtin_amdgcn_ballot_w64(mn < 0.125f) != 0ull) {
-                            unsigned nearm = 0u;              // bit r: |dd[r]| < 2^-3
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) nearm |= (fabsf(dd[r]) < 0.125f ? 1u : 0u) << r;
-                            const int col = slice * GP_TN + nb * 32 + l31;
-                            float wv[8];
-#pragma unroll
-                            for (int d = 0; d < 8; ++d) wv[d] = a.fl_wp[(size_t)col * a.fl_ldw + d];
-                            const float bv = a.fl_bp[col];
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                // (the tile's attribute rows are staged in LDS for the first-layer gradients: no global round trip per row)
-                                const int rr = 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h;
-                                const f32x4 t0 = *(const f32x4*)(flas + rr * 32), t1 = *(const f32x4*)(flas + rr * 32 + 16);
-                                float t = bv;
-#pragma unroll
-                                for (int d = 0; d < 8; ++d) t = fmaf(wv[d], d < 4 ? t0[d & 3] : t1[d & 3], t);
-                                fixsign |= (t > 0.f ? 1u : 0u) << r;
-                            }
-                            fixmask = nearm;
-                        }
-                    }
                     auto store_col = [&](auto full_tag) {
                         constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
@@ -707,7 +659,11 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                             const int row = r0 + rr;
                             float v = acc[e][nb][r] * (Es[rr] * ucv[nb]);
                             acc[e][nb][r] = 0.f;
-                            const bool pos = ((fixmask >> r) & 1u) ? ((fixsign >> r) & 1u) != 0u : dd[r] > 0.f;
+                            // keep-mask of the 64 lanes for (row, column block): lanes 0..31 hold row rr0's columns, lanes 32..63 row
+                            // rr0 + 4's - the two mask words as one 64-bit lane mask (as in the bit-mask epilogue below)
+                            const int rr0 = 32 * e + (r & 3) + 8 * (r >> 2);
+                            const unsigned w0 = __builtin_amdgcn_readlane(mw[nb], rr0), w1 = __builtin_amdgcn_readlane(mw[nb], rr0 + 4);
+                            const bool pos = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)w1 << 32) | w0);
                             v = pos ? v : 0.f;
                             if (!a.fl_skip_store && (FULL || row < rend)) Cout[(size_t)row * a.ldc + slice * GP_TN + nb * 32 + l31] = v;
                             if (dw_on) {
@@ -906,15 +862,16 @@ int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a_in, float* row_scale_ws, 
                              gpde_gemm_f16s_nt_kernel<false, 2>)) return rc;
     if (a.fl_mode) {
         // the first hidden layer generated in the kernel (see the kernel's header): split-K form -> B chunks, row tiles -> mask
-        if ((a.fl_mode == 1) != (a.ksplits > 1) || a.fl_mode > 2 || !a.fl_attr || !a.fl_wimg || !a.fl_alpha || a.fl_ld0 < 8 || a.fl_ld0 % 4 != 0 || a.fl_rows < 1 || (a.fl_mode == 2 && (!a.fl_wp || !a.fl_bp)) ||
-            a.xc_x || a.mask || a.maskbits || (a.fl_mode == 1 && a.K / a.ksplits / GP_BK < 6)) {
+        if ((a.fl_mode == 1) != (a.ksplits > 1) || a.fl_mode > 2 || !a.fl_attr || a.fl_ld0 < 8 || a.fl_ld0 % 4 != 0 || a.fl_rows < 1 || a.xc_x || a.mask ||
+            (a.fl_mode == 1 && (!a.fl_wimg || !a.fl_alpha || a.maskbits || a.K / a.ksplits / GP_BK < 6)) ||
+            (a.fl_mode == 2 && (!a.maskbits || !a.fl_dw_part))) {
             gpde_set_error("gpde_gemm_f16s_nt: inconsistent in-kernel first-layer arguments (mode %d, ksplits %d)", a.fl_mode, a.ksplits);
             return GPDE_EINVAL;
         }
         if (a.fl_mode == 1) hipLaunchKernelGGL((gpde_gemm_f16s_nt_kernel<false, 1>), dim3(groups * ns), dim3(256), lds + NW * 3 * 1024, stream, a);
         else {
             if (a.fl_dw_part && (!a.fl_dw_out || !a.fl_db_out || a.fl_dw_ld < 8)) { gpde_set_error("gpde_gemm_f16s_nt: first-layer gradient outputs missing"); return GPDE_EINVAL; }
-            hipLaunchKernelGGL((gpde_gemm_f16s_nt_kernel<false, 2>), dim3(groups * ns), dim3(256), lds + 4096 + NW * 2048, stream, a);
+            hipLaunchKernelGGL((gpde_gemm_f16s_nt_kernel<false, 2>), dim3(groups * ns), dim3(256), lds + NW * 2048, stream, a);
             if (a.fl_dw_part) {
                 // tile partials [ntile][N][8] -> their ordered sum [N][8] (behind the partials) -> dW_1 / db_1
                 float* tot = a.fl_dw_part + (size_t)ntile * a.N * 8;
@@ -1268,12 +1225,51 @@ __global__ __launch_bounds__(256) void k_first_layer_pack(GpdeFirstLayerSpec f, 
         __syncthreads();                     // img / h0s are rewritten by the next tile
     }
 }
+// The ReLU mask of the first hidden layer as bits [rows][n_in / 32], from the exact fp32 chain (k_first_layer's: bias, then d ascending) -
+// k_first_layer_pack without its image: what is left of that kernel when the dW_2 GEMM generates H_1 itself (fl_mode 1).
+__global__ __launch_bounds__(256) void k_first_layer_maskbits(GpdeFirstLayerSpec f, int rows, int n_in) {
+    __shared__ __attribute__((aligned(16))) float h0s[2][32][8];
+    const int n = threadIdx.x & 127, m = threadIdx.x >> 7;
+    const int slice = blockIdx.y;
+    const int col = slice * 128 + n;
+    const float b = f.bp[col];
+    float wd[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) wd[d] = f.Wp[(size_t)col * f.ldw + d];
+    const int nkct = (rows + 31) / 32;
+    const int kc_end = min((int)(blockIdx.x + 1) * FLP_TILES, nkct);
+    auto load_h0 = [&](int kc) {
+        const int e = kc * 32 + (threadIdx.x >> 3), d = threadIdx.x & 7;
+        return e < rows ? f.H0[(size_t)e * f.ld0 + d] : 0.f;
+    };
+    int buf = 0;
+    float h0n = blockIdx.x * FLP_TILES < kc_end ? load_h0(blockIdx.x * FLP_TILES) : 0.f;
+    for (int kcn = blockIdx.x * FLP_TILES; kcn < kc_end; ++kcn, buf ^= 1) {
+        h0s[buf][threadIdx.x >> 3][threadIdx.x & 7] = h0n;
+        __syncthreads();                     // (double-buffered: the next tile's store cannot overtake this tile's readers)
+        if (kcn + 1 < kc_end) h0n = load_h0(kcn + 1);
+        const int e0 = kcn * 32 + 16 * m;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float t = b;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) t = fmaf(wd[d], h0s[buf][16 * m + k][d], t);
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(t > 0.f);
+            if ((threadIdx.x & 63) == 0 && e0 + k < rows) {
+                uint32_t* mp = f.maskbits + (size_t)(e0 + k) * (n_in / 32) + slice * 4 + ((n >> 6) << 1);
+                mp[0] = (uint32_t)bal;
+                mp[1] = (uint32_t)(bal >> 32);
+            }
+        }
+    }
+}
 }  // namespace
 
 size_t gpde_gemm_f16s_tn_ws_floats(int rows_max, int n_out, int n_in, int ksplits) {
     size_t epad = (size_t)rows_max + 64 * (size_t)ksplits;
     if (epad < (size_t)256 * ksplits) epad = (size_t)256 * ksplits;       // the launcher pads every K split to >= 256 rows
     return epad * n_out + epad * n_in + 3 * (size_t)(n_out + n_in) + 64 +
+           (size_t)n_in * 8 + 64 +                                                        // in-kernel first layer: operand image + slot scales
            (epad / 1024 + 2) * (size_t)n_out + (size_t)(n_out / 64 + 1) * epad + 64;   // GpdeDuStats: column-sum partials per
                                                                                           // 1024-row strip, row maxima per column block
 }
@@ -1311,6 +1307,7 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
     const int nstrip = (epad + TS_STRIP - 1) / TS_STRIP;
     float* csum_part = (float*)(bits + n_out + n_in) + 16;    // [nstrip][n_out]   (GpdeDuStats)
     unsigned* rowpart = (unsigned*)(csum_part + (size_t)nstrip * n_out);        // [n_out / 64][epad]
+    float* flimg = (float*)(rowpart + (size_t)(n_out / 64 + 1) * epad) + 16;    // [n_in][16] f16 image, then 16 floats (in-kernel first layer)
     GP_HIP_CHECK(gpde_zero_async(bits, (size_t)(n_out + n_in) * 4, stream));
     int splits = 1;
     while (splits < 256 && rows / (splits * 2) >= 64) splits *= 2;
@@ -1345,10 +1342,11 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
         if (fl_gen && fl->amax_bits) GP_HIP_CHECK(gpde_copy_async(bits + n_out, fl->amax_bits, 8 * 4, stream));     // the call-wide bound (see GpdeFirstLayerSpec)
         else hipLaunchKernelGGL(k_attr_absmax8, dim3(nb), dim3(256), 0, stream, fl->H0, rows, fl->ld0, bits + n_out);
         if (fl_gen) {
-            // round 6: no image, no mask bits - the GEMM below (and the dU_1 GEMM after it) generate H_1 from the attributes; the
-            // spec's `maskbits` buffer carries the column image + slot scales to both
+            // round 6: no image - the GEMM below generates its B chunks from the attributes; the ReLU mask bits of the dU_1 GEMM come
+            // from the exact fp32 chain in a pass of their own (k_first_layer_pack minus its 4 bytes per edge and column of image)
             hipLaunchKernelGGL(k_first_layer_wimg, dim3((n_in + 255) / 256), dim3(256), 0, stream, fl->Wp, fl->ldw, fl->bp, bits + n_out,
-                               fl->k0, n_in, scb, ucolb, (_Float16*)fl->maskbits, (float*)gpde_first_layer_alpha(fl->maskbits, n_in));
+                               fl->k0, n_in, scb, ucolb, (_Float16*)flimg, flimg + (size_t)n_in * 8);
+            hipLaunchKernelGGL(k_first_layer_maskbits, dim3(((rows + 31) / 32 + FLP_TILES - 1) / FLP_TILES, n_in / 128), dim3(256), 0, stream, *fl, rows, n_in);
         } else {
             hipLaunchKernelGGL(k_first_layer_scales, dim3((n_in + 255) / 256), dim3(256), 0, stream, fl->Wp, fl->ldw, fl->bp,
                                bits + n_out, n_in, scb, ucolb);
@@ -1366,13 +1364,13 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
     g.ksplits = ksplits; g.cstride = (size_t)n_out * n_in;
     if (fl_gen) {
         g.fl_mode = 1; g.fl_attr = fl->H0; g.fl_ld0 = fl->ld0; g.fl_rows = rows;
-        g.fl_wimg = gpde_first_layer_wimg(fl->maskbits); g.fl_alpha = gpde_first_layer_alpha(fl->maskbits, n_in);
+        g.fl_wimg = flimg; g.fl_alpha = flimg + (size_t)n_in * 8;
     }
     return gpde_launch_gemm_f16s_nt(g, nullptr, stream);
 }
 
-// Whether gpde_launch_gemm_f16s_tn generates the first hidden layer inside its GEMM for this spec (then `maskbits` holds the operand
-// image, not mask words, and the dU_1 launch must use fl_mode 2): a free slot for the bias, 16-byte aligned attribute rows,
+// Whether gpde_launch_gemm_f16s_tn generates the first hidden layer inside its GEMM for this spec (`maskbits` receives the mask words
+// either way): a free slot for the bias, 16-byte aligned attribute rows,
 // the split-K form (ksplits > 1), and not switched off (GPDE_BWD_H1_IMAGE=1: rounds 3-5's image + mask bits, A/B)
 bool gpde_first_layer_in_kernel(const GpdeFirstLayerSpec& f, int rows, int ksplits) {
     return f.k0 >= 1 && f.k0 <= 7 && f.ld0 >= 8 && f.ld0 % 4 == 0 && rows >= 1 && ksplits > 1 && !gpde_switches().bwd_h1_image;     // (a K split is >= 256 edges = 8 chunks)
