@@ -121,6 +121,12 @@ def lib() -> ctypes.CDLL:
                     fn = getattr(l, name)          # AttributeError if a declared symbol is missing
                     fn.restype, fn.argtypes = res, args
                 ver = int(l.gpde_version())
+                # the binding was generated from HEADER_PATH: a library built from another header generation has the same symbol
+                # names and other argument lists - every pointer is a void* to ctypes, nothing else would notice
+                m = re.search(r"#define\s+GPDE_VERSION\s+(\d+)", open(HEADER_PATH).read())
+                if m is None or int(m.group(1)) != (ver & 0xffff):
+                    raise GpdeError(f"{LIB_PATH} reports ABI version {ver & 0xffff}, {HEADER_PATH} declares "
+                                    f"{m.group(1) if m else '?'}: header and library do not belong together (GPDE_LIB / GPDE_HEADER)")
                 if ver & GPDE_VERSION_ABLATION and os.environ.get("GPDE_ALLOW_ABLATION") != "1":
                     raise GpdeError(
                         f"{LIB_PATH} is an ABLATION build (gpde_version() = {ver:#x}: arithmetic compiled out, results are "

@@ -104,6 +104,20 @@ def test_ablation_builds_are_refused(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
 
 
+def test_a_library_of_another_header_generation_is_refused(monkeypatch):
+    """The ctypes binding is generated from include/gpde.h and every pointer is a void* to it: a libgpde.so built from another
+    generation of the header (GPDE_LIB pointing at another tree) would be called with the wrong argument lists without a sound.
+    gpde_version() must equal the header's GPDE_VERSION."""
+    class Fake:
+        def __getattr__(self, name):
+            return lambda *a: _lib.GPDE_VERSION + 1
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(ctypes, "CDLL", lambda path: Fake())
+    with pytest.raises(_lib.GpdeError, match="do not belong together"):
+        _lib.lib()
+    monkeypatch.setattr(_lib, "_lib", None)
+
+
 def test_library_exports_every_declared_symbol():
     l = ctypes.CDLL(_lib.LIB_PATH)
     for name in _declared_functions():
