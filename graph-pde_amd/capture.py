@@ -31,6 +31,9 @@ the cache policies of hidden_cache.py) is decided during the warm-up / recording
     No autograd graph of an EARLIER direct step may still be alive when a training step is recorded (a `loss` tensor kept in a
     variable is enough): its AccumulateGrad nodes stay bound to the stream that step ran on, and the recorded gradient
     accumulation would fork onto that stream - `hipStreamEndCapture` aborts the process on such an unjoined fork.
+    Known limit (round 6, not understood): a SECOND model training eagerly on the same device between a recorded training step and
+    its replays changed what the next replay computed (tests/test_gpu_capture.py; a forward-only neighbour did not, and a recording
+    replayed on its own follows the direct steps exactly).  Record and replay a training step without other training in between.
 Not a tracing compiler: nothing is transformed, fused or re-ordered.
 """
 from __future__ import annotations

@@ -324,7 +324,8 @@ struct GpdeGemmF16sArgs {
     // images [128 n][32 edges] are generated from the attributes instead of read from memory (no H_1^T image, no k_first_layer_pack);
     // fl_mode 2 (plain row tiles): the epilogue forms dW_1 / db_1 from the tile and the attribute rows (below)
     int fl_mode;
-    const float* fl_attr; int fl_ld0;   // gathered attributes [fl_rows][fl_ld0] (the first 8 floats of a row are used), slots >= k0 zero
+    const float* fl_attr; int fl_ld0;   // fl_mode 2: gathered attributes [fl_rows][fl_ld0] (the first 8 floats of a row are used), slots >= k0 zero;
+                                        // fl_mode 1: the split OPERAND image of k_first_layer_aops, [fl_rows = padded K][16] f16 (fl_ld0 = 8 floats)
     int fl_rows;                        // rows of fl_attr that exist (edges beyond it are zero columns of the K padding)
     const void* fl_wimg;                // fl_mode 1: [N][2][8] f16: w'_hi | w'_lo per column
     const float* fl_alpha;              // fl_mode 1: [16]: alpha[d] (0 in the bias slot and beyond), then beta[d] (1 in the bias slot, else 0)

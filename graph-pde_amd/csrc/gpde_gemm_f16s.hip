@@ -84,8 +84,10 @@ constexpr int A_SLOT = NW * TE * 128;      // 32 KiB: one 32-k chunk of the work
 // contraction runs over the edges.
 //   FL == 1 (split-K form, dW_2 = dU_2^T . H_1): wave w generates column block w of chunk c + 2's B image during chunk c - 2 MFMAs,
 //     8 conversion pairs, 4 ds_write_b128 into the ring slot the DMA used to fill.  The H_1^T split image (4 bytes per edge and
-//     column: 25.8 GB written and read back per backward at s=121) and k_first_layer_pack (9 ms) are gone.  The chunk's attributes
-//     (1 KiB) arrive by ONE LDS-DMA per wave and chunk into a private 3-slot stage, issued five chunks ahead in front of the A pieces.
+//     column: 25.8 GB written and read back per backward at s=121) and k_first_layer_pack (9 ms) are gone.  The chunk's attribute
+//     OPERANDS (32 edges x [a_hi | a_lo] = 1 KiB, scaled and split once per edge by k_first_layer_aops: 32 bytes per edge instead of
+//     28 VALU per chunk in each of the four waves of each of the 32 workgroups that share a K range) arrive by ONE LDS-DMA per wave
+//     and chunk into a private 3-slot stage, issued five chunks ahead in front of the A pieces.
 //   FL == 2 (plain row tiles, dU_1 = (dU_2 . W_2) (.) [H_1 > 0]): the epilogue also forms the FIRST layer's gradients from the tile in
 //     its registers - dW_1[n][d] += dU_1[e][n] . attr[e][d], db_1[n] += dU_1[e][n], one [128][8] partial per 64-row tile summed in tile
 //     order by the launcher - so dU_1 (4 KiB per edge) is neither written nor read back by k_dw_first.  The ReLU mask comes as bits from
@@ -192,7 +194,6 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
     const int boff[2] = {l31 * 128 + (((0 + h) ^ sw) << 4), l31 * 128 + (((2 + h) ^ sw) << 4)};
 
     // ---- FL: operands of the H_1 MFMA pair --------------------------------------------------------------------------
-    [[maybe_unused]] float fl_al[8], fl_be[8];
     [[maybe_unused]] h8 flB1 = {}, flB2 = {};          // FL == 1: this wave's column block (nb = wave) of the image: h ? w_lo : w_hi ; h ? 0 : w_hi
     [[maybe_unused]] char* flst = flst_all + wave * (3 * 1024);
     auto fl_wops = [&](int nb, h8& b1, h8& b2) {
@@ -202,32 +203,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
         b1 = h ? wlo : whi;
         b2 = h ? zero : whi;
     };
-    if constexpr (FL != 0) {
-#pragma unroll
-        for (int d = 0; d < 8; ++d) { fl_al[d] = a.fl_alpha[d]; fl_be[d] = a.fl_alpha[8 + d]; }
-        if constexpr (FL == 1) fl_wops(wave, flB1, flB2);
-    }
-    // attributes of one edge (8 slots) -> the A operands [a_hi | a_hi] and [a_lo | a_lo] (both lane halves hold the same edge)
-    auto fl_aops = [&](f32x4 v0, f32x4 v1, bool valid, h8& a1, h8& a2) {
-        float q[8];
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            const float t = fmaf(d < 4 ? v0[d & 3] : v1[d & 3], fl_al[d], fl_be[d]);     // (alpha = 0 in the bias slot: t = 1)
-            q[d] = valid ? t : 0.f;
-        }
-        u4 ph, pl;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            unsigned hh, ll;
-            asm("v_cvt_pkrtz_f16_f32 %0, %2, %3\n\t"
-                "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
-                "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                : "=&v"(hh), "=&v"(ll) : "v"(q[2 * p]), "v"(q[2 * p + 1]));
-            ph[p] = hh; pl[p] = ll;
-        }
-        a1 = __builtin_bit_cast(h8, ph);
-        a2 = __builtin_bit_cast(h8, pl);
-    };
+    if constexpr (FL == 1) fl_wops(wave, flB1, flB2);
     // D[edge][n] = [a_hi|a_hi] x [w_hi;w_lo] + [a_lo|a_lo] x [w_hi;0]  (asm: VGPR destination; the leading s_nop covers a VALU write
     // of an operand right in front - gpde_fused_f16v6.hip)
     // BOTH MFMAs in ONE asm statement: as two statements the compiler scheduled the VALU that forms b2 (h ? 0 : w_hi) between them,
@@ -254,15 +230,16 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
     // FL == 1: the attribute rows of chunk `ch` (32 edges x the first 32 bytes of each row) -> the 1 KiB stage slot ch % 3 by ONE LDS-DMA
     // (lane = 16 bytes; rows beyond fl_rows are clamped here and zeroed when read)
     auto fl_issue_attr = [&](int ch) {
-        const int e = min(kc(min(ch, NKC - 1)) * GP_BK + (lane >> 1), a.fl_rows - 1);
-        GPDE_GLDS(a.fl_attr + (size_t)e * a.fl_ld0 + 4 * (lane & 1), flst + (ch % 3) * 1024, 0);
+        // (fl_attr is the operand IMAGE here: [K padded][2][8] f16 = a_hi | a_lo per edge, zero rows beyond the tensor -
+        //  k_first_layer_aops; one wave-wide DMA = the chunk's 32 edges x 32 bytes, contiguous)
+        const int e = kc(min(ch, NKC - 1)) * GP_BK + (lane >> 1);
+        GPDE_GLDS(a.fl_attr + (size_t)e * 8 + 4 * (lane & 1), flst + (ch % 3) * 1024, 0);
     };
-    // ... read back by lane (edge = l31) and turned into the A operands
+    // ... read back by lane (edge = l31): the A operands [a_hi | a_hi] and [a_lo | a_lo] as they lie
     auto fl_read_attr = [&](int ch, h8& a1, h8& a2) {
         const char* l = flst + (ch % 3) * 1024 + l31 * 32;
-        const f32x4 v0 = *(const f32x4*)l, v1 = *(const f32x4*)(l + 16);
-        const bool valid = kc(min(ch, NKC - 1)) * GP_BK + l31 < a.fl_rows && ch < NKC;
-        fl_aops(v0, v1, valid, a1, a2);
+        a1 = *(const h8*)l;
+        a2 = *(const h8*)(l + 16);
     };
     // ... and the generated column block of chunk `ch` written into ring slot `sl`: lane (n = l31 of block `wave`, half h) holds the
     // edges 16 m + {4h .. 4h+3, 8+4h .. 8+4h+3} of k16 step m in registers 8 m .. 8 m + 7 = unit 2 m + h of its row (hi), unit
@@ -299,8 +276,6 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
     [[maybe_unused]] h8 fl_a1 = {}, fl_a2 = {};      // FL == 1: A operands of the chunk whose image is generated next (chunk c + 2 in chunk c)
     [[maybe_unused]] f32x16 fl_d;
     // ... and the pieces of one chunk's generation, spread over the MFMA gaps of the K loop (state between the gaps:)
-    [[maybe_unused]] f32x4 fl_v0 = {}, fl_v1 = {};   // raw attributes of chunk c + 3
-    [[maybe_unused]] float fl_q[8];
     [[maybe_unused]] u4 fl_oh = {}, fl_ol = {};      // the four pairs of one 16-byte unit of the generated row
     auto fl_dpair = [&](int p) {
         unsigned hh, ll;
@@ -311,16 +286,6 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
         char* row = ring + sl * TILE_B + wave * 4096 + l31 * 128;
         *(u4*)(row + (((2 * m + h) ^ sw) << 4)) = fl_oh;
         *(u4*)(row + (((4 + 2 * m + h) ^ sw) << 4)) = fl_ol;
-    };
-    auto fl_apair = [&](int p) {
-        unsigned hh, ll;
-        asm("v_cvt_pkrtz_f16_f32 %0, %2, %3\n\t"
-            "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-            : "=&v"(hh), "=&v"(ll) : "v"(fl_q[2 * p]), "v"(fl_q[2 * p + 1]));
-        u4 t1 = __builtin_bit_cast(u4, fl_a1), t2 = __builtin_bit_cast(u4, fl_a2);
-        t1[p] = hh; t2[p] = ll;
-        fl_a1 = __builtin_bit_cast(h8, t1); fl_a2 = __builtin_bit_cast(h8, t2);
     };
     if constexpr (FL == 1) {
         // chunks 0 and 1 of this slice's B generated here, the A operands of chunk 2 prepared, the attributes of chunks 3 and 4 staged
@@ -518,10 +483,6 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                             if (m == 0) {
                                 if (i == 2) fl_h1gen(fl_d, fl_a1, fl_a2, flB1, flB2);
                                 if (i == 4) fl_issue_attr(c + 5);
-                                if (i == 5) {
-                                    const char* l = flst + ((c + 3) % 3) * 1024 + l31 * 32;
-                                    fl_v0 = *(const f32x4*)l; fl_v1 = *(const f32x4*)(l + 16);
-                                }
                                 if (i == 8) fl_dpair(0);
                                 if (i == 11) fl_dpair(1);
                                 if (i == 14) fl_dpair(2);
@@ -531,17 +492,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                             } else {
                                 if (i == 5) fl_dpair(6);
                                 if (i == 11) { fl_dpair(7); fl_dwrite(1, slot2); }
-                                if (i == 13) {
-#pragma unroll
-                                    for (int d = 0; d < 8; ++d) fl_q[d] = fmaf(d < 4 ? fl_v0[d & 3] : fl_v1[d & 3], fl_al[d], fl_be[d]);
-                                }
-                                if (i == 16) {
-                                    const bool valid = kc(min(c + 3, NKC - 1)) * GP_BK + l31 < a.fl_rows && c + 3 < NKC;
-#pragma unroll
-                                    for (int d = 0; d < 8; ++d) fl_q[d] = valid ? fl_q[d] : 0.f;
-                                }
-                                if (i == 17) { fl_apair(0); fl_apair(1); }
-                                if (i == 23) { fl_apair(2); fl_apair(3); }
+                                if (i == 17) fl_read_attr(c + 3, fl_a1, fl_a2);       // (ready-made operands: two ds_read_b128)
                             }
                         } else if (m == 0) {
                             if (i == 2) GPDE_GLDS(gsrc, ldst, 0);
@@ -1159,6 +1110,27 @@ __global__ void k_first_layer_wimg(const float* __restrict__ Wp, int ldw, const 
         o[8 + d] = (_Float16)(w - (float)hi);
     }
 }
+// A operands of the in-kernel first layer, once per edge: out[e] = [a_hi(8) | a_lo(8)] f16 with a[d] = attr[e][d] * alpha[d] + beta[d]
+// (beta = 1 in the bias slot), hi = rtz16, lo = rn16(a - hi); rows beyond `rows` (the K padding of the split GEMM) are zero
+__global__ __launch_bounds__(256) void k_first_layer_aops(const float* __restrict__ H0, int ld0, int rows, int epad, const float* __restrict__ alpha,
+                                                          _Float16* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= epad) return;
+    h8 hi = {}, lo = {};
+    if (e < rows) {
+        const f32x4 v0 = *(const f32x4*)(H0 + (size_t)e * ld0), v1 = *(const f32x4*)(H0 + (size_t)e * ld0 + 4);
+#pragma unroll
+        for (int d = 0; d < 8; d += 2) {
+            const float q0 = fmaf(d < 4 ? v0[d & 3] : v1[d & 3], alpha[d], alpha[8 + d]);
+            const float q1 = fmaf(d + 1 < 4 ? v0[(d + 1) & 3] : v1[(d + 1) & 3], alpha[d + 1], alpha[8 + d + 1]);
+            const auto pk = __builtin_amdgcn_cvt_pkrtz(q0, q1);
+            hi[d] = pk[0]; hi[d + 1] = pk[1];
+            lo[d] = (_Float16)(q0 - (float)pk[0]); lo[d + 1] = (_Float16)(q1 - (float)pk[1]);
+        }
+    }
+    *(h8*)(out + (size_t)e * 16) = hi;
+    *(h8*)(out + (size_t)e * 16 + 8) = lo;
+}
 // k_pack_split_kn with H computed on the fly: B[n][k = edge] = relu(bp[n] + sum_d Wp[n][d] H0[edge][d]) * sc[n], plus
 // the ReLU mask bits [rows][n_in / 32].  Workgroup = one 16 KiB tile (slice of 128 n, chunk of 32 edges), thread =
 // (n, k16 step m).  The fp32 fmaf chain is the one k_first_layer / the fp32 GEMM path evaluate (d ascending from the bias).
@@ -1269,7 +1241,7 @@ size_t gpde_gemm_f16s_tn_ws_floats(int rows_max, int n_out, int n_in, int ksplit
     size_t epad = (size_t)rows_max + 64 * (size_t)ksplits;
     if (epad < (size_t)256 * ksplits) epad = (size_t)256 * ksplits;       // the launcher pads every K split to >= 256 rows
     return epad * n_out + epad * n_in + 3 * (size_t)(n_out + n_in) + 64 +
-           (size_t)n_in * 8 + 64 +                                                        // in-kernel first layer: operand image + slot scales
+           (size_t)n_in * 8 + 64 + epad * 8 +                                             // in-kernel first layer: column image + slot scales, [epad][16] f16 attribute operands
            (epad / 1024 + 2) * (size_t)n_out + (size_t)(n_out / 64 + 1) * epad + 64;   // GpdeDuStats: column-sum partials per
                                                                                           // 1024-row strip, row maxima per column block
 }
@@ -1308,6 +1280,7 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
     float* csum_part = (float*)(bits + n_out + n_in) + 16;    // [nstrip][n_out]   (GpdeDuStats)
     unsigned* rowpart = (unsigned*)(csum_part + (size_t)nstrip * n_out);        // [n_out / 64][epad]
     float* flimg = (float*)(rowpart + (size_t)(n_out / 64 + 1) * epad) + 16;    // [n_in][16] f16 image, then 16 floats (in-kernel first layer)
+    float* flaops = flimg + (size_t)n_in * 8 + 32;                              // [epad][16] f16 attribute operands
     GP_HIP_CHECK(gpde_zero_async(bits, (size_t)(n_out + n_in) * 4, stream));
     int splits = 1;
     while (splits < 256 && rows / (splits * 2) >= 64) splits *= 2;
@@ -1346,6 +1319,8 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
             // from the exact fp32 chain in a pass of their own (k_first_layer_pack minus its 4 bytes per edge and column of image)
             hipLaunchKernelGGL(k_first_layer_wimg, dim3((n_in + 255) / 256), dim3(256), 0, stream, fl->Wp, fl->ldw, fl->bp, bits + n_out,
                                fl->k0, n_in, scb, ucolb, (_Float16*)flimg, flimg + (size_t)n_in * 8);
+            hipLaunchKernelGGL(k_first_layer_aops, dim3((epad + 255) / 256), dim3(256), 0, stream, fl->H0, fl->ld0, rows, epad, flimg + (size_t)n_in * 8,
+                               (_Float16*)flaops);
             hipLaunchKernelGGL(k_first_layer_maskbits, dim3(((rows + 31) / 32 + FLP_TILES - 1) / FLP_TILES, n_in / 128), dim3(256), 0, stream, *fl, rows, n_in);
         } else {
             hipLaunchKernelGGL(k_first_layer_scales, dim3((n_in + 255) / 256), dim3(256), 0, stream, fl->Wp, fl->ldw, fl->bp,
@@ -1363,7 +1338,7 @@ int gpde_launch_gemm_f16s_tn(const float* dU, int ldu, int n_out, const float* H
     g.C = part; g.ldc = n_in; g.K = epad; g.N = n_in; g.sc = sca; g.isc = isca;
     g.ksplits = ksplits; g.cstride = (size_t)n_out * n_in;
     if (fl_gen) {
-        g.fl_mode = 1; g.fl_attr = fl->H0; g.fl_ld0 = fl->ld0; g.fl_rows = rows;
+        g.fl_mode = 1; g.fl_attr = flaops; g.fl_ld0 = 8; g.fl_rows = epad;          // (the operand image: 8 floats = 16 halves per edge, K padding included)
         g.fl_wimg = flimg; g.fl_alpha = flimg + (size_t)n_in * 8;
     }
     return gpde_launch_gemm_f16s_nt(g, nullptr, stream);
