@@ -937,12 +937,14 @@ def main():
             # pipe is per NODE (dZ = gT . W3, dW_3 = gT^T . Z: 2 x 2 x 64 x 64 x k2 per node; Z comes from the forward: keep-Z)
             kwp = (kw + 127) // 128 * 128
             f16_rec = 3 * 2 * kwp * kwp + 2 * 2 * 16 * kwp * (kwp // 128)         # the recompute's share: hidden GEMM + H1 regeneration
-            f16_bwd_r = 3 * (3 * 2 * kwp * kwp) + 2 * 2 * 16 * kwp * (kwp // 128) + 2 * (3 * 2 * 64 * kwp)
+            f16_bwd_r = 3 * (3 * 2 * kwp * kwp) + 2 * 2 * 16 * kwp * (kwp // 128) + 2 * (3 * 2 * 64 * kwp) + \
+                (kwp // 256) * 2 * 2 * 16 * kwp          # round 6: H_1 generated inside the dW_2 GEMM (MFMA pair per 32 x 32 block, once per row quad)
             f16_bwd = f16_bwd_r - (f16_rec if kept_h else 0)
             f32_bwd = 2 * (2 * 64 * 64 * kwp) * nb_ / max(int(eib.shape[1]), 1)
             bwd_rate = eb_ / tb_med / 1e12
             trec = None
-            tfile = next((f for f in (os.path.join(REPO, "profiles", f"traffic_r05{'k' if kept_h else ''}_bwd.json"),
+            tfile = next((f for f in (os.path.join(REPO, "profiles", f"traffic_r06{'k' if kept_h else ''}_bwd.json"),
+                                      os.path.join(REPO, "profiles", f"traffic_r05{'k' if kept_h else ''}_bwd.json"),
                                       os.path.join(REPO, "profiles", "traffic_r05_bwd.json"),
                                       os.path.join(REPO, "profiles", "traffic_r04_bwd.json")) if os.path.exists(f)), "")
             if os.path.exists(tfile):

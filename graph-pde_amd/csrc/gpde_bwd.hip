@@ -787,7 +787,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     // per-chunk buffers: per edge (hsum + 2*kmax) floats (+ KP1 + KP2 for the transposed operands of dW_2), per node
     // (2*64*K2P + 3*64) floats
     const size_t tn_edge = P->f16s_dw2 ? (size_t)P->KP[1] + P->KP[2] : 0;
-    const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0) + tn_edge + GP_W) * 4 + (P->f16s_dw2 ? P->KP[1] / 8 + (P->KP[2] / 64 + 2) * 4 + 8 + P->KP[2] / 4 : 0) + (n_defer > 0 ? 1 : 0),
+    const size_t per_edge = (hsum + 2 * (size_t)kmax + (P->f16s_du1 ? 2 : 0) + tn_edge + GP_W) * 4 + (P->f16s_dw2 ? P->KP[1] / 8 + (P->KP[2] / 64 + 2) * 4 + 8 + P->KP[2] / 4 + 32 /* attribute operands of the in-kernel first layer */ : 0) + (n_defer > 0 ? 1 : 0),
                  per_node = ((size_t)2 * GP_W * P->K2P + 3 * GP_W + 1) * 4 +
                             (n_defer > 0 ? (size_t)(P->L + P->Lp) * GP_W * P->K2P * 4 + 64 : 0);   // dZ of every deferred layer (fp32) + the node's split image + tile records
     int64_t Ec, Nc;
