@@ -1159,7 +1159,7 @@ def main():
             "mgkn_fwd_ms": None if not mgkn else {k_[5:12]: [v_.get("ms_per_forward"), v_.get("ms_per_forward_captured"), v_.get("ms_per_forward_grouped")]
                                                   for k_, v_ in mgkn.items()},
             "mgkn_train_ms": None if not mgkn else {k_[5:12]: [v_.get("train_step_ms"), v_.get("train_step_captured_ms")] for k_, v_ in mgkn.items()},
-            "mgkn_keys": "[unmodified calls, captured, grouped] / [direct, captured]",
+            "mgkn_keys": "[unmodified calls, captured, grouped] / [direct, captured]; depth6: [direct, shared H]",
             "bwd_g121": None if not backward else {
                 "ms": backward.get("ms"), "M_edges_s": backward.get("M_edges_per_s"), "fwd_ms": backward.get("training_forward_ms"),
                 "pair_ms": backward.get("pair_ms"), "frac": bwd_roof.get("frac"), "traffic": bwd_roof.get("traffic"),
@@ -1170,13 +1170,16 @@ def main():
             "g241_depth6_train_step": None if not g241t else {
                 "s": g241t.get("s"), "first_s": g241t.get("first_step_s"), "distinct_samples_s": g241t.get("distinct_samples", {}).get("s"),
                 "peak_GiB": g241t.get("peak_GiB"), "M_edge_applications_s": g241t.get("M_edge_applications_per_s")},
-            "depth6_fwd": None if not reuse else {k_: (v_.get("ms") if isinstance(v_, dict) else v_) for k_, v_ in list(reuse.items())[:3]},
+            "depth6_s61_ms": None if not reuse else {"fwd": [reuse.get("forward_ms", {}).get("direct"), reuse.get("forward_ms", {}).get("reuse")],
+                                                     "fwd_bwd": [reuse.get("forward_backward_ms", {}).get("direct"), reuse.get("forward_backward_ms", {}).get("reuse")]},
+            "depth6_g241_fwd_ms": None if not reuse or "g241_depth6_forward" not in reuse else
+            [reuse["g241_depth6_forward"].get("direct_ms"), reuse["g241_depth6_forward"].get("reuse_ms")],
         },
         "detail": detail_path,
     }
     txt = json.dumps(line, separators=(",", ":"))
     if len(txt) > 2500:                                  # never let the line outgrow the driver's tail: drop the least essential
-        for k_ in ("depth6_fwd", "mgkn_keys", "node_table_M_edges_s", "bwd_g241_one_layer"):
+        for k_ in ("depth6_s61_ms", "depth6_g241_fwd_ms", "mgkn_keys", "node_table_M_edges_s", "bwd_g241_one_layer"):
             line["summary"].pop(k_, None)
             txt = json.dumps(line, separators=(",", ":"))
             if len(txt) <= 2500:
