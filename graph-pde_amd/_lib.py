@@ -15,7 +15,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPDE_LIB", os.path.join(_PKG, "libgpde.so"))   # GPDE_LIB: experiments
 
 GPDE_OK = 0
-GPDE_VERSION, GPDE_VERSION_ABLATION, GPDE_VERSION_INSTRUMENTED = 100, 0x10000, 0x20000
+GPDE_VERSION, GPDE_VERSION_ABLATION, GPDE_VERSION_INSTRUMENTED = 101, 0x10000, 0x20000
+GPDE_ACC_EDGE_WEIGHTS, GPDE_ACC_ROOT, GPDE_ACC_BIAS = 1, 2, 4      # include/gpde.h (gpde_nnconv_bwd_edgeweights_acc)
 GPDE_AGGR_ADD, GPDE_AGGR_MEAN, GPDE_AGGR_MAX = 0, 1, 2
 GPDE_WECONV_MAX_GROUP = 16
 GPDE_FWD_DEFAULT, GPDE_FWD_F16SPLIT = 0, 1

@@ -91,7 +91,7 @@ class NNConvFunction(torch.autograd.Function):
 class HiddenToken:
     """Validity flag shared between a cached H and its autograd node: once the node's backward has
     run, the graph behind H is gone and the cached tensor must not be reused for a new forward."""
-    __slots__ = ("valid", "hmax", "gh_acc", "gh_tid", "gh_adds")
+    __slots__ = ("valid", "hmax", "gh_acc", "gh_tid", "gh_adds", "side_acc", "side_in")
 
     def __init__(self):
         self.valid = True
@@ -99,6 +99,8 @@ class HiddenToken:
         self.gh_acc = None      # the running sum of dL/dH of the applications of ONE backward pass (NNConvHiddenFunction.backward)
         self.gh_tid = -1        # ... and that pass (autograd graph task id)
         self.gh_adds = 0        # ... and how many applications added to it in place
+        self.side_acc = None    # (W_e token) the (grad_root, grad_bias) the applications of that pass add to in place as well
+        self.side_in = None     # (W_e token) (root, bias) behind SharedParamFunction: private nodes only WeConvFunction consumes
 
 
 class HiddenFunction(torch.autograd.Function):
@@ -305,10 +307,41 @@ class EdgeWeightsFunction(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_we):
-        ctx.token.valid = False
+        tok = ctx.token
+        tok.valid = False
+        if tok.gh_acc is not None and tok.gh_adds > 0 and hasattr(torch._C, "_current_graph_task_id") and \
+                tok.gh_tid == torch._C._current_graph_task_id() and grad_we.data_ptr() != tok.gh_acc.data_ptr():
+            # (as HiddenFunction.backward: the applications added in place to the first one's tensor, autograd hands over another)
+            raise RuntimeError("graph_pde_amd: the in-place sum of dL/dW_e lost its buffer (W_e has a consumer outside WeConvFunction); "
+                               "set GPDE_ACCUMULATE_DLDH=0")
+        tok.gh_acc, tok.gh_adds, tok.side_acc = None, 0, None
         hidden, w_last = ctx.saved_tensors
         gh, gw, gb = ops.edge_weights_backward_raw(grad_we, hidden, ctx.dims, w_last, need_b=ctx.has_b)
         return gh, None, gw, gb, None
+
+
+class SharedParamFunction(torch.autograd.Function):
+    """Identity on a parameter (root / bias) of a module whose applications share W_e: a PRIVATE autograd node between the leaf
+    and the WeConvFunction calls of one step.  The in-place sum of the applications' gradients (WeConvFunction.backward) needs a
+    tensor that nothing else contributes to - a leaf's gradient buffer also collects whatever else the user's loss does with the
+    parameter, and an out-of-place sum there would silently drop the later in-place additions.  Here the only consumers are
+    ours, and the backward checks that what arrives IS the tensor the applications added to."""
+
+    @staticmethod
+    def forward(ctx, p, token, which):
+        ctx.token, ctx.which = token, which
+        return p.view_as(p)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        tok = ctx.token
+        if tok.side_acc is not None and tok.gh_adds > 0 and hasattr(torch._C, "_current_graph_task_id") and \
+                tok.gh_tid == torch._C._current_graph_task_id():
+            mine = tok.side_acc[ctx.which]
+            if mine is not None and g.data_ptr() != mine.data_ptr():
+                raise RuntimeError("graph_pde_amd: the in-place sum of a root / bias gradient lost its buffer; set GPDE_ACCUMULATE_DLDH=0")
+        return g, None, None
 
 
 class WeConvFunction(torch.autograd.Function):
@@ -316,9 +349,10 @@ class WeConvFunction(torch.autograd.Function):
     streaming kernel), differentiable in x, W_e, root and bias (gpde_nnconv_bwd_edgeweights)."""
 
     @staticmethod
-    def forward(ctx, x, we, csr, root, bias, aggr):
+    def forward(ctx, x, we, csr, root, bias, aggr, token=None):
         out = ops.nnconv_forward_edgeweights_raw(x.detach(), csr, we.detach(), root, bias, aggr)
         ctx.csr, ctx.aggr, ctx.has_bias = csr, aggr, bias is not None
+        ctx.token = token           # the HiddenToken of the shared W_e node (None: W_e is the caller's own tensor)
         ctx.save_for_backward(x, we, root)
         return out
 
@@ -326,6 +360,27 @@ class WeConvFunction(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, grad_out):
         x, we, root = ctx.saved_tensors
+        # The applications of a module that share W_e each produce dL/dW_e [E, 4096] (and grad_root, grad_bias of the same
+        # parameters); autograd would keep the first and add the others with one elementwise kernel per application and tensor
+        # (MGKN training steps: 190 - 220 such launches, 2.3 - 2.6 ms of a 20 - 28 ms step).  As NNConvHiddenFunction does for
+        # dL/dH: the first application of a backward pass hands autograd its tensors and remembers them on the W_e token, the
+        # others add to them inside the kernels (gpde_nnconv_bwd_edgeweights_acc: same additions, same order, the same bits)
+        # and return nothing.  Keyed on the autograd graph task: another pass always starts new tensors.
+        tok, acc, tid = ctx.token, None, -1
+        needs = ctx.needs_input_grad
+        share = tok is not None and tok.side_in is not None and ACCUMULATE_GRAD_HIDDEN and needs[1] and \
+            hasattr(torch._C, "_current_graph_task_id") and (root is None or needs[3]) and (not ctx.has_bias or needs[4])
+        if share:
+            tid = torch._C._current_graph_task_id()
+            if tid >= 0 and tok.gh_acc is not None and tok.gh_tid == tid and tok.side_acc is not None and \
+                    tok.gh_acc.shape == we.shape:
+                acc = (tok.gh_acc, *tok.side_acc)
         gx, gwe, groot, gbias = ops.nnconv_backward_edgeweights_raw(x, ctx.csr, we, root, ctx.aggr, grad_out,
-                                                                    need_root=root is not None, need_bias=ctx.has_bias)
-        return gx, gwe, None, groot, gbias if ctx.has_bias else None, None
+                                                                    need_root=root is not None, need_bias=ctx.has_bias, acc=acc)
+        if acc is not None:
+            tok.gh_adds += 1
+            ops.n_grad_hidden_accumulated += 1
+            return gx, None, None, None, None, None, None
+        if share and tid >= 0:
+            tok.gh_acc, tok.gh_tid, tok.gh_adds, tok.side_acc = gwe, tid, 0, (groot, gbias)
+        return gx, gwe, None, groot, gbias if ctx.has_bias else None, None, None

@@ -190,6 +190,12 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ M, int
 // (a node table is read through the edge's end points): the maximum of every edge's slot d over the WHOLE call - the in-kernel first layer
 // (gpde_gemm_f16s.hip, fl_mode) scales its operands from it, so that every edge chunk of the call - and every chunking - uses the
 // same scales and forms the same H_1 bits (ReLU mask included) for an edge
+// bits of the a-priori bound of every last-hidden activation: max|b2| + max_k ||W2_k||_1 . max_e B_e (fcol[8], fcol[9] of the pack
+// image, scal[1] from k_attr_bound) - the word gpde_zagg_kernel<true> takes its power-of-two H scale from
+__global__ void k_h_bound_word(const float* __restrict__ fcol, const unsigned* __restrict__ scal, unsigned* __restrict__ out) {
+    out[0] = __float_as_uint(fcol[8] + fcol[9] * __uint_as_float(scal[1]));
+}
+
 __global__ __launch_bounds__(256) void k_attr_absmax_all(const float* __restrict__ T, int64_t rows, int ld, int k0, NodeAttrSel nas,
                                                          const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                                          unsigned* __restrict__ amax) {
@@ -732,6 +738,7 @@ struct BwdPlan {
     size_t off_dzun;                  // per chunk node un-scale of its split dZ image (gpde_edge_bwd3.hip)
     size_t off_tcs, off_tcm;          // per 32-slot tile column sums / max bits of dU_2 [Ec / 32 + 1][KP2] (gpde_edge_bwd3.hip -> dW_2 GEMM)
     size_t off_amax8;                 // [8] words: bits of max |attribute slot d| over ALL edges of the call (in-kernel first layer: one set of scales for every chunk)
+    size_t off_xs;                    // [N][64] words: x as split-f16 pairs for the Z re-aggregation (gpde_zagg_kernel<true>); off_scal[0] = its scale, off_scal[2] = the H bound
     size_t off_scal;                  // [2] words: bits of max_e B_e for the one-pass kernel's global H scale (gpde_launch_attr_bound)
     size_t total;
     size_t one_chunk;                 // workspace bytes with which everything is one chunk
@@ -765,6 +772,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     const int ks_max = tn_ksplits(E);
     const int max_splits = ks_max > 16 ? ks_max : 16;
     P->part_floats = (size_t)max_splits * (wmax > 4096 ? wmax : 4096);
+    if (P->part_floats < (size_t)64 * GP_W * GP_W) P->part_floats = (size_t)64 * GP_W * GP_W;      // 64 node-range splits of a 64 x 64 output (gemm_tn_acc)
     P->off_part = take(P->part_floats);
     // packed MLP image for the fused f16-split recompute of the last hidden layer (3-Linear kernels)
     P->pack_bytes = (n_layers == 3 && dims[0] + 1 <= 8) ? gpde_mlp_pack_bytes(n_layers, dims) : 0;
@@ -782,6 +790,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     if (n_defer > 0 && P->Lp < 4) P->Lp = 4;
     P->off_xsc = take(n_defer > 0 ? (size_t)2 * (N > 0 ? N : 1) : 1);      // per source node row scales of the layer-input stack
     P->off_scal = take(4);
+    P->off_xs = take(P->pack_bytes ? (size_t)(N > 0 ? N : 1) * GP_W : 1);
     P->off_amax8 = take(16);
     const size_t fixed = off;
     // per-chunk buffers: per edge (hsum + 2*kmax) floats (+ KP1 + KP2 for the transposed operands of dW_2), per node
@@ -848,7 +857,7 @@ int gemm_tn_acc(const float* A, int lda, int M, const float* B, int ldb, int Nco
     int splits = 1;
     // skinny outputs (dW_1: 1024 x 8) are pure streaming of the tall operand: enough splits to put ~1024 workgroups
     // on it (16 splits = 128 workgroups read dU_1 at 0.8 TB/s)
-    while (splits < 256 && tiles * splits < 1024 && rows / (splits * 2) >= 256) splits *= 2;
+    while (splits < 256 && tiles * splits < 1024 && rows / (splits * 2) >= (tiles == 1 ? 64 : 256)) splits *= 2;
     const size_t cn = (size_t)M * Ncols;
     if ((size_t)splits * cn > part_floats) splits = (int)(part_floats / cn) ? (int)(part_floats / cn) : 1;
     GpdeGemmArgs g = gemm0();
@@ -863,7 +872,7 @@ int gemm_tn_acc(const float* A, int lda, int M, const float* B, int ldb, int Nco
 
 // node-side terms of update() (nn_conv.py:277-282): dx += g root^T, droot = X^T g, dbias = colsum g
 int bwd_node_terms(const float* x, int N, const float* root, const float* grad_out, float* dx, float* grad_root, float* grad_bias,
-                   float* part, size_t part_floats, hipStream_t st) {
+                   float* part, size_t part_floats, hipStream_t st, int acc_root = 0, int acc_bias = 0) {
     int rc;
     if (root && dx) {
         GpdeGemmArgs g = gemm0();
@@ -872,11 +881,11 @@ int bwd_node_terms(const float* x, int N, const float* root, const float* grad_o
         if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
     }
     if (grad_root)
-        if ((rc = gemm_tn_acc(x, GP_W, GP_W, grad_out, GP_W, GP_W, N, grad_root, GP_W, part, part_floats, 0, st)) != GPDE_OK) return rc;
+        if ((rc = gemm_tn_acc(x, GP_W, GP_W, grad_out, GP_W, GP_W, N, grad_root, GP_W, part, part_floats, acc_root, st)) != GPDE_OK) return rc;
     if (grad_bias) {
         int splits = 1; while (splits < 64 && N / (splits * 2) >= 64) splits *= 2;
         hipLaunchKernelGGL(k_colsum, dim3(1, splits), dim3(256), 0, st, grad_out, N, GP_W, GP_W, splits, part, (unsigned*)nullptr);
-        if ((rc = gpde_launch_reduce_splits(part, GP_W, splits, GP_W, grad_bias, 0, st)) != GPDE_OK) return rc;
+        if ((rc = gpde_launch_reduce_splits(part, GP_W, splits, GP_W, grad_bias, acc_bias, st)) != GPDE_OK) return rc;
     }
     return GPDE_OK;
 }
@@ -892,6 +901,9 @@ struct WeBwdArgs {
     const float* x; const float* we; const int32_t* rowptr; const int32_t* src; const float* g; int aggr;
     float* dwe; float* dxe; float* dx;
 };
+// ACC: dW_e += x_j (x) gT_i - the second .. last application of a module in one backward pass add to the tensor the first one
+// wrote (the additions autograd would perform with one elementwise kernel per application, in the same order: the same bits)
+template <bool ACC>
 __global__ __launch_bounds__(256) void gpde_weconv_bwd_kernel(WeBwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -913,13 +925,25 @@ __global__ __launch_bounds__(256) void gpde_weconv_bwd_kernel(WeBwdArgs a) {
         f32x4 v[16];
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) v[cc] = *(const f32x4*)(w + (size_t)(4 * cc + q) * GP_W + o4);
+        [[maybe_unused]] f32x4 old[16];
+        if constexpr (ACC) {
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) old[cc] = *(const f32x4*)(dw + (size_t)(4 * cc + q) * GP_W + o4);
+        }
         float mine = 0.f;
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) {
             const float xv = __int_as_float(__builtin_amdgcn_ds_bpermute((4 * cc + q) * 4, __float_as_int(xa)));
             f32x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = xv * gt[j];
+            for (int j = 0; j < 4; ++j) {
+                float pr = xv * gt[j];
+                if constexpr (ACC) {
+                    asm volatile("" : "+v"(pr));      // the rounded product, THEN the sum - as the two kernels it replaces (hipcc contracts
+                    pr = old[cc][j] + pr;             // a * b + c into one fma otherwise, and __fmul_rn is a plain `*` here)
+                }
+                o[j] = pr;
+            }
             *(f32x4*)(dw + (size_t)(4 * cc + q) * GP_W + o4) = o;
             float p = fmaf(v[cc][3], gt[3], fmaf(v[cc][2], gt[2], fmaf(v[cc][1], gt[1], v[cc][0] * gt[0])));
             p += __shfl_xor(p, 1); p += __shfl_xor(p, 2); p += __shfl_xor(p, 4); p += __shfl_xor(p, 8);   // the quarter's 16 lanes: all 64 outputs
@@ -943,7 +967,17 @@ extern "C" int gpde_nnconv_bwd_edgeweights(const float* x, int64_t n_nodes, cons
                                            const int32_t* src_slots, const float* root, int aggr, const float* grad_out,
                                            float* grad_x, float* grad_edge_weights, float* grad_root, float* grad_bias, void* ws,
                                            size_t ws_bytes, void* stream_) {
+    return gpde_nnconv_bwd_edgeweights_acc(x, n_nodes, edge_weights, n_edges, rowptr, src, src_rowptr, src_slots, root, aggr, grad_out, grad_x,
+                                           grad_edge_weights, grad_root, grad_bias, 0, ws, ws_bytes, stream_);
+}
+
+extern "C" int gpde_nnconv_bwd_edgeweights_acc(const float* x, int64_t n_nodes, const float* edge_weights, int64_t n_edges,
+                                               const int32_t* rowptr, const int32_t* src, const int32_t* src_rowptr,
+                                               const int32_t* src_slots, const float* root, int aggr, const float* grad_out,
+                                               float* grad_x, float* grad_edge_weights, float* grad_root, float* grad_bias,
+                                               int accumulate, void* ws, size_t ws_bytes, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
+    if (accumulate & ~(GPDE_ACC_EDGE_WEIGHTS | GPDE_ACC_ROOT | GPDE_ACC_BIAS)) { gpde_set_error("gpde_nnconv_bwd_edgeweights_acc: unknown accumulate bits %d", accumulate); return GPDE_EINVAL; }
     if (n_nodes < 0 || n_edges < 0 || !rowptr || !grad_out || !ws || (n_nodes > 0 && (!x || !grad_x)) ||
         (n_edges > 0 && (!edge_weights || !src || !grad_edge_weights)) || n_edges >= ((int64_t)1 << 31) / GP_W) {
         gpde_set_error("gpde_nnconv_bwd_edgeweights: null/negative argument");
@@ -960,11 +994,13 @@ extern "C" int gpde_nnconv_bwd_edgeweights(const float* x, int64_t n_nodes, cons
     GP_HIP_CHECK(gpde_zero_async(grad_x, (size_t)n_nodes * GP_W * 4, st));
     if (n_edges > 0) {
         WeBwdArgs a{x, edge_weights, rowptr, src, grad_out, aggr, grad_edge_weights, ordered ? dxe : nullptr, grad_x};
-        hipLaunchKernelGGL(gpde_weconv_bwd_kernel, dim3((unsigned)n_nodes), dim3(256), 0, st, a);
+        if (accumulate & GPDE_ACC_EDGE_WEIGHTS) hipLaunchKernelGGL(gpde_weconv_bwd_kernel<true>, dim3((unsigned)n_nodes), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(gpde_weconv_bwd_kernel<false>, dim3((unsigned)n_nodes), dim3(256), 0, st, a);
         if (ordered) hipLaunchKernelGGL(k_dx_reduce, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, st, dxe, src_rowptr, src_slots, (int)n_nodes, 0, (int)n_edges, grad_x, 1, (size_t)0);
         GP_LAUNCH_CHECK("gpde_weconv_bwd_kernel");
     }
-    return bwd_node_terms(x, (int)n_nodes, root, grad_out, grad_x, grad_root, grad_bias, part, part_floats, st);
+    return bwd_node_terms(x, (int)n_nodes, root, grad_out, grad_x, grad_root, grad_bias, part, part_floats, st,
+                          (accumulate & GPDE_ACC_ROOT) ? 2 : 0, (accumulate & GPDE_ACC_BIAS) ? 2 : 0);      // 2: += sum of the partials
 }
 
 // ---- backward of gpde_edge_weights_fwd: W_e = view(W3 . h_e + b3, 64, 64) -------------------------------------------------
@@ -1199,6 +1235,17 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
         onepass_ok = gpde_fused_f16v6_supported(probe);
         if (onepass_ok && (rc = gpde_launch_attr_bound(edge_attr, n_edges, PL.k0, F(P.off_pack) + PL.off_w1 + (size_t)PL.K1P * 8,
                                                        (unsigned*)F(P.off_scal), st, kt, kt ? nas.sel : nullptr, src, dst)) != GPDE_OK) return rc;
+    }
+    // Z re-aggregation (no Z kept by the forward: G241, the light passes) on the split-f16 aggregation kernel the forward's
+    // given-H path uses (gpde_zagg_kernel<true>, ~3x the fp32-MFMA form's rate): x as split pairs once per call, and ONE bound for
+    // every H value - the forward's a-priori bound max|b2| + max_k ||W2_k||_1 . max_e B_e, which holds for recomputed and for
+    // given (partial-H) rows alike since both come from this kernel MLP.  GPDE_BWD_ZAGG_F32=1: the fp32 kernel (A/B).
+    bool zagg16 = false;
+    if ((phase == BWD_FULL || light) && fast_last && !z_saved && !SW.bwd_zagg_f32 && n_edges >= 32768 && N > 0 && x) {
+        if ((rc = gpde_launch_g2_prep(x, N, edge_attr, n_edges, PL.k0, F(P.off_pack) + PL.off_w1 + (size_t)PL.K1P * 8, (unsigned*)F(P.off_scal),
+                                      (unsigned*)F(P.off_xs), st, kt, kt ? nas.sel : nullptr, src, dst)) != GPDE_OK) return rc;
+        hipLaunchKernelGGL(k_h_bound_word, dim3(1), dim3(1), 0, st, F(P.off_pack) + PL.off_fcol, (const unsigned*)F(P.off_scal), (unsigned*)F(P.off_scal) + 2);
+        zagg16 = true;
     }
     const float* chunk_h = nullptr;          // the current chunk's last hidden activations when they are given (hpart)
     bool skip_store = false;                 // the chunk runs the one-pass kernel: the last hidden layer is not written
@@ -1436,6 +1483,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 f.x = x; f.attr = edge_attr; f.rowptr = rowptr; f.src = src; f.dst = dst; f.perm = perm;
                 f.hbuf = Hlast; f.zbuf = Z; f.k0 = dims[0]; f.K1P = 32; f.K2P = K2P;
                 f.nc0 = na; f.nc1 = nb; f.e_chunk0 = e0;
+                if (zagg16) { f.xs = (const unsigned*)F(P.off_xs); f.scal = (const unsigned*)F(P.off_scal); f.hmax = (const unsigned*)F(P.off_scal) + 2; }
                 const int ns = K2P / GP_TN;
                 int groups = gpde_num_cus() / ns; if (groups < 1) groups = 1;
                 const int gcap = (rows / GP_TE + GP_WAVES) / GP_WAVES; if (groups > gcap) groups = gcap;
@@ -1450,15 +1498,17 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 g.A = gT; g.lda = GP_W; g.a_kcontig = 0; g.B = Z; g.ldb = GP_W * K2P; g.b_kcontig = 0;
                 g.C = F(P.off_dw3p); g.ldc = K2P; g.M = GP_W; g.N = K2P; g.K = nn; g.accumulate = 1;
                 g.batches = GP_W; g.strideA = 0; g.strideB = K2P; g.strideC = (size_t)GP_W * K2P;
-                // narrow kernels (the MGKN levels: K2P = 128 / 256) give 64 - 128 workgroups that each walk all nn nodes: split
-                // the node range (ordered partial reduction: deterministic) until ~512 workgroups are busy
+                // narrow kernels (the MGKN levels: K2P = 128 / 256) give 64 - 128 workgroups that each walk all nn nodes (365 us at
+                // nn = 4525): split the node range (ordered partial reduction: deterministic) until ~512 workgroups are busy.  The
+                // partials live in the chunk's dZ buffer - nn x 64 x K2P floats that are written only by the next GEMM below, and
+                // sp <= nn / 128 of these 64 x 64 x K2P images always fit
                 int sp = 1;
                 const int wgs = GP_W * ((K2P + 127) / 128);
-                while (sp < 16 && wgs * sp < 512 && (size_t)(sp * 2) * w3n <= P.part_floats && nn / (sp * 2) >= 128) sp *= 2;
+                while (sp < 16 && wgs * sp < 512 && nn / (sp * 2) >= 64) sp *= 2;
                 if (sp > 1) {
-                    g.C = F(P.off_part); g.accumulate = 0; g.splits = sp; g.strideSplit = w3n;
+                    g.C = dZ; g.accumulate = 0; g.splits = sp; g.strideSplit = w3n;
                     if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
-                    if ((rc = gpde_launch_reduce_splits(F(P.off_part), w3n, sp, w3n, F(P.off_dw3p), 1, st)) != GPDE_OK) return rc;
+                    if ((rc = gpde_launch_reduce_splits(dZ, w3n, sp, w3n, F(P.off_dw3p), 1, st)) != GPDE_OK) return rc;
                 } else if ((rc = gpde_launch_gemm(g, st)) != GPDE_OK) return rc;
             }
             // dZ[i][c][k] = sum_o gT[i][o] W3[c*64+o][k] ;  dS[i][c] = sum_o gT[i][o] b3[c*64+o]

@@ -14,6 +14,7 @@
 // with K as the slow index is stored [k][132] and read per k with lanes along the row index.
 #include "gpde_common.h"
 #include <cstdlib>
+#include <cstdio>
 
 namespace {
 
@@ -158,18 +159,28 @@ __global__ __launch_bounds__(256) void gpde_gemm_kernel(GpdeGemmArgs g) {
         if (n >= g.N) continue;
         const float bias = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            // what the epilogue READS (the old C of an accumulating call, the ReLU mask) is loaded for all 16 rows before the first
+            // store: C may alias neither (checked by the launcher), but the compiler cannot know - interleaved, every row paid one
+            // full memory latency (64 dependent round trips: 14 us of a 17 us K = 64 call)
+            float old[16], mk[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                old[r] = (g.accumulate && m < g.M) ? C[(size_t)m * g.ldc + n] : 0.f;
+                mk[r] = (g.mask && m < g.M) ? g.mask[(size_t)m * g.ldmask + n] : 1.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m >= g.M) continue;
                 float v = acc[i][j][r] + bias;
                 if (g.relu) v = fmaxf(v, 0.f);
-                if (g.mask) v = (g.mask[(size_t)m * g.ldmask + n] > 0.f) ? v : 0.f;
-                float* cp = &C[(size_t)m * g.ldc + n];
-                if (g.accumulate) v += *cp;
-                *cp = v;
+                if (g.mask) v = (mk[r] > 0.f) ? v : 0.f;
+                if (g.accumulate) v += old[r];
+                C[(size_t)m * g.ldc + n] = v;
             }
+        }
     }
 }
 
@@ -178,9 +189,11 @@ __global__ void gpde_reduce_splits_kernel(const float* __restrict__ P, size_t n,
                                           size_t stride, float* __restrict__ C, int accumulate) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float s = accumulate ? C[i] : 0.f;
+    // accumulate 1: C is the running sum the partials join one by one; 2: C += (sum of the partials) - what a separate
+    // `C = C + new` after a writing call computes (the in-kernel sums over a module's applications: same bits as autograd's)
+    float s = accumulate == 1 ? C[i] : 0.f;
     for (int k = 0; k < splits; ++k) s += P[(size_t)k * stride + i];
-    C[i] = s;
+    C[i] = accumulate == 2 ? C[i] + s : s;
 }
 
 // first level for very many partials: P[g * G][i] = sum of the G partials of group g (in place: a thread reads its own element
@@ -214,6 +227,9 @@ int gpde_launch_gemm(const GpdeGemmArgs& g_in, hipStream_t stream) {
         }
     }
     const dim3 grid((g.M + GT - 1) / GT, (g.N + GT - 1) / GT, g.batches * g.splits), block(256);
+    static const bool log_shapes = getenv("GPDE_DEBUG_GEMM_LOG") != nullptr;      // one stderr line per launch (pairs with a rocprofv3 kernel trace)
+    if (log_shapes) fprintf(stderr, "[gpde_gemm] <%d,%d> M %d N %d K %d batches %d splits %d acc %d mask %d wgs %u\n", g.a_kcontig, g.b_kcontig, g.M, g.N, g.K,
+                            g.batches, g.splits, g.accumulate, g.mask != nullptr, grid.x * grid.y * grid.z);
     if (g.a_kcontig && g.b_kcontig) hipLaunchKernelGGL((gpde_gemm_kernel<true, true>), grid, block, 0, stream, g);
     else if (g.a_kcontig && !g.b_kcontig) hipLaunchKernelGGL((gpde_gemm_kernel<true, false>), grid, block, 0, stream, g);
     else if (!g.a_kcontig && !g.b_kcontig) hipLaunchKernelGGL((gpde_gemm_kernel<false, false>), grid, block, 0, stream, g);

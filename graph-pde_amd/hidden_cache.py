@@ -311,6 +311,13 @@ def edge_weights_qualify(csr, force: bool = False, explicit: bool = False) -> bo
         e * ops.EDGE_WEIGHT_BYTES <= WE_BUDGET_BYTES
 
 
+def we_token_of(module: torch.nn.Module, we: torch.Tensor):
+    """The token of the module's shared W_e node when `we` is that node (WeConvFunction sums the applications' gradients in place
+    on it), else None."""
+    ent = _entries.get(module)
+    return ent.twe_token if ent is not None and ent.twe is we else None
+
+
 def lookup_edge_weights_train(module: torch.nn.Module, hidden: torch.Tensor, csr, pm, weights, biases):
     """W_e [E, 4096] as an AUTOGRAD node for a call that needs gradients and was just handed the module's full cached H
     (`hidden`: the HiddenFunction output `lookup` returned) - or None when the graph does not qualify / the policy is off.
@@ -325,6 +332,8 @@ def lookup_edge_weights_train(module: torch.nn.Module, hidden: torch.Tensor, csr
     key = ((w_last.data_ptr(), ops._ver(w_last)), (0, 0) if b_last is None else (b_last.data_ptr(), ops._ver(b_last)))
     if ent.twe is not None and ent.twe_h is hidden and ent.twe_key == key and ent.twe_token.valid:
         stats["we_hits"] += 1
+        # (a backward pass that never reached the W_e node left its running sums on the token: no pass is in flight at forward time)
+        ent.twe_token.gh_acc, ent.twe_token.gh_adds, ent.twe_token.side_acc = None, 0, None
         return ent.twe
     ent.twe, ent.twe_key, ent.twe_token, ent.twe_h = None, None, None, None
     # memory of the training form: W_e, one dL/dW_e per application in flight and autograd's running sum of them - 16 KiB per

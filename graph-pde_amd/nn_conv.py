@@ -22,7 +22,8 @@ import torch
 from torch.nn import Parameter
 
 from . import hidden_cache, ops
-from .autograd import NNConvDeferredFunction, NNConvFunction, NNConvHiddenFunction, WeConvFunction
+from . import autograd as _ag
+from .autograd import NNConvDeferredFunction, NNConvFunction, NNConvHiddenFunction, SharedParamFunction, WeConvFunction
 from .message_passing import MessagePassing
 
 
@@ -236,7 +237,15 @@ class NNConv_old(MessagePassing):
                     # call itself one streaming kernel forward and one backward
                     we = hidden_cache.lookup_edge_weights_train(self, hidden, csr, pm, weights, biases)
                     if we is not None:
-                        return WeConvFunction.apply(x, we, csr, root, bias, self.aggr)
+                        tok = hidden_cache.we_token_of(self, we)
+                        if tok is not None and _ag.ACCUMULATE_GRAD_HIDDEN:
+                            # root / bias behind private identity nodes, one per step and module: the applications sum their
+                            # gradients in place there (autograd.SharedParamFunction)
+                            if tok.side_in is None or tok.side_in[2] is not root or tok.side_in[3] is not bias:
+                                tok.side_in = (None if root is None else SharedParamFunction.apply(root, tok, 0),
+                                               None if bias is None else SharedParamFunction.apply(bias, tok, 1), root, bias)
+                            return WeConvFunction.apply(x, we, csr, tok.side_in[0], tok.side_in[1], self.aggr, tok)
+                        return WeConvFunction.apply(x, we, csr, root, bias, self.aggr, None)
                 return NNConvHiddenFunction.apply(x, hidden, csr, pm, weights[-1], biases[-1],
                                                   root, bias, self.aggr, hmax, hidden_cache.token_of(self, hidden, csr))
             if not no_grad:

@@ -1171,9 +1171,10 @@ def nnconv_forward_edgeweights_raw(x, csr, edge_weights, root, bias, aggr, resid
 
 
 def nnconv_backward_edgeweights_raw(x: torch.Tensor, csr: Csr, edge_weights: torch.Tensor, root: Optional[torch.Tensor], aggr: str,
-                                    grad_out: torch.Tensor, need_root: bool = True, need_bias: bool = True):
-    """gpde_nnconv_bwd_edgeweights: backward of the operator given the per-edge weights.  Returns (grad_x, grad_edge_weights
-    [E, 4096], grad_root or None, grad_bias or None)."""
+                                    grad_out: torch.Tensor, need_root: bool = True, need_bias: bool = True, acc=None):
+    """gpde_nnconv_bwd_edgeweights(_acc): backward of the operator given the per-edge weights.  Returns (grad_x,
+    grad_edge_weights [E, 4096], grad_root or None, grad_bias or None).  `acc` = (grad_edge_weights, grad_root or None, grad_bias
+    or None) of an earlier application of the same backward pass: this call ADDS to them in the kernels and returns them."""
     lib = _lib.lib()
     for t, nm in ((x, "x"), (edge_weights, "edge_weights"), (grad_out, "grad_out")):
         _require_cuda(t, nm)
@@ -1187,17 +1188,26 @@ def nnconv_backward_edgeweights_raw(x: torch.Tensor, csr: Csr, edge_weights: tor
         raise ValueError(f"edge_weights must be contiguous float32 [{e},{WIDTH * WIDTH}]")
     root_c = None if root is None else root.detach().contiguous()
     gx = torch.empty(n, WIDTH, dtype=torch.float32, device=dev)
-    gwe = torch.empty(e, WIDTH * WIDTH, dtype=torch.float32, device=dev)
-    groot = torch.empty(WIDTH, WIDTH, dtype=torch.float32, device=dev) if (need_root and root is not None) else None
-    gbias = torch.empty(WIDTH, dtype=torch.float32, device=dev) if need_bias else None
+    want_root = need_root and root is not None
+    bits = 0
+    if acc is not None:
+        gwe, groot, gbias = acc
+        if tuple(gwe.shape) != (e, WIDTH * WIDTH) or gwe.dtype != torch.float32 or not gwe.is_contiguous() or gwe.device != dev or \
+                (groot is not None) != want_root or (gbias is not None) != bool(need_bias):
+            raise ValueError("acc: (grad_edge_weights [E,4096], grad_root, grad_bias) of an application of the same module expected")
+        bits = _lib.GPDE_ACC_EDGE_WEIGHTS | (_lib.GPDE_ACC_ROOT if want_root else 0) | (_lib.GPDE_ACC_BIAS if need_bias else 0)
+    else:
+        gwe = torch.empty(e, WIDTH * WIDTH, dtype=torch.float32, device=dev)
+        groot = torch.empty(WIDTH, WIDTH, dtype=torch.float32, device=dev) if want_root else None
+        gbias = torch.empty(WIDTH, dtype=torch.float32, device=dev) if need_bias else None
     ws = _alloc_ws(int(lib.gpde_nnconv_bwd_edgeweights_workspace_bytes(n, e)), dev)
     srp, ssl = csr.src_order
     p = lambda t: None if t is None else t.data_ptr()
     with torch.cuda.device(dev):
-        rc = lib.gpde_nnconv_bwd_edgeweights(x.data_ptr(), n, we.data_ptr(), e, csr.rowptr.data_ptr(), csr.src.data_ptr(), p(srp), p(ssl),
-                                             p(root_c), _AGGR[aggr], grad_out.data_ptr(), gx.data_ptr(), gwe.data_ptr(), p(groot), p(gbias),
-                                             ws.data_ptr(), ws.numel(), _stream_ptr(dev))
-    _lib.check(rc, "gpde_nnconv_bwd_edgeweights")
+        rc = lib.gpde_nnconv_bwd_edgeweights_acc(x.data_ptr(), n, we.data_ptr(), e, csr.rowptr.data_ptr(), csr.src.data_ptr(), p(srp), p(ssl),
+                                                 p(root_c), _AGGR[aggr], grad_out.data_ptr(), gx.data_ptr(), gwe.data_ptr(), p(groot), p(gbias),
+                                                 bits, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "gpde_nnconv_bwd_edgeweights_acc")
     _lib.n_native_calls += 1
     return gx, gwe, groot, gbias
 

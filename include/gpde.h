@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPDE_VERSION 100 /* 0.1.0 */
+#define GPDE_VERSION 101 /* 0.1.1: + gpde_nnconv_bwd_edgeweights_acc */
 /* gpde_version() of a developer build carries one of these on top of GPDE_VERSION: an ABLATION build has part of the arithmetic
  * compiled out (timing experiments; its results are WRONG and a binding must refuse it), an INSTRUMENTED build carries
  * clock probes (results correct). */
@@ -407,6 +407,21 @@ GPDE_API int gpde_nnconv_bwd_edgeweights(const float* x, int64_t n_nodes, const 
                                 const int32_t* src_slots, const float* root, int aggr, const float* grad_out,
                                 float* grad_x, float* grad_edge_weights, float* grad_root, float* grad_bias, void* ws,
                                 size_t ws_bytes, void* stream);
+/* ... the same call adding into gradients that already hold the sum of the module's earlier applications of this backward pass
+ * (`accumulate`: GPDE_ACC_* bits; 0 = gpde_nnconv_bwd_edgeweights).  What autograd's `grad = grad + new` does for a tensor used
+ * by several applications (the reference's MGKN loops apply each NNConv `depth` times, MGKN_general_darcy2d.py:76-90): one
+ * elementwise kernel per application and gradient - 16 KiB per edge read twice and written once for W_e.  In-kernel: the same
+ * additions in the same order (unfused multiply, then add: the same bits), the old value read once. */
+enum {
+    GPDE_ACC_EDGE_WEIGHTS = 1,   /* grad_edge_weights[e] += x_j (x) gT_i */
+    GPDE_ACC_ROOT = 2,           /* grad_root += X^T g */
+    GPDE_ACC_BIAS = 4            /* grad_bias += colsum g */
+};
+GPDE_API int gpde_nnconv_bwd_edgeweights_acc(const float* x, int64_t n_nodes, const float* edge_weights, int64_t n_edges,
+                                    const int32_t* rowptr, const int32_t* src, const int32_t* src_rowptr,
+                                    const int32_t* src_slots, const float* root, int aggr, const float* grad_out,
+                                    float* grad_x, float* grad_edge_weights, float* grad_root, float* grad_bias,
+                                    int accumulate, void* ws, size_t ws_bytes, void* stream);
 GPDE_API size_t gpde_edge_weights_bwd_workspace_bytes(int64_t n_edges, int n_layers, const int32_t* dims);
 GPDE_API int gpde_edge_weights_bwd(const float* grad_edge_weights, const float* hidden, int64_t n_edges, int n_layers,
                           const int32_t* dims, const float* w_last, float* grad_hidden, float* grad_w_last,

@@ -126,7 +126,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_pack_queries():
     l = _lib.lib()
-    assert l.gpde_version() == 100
+    assert l.gpde_version() == _lib.GPDE_VERSION == 101
     d = _lib.dims_array([6, 1024, 1024, 4096])
     nbytes = l.gpde_mlp_pack_bytes(3, d)
     # W1|b1 [1024+1][8] + W2 tiles (fp32 and f16-split) 2*1024*1024 + b2, ucol 2*1024 + W3 + B3
