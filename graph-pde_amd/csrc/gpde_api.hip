@@ -72,6 +72,7 @@ GpdeSwitches load_switches() {
     s.bwd_h1_image = on("GPDE_BWD_H1_IMAGE");
     s.bwd_dw1_pass = on("GPDE_BWD_DW1_PASS");
     s.bwd_zagg_f32 = on("GPDE_BWD_ZAGG_F32");
+    s.bwd_node_terms_gemm = on("GPDE_BWD_NODE_TERMS_GEMM");
     s.bwd_dw1_gemm = on("GPDE_BWD_DW1_GEMM");
     s.bwd_du_passes = on("GPDE_BWD_DU_PASSES");
     s.bwd_du_transpose_pass = on("GPDE_BWD_DU_TRANSPOSE_PASS");

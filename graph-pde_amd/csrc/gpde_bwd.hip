@@ -864,16 +864,128 @@ int gemm_tn_acc(const float* A, int lda, int M, const float* B, int ldb, int Nco
     g.A = A; g.lda = lda; g.a_kcontig = 0; g.B = B; g.ldb = ldb; g.b_kcontig = 0;
     g.M = M; g.N = Ncols; g.K = rows; g.ldc = Ncols;
     (void)ldc_dense;
+    if (splits == 1) {            // one partial: straight into C (C + P is what either accumulate form computes)
+        g.C = C; g.accumulate = accumulate ? 1 : 0;
+        return gpde_launch_gemm(g, st);
+    }
     g.C = part; g.splits = splits; g.strideSplit = cn;
     int rc = gpde_launch_gemm(g, st);
     if (rc != GPDE_OK) return rc;
     return gpde_launch_reduce_splits(part, cn, splits, cn, C, accumulate, st);
 }
 
+
+// ---- node-side terms of update() in ONE pass (round 6) ---------------------------------------------------------------------
+// out_i += x_i . root + bias (nn_conv.py:277-282): dx_i += g_i . root^T, droot = X^T g, dbias = colsum g.  Rounds 2-5 ran three
+// generic 128 x 128-tile GEMM / column-sum launches plus two partial reductions per call - 60 us of a 52-call MGKN training
+// step's every call, for 64-wide operands with K = 64.  Here a workgroup walks a contiguous range of 64-node strips: x and g
+// strips and root staged in LDS, each wave owns one 32 x 32 block of dx (32 v_mfma_f32_32x32x2_f32 per strip, added to dx in
+// place) and one of droot (accumulated over the workgroup's strips in registers); partials [wg][64 x 64 + 64] summed in
+// workgroup order by k_node_terms_reduce.  fp32 MFMA: the arithmetic class of the GEMMs it replaces.
+constexpr int NT_LD = GP_W + 1;
+struct NodeTermsArgs {
+    const float* x; const float* g; const float* root; float* dx; float* part;
+    int N, strips_per_wg, do_dx, do_root;
+};
+__global__ __launch_bounds__(256) void k_node_terms(NodeTermsArgs a) {
+    __shared__ float gs[GP_W * NT_LD], xs[GP_W * NT_LD], rs[GP_W * NT_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5, bm = wave >> 1, bn = wave & 1;
+    if (a.do_dx)
+        for (int f = tid; f < GP_W * GP_W; f += 256) rs[(f >> 6) * NT_LD + (f & 63)] = a.root[f];
+    f32x16 racc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+    float bsum = 0.f;
+    const int s_lo = blockIdx.x * a.strips_per_wg, s_hi = min(s_lo + a.strips_per_wg, (a.N + GP_W - 1) / GP_W);
+    for (int sidx = s_lo; sidx < s_hi; ++sidx) {
+        const int i0 = sidx * GP_W;
+        __syncthreads();                      // the previous strip's LDS reads are done (and rs is written, first round)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int f4 = tid + 256 * k, row = f4 >> 4, c4 = (f4 & 15) * 4;
+            f32x4 gv = {0.f, 0.f, 0.f, 0.f}, xv = gv;
+            if (i0 + row < a.N) {
+                gv = *(const f32x4*)(a.g + (size_t)(i0 + row) * GP_W + c4);
+                if (a.do_root) xv = *(const f32x4*)(a.x + (size_t)(i0 + row) * GP_W + c4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { gs[row * NT_LD + c4 + j] = gv[j]; xs[row * NT_LD + c4 + j] = xv[j]; }
+        }
+        __syncthreads();
+        if (tid < GP_W) {
+            float sm = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < GP_W; ++i) sm += gs[i * NT_LD + tid];
+            bsum += sm;
+        }
+        if (a.do_dx) {
+            // dx[i][c] += sum_o g[i][o] root[c][o]: A[m = i][k = o], B[k = o][n = c]
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < GP_W / 2; ++t)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[(bm * 32 + l31) * NT_LD + 2 * t + h], rs[(bn * 32 + l31) * NT_LD + 2 * t + h], acc, 0, 0, 0);
+            float old[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                old[r] = i < a.N ? a.dx[(size_t)i * GP_W + bn * 32 + l31] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (i < a.N) a.dx[(size_t)i * GP_W + bn * 32 + l31] = old[r] + acc[r];
+            }
+        }
+        if (a.do_root) {
+            // droot[c][o] += sum_i x[i][c] g[i][o]: A[m = c][k = i], B[k = i][n = o]
+#pragma unroll
+            for (int t = 0; t < GP_W / 2; ++t)
+                racc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[(2 * t + h) * NT_LD + bm * 32 + l31], gs[(2 * t + h) * NT_LD + bn * 32 + l31], racc, 0, 0, 0);
+        }
+    }
+    float* P = a.part + (size_t)blockIdx.x * (GP_W * GP_W + GP_W);
+    if (a.do_root) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P[(bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * GP_W + bn * 32 + l31] = racc[r];
+    }
+    if (tid < GP_W) P[GP_W * GP_W + tid] = bsum;
+}
+// droot / dbias = (their old value, accumulate) + the workgroups' partials in order
+__global__ void k_node_terms_reduce(const float* __restrict__ part, int nwg, float* __restrict__ droot, float* __restrict__ dbias,
+                                    int acc_root, int acc_bias) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= GP_W * GP_W + GP_W) return;
+    float* out = i < GP_W * GP_W ? (droot ? droot + i : nullptr) : (dbias ? dbias + (i - GP_W * GP_W) : nullptr);
+    if (!out) return;
+    float sm = 0.f;
+    for (int k = 0; k < nwg; ++k) sm += part[(size_t)k * (GP_W * GP_W + GP_W) + i];
+    const int acc = i < GP_W * GP_W ? acc_root : acc_bias;
+    *out = acc ? *out + sm : sm;
+}
+
 // node-side terms of update() (nn_conv.py:277-282): dx += g root^T, droot = X^T g, dbias = colsum g
 int bwd_node_terms(const float* x, int N, const float* root, const float* grad_out, float* dx, float* grad_root, float* grad_bias,
                    float* part, size_t part_floats, hipStream_t st, int acc_root = 0, int acc_bias = 0) {
     int rc;
+    const size_t rec = (size_t)GP_W * GP_W + GP_W;
+    if (!gpde_switches().bwd_node_terms_gemm && N > 0 && (grad_root || grad_bias || (root && dx)) && (!grad_root || x) && part_floats >= rec) {
+        // one pass: workgroups of contiguous 64-node strips, as many as the partial buffer holds (<= 256)
+        const int strips = (N + GP_W - 1) / GP_W;
+        int nwg = strips < 256 ? strips : 256;
+        if ((size_t)nwg * rec > part_floats) nwg = (int)(part_floats / rec);
+        const int spw = (strips + nwg - 1) / nwg;
+        nwg = (strips + spw - 1) / spw;
+        NodeTermsArgs a{x, grad_out, root, dx, part, N, spw, (root && dx) ? 1 : 0, grad_root ? 1 : 0};
+        hipLaunchKernelGGL(k_node_terms, dim3(nwg), dim3(256), 0, st, a);
+        if (grad_root || grad_bias)
+            hipLaunchKernelGGL(k_node_terms_reduce, dim3((unsigned)((rec + 255) / 256)), dim3(256), 0, st, part, nwg, grad_root, grad_bias, acc_root, acc_bias);
+        GP_LAUNCH_CHECK("k_node_terms");
+        return GPDE_OK;
+    }
     if (root && dx) {
         GpdeGemmArgs g = gemm0();
         g.A = grad_out; g.lda = GP_W; g.B = root; g.ldb = GP_W; g.C = dx; g.ldc = GP_W;

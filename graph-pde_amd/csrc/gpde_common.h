@@ -81,6 +81,7 @@ struct GpdeSwitches {
     bool bwd_recompute_f32;      // GPDE_BWD_RECOMPUTE_F32: H recomputed by fp32 GEMMs in the full backward
     bool bwd_h1_materialize;     // GPDE_BWD_H1_MATERIALIZE: round-2 plan (H_1 written)
     bool bwd_h1_gemm;            // GPDE_BWD_H1_GEMM
+    bool bwd_node_terms_gemm;    // GPDE_BWD_NODE_TERMS_GEMM: dx += g root^T, droot, dbias on the generic GEMM / column-sum launches (rounds 2-5) - A/B
     bool bwd_zagg_f32;           // GPDE_BWD_ZAGG_F32: the backward's Z re-aggregation on fp32 MFMA (gpde_zagg_kernel<false>, rounds 2-5) - A/B
     bool bwd_dw1_pass;           // GPDE_BWD_DW1_PASS: dW_1 / db_1 from k_dw_first's pass over a materialised dU_1 (rounds 2-5) - A/B
     bool bwd_h1_image;           // GPDE_BWD_H1_IMAGE: rounds 3-5 plan (H_1^T split image + mask bits written by k_first_layer_pack) - A/B
