@@ -92,12 +92,21 @@ __global__ void pack_w2_kernel(const float* __restrict__ W, int k2, int k1, int 
 
 // per-input-slot max_k |W1b[k][d]| appended to the packed W1 as row `rows` ([h][s] order): the
 // fused kernel bounds max_k |H1[e][k]| <= sum_d wmax[d] |attr_e[d]| with it (f16-split scaling)
-__global__ void pack_w1max_kernel(const float* __restrict__ w1p, int rows, float* __restrict__ out) {
-    const int d8 = threadIdx.x;          // 8 threads: position in the [h][s] row
-    if (d8 >= 8) return;
+__global__ __launch_bounds__(256) void pack_w1max_kernel(const float* __restrict__ w1p, int rows, float* __restrict__ out,
+                                                         float* __restrict__ zero2) {
+    // thread t: slot position t & 7 of rows t >> 3, + 32, ...; then the 32 row groups fold through LDS
+    __shared__ float sm[256];
+    const int d8 = threadIdx.x & 7;
     float m = 0.f;
-    for (int r = 0; r < rows; ++r) m = fmaxf(m, fabsf(w1p[(size_t)r * 8 + d8]));
-    out[d8] = m;
+    for (int r = threadIdx.x >> 3; r < rows; r += 32) m = fmaxf(m, fabsf(w1p[(size_t)r * 8 + d8]));
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+#pragma unroll 8
+        for (int g = 1; g < 32; ++g) m = fmaxf(m, sm[g * 8 + threadIdx.x]);
+        out[threadIdx.x] = m;
+    }
+    if (threadIdx.x < 2 && zero2) zero2[threadIdx.x] = 0.f;          // the two maxima pack_g2_consts_kernel forms with atomicMax
 }
 
 // (W1|b1) -> f16 two-term split image for the f16 H1 generation: column d (input slot) is scaled
@@ -201,26 +210,22 @@ __global__ void pack_w3_kernel(const float* __restrict__ W3, int k2, int K2P, fl
 
 // a-priori bound of the last hidden layer for the f16-split aggregation (gpde_fused_f16v3.hip):
 // h_e[k] <= |b2_k| + (sum_j |W2[k][j]|) * max_j H1_e[j];  out[0] = max_k |b2_k|, out[1] = max_k ||W2_k||_1
-__global__ void pack_g2_consts_kernel(const float* __restrict__ W2, const float* __restrict__ b2, int k2,
-                                      int k1, float* __restrict__ out) {
-    __shared__ float sb[256], sl[256];
-    float mb = 0.f, ml = 0.f;
-    for (int k = threadIdx.x; k < k2; k += blockDim.x) {
-        float l1 = 0.f;
-        for (int j = 0; j < k1; ++j) l1 += fabsf(W2[(size_t)k * k1 + j]);
-        ml = fmaxf(ml, l1);
-        if (b2) mb = fmaxf(mb, fabsf(b2[k]));
+// One wave per row of W2 (coalesced), maxima of non-negative floats as bit patterns; out[0..1] zeroed by pack_w1max_kernel
+// (same stream, earlier).  (Rounds 1-5: one workgroup, a thread per row striding k1 floats - 55 us at 1024 x 1024, once per
+// module and optimisation step.)
+__global__ __launch_bounds__(256) void pack_g2_consts_kernel(const float* __restrict__ W2, const float* __restrict__ b2, int k2,
+                                                             int k1, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= k2) return;
+    float l1 = 0.f;
+    for (int j = lane; j < k1; j += 64) l1 += fabsf(W2[(size_t)k * k1 + j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) l1 += __shfl_xor(l1, o);
+    if (lane == 0) {
+        atomicMax((unsigned*)out + 1, __float_as_uint(l1));
+        if (b2) atomicMax((unsigned*)out, __float_as_uint(fabsf(b2[k])));
     }
-    sb[threadIdx.x] = mb; sl[threadIdx.x] = ml;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            sb[threadIdx.x] = fmaxf(sb[threadIdx.x], sb[threadIdx.x + s]);
-            sl[threadIdx.x] = fmaxf(sl[threadIdx.x], sl[threadIdx.x + s]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { out[0] = sb[0]; out[1] = sl[0]; }
 }
 
 }  // namespace
@@ -265,13 +270,13 @@ extern "C" int gpde_mlp_pack(int n_layers, const int32_t* dims, const float* con
                            W[1], dims[2], dims[1], L.K2P, L.K1P, P + L.off_w2t);
         hipLaunchKernelGGL(pack_pad_vec_kernel, dim3(blocks(L.K2P)), dim3(T), 0, stream, b[1],
                            dims[2], L.K2P, P + L.off_b2);
-        hipLaunchKernelGGL(pack_w1max_kernel, dim3(1), dim3(64), 0, stream, P + L.off_w1, L.K1P,
-                           P + L.off_w1 + (size_t)L.K1P * 8);
+        hipLaunchKernelGGL(pack_w1max_kernel, dim3(1), dim3(256), 0, stream, P + L.off_w1, L.K1P,
+                           P + L.off_w1 + (size_t)L.K1P * 8, P + L.off_fcol + 8);
         hipLaunchKernelGGL(pack_w1_f16split_kernel, dim3((L.K1P * 8 + 255) / 256), dim3(256), 0, stream,
                            P + L.off_w1, L.K1P, (_Float16*)(P + L.off_w1h), P + L.off_fcol);
         hipLaunchKernelGGL(pack_w2_f16split_kernel, dim3(L.K2P), dim3(256), 0, stream, W[1], dims[2],
                            dims[1], L.K2P, L.K1P, (_Float16*)(P + L.off_w2h), P + L.off_ucol);
-        hipLaunchKernelGGL(pack_g2_consts_kernel, dim3(1), dim3(256), 0, stream, W[1], b[1], dims[2], dims[1],
+        hipLaunchKernelGGL(pack_g2_consts_kernel, dim3((dims[2] + 3) / 4), dim3(256), 0, stream, W[1], b[1], dims[2], dims[1],
                            P + L.off_fcol + 8);
     } else {
         for (int l = 0; l < n_layers - 1; ++l) {
