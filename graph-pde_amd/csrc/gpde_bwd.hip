@@ -659,7 +659,9 @@ namespace {
 // contribution is their sum in ascending s (fixed order).
 __global__ __launch_bounds__(256) void k_dx_reduce(const float* __restrict__ dxe, const int32_t* __restrict__ srp,
                                                    const int32_t* __restrict__ ssl, int n_nodes, int e0, int e1,
-                                                   float* __restrict__ dx, int nparts, size_t part_stride) {
+                                                   float* __restrict__ dx, int nparts, size_t part_stride, int init) {
+    // `init`: dx is not initialised - the sum starts at 0 and a node without out-edges in the range gets 0 (the one-chunk callers:
+    // saves the zero-fill launch; 0 + v is exact, the bits are those of the zero-filled form)
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= n_nodes) return;
@@ -670,8 +672,8 @@ __global__ __launch_bounds__(256) void k_dx_reduce(const float* __restrict__ dxe
         if (ssl[mid] < e0) lo = mid + 1; else hi = mid;
     }
     int p = lo;
-    if (p >= end || ssl[p] >= e1) return;
-    float acc = dx[(size_t)j * GP_W + lane];            // continue the running sum: the result does not depend on the chunking
+    if (p >= end || ssl[p] >= e1) { if (init) dx[(size_t)j * GP_W + lane] = 0.f; return; }
+    float acc = init ? 0.f : dx[(size_t)j * GP_W + lane];            // continue the running sum: the result does not depend on the chunking
     for (; p + 8 <= end; p += 8) {
         int sl[8];
         float v[8];
@@ -1103,12 +1105,12 @@ extern "C" int gpde_nnconv_bwd_edgeweights_acc(const float* x, int64_t n_nodes, 
     float* part = (float*)(w + al((size_t)(n_edges > 0 ? n_edges : 1) * GP_W * 4));
     const size_t part_floats = (size_t)64 * GP_W * GP_W;
     const bool ordered = src_rowptr && src_slots;
-    GP_HIP_CHECK(gpde_zero_async(grad_x, (size_t)n_nodes * GP_W * 4, st));
+    if (!(ordered && n_edges > 0)) GP_HIP_CHECK(gpde_zero_async(grad_x, (size_t)n_nodes * GP_W * 4, st));      // (ordered: k_dx_reduce initialises it)
     if (n_edges > 0) {
         WeBwdArgs a{x, edge_weights, rowptr, src, grad_out, aggr, grad_edge_weights, ordered ? dxe : nullptr, grad_x};
         if (accumulate & GPDE_ACC_EDGE_WEIGHTS) hipLaunchKernelGGL(gpde_weconv_bwd_kernel<true>, dim3((unsigned)n_nodes), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(gpde_weconv_bwd_kernel<false>, dim3((unsigned)n_nodes), dim3(256), 0, st, a);
-        if (ordered) hipLaunchKernelGGL(k_dx_reduce, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, st, dxe, src_rowptr, src_slots, (int)n_nodes, 0, (int)n_edges, grad_x, 1, (size_t)0);
+        if (ordered) hipLaunchKernelGGL(k_dx_reduce, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, st, dxe, src_rowptr, src_slots, (int)n_nodes, 0, (int)n_edges, grad_x, 1, (size_t)0, 1);
         GP_LAUNCH_CHECK("gpde_weconv_bwd_kernel");
     }
     return bwd_node_terms(x, (int)n_nodes, root, grad_out, grad_x, grad_root, grad_bias, part, part_floats, st,
@@ -1121,7 +1123,7 @@ extern "C" int gpde_nnconv_bwd_edgeweights_acc(const float* x, int64_t n_nodes, 
 // dW_e is the SUM over the applications of the module (autograd adds them): the two 4096 x k2 products per edge run once per
 // step, on the split-f16 GEMMs where the shapes allow (K2P a multiple of 128), else on the fp32 MFMA GEMM.
 namespace {
-struct WeBwdPlan { size_t off_w3p, off_w3t, off_img, off_ucol, off_rsc, off_tn, off_part, off_dw3p, total; int K2P; bool split; int ks; };
+struct WeBwdPlan { size_t off_w3p, off_w3t, off_img, off_ucol, off_rsc, off_tn, off_part, off_dw3p, off_cbits, total; int K2P; bool split; int ks; };
 WeBwdPlan we_bwd_plan(int64_t E, int k2) {
     WeBwdPlan P{};
     P.K2P = gp_round_up(k2, 128);
@@ -1135,6 +1137,7 @@ WeBwdPlan we_bwd_plan(int64_t E, int k2) {
     P.off_tn = take(P.split ? gpde_gemm_f16s_tn_ws_floats((int)(E > 0 ? E : 1), GP_W * GP_W, P.K2P, P.ks) : 1);
     P.off_part = take((size_t)(P.split ? P.ks : 16) * wn);
     P.off_dw3p = take(wn);
+    P.off_cbits = take((size_t)GP_W * GP_W);      // column maxima of dW_e (bit patterns) from the db3 pass, for the dW3 GEMM's scales
     P.total = off + 512;
     return P;
 }
@@ -1168,6 +1171,19 @@ extern "C" int gpde_edge_weights_bwd(const float* grad_edge_weights, const float
         return GPDE_OK;
     }
     hipLaunchKernelGGL(k_pad_mat, dim3(nblk(wn)), dim3(T), 0, st, w_last, NW3, k2, k2, NW3, K2P, F(P.off_w3p));
+    // db3 = column sums of dW_e (ordered split partials) - FIRST: the same pass collects the column maxima the dW3 GEMM scales
+    // its transposed operand with (round 6: that GEMM's own k_colabsmax pass read the 16 KiB per edge a second time)
+    const unsigned* cbits = nullptr;
+    if (grad_b_last) {
+        const int cb = (NW3 + 255) / 256;
+        int splits = 1; while (splits < 256 && cb * splits < 1024 && E / (splits * 2) >= 16) splits *= 2;
+        const bool want_bits = P.split && grad_w_last;
+        if (want_bits) GP_HIP_CHECK(gpde_zero_async(F(P.off_cbits), (size_t)NW3 * 4, st));
+        hipLaunchKernelGGL(k_colsum, dim3(cb, splits), dim3(T), 0, st, grad_edge_weights, E, NW3, NW3, splits, F(P.off_part),
+                           want_bits ? (unsigned*)F(P.off_cbits) : (unsigned*)nullptr);
+        if ((rc = gpde_launch_reduce_splits(F(P.off_part), NW3, splits, NW3, grad_b_last, 0, st)) != GPDE_OK) return rc;
+        if (want_bits) cbits = (const unsigned*)F(P.off_cbits);
+    }
     if (P.split) {
         // dU = (dW_e . W3) (.) [H > 0]: A = dW_e rows [E][4096], B[n = k][K = (c, o)] = W3[(c, o)][k] = W3^T as a split image
         hipLaunchKernelGGL(k_transpose, dim3(nblk(wn)), dim3(T), 0, st, F(P.off_w3p), NW3, K2P, F(P.off_w3t));
@@ -1178,7 +1194,7 @@ extern "C" int gpde_edge_weights_bwd(const float* grad_edge_weights, const float
         if ((rc = gpde_launch_gemm_f16s_nt(g, F(P.off_rsc), st)) != GPDE_OK) return rc;
         // dW3 = dW_e^T . H (contraction over the edges)
         if (grad_w_last) {
-            if ((rc = gpde_launch_gemm_f16s_tn(grad_edge_weights, NW3, NW3, hidden, K2P, K2P, E, P.ks, F(P.off_tn), F(P.off_part), st)) != GPDE_OK) return rc;
+            if ((rc = gpde_launch_gemm_f16s_tn(grad_edge_weights, NW3, NW3, hidden, K2P, K2P, E, P.ks, F(P.off_tn), F(P.off_part), st, cbits)) != GPDE_OK) return rc;
             if ((rc = gpde_launch_reduce_splits(F(P.off_part), wn, P.ks, wn, F(P.off_dw3p), 0, st)) != GPDE_OK) return rc;
         }
     } else {
@@ -1191,12 +1207,6 @@ extern "C" int gpde_edge_weights_bwd(const float* grad_edge_weights, const float
     }
     if (grad_w_last)
         hipLaunchKernelGGL(k_unpad_mat, dim3(nblk((size_t)NW3 * k2)), dim3(T), 0, st, F(P.off_dw3p), NW3, k2, K2P, grad_w_last);
-    if (grad_b_last) {       // db3 = column sums of dW_e (ordered split partials)
-        const int cb = (NW3 + 255) / 256;
-        int splits = 1; while (splits < 256 && cb * splits < 1024 && E / (splits * 2) >= 16) splits *= 2;
-        hipLaunchKernelGGL(k_colsum, dim3(cb, splits), dim3(T), 0, st, grad_edge_weights, E, NW3, NW3, splits, F(P.off_part), (unsigned*)nullptr);
-        if ((rc = gpde_launch_reduce_splits(F(P.off_part), NW3, splits, NW3, grad_b_last, 0, st)) != GPDE_OK) return rc;
-    }
     GP_LAUNCH_CHECK("gpde_edge_weights_bwd kernels");
     return GPDE_OK;
 }
@@ -1668,7 +1678,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                     du_pre = true;
                 }
                 hipLaunchKernelGGL(k_dx_reduce, dim3((N + 3) / 4), dim3(T), 0, st, F(P.off_H[n - 1]), src_rowptr, src_slots, N, e0, e1, dx, ns,
-                                   (size_t)rows * GP_W);
+                                   (size_t)rows * GP_W, 0);
             } else {
                 const bool ordered = src_rowptr && src_slots;
                 EdgeBwdArgs ea{x, rowptr, src, dst, dZ, dS, Hlast, dUc, dx, e0, e1, na, K2P, ordered ? F(P.off_dxe) : nullptr};
@@ -1705,7 +1715,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                     return GPDE_EUNSUPPORTED;
                 } else if (staged) hipLaunchKernelGGL(gpde_edge_bwd2_kernel, dim3(((rows + 127) / 128 + 7) / 8 * 8), dim3(T), lds2, st, ea);
                 else hipLaunchKernelGGL(gpde_edge_bwd_kernel, dim3((rows + 127) / 128), dim3(T), lds, st, ea);
-                if (ordered) hipLaunchKernelGGL(k_dx_reduce, dim3((N + 3) / 4), dim3(T), 0, st, F(P.off_dxe), src_rowptr, src_slots, N, e0, e1, dx, 1, (size_t)0);
+                if (ordered) hipLaunchKernelGGL(k_dx_reduce, dim3((N + 3) / 4), dim3(T), 0, st, F(P.off_dxe), src_rowptr, src_slots, N, e0, e1, dx, 1, (size_t)0, 0);
             }
             // MLP backward over the chunk's edges
             if (phase == BWD_FULL) { mlp_e0 = e0; if ((rc = mlp_backward(dUc, rows)) != GPDE_OK) return rc; }
