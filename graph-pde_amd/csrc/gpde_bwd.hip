@@ -714,12 +714,18 @@ unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 // K splits of the dW_2 GEMM (contraction over the chunk's edges): 4 row quads x 8 splits x 8 slices = 256 workgroups up to
 // 786 k edges, then 8 more per 786 k so that no fp32 accumulator runs over more than ~100 k edges: with the whole s=121
 // graph as ONE chunk (5.9 M edges) 8 splits left 741 k-term chains and dW_2 3e-5 away from the 10-chunk result.
-int tn_ksplits(int64_t rows) {
+int tn_ksplits(int64_t rows, int n_out = 1024, int n_in = 1024) {
     int64_t g = (rows + 786431) / 786432;
     if (g < 1) g = 1;
     if (g > 16) g = 16;
-    return (int)(8 * g);
+    int ks = (int)(8 * g);
+    // narrow kernel MLPs (the MGKN levels: a 256 x 256 gradient is four tiles): more splits until ~256 workgroups run - with 8
+    // splits the 131 k edges of config 4's finest level were 16 k-row chains in 32 workgroups (588 us; 64 splits: round 6)
+    const int tiles = ((n_out + 127) / 128) * ((n_in + 127) / 128);
+    while (ks < 128 && tiles * ks < 256 && rows / (ks * 2) >= 512) ks *= 2;
+    return ks;
 }
+
 struct BwdPlan {
     int n_layers, nh;                 // nh = hidden layers = n_layers - 1
     int KP[GPDE_MAX_LAYERS + 1];      // padded widths: KP[0] = pad32(k0), KP[l] = pad128(k_l), l < n_layers
@@ -771,7 +777,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     const size_t w3 = (size_t)GP_W * GP_W * P->K2P;
     P->off_w3p = take(w3); P->off_b3 = take(GP_W * GP_W);
     P->off_dw3p = take(w3); P->off_db3 = take(GP_W * GP_W);      // adjacent: zeroed by one launch
-    const int ks_max = tn_ksplits(E);
+    const int ks_max = tn_ksplits(E, P->KP[n_layers - 1], n_layers >= 3 ? P->KP[n_layers - 2] : 1024);
     const int max_splits = ks_max > 16 ? ks_max : 16;
     P->part_floats = (size_t)max_splits * (wmax > 4096 ? wmax : 4096);
     if (P->part_floats < (size_t)64 * GP_W * GP_W) P->part_floats = (size_t)64 * GP_W * GP_W;      // 64 node-range splits of a 64 x 64 output (gemm_tn_acc)
@@ -830,7 +836,7 @@ int make_bwd_plan(int64_t N, int64_t E, int n_layers, const int32_t* dims, size_
     P->off_gT = take((size_t)Nc * GP_W); P->off_S = take((size_t)Nc * GP_W); P->off_dS = take((size_t)Nc * GP_W);
     P->off_rowsc = take(P->f16s_du1 ? (size_t)2 * Ec : 1);
     P->off_dxe = take((size_t)Ec * GP_W);
-    P->off_tnws = take(P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats((int)Ec, P->KP[2], P->KP[1], tn_ksplits(Ec)) : 1);
+    P->off_tnws = take(P->f16s_dw2 ? gpde_gemm_f16s_tn_ws_floats((int)Ec, P->KP[2], P->KP[1], tn_ksplits(Ec, P->KP[2], P->KP[1])) : 1);
     P->off_dubits = take((size_t)(kmax > 0 ? kmax : 1));
     P->off_maskbits = take(P->f16s_dw2 ? (size_t)Ec * (P->KP[1] / 32) : 1);
     P->off_dzstack = take(n_defer > 0 ? (size_t)P->L * Nc * GP_W * P->K2P : 1);
@@ -1123,7 +1129,7 @@ extern "C" int gpde_nnconv_bwd_edgeweights_acc(const float* x, int64_t n_nodes, 
 // dW_e is the SUM over the applications of the module (autograd adds them): the two 4096 x k2 products per edge run once per
 // step, on the split-f16 GEMMs where the shapes allow (K2P a multiple of 128), else on the fp32 MFMA GEMM.
 namespace {
-struct WeBwdPlan { size_t off_w3p, off_w3t, off_img, off_ucol, off_rsc, off_tn, off_part, off_dw3p, off_cbits, total; int K2P; bool split; int ks; };
+struct WeBwdPlan { size_t off_w3p, off_w3t, off_img, off_ucol, off_rsc, off_tn, off_part, off_dw3p, off_cbits, off_ntpart, total; int K2P; bool split; int ks, ks_nt; };
 WeBwdPlan we_bwd_plan(int64_t E, int k2) {
     WeBwdPlan P{};
     P.K2P = gp_round_up(k2, 128);
@@ -1138,6 +1144,10 @@ WeBwdPlan we_bwd_plan(int64_t E, int k2) {
     P.off_part = take((size_t)(P.split ? P.ks : 16) * wn);
     P.off_dw3p = take(wn);
     P.off_cbits = take((size_t)GP_W * GP_W);      // column maxima of dW_e (bit patterns) from the db3 pass, for the dW3 GEMM's scales
+    // dU = dW_e . W3 with few rows and a narrow K2P (the coarse MGKN levels) is a handful of workgroups that each walk K = 4096
+    // alone: 130 us whatever E is.  Up to 64 (row quad, column slice) workgroups: 8 K splits, partials summed in order
+    P.ks_nt = (P.split && ((E + 255) / 256) * (int64_t)(P.K2P / GP_TN) <= 64) ? 8 : 1;
+    P.off_ntpart = take(P.ks_nt > 1 ? (size_t)P.ks_nt * (E > 0 ? E : 1) * P.K2P : 1);
     P.total = off + 512;
     return P;
 }
@@ -1191,7 +1201,11 @@ extern "C" int gpde_edge_weights_bwd(const float* grad_edge_weights, const float
         GpdeGemmF16sArgs g{};
         g.A = grad_edge_weights; g.lda = NW3; g.M = E; g.bsplit = F(P.off_img); g.ucol = F(P.off_ucol);
         g.mask = hidden; g.ldmask = K2P; g.C = grad_hidden; g.ldc = K2P; g.K = NW3; g.N = K2P; g.ksplits = 1;
-        if ((rc = gpde_launch_gemm_f16s_nt(g, F(P.off_rsc), st)) != GPDE_OK) return rc;
+        if (P.ks_nt > 1) {          // (the ReLU mask multiplies every partial: the sum of the masked partials is the masked sum)
+            g.C = F(P.off_ntpart); g.ksplits = P.ks_nt; g.cstride = (size_t)E * K2P;
+            if ((rc = gpde_launch_gemm_f16s_nt(g, F(P.off_rsc), st)) != GPDE_OK) return rc;
+            if ((rc = gpde_launch_reduce_splits(F(P.off_ntpart), (size_t)E * K2P, P.ks_nt, (size_t)E * K2P, grad_hidden, 0, st)) != GPDE_OK) return rc;
+        } else if ((rc = gpde_launch_gemm_f16s_nt(g, F(P.off_rsc), st)) != GPDE_OK) return rc;
         // dW3 = dW_e^T . H (contraction over the edges)
         if (grad_w_last) {
             if ((rc = gpde_launch_gemm_f16s_tn(grad_edge_weights, NW3, NW3, hidden, K2P, K2P, E, P.ks, F(P.off_tn), F(P.off_part), st, cbits)) != GPDE_OK) return rc;
@@ -1472,13 +1486,13 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 // dW_2 += dU_2^T . H_1 on the split-f16 GEMM (contraction over the edges: both operands transposed)
                 GpdeFirstLayerSpec fl{F(P.off_H[0]), P.KP[0], F(P.off_wp[1]), P.KP[0], F(P.off_bp[1]), (uint32_t*)F(P.off_maskbits), dims[0],
                                       call_amax ? (const unsigned*)F(P.off_amax8) : nullptr};
-                fl_in_kernel = skip_h1(rows) && gpde_first_layer_in_kernel(fl, rows, tn_ksplits(rows));
+                fl_in_kernel = skip_h1(rows) && gpde_first_layer_in_kernel(fl, rows, tn_ksplits(rows, P.KP[2], P.KP[1]));
                 GpdeDuStats dst_{F(P.off_dbp[l]), F(P.off_rowsc), F(P.off_rowsc) + rows,
                                  du_pre ? F(P.off_tcs) : nullptr, du_pre ? (const unsigned*)F(P.off_tcm) : nullptr};
-                if ((rc2 = gpde_launch_gemm_f16s_tn(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, tn_ksplits(rows),
+                if ((rc2 = gpde_launch_gemm_f16s_tn(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, tn_ksplits(rows, P.KP[2], P.KP[1]),
                                                     F(P.off_tnws), F(P.off_part), st, du_one_pass ? nullptr : du_bits,
                                                     skip_h1(rows) ? &fl : nullptr, du_one_pass ? &dst_ : nullptr)) != GPDE_OK) return rc2;
-                if ((rc2 = gpde_launch_reduce_splits(F(P.off_part), (size_t)Kl * Kin, tn_ksplits(rows), (size_t)Kl * Kin,
+                if ((rc2 = gpde_launch_reduce_splits(F(P.off_part), (size_t)Kl * Kin, tn_ksplits(rows, P.KP[2], P.KP[1]), (size_t)Kl * Kin,
                                                      F(P.off_dwp[l]), 1, st)) != GPDE_OK) return rc2;
             } else if ((rc2 = gemm_tn_acc(dUc, Kl, Kl, F(P.off_H[l - 1]), Kin, Kin, rows, F(P.off_dwp[l]), Kin,
                                           F(P.off_part), P.part_floats, 1, st)) != GPDE_OK) return rc2;
@@ -1665,7 +1679,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                 const int ns = K2P / GP_TN;
                 if (dUc) f.bw_dU = dUc;
                 if (use1_by) {
-                    f.bw_dUt = gpde_gemm_f16s_tn_at(F(P.off_tnws), rows, tn_ksplits(rows), &f.bw_ldt);
+                    f.bw_dUt = gpde_gemm_f16s_tn_at(F(P.off_tnws), rows, tn_ksplits(rows, P.KP[2], P.KP[1]), &f.bw_ldt);
                     f.bw_rowmax = F(P.off_dxe);            // [ns][rows] (the per-edge dx rows of the two-pass form are not used)
                     f.bw_csum = F(P.off_tcs); f.bw_cmax = (unsigned*)F(P.off_tcm);
                 }
@@ -1703,7 +1717,7 @@ int bwd_impl(BwdPhase phase, const float* x, int64_t n_nodes, const float* edge_
                     // (mlp_backward's tn_split && du_one_pass case; GPDE_BWD_DU_TRANSPOSE_PASS=1: that pass, A/B)
                     if (phase == BWD_FULL && n == 3 && f16s_dw2 && f16s_du1 && rows >= 8192 && !SW.bwd_du_passes &&
                         !SW.bwd_du_transpose_pass) {
-                        e3.dUt = gpde_gemm_f16s_tn_at(F(P.off_tnws), rows, tn_ksplits(rows), &e3.ldt);
+                        e3.dUt = gpde_gemm_f16s_tn_at(F(P.off_tnws), rows, tn_ksplits(rows, P.KP[2], P.KP[1]), &e3.ldt);
                         e3.row_sc = F(P.off_rowsc); e3.row_isc = F(P.off_rowsc) + rows;
                         e3.csum_part = F(P.off_tcs); e3.cmax_part = (unsigned*)F(P.off_tcm);
                         du_pre = true;

@@ -21,6 +21,7 @@
 // Rows are independent: tiles of 64 rows are dealt round-robin to the waves, no node alignment, no aggregation.
 #include "gpde_common.h"
 #include <cstdlib>
+#include <cstdio>
 #include <type_traits>
 
 namespace {
@@ -771,6 +772,9 @@ int gpde_launch_gemm_f16s_nt(const GpdeGemmF16sArgs& a_in, float* row_scale_ws, 
     if (a.ksplits < 1) a.ksplits = 1;
     a.skew_us = gpde_debug_skew_us();
     a.no_tile_prefetch = gpde_switches().nt_no_prefetch; a.no_ks_xcd = gpde_switches().tn_no_ks_xcd;
+    static const bool log_shapes = getenv("GPDE_DEBUG_GEMM_LOG") != nullptr;      // one stderr line per launch (pairs with a rocprofv3 kernel trace)
+    if (log_shapes) fprintf(stderr, "[gpde_gemm_f16s] M %d N %d K %d ksplits %d fl %d gather %d mask %d\n", a.M, a.N, a.K, a.ksplits, a.fl_mode,
+                            a.g_src != nullptr, a.mask != nullptr);
     if (!gpde_gemm_f16s_supported(a.M, a.N, a.K, a.lda) || a.K % (64 * a.ksplits) != 0 || a.K / a.ksplits < 256) {
         gpde_set_error("gpde_gemm_f16s_nt: unsupported shape M=%d N=%d K=%d ksplits=%d", a.M, a.N, a.K, a.ksplits);
         return GPDE_EUNSUPPORTED;
