@@ -105,7 +105,7 @@ def test_one_pass_light_pass_and_chunking(monkeypatch):
     assert torch.equal(lroot, froot) and torch.equal(lbias, fbias)
     # several node / edge chunks: grad_x keeps its bits (per-edge partial rows, one owner per element, chunks in order), the
     # weight gradients move by the split-K summation order only
-    cx, cW, cb, croot, cbias = _run(*case, ws_div=4)
+    cx, cW, cb, croot, cbias = _run(*case, ws_div=2)      # (three edge chunks: the call-wide buffers of a 256-wide MLP are a quarter of `full` here)
     assert torch.equal(cx, fx)
     for l in range(3):
         assert rel_l2(cW[l].cpu(), fW[l].cpu()) <= 5e-6 and rel_l2(cb[l].cpu(), fb[l].cpu()) <= 5e-6, l
