@@ -257,8 +257,8 @@ class NNConvDeferredFunction(torch.autograd.Function):
         biases = list(params[n_layers:])
         ops._require_cuda(x, "x")
         pm = ops.pack_mlp(weights, biases)
-        ctx.z = ops.z_buffer(csr, pm.dims, x.device) if aggr in ("add", "mean") else None
         hp = token.hpart
+        ctx.z = ops.z_buffer(csr, pm.dims, x.device) if aggr in ("add", "mean") else None
         if hp is not None:          # the in-edges of the leading nodes from the kept partial H, the rest through the fused kernel
             out = ops.nnconv_forward_mixed_raw(x.detach(), csr, edge_attr.detach(), hp[0], hp[1], hp[2], pm, root, bias, aggr,
                                                z_keep=ctx.z)

@@ -38,7 +38,9 @@ MODE = os.environ.get("GPDE_HIDDEN_CACHE", "auto")
 _env_gb = os.environ.get("GPDE_HIDDEN_CACHE_GB", "")
 # None = sized to the device at the moment H is built (budget_bytes); a number pins it (tests / A-B runs set this variable)
 BUDGET_BYTES: Optional[int] = None if _env_gb in ("", "auto") else int(float(_env_gb) * (1 << 30))
-AUTO_FRACTION = 0.7                  # of the device's HBM
+AUTO_FRACTION = 0.7                  # of the device's HBM.  Round 6 tried 0.8 on the 241^2 training step (30 GiB more of H instead of two kept Z:
+                                     # 7.02 -> 6.79 s pinned, 6.95 s under this policy) - and the distinct-samples step ran out of memory
+                                     # on its 26.9 GiB workspace with 15.7 GiB free: left at 0.7 (profiles/r06_g241_memory_budget.txt)
 AUTO_RESERVE_BYTES = 48 << 30        # left free for workspaces (Z of the 241^2 graph: 15 GB), the caller's tensors, RCCL
 
 
@@ -78,7 +80,7 @@ stats = {"hits": 0, "builds": 0, "direct": 0, "we_hits": 0, "we_builds": 0}     
 
 class _Entry:
     __slots__ = ("key", "hidden", "token", "attr_ref", "csr", "last_key", "repeats", "hits_on_hidden", "hn", "we", "we_key",
-                 "we_refs", "big_key", "dkey", "dtoken", "dvirtual", "dcount", "drefs", "twe", "twe_key", "twe_token", "twe_h")
+                 "we_refs", "big_key", "dkey", "dtoken", "dvirtual", "dcount", "drefs", "twe", "twe_key", "twe_token", "twe_h", "last_partial")
 
     def __init__(self):
         self.key = None
@@ -102,6 +104,7 @@ class _Entry:
         self.twe = None             # training: W_e as an autograd node shared by the applications of a step, its key,
         self.twe_key = None         # validity token (cleared by its backward) and the H tensor it was built from
         self.twe_token = None
+        self.last_partial = None    # (n_edges, hn) of the last PARTIAL H built: the next build keeps that size while it still fits (see lookup)
         self.twe_h = None
 
 
@@ -201,6 +204,13 @@ def lookup(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, b
         rp = csr.rowptr_host
         hn = int(torch.searchsorted(rp.to(torch.int64), torch.tensor(budget // row_bytes), right=True)) - 1
         hn = hn // 64 * 64
+        # Keep the previous build's size while it still fits and is within 10 % of what the budget allows now: the budget follows
+        # the free memory of the moment, and a partial H a few MiB LARGER than the last one cannot reuse the block the allocator
+        # just got back - on the 241^2 graph a second 230 GiB request that ends in the allocator's out-of-memory retry (round 6,
+        # with the budget's free-memory term binding instead of the fixed fraction: every other training step took 14.8 s instead of 6.7)
+        lp = ent.last_partial
+        if lp is not None and lp[0] == csr.n_edges and lp[1] <= hn and lp[1] >= 0.9 * hn:
+            hn = lp[1]
         nbytes = int(rp[hn]) * row_bytes if hn >= csr.n_nodes // 8 and hn > 0 else budget + 1
     if not want or nbytes > budget or csr.n_edges == 0 or edge_attr.requires_grad:
         ent.hidden, ent.key, ent.token, ent.attr_ref, ent.csr = None, None, None, None, None
@@ -230,6 +240,7 @@ def lookup(module: torch.nn.Module, edge_attr: torch.Tensor, csr, pm, weights, b
     ent.hits_on_hidden = 0
     if hn < csr.n_nodes:
         ent.big_key = key            # the whole H does not fit: a training call shares a virtual-H node (lookup_deferred)
+        ent.last_partial = (csr.n_edges, hn)
     stats["builds"] += 1
     return hidden, token.hmax, hn
 
