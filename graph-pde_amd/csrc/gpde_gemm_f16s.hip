@@ -589,11 +589,15 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
         }
         if constexpr (FL == 2) {
             const bool dw_on = a.fl_dw_part != nullptr;
-            float dws[4][8];          // this tile's partial first-layer gradients: column (nb, l31), slot d < 7 | 7 = bias, over the lane's 32 rows
+            // this tile's partial first-layer gradients: column (nb, l31), slot d < 7 | 7 = bias, over the lane's 32 rows - as four
+            // float pairs per column block (v_pk_fma_f32: two slots per instruction; slot 7's multiplier is 1.0, and fma(v, 1, s) is the
+            // sum's own rounding)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 dws[4][4];
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-                for (int d = 0; d < 8; ++d) dws[nb][d] = 0.f;
+                for (int d = 0; d < 4; ++d) dws[nb][d] = f32x2{0.f, 0.f};
             {     // the tile's attribute rows where every lane can read the rows its accumulator registers belong to (rows beyond the
                   // end hold a clamped copy: their sums are masked by the row's validity, their stores skipped)
                 *(f32x4*)(flas + lane * 32) = h ? fa[1][0] : fa[0][0];
@@ -601,38 +605,47 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
+                // row-major over the lane's 16 rows of this half, the four column blocks inside: the row's staged attributes are
+                // read ONCE (round 6 first had the column block outside: 256 ds_read_b128 per lane and tile instead of 64, and the
+                // epilogue took 14 k cycles of a tile's 84 k).  For a fixed (column, slot) the rows still arrive in ascending order:
+                // the sums keep their bits.
+                auto store_rows2 = [&](auto full_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    auto store_col = [&](auto full_tag) {
-                        constexpr bool FULL = decltype(full_tag)::value;
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const int row = r0 + rr;
+                        const float es = Es[rr];
+                        const bool valid = FULL || row < rend;
+                        f32x2 t[4];
+                        if (dw_on) {
+                            const f32x4 t0 = *(const f32x4*)(flas + rr * 32), t1 = *(const f32x4*)(flas + rr * 32 + 16);
+                            t[0] = f32x2{t0[0], t0[1]}; t[1] = f32x2{t0[2], t0[3]}; t[2] = f32x2{t1[0], t1[1]}; t[3] = f32x2{t1[2], 1.f};
+                        }
+                        // keep-mask of the 64 lanes for (row, column block): lanes 0..31 hold row rr0's columns, lanes 32..63 row
+                        // rr0 + 4's - the two mask words as one 64-bit lane mask (as in the bit-mask epilogue below)
+                        const int rr0 = 32 * e + (r & 3) + 8 * (r >> 2);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int rr = 32 * e + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            const int row = r0 + rr;
-                            float v = acc[e][nb][r] * (Es[rr] * ucv[nb]);
+                        for (int nb = 0; nb < 4; ++nb) {
+                            float v = acc[e][nb][r] * (es * ucv[nb]);
                             acc[e][nb][r] = 0.f;
-                            // keep-mask of the 64 lanes for (row, column block): lanes 0..31 hold row rr0's columns, lanes 32..63 row
-                            // rr0 + 4's - the two mask words as one 64-bit lane mask (as in the bit-mask epilogue below)
-                            const int rr0 = 32 * e + (r & 3) + 8 * (r >> 2);
                             const unsigned w0 = __builtin_amdgcn_readlane(mw[nb], rr0), w1 = __builtin_amdgcn_readlane(mw[nb], rr0 + 4);
                             const bool pos = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)w1 << 32) | w0);
                             v = pos ? v : 0.f;
-                            if (!a.fl_skip_store && (FULL || row < rend)) Cout[(size_t)row * a.ldc + slice * GP_TN + nb * 32 + l31] = v;
+                            if (!a.fl_skip_store && valid) Cout[(size_t)row * a.ldc + slice * GP_TN + nb * 32 + l31] = v;
                             if (dw_on) {
                                 // dW_1[col][d] += v * attr[row][d], db_1[col] += v  (rows beyond the end: v is whatever the clamped
-                                // loads gave - their staged attribute row is zero, the bias sum takes the row's validity)
-                                const f32x4 t0 = *(const f32x4*)(flas + rr * 32), t1 = *(const f32x4*)(flas + rr * 32 + 16);
-                                const float vb = (FULL || row < rend) ? v : 0.f;
-                                dws[nb][0] = fmaf(vb, t0[0], dws[nb][0]); dws[nb][1] = fmaf(vb, t0[1], dws[nb][1]);
-                                dws[nb][2] = fmaf(vb, t0[2], dws[nb][2]); dws[nb][3] = fmaf(vb, t0[3], dws[nb][3]);
-                                dws[nb][4] = fmaf(vb, t1[0], dws[nb][4]); dws[nb][5] = fmaf(vb, t1[1], dws[nb][5]);
-                                dws[nb][6] = fmaf(vb, t1[2], dws[nb][6]); dws[nb][7] += vb;
+                                // loads gave - the sums take the row's validity)
+                                const float vb = valid ? v : 0.f;
+                                const f32x2 vv = f32x2{vb, vb};
+#pragma unroll
+                                for (int d = 0; d < 4; ++d) dws[nb][d] = __builtin_elementwise_fma(vv, t[d], dws[nb][d]);
                             }
                         }
-                    };
-                    if (r0 + TE <= rend) store_col(std::true_type{});
-                    else store_col(std::false_type{});
-                }
+                    }
+                };
+                if (r0 + TE <= rend) store_rows2(std::true_type{});
+                else store_rows2(std::false_type{});
             }
             if (dw_on && r0 < rend) {
                 // the two lane halves hold different rows of the same column: fold them; the lower half writes the TILE's partial
@@ -644,7 +657,7 @@ void gpde_gemm_f16s_nt_kernel(GpdeGemmF16sArgs a) {
                 for (int nb = 0; nb < 4; ++nb) {
                     float o[8];
 #pragma unroll
-                    for (int d = 0; d < 8; ++d) o[d] = dws[nb][d] + __shfl_xor(dws[nb][d], 32);
+                    for (int d = 0; d < 8; ++d) o[d] = dws[nb][d >> 1][d & 1] + __shfl_xor(dws[nb][d >> 1][d & 1], 32);
                     if (h == 0) {
                         f32x4* q = (f32x4*)(pp + (size_t)(nb * 32 + l31) * 8);
                         q[0] = f32x4{o[0], o[1], o[2], o[3]};
