@@ -1217,14 +1217,19 @@ __global__ __launch_bounds__(256) void k_first_layer_pack(GpdeFirstLayerSpec f, 
 // The ReLU mask of the first hidden layer as bits [rows][n_in / 32], from the exact fp32 chain (k_first_layer's: bias, then d ascending) -
 // k_first_layer_pack without its image: what is left of that kernel when the dW_2 GEMM generates H_1 itself (fl_mode 1).
 __global__ __launch_bounds__(256) void k_first_layer_maskbits(GpdeFirstLayerSpec f, int rows, int n_in) {
+    // A wave owns 8 of the tile's 32 rows and all 128 columns of the slice: lane l computes columns l and l + 64 as one float pair
+    // (v_pk_fma_f32: the same bias-then-d-ascending chain per column, two columns per instruction), two ballots give the row's four
+    // mask words, lane 0 stores them as 16 bytes.  (Round 6 first had one column per thread: twice the LDS reads, FMA and store
+    // instructions per row - 3.2 ms per s=121 backward where the FMA count allows 0.6.)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     __shared__ __attribute__((aligned(16))) float h0s[2][32][8];
-    const int n = threadIdx.x & 127, m = threadIdx.x >> 7;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int slice = blockIdx.y;
-    const int col = slice * 128 + n;
-    const float b = f.bp[col];
-    float wd[8];
+    const int c0 = slice * 128 + lane, c1 = c0 + 64;
+    const f32x2 b = f32x2{f.bp[c0], f.bp[c1]};
+    f32x2 wd[8];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) wd[d] = f.Wp[(size_t)col * f.ldw + d];
+    for (int d = 0; d < 8; ++d) wd[d] = f32x2{f.Wp[(size_t)c0 * f.ldw + d], f.Wp[(size_t)c1 * f.ldw + d]};
     const int nkct = (rows + 31) / 32;
     const int kc_end = min((int)(blockIdx.x + 1) * FLP_TILES, nkct);
     auto load_h0 = [&](int kc) {
@@ -1237,17 +1242,20 @@ __global__ __launch_bounds__(256) void k_first_layer_maskbits(GpdeFirstLayerSpec
         h0s[buf][threadIdx.x >> 3][threadIdx.x & 7] = h0n;
         __syncthreads();                     // (double-buffered: the next tile's store cannot overtake this tile's readers)
         if (kcn + 1 < kc_end) h0n = load_h0(kcn + 1);
-        const int e0 = kcn * 32 + 16 * m;
+        const int e0 = kcn * 32 + 8 * w;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            float t = b;
+        for (int k = 0; k < 8; ++k) {
+            const f32x4 ha = *(const f32x4*)&h0s[buf][8 * w + k][0], hb = *(const f32x4*)&h0s[buf][8 * w + k][4];
+            f32x2 t = b;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) t = fmaf(wd[d], h0s[buf][16 * m + k][d], t);
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(t > 0.f);
-            if ((threadIdx.x & 63) == 0 && e0 + k < rows) {
-                uint32_t* mp = f.maskbits + (size_t)(e0 + k) * (n_in / 32) + slice * 4 + ((n >> 6) << 1);
-                mp[0] = (uint32_t)bal;
-                mp[1] = (uint32_t)(bal >> 32);
+            for (int d = 0; d < 4; ++d) t = __builtin_elementwise_fma(wd[d], f32x2{ha[d], ha[d]}, t);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) t = __builtin_elementwise_fma(wd[4 + d], f32x2{hb[d], hb[d]}, t);
+            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(t[0] > 0.f), b1 = __builtin_amdgcn_ballot_w64(t[1] > 0.f);
+            if (lane == 0 && e0 + k < rows) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                *(u32x4*)(f.maskbits + (size_t)(e0 + k) * (n_in / 32) + slice * 4) =
+                    u32x4{(uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32)};
             }
         }
     }
