@@ -609,13 +609,27 @@ def main():
     ops.attr_in_slot_order(csr, ea)              # edge_attr rows in CSR slot order (gpde_gather_rows): once per (graph, edge_attr)
     torch.cuda.synchronize()
     t3 = time.time()
+    # ... and for a SECOND edge_attr tensor on the same graph (a new sample of the same mesh): the gather alone.  The first call above also
+    # pays the process's first launches of these kernels and the identity probe of `perm` (22 - 108 ms across boxes); the cache entry of the
+    # probe tensor is dropped again (2.3 GB)
+    ea2 = ea.clone()
+    torch.cuda.synchronize()
+    t4 = time.time()
+    ops.attr_in_slot_order(csr, ea2)
+    torch.cuda.synchronize()
+    t5 = time.time()
+    if getattr(csr, "_attr_sorted", None):
+        for k_ in [k_ for k_, v_ in csr._attr_sorted.items() if v_[0] is ea2]:
+            csr._attr_sorted.pop(k_)
+    del ea2
     # per-(graph, edge_attr) preparation every NEW sample pays before its first forward; never inside the timed region
     graph_prep = {"csr_build_ms": round(1e3 * (t2 - t1), 2), "attr_reorder_ms": round(1e3 * (t3 - t2), 2),
+                  "attr_reorder_next_sample_ms": round(1e3 * (t5 - t4), 2),
                   "note": "gpde_csr_from_coo (stable sort by destination of the int64 [2,E] list) and gpde_gather_rows (edge_attr into "
                           "CSR slot order); both cached per tensor + version, `depth` applications and every epoch reuse them"}
     if rank == 0:
         log(f"[bench] graph {args.config}: N={n} E={e} generated in {t1 - t0:.2f}s; "
-            f"dst-CSR build {1e3 * (t2 - t1):.1f} ms, attribute reorder {1e3 * (t3 - t2):.1f} ms (not in the timed region)")
+            f"dst-CSR build {1e3 * (t2 - t1):.1f} ms, attribute reorder {1e3 * (t3 - t2):.1f} ms (first call; next sample {1e3 * (t5 - t4):.1f} ms; not in the timed region)")
 
     lin = ops.mlp_linears(conv.nn)
     pm = ops.pack_mlp([l.weight for l in lin], [l.bias for l in lin])
@@ -1154,7 +1168,7 @@ def main():
             "traffic_over_algorithmic", "avg_launch_ms", "launches_per_step", "hbm_frac")},
         "cpu_baseline": None if not cpu else dict(pick(cpu, "value", "unit", "cores", "kind"), sample=str(cpu.get("sample", ""))[:96]),
         "summary": {
-            "graph_prep_ms": pick(graph_prep, "csr_build_ms", "attr_reorder_ms"),
+            "graph_prep_ms": pick(graph_prep, "csr_build_ms", "attr_reorder_ms", "attr_reorder_next_sample_ms"),
             "node_table_M_edges_s": None if not nodeattr else nodeattr.get("M_edges_per_s", nodeattr.get("value")),
             "mgkn_fwd_ms": None if not mgkn else {k_[5:12]: [v_.get("ms_per_forward"), v_.get("ms_per_forward_captured"), v_.get("ms_per_forward_grouped")]
                                                   for k_, v_ in mgkn.items()},
