@@ -111,6 +111,8 @@ class NNConv_old(MessagePassing):
         x = x.unsqueeze(-1) if x.dim() == 1 else x
         if not x.is_cuda:
             return self._forward_staged(x, edge_index, edge_attr)
+        if isinstance(edge_attr, ops.NodeAttr) and not self._nn_is_linear_relu_chain():
+            edge_attr = edge_attr.materialize(edge_index.edge_index if isinstance(edge_index, ops.Csr) else edge_index)
         if isinstance(edge_attr, ops.NodeAttr):
             # opt-in: attributes read from node data inside the kernel.  Inference on
             # the default f16-split kernel; anything else takes the tensor the reference would build.
@@ -152,10 +154,50 @@ class NNConv_old(MessagePassing):
                 raise NotImplementedError("bipartite propagate (size != [N, N]) is not built: no graph-pde script uses it")
         if not x.is_cuda:
             return self._forward_staged(x, edge_index, pseudo)
+        if not self._nn_is_linear_relu_chain():
+            return self._propagate_general_nn(x, edge_index, pseudo)
         lin = ops.mlp_linears(self.nn)
         weights = [l.weight for l in lin]
         biases = [l.bias for l in lin]
         return self._propagate(x, edge_index, pseudo, weights, biases, self.root, self.bias, use_hidden_cache=True)
+
+    def _nn_is_linear_relu_chain(self) -> bool:
+        try:
+            ops.mlp_linears(self.nn)
+            return True
+        except NotImplementedError:
+            return False
+
+    def _propagate_general_nn(self, x, edge_index, pseudo):
+        """`nn` is "a neural network h_Theta ... e.g. torch.nn.Sequential" (nn_conv.py:217-221): anything that is not the
+        Linear / ReLU chain the fused kernels re-associate - `DenseNet(normalize=True)` (BatchNorm1d) or `out_nonlinearity`
+        (utilities.py:207-221), `DenseNet_sin` (multipole utilities.py:233-252), a user's own module.  The reference's own order
+        then: `weight = self.nn(pseudo).view(-1, in, out)` (nn_conv.py:274) by the caller's module as torch ops on the device -
+        16 KiB per edge, exactly the tensor the reference materialises - and message / aggregate / update (nn_conv.py:275-282) as
+        ONE native kernel over it (gpde_nnconv_fwd_edgeweights; backward gpde_nnconv_bwd_edgeweights, whose dL/dW_e autograd
+        carries back into `nn`).  The operator itself never leaves libgpde.so; what cannot be fused is the caller's network."""
+        self._check_width()
+        if self.aggr not in ("add", "mean"):
+            return MessagePassing.propagate(self, edge_index.edge_index if isinstance(edge_index, ops.Csr) else edge_index, x=x, pseudo=pseudo)
+        if x.dtype != torch.float32:
+            raise NotImplementedError(f"a kernel network outside the Linear / ReLU chain: float32 only (x is {x.dtype})")
+        csr = ops.csr_for(edge_index, x.size(0))
+        need = csr.n_edges * ops.WIDTH * ops.WIDTH * 4
+        free, _ = ops.device_free_bytes(x.device)
+        if 2 * need > free:
+            raise RuntimeError(f"kernel network {type(self.nn).__name__} is not a Linear / ReLU chain: its per-edge weights are materialised as in the "
+                               f"reference (nn_conv.py:274) - {csr.n_edges} edges x 16 KiB = {need / 2**30:.1f} GiB (twice that with gradients), "
+                               f"{free / 2**30:.1f} GiB free")
+        perm = csr.perm.long()
+        # rows in CSR slot order (the order the kernels address W_e in); `nn` acts row by row, batch statistics are order-free
+        pseudo_s = pseudo if bool(getattr(csr, "_perm_is_identity", False)) else pseudo.index_select(0, perm)
+        weight = self.nn(pseudo_s)
+        if weight.dim() != 2 or weight.size(0) != csr.n_edges or weight.size(1) != ops.WIDTH * ops.WIDTH:
+            raise ValueError(f"nn(pseudo) must be [E, {ops.WIDTH * ops.WIDTH}] (in_channels * out_channels, nn_conv.py:274), got {tuple(weight.shape)}")
+        weight = weight.float().contiguous()
+        if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or any(p is not None and p.requires_grad for p in (self.root, self.bias))):
+            return WeConvFunction.apply(x, weight, csr, self.root, self.bias, self.aggr, None)
+        return ops.nnconv_forward_edgeweights_raw(x, csr, weight.detach(), self.root, self.bias, self.aggr)
 
     def _forward_act(self, x, edge_index, edge_attr, residual, relu):
         attr_grad = (not isinstance(edge_attr, ops.NodeAttr)) and torch.is_tensor(edge_attr) and edge_attr.requires_grad
@@ -163,7 +205,7 @@ class NNConv_old(MessagePassing):
                                                   (residual is not None and residual.requires_grad) or
                                                   any(p.requires_grad for p in self.parameters()))
         fusable = x.is_cuda and x.dim() == 2 and not isinstance(edge_attr, ops.NodeAttr) and not needs_grad and \
-            x.dtype == torch.float32 and (residual is None or residual.device == x.device)
+            x.dtype == torch.float32 and (residual is None or residual.device == x.device) and self._nn_is_linear_relu_chain()
         if not fusable:
             y = self.forward(x, edge_index, edge_attr)
             if residual is not None:
