@@ -7,6 +7,8 @@ widths 16..300 (none of them tile multiples, as `DenseNet` allows: utilities.py:
 gradients (`loss.backward()`, UAI1_full_resolution.py:266) are compared with the float64 oracle.  The examples are derived
 with `derandomize=True` (no example database; the drawn set still depends on the process it runs in - see FWD_FACTOR).  Edges on the ReLU kink
 are removed (tests/helpers/kinks.py) so the gradient tolerance is the plain one."""
+import os
+
 import pytest
 import torch
 from hypothesis import HealthCheck, given, settings
@@ -49,7 +51,39 @@ def cases(draw):
     }
 
 
-@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+def _magnitude_norm(x, ei, ea, W, B, root, bias, aggr):
+    """|| M || with M[i][o] = sum_c sum_k (sum_e |x_j[c]| h_e[k]) |W3[(c,o)][k]| + sum_c (sum_e |x_j[c]|) |b3[(c,o)]| (+ |x_i| . |root| + |bias|),
+    'mean'-scaled, in float64: the sum of the MAGNITUDES of the terms the re-associated operator adds up - what a
+    rounding error of relative size eps per term can amount to.  || M || / || out || is the condition number of the sum."""
+    n = x.shape[0]
+    h = ea.double()
+    for l in range(len(W) - 1):
+        h = torch.relu(h @ W[l].double().t() + B[l].double())
+    k2 = h.shape[1]
+    xa = x.double().abs()
+    A = torch.zeros(n, 64, k2, dtype=torch.float64)
+    S = torch.zeros(n, 64, dtype=torch.float64)
+    for a0 in range(0, ei.shape[1], 2048):
+        sl = slice(a0, a0 + 2048)
+        xs = xa[ei[0, sl]]
+        A.index_add_(0, ei[1, sl], xs.unsqueeze(2) * h[sl].abs().unsqueeze(1))
+        S.index_add_(0, ei[1, sl], xs)
+    W3 = W[-1].double().abs().view(64, 64, k2)                                   # [(c, o)][k]
+    M = torch.einsum("ick,cok->io", A, W3) + torch.einsum("ic,co->io", S, B[-1].double().abs().view(64, 64))
+    if aggr == "mean":
+        deg = torch.zeros(n, dtype=torch.float64).index_add_(0, ei[1], torch.ones(ei.shape[1], dtype=torch.float64))
+        M = M / deg.clamp_min(1).unsqueeze(1)
+    if root is not None:
+        M = M + xa @ root.double().abs()
+    if bias is not None:
+        M = M + bias.double().abs()
+    return float(M.norm())
+
+
+CALIBRATION = []      # (err / (2^-22 kappa), err / e32, kappa) per example when GPDE_HYP_CALIBRATE is set (developer runs)
+
+
+@settings(max_examples=int(os.environ.get("GPDE_HYP_EXAMPLES", "30")), deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 @given(cases())
 def test_random_graphs_forward_and_gradients_vs_float64(c):
     d = torch.device("cuda:0")
@@ -100,6 +134,12 @@ def test_random_graphs_forward_and_gradients_vs_float64(c):
     (out * gout.to(d)).sum().backward()
     torch.cuda.synchronize()
     err = rel_l2(out.detach().cpu(), ref)
+    if os.environ.get("GPDE_HYP_CALIBRATE"):
+        kappa = _magnitude_norm(x, ei, ea, W, B, root, bias, c["aggr"]) / max(float(ref.norm()), 1e-300)
+        CALIBRATION.append((err / (2.0 ** -22 * kappa), err / max(e32, 1e-300), kappa, err, e32))
+        with open(os.environ["GPDE_HYP_CALIBRATE"], "a") as fh:
+            fh.write(f"{err / (2.0 ** -22 * kappa):.4f} {err / max(e32, 1e-300):.3f} {kappa:.3e} {err:.3e} {e32:.3e} n={c['n']} e={e} widths={c['widths']} {c['aggr']} root={c['root']} bias={c['bias']}\n")
+        return
     assert err <= max(TOL_FWD, FWD_FACTOR * e32), ("forward", c, err, "fp32 oracle vs float64:", e32)
     lin = ops.mlp_linears(conv.nn)
     errs = {"dx": rel_l2(xin.grad.cpu(), rx)}
