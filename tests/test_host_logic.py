@@ -148,6 +148,12 @@ def test_unsupported_configurations_fail_loudly():
     lin = ops.mlp_linears(torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.ReLU(),
                                               torch.nn.Linear(8, 4096)))
     assert len(lin) == 2
+    # round 6: a kernel network outside the Linear / ReLU chain is no longer refused by the MODULE - it is routed to nn(pseudo) + the
+    # native per-edge-weight operator (NNConv_old._propagate_general_nn; GPU test: tests/test_gpu_general_nn.py); the fused kernels'
+    # own parser above still refuses it
+    tanh = gp.NNConv_old(64, 64, torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 4096)))
+    assert not tanh._nn_is_linear_relu_chain()
+    assert gp.NNConv_old(64, 64, DenseNet([6, 8, 16, 4096], torch.nn.ReLU))._nn_is_linear_relu_chain()
 
 
 def test_synthetic_graphs_have_reference_shape():
@@ -326,6 +332,46 @@ def test_partial_hidden_cache_split_point(monkeypatch):
     monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", 500 * 10 * row)
     with torch.no_grad():
         assert hidden_cache.lookup(conv, ea, csr, pm, w, b, mode="on", allow_partial=True) is None
+
+
+def test_partial_hidden_size_is_kept_while_it_fits(monkeypatch):
+    """Round 6: the budget follows the free memory of the moment; a rebuilt partial H (the weights changed: every training step) keeps
+    the PREVIOUS build's node count while that still fits and lies within 10 % of what the budget allows now - a few MiB more could
+    not reuse the block the allocator just got back (on the 241^2 graph: a second 230 GiB request).  A smaller budget shrinks it, a
+    budget more than 10 % larger grows it."""
+    from graph_pde_amd import hidden_cache, ops
+
+    class FakeCsr:
+        n_nodes, deg = 1024, 10
+        n_edges = n_nodes * deg
+        rowptr_host = torch.arange(0, (n_nodes + 1) * deg, deg, dtype=torch.int32)
+    class FakePm:
+        dims = (6, 8, 100, 4096)
+    conv = gp.NNConv_old(64, 64, DenseNet([6, 8, 100, 4096], torch.nn.ReLU), aggr="mean")
+    lin = ops.mlp_linears(conv.nn)
+    w, b = [l.weight for l in lin], [l.bias for l in lin]
+    csr, pm = FakeCsr(), FakePm()
+    calls = []
+
+    def fake_hidden(csr_, attr, pm_, ws_, bs_, precision, n_nodes_limit=None):
+        calls.append(n_nodes_limit)
+        return torch.zeros(int(csr_.rowptr_host[n_nodes_limit]), 128), None
+    monkeypatch.setattr(ops, "hidden_forward_raw", fake_hidden)
+    row = 128 * 4
+    hidden_cache.clear()
+
+    def build(nodes_worth):
+        monkeypatch.setattr(hidden_cache, "BUDGET_BYTES", nodes_worth * 10 * row)
+        ea = torch.randn(FakeCsr.n_edges, 6)                    # a new edge_attr tensor: a new key, H is rebuilt
+        with torch.no_grad():
+            return hidden_cache.lookup(conv, ea, csr, pm, w, b, mode="on", allow_partial=True)[2]
+    assert build(600) == 576                                     # 9 * 64
+    assert build(660) == 576                                     # 640 would fit now - within 10 %: the previous size stays
+    assert build(590) == 576                                     # still fits
+    assert build(520) == 512                                     # no longer fits: shrinks
+    assert build(560) == 512                                     # 10 % hysteresis around the new size
+    assert build(800) == 768                                     # far more room: grows
+    assert calls == [576, 576, 576, 512, 512, 768]
 
 
 def test_bench_flop_accounting_matches_survey():
