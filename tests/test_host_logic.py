@@ -374,6 +374,84 @@ def test_partial_hidden_size_is_kept_while_it_fits(monkeypatch):
     assert calls == [576, 576, 576, 512, 512, 768]
 
 
+def test_in_place_gradient_sums_over_a_modules_applications_host_logic(monkeypatch):
+    """autograd.WeConvFunction / SharedParamFunction (round 6) with the two native calls replaced by torch CPU arithmetic of the same
+    contract: the first application of a backward pass returns dL/dW_e, grad_root, grad_bias and leaves them on the token, the others
+    ADD to those tensors (`acc`) and return None - autograd must end up with the sums it would have formed itself, a second pass over
+    a retained graph must start new tensors, and a second use of root in the loss must not lose the in-place additions."""
+    from graph_pde_amd import autograd as gpa
+
+    class FakeCsr:
+        def __init__(self, src, dst, n):
+            self.src, self.dst, self.n_nodes, self.n_edges = src, dst, n, int(src.numel())
+    n, e = 5, 12
+    g = torch.Generator().manual_seed(0)
+    csr = FakeCsr(torch.randint(0, n, (e,), generator=g), torch.randint(0, n, (e,), generator=g), n)
+    n_acc = {"calls": 0, "acc": 0}
+
+    def fwd(x, csr_, we, root, bias, aggr, **kw):
+        m = torch.bmm(x[csr_.src].unsqueeze(1), we.view(-1, 64, 64)).squeeze(1)
+        out = torch.zeros(csr_.n_nodes, 64).index_add_(0, csr_.dst, m)
+        if root is not None:
+            out = out + x @ root
+        return out if bias is None else out + bias
+
+    def bwd(x, csr_, we, root, aggr, grad_out, need_root=True, need_bias=True, acc=None):
+        n_acc["calls"] += 1
+        gt = grad_out[csr_.dst]
+        gwe = (x[csr_.src].unsqueeze(2) * gt.unsqueeze(1)).reshape(-1, 4096)
+        gx = torch.zeros_like(x).index_add_(0, csr_.src, torch.bmm(we.view(-1, 64, 64), gt.unsqueeze(2)).squeeze(2))
+        groot = x.t() @ grad_out if (need_root and root is not None) else None
+        if root is not None:
+            gx = gx + grad_out @ root.t()
+        gbias = grad_out.sum(0) if need_bias else None
+        if acc is not None:
+            n_acc["acc"] += 1
+            acc[0].add_(gwe)
+            if groot is not None:
+                acc[1].add_(groot)
+            if gbias is not None:
+                acc[2].add_(gbias)
+            return gx, acc[0], acc[1], acc[2]
+        return gx, gwe, groot, gbias
+    monkeypatch.setattr(ops, "nnconv_forward_edgeweights_raw", fwd)
+    monkeypatch.setattr(ops, "nnconv_backward_edgeweights_raw", bwd)
+
+    def run(shared, passes=1, reg=False):
+        monkeypatch.setattr(gpa, "ACCUMULATE_GRAD_HIDDEN", shared)
+        gg = torch.Generator().manual_seed(1)
+        x = torch.randn(n, 64, generator=gg).requires_grad_(True)
+        we = (0.1 * torch.randn(e, 4096, generator=gg)).requires_grad_(True)
+        root = (0.1 * torch.randn(64, 64, generator=gg)).requires_grad_(True)
+        bias = torch.randn(64, generator=gg).requires_grad_(True)
+        w = torch.randn(n, 64, generator=gg)
+        tok = gpa.HiddenToken() if shared else None
+        we_node = we * 1.0                                           # a non-leaf node shared by the applications, as W_e is
+        if shared:
+            tok.side_in = (gpa.SharedParamFunction.apply(root, tok, 0), gpa.SharedParamFunction.apply(bias, tok, 1), root, bias)
+            r_, b_ = tok.side_in[0], tok.side_in[1]
+        else:
+            r_, b_ = root, bias
+        h = x
+        for _ in range(3):
+            h = torch.tanh(gpa.WeConvFunction.apply(h, we_node, csr, r_, b_, "add", tok))
+        loss = (h * w).sum() + (0.5 * root.square().sum() if reg else 0.0)
+        for k in range(passes):
+            loss.backward(retain_graph=k + 1 < passes)
+        return [t.grad.clone() for t in (x, we, root, bias)]
+    c0 = dict(n_acc)
+    ref = run(False)
+    assert n_acc["acc"] == c0["acc"]
+    got = run(True)
+    assert n_acc["acc"] - c0["acc"] == 2                              # the first application writes, the other two add
+    for a, b in zip(got, ref):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    for a, b in zip(run(True, passes=2), run(False, passes=2)):       # a second pass starts its own tensors
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    for a, b in zip(run(True, reg=True), run(False, reg=True)):       # root used by the loss as well
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
 def test_bench_flop_accounting_matches_survey():
     """bench.py's roofline inputs: the reference formulation's FLOPs per edge and what the
     kernels execute."""
